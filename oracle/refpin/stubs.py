@@ -1,0 +1,199 @@
+"""Stand-ins for the third-party names the reference's hot-path files import
+(TEST INFRASTRUCTURE; semantics restated from the pinned versions, see
+oracle/thirdparty.py - PARITY UNPINNED at these boundaries)."""
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import thirdparty as tp
+from ..locatt import CLocatt, TorchLocatt
+
+STUB_ROOTS = ('mmcv', 'mmdet', 'mmdet3d', 'detectron2', 'cv2')
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    if '.' in name:
+        parent, child = name.rsplit('.', 1)
+        if parent in sys.modules:
+            setattr(sys.modules[parent], child, m)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+class Registry:
+    """mmcv.utils.Registry surface used by the plugin: `@X.register_module()` + build."""
+
+    def __init__(self, name):
+        self.name, self.module_dict = name, {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.module_dict[name or cls.__name__] = cls
+            return cls
+        return deco(module) if module is not None else deco
+
+    def build(self, cfg, **default):
+        cfg = dict(cfg)
+        cls = self.module_dict[cfg.pop('type')]
+        return cls(**cfg, **default)
+
+
+# ---- mmcv.cnn --------------------------------------------------------------
+def build_conv_layer(cfg, *args, **kwargs):
+    typ = 'Conv2d' if cfg is None else cfg['type']
+    return {'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d, 'Conv': nn.Conv2d}[typ](*args, **kwargs)
+
+
+def kaiming_init(module, a=0, mode='fan_out', nonlinearity='relu', bias=0, distribution='normal'):
+    nn.init.kaiming_normal_(module.weight, a=a, mode=mode, nonlinearity=nonlinearity)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+class ConvModule(nn.Module):
+    """mmcv 1.3.18 ConvModule: conv -> norm -> ReLU, sub-modules `.conv`, `.bn`, `.activate`;
+    bias='auto' = bias only without a norm."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias='auto', conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), **kw):
+        super().__init__()
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        self.conv = build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride,
+                                     padding=padding, dilation=dilation, groups=groups, bias=bias)
+        if self.with_norm:
+            typ = norm_cfg['type']
+            bn = {'BN1d': nn.BatchNorm1d, 'BN2d': nn.BatchNorm2d, 'BN': nn.BatchNorm2d}[typ]
+            args = {k: v for k, v in norm_cfg.items() if k != 'type'}
+            args.pop('requires_grad', None)
+            self.bn = bn(out_channels, **args)
+        if self.with_activation:
+            self.activate = nn.ReLU(inplace=True)
+        kaiming_init(self.conv)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.bn(x)
+        if self.with_activation:
+            x = self.activate(x)
+        return x
+
+
+class _Unused(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+
+
+# ---- mmdet3d.core ----------------------------------------------------------
+class LiDARInstance3DBoxes:
+    def __init__(self, tensor, box_dim=7, **kw):
+        self.tensor = tensor
+
+    @property
+    def corners(self):
+        return tp.lidar_box_corners(self.tensor)
+
+
+# ---- detectron2 ------------------------------------------------------------
+class Boxes:
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+
+class ROIPooler(nn.Module):
+    def __init__(self, output_size, scales, sampling_ratio, pooler_type):
+        super().__init__()
+        assert pooler_type == 'ROIAlignV2' and len(scales) == 1
+        self.output_size, self.scale, self.sampling_ratio = output_size, scales[0], sampling_ratio
+
+    def forward(self, x, box_lists):
+        assert len(x) == 1 and len(box_lists) == 1
+        return tp.roi_align_v2(x[0], box_lists[0].tensor, self.output_size, self.scale, self.sampling_ratio)
+
+
+# ---- cv2 -------------------------------------------------------------------
+def _cv2_module():
+    MORPH_CLOSE = 3
+
+    def morphologyEx(img, op, kernel):
+        assert op == MORPH_CLOSE
+        return tp.cv_morph_close(img, kernel)
+
+    def medianBlur(img, k):
+        assert k == 5
+        return tp.cv_median_blur5(img)
+
+    return dict(dilate=tp.cv_dilate, morphologyEx=morphologyEx, MORPH_CLOSE=MORPH_CLOSE,
+                medianBlur=medianBlur, bilateralFilter=tp.cv_bilateral_filter)
+
+
+def make_locatt_module(kind):
+    """`locatt_ops.localattention` bound to the reference's kernels compiled for the host."""
+    m = types.ModuleType('projects.mmdet3d_plugin.models.utils.ops.locatt_ops')
+    if kind == 'torch':
+        m.localattention = TorchLocatt
+    else:
+        m.localattention = CLocatt(kind)
+    return m
+
+
+def install(locatt_kind='reference'):
+    BBOX_CODERS, NECKS, HEADS = Registry('bbox_coder'), Registry('neck'), Registry('head')
+
+    def force_fp32(*a, **k):
+        return lambda f: f
+
+    def build_loss(cfg):
+        return _Unused()
+
+    def multi_apply(func, *args, **kwargs):
+        from functools import partial
+        pfunc = partial(func, **kwargs) if kwargs else func
+        return tuple(map(list, zip(*map(pfunc, *args))))
+
+    def clip_sigmoid(x, eps=1e-4):
+        return torch.clamp(x.sigmoid_(), min=eps, max=1 - eps)
+
+    def _na(*a, **k):
+        raise NotImplementedError('outside the pinned hot path')
+
+    class BaseBBoxCoder:
+        def __init__(self, **kw):
+            pass
+
+    _mod('mmcv')
+    _mod('mmcv.cnn', ConvModule=ConvModule, build_conv_layer=build_conv_layer, kaiming_init=kaiming_init)
+    _mod('mmcv.cnn.bricks')
+    _mod('mmcv.cnn.bricks.transformer', FFN=_Unused)
+    _mod('mmcv.runner', force_fp32=force_fp32)
+    _mod('mmdet')
+    _mod('mmdet.core', build_bbox_coder=BBOX_CODERS.build, multi_apply=multi_apply, build_assigner=_na,
+         build_sampler=_na, AssignResult=_Unused)
+    _mod('mmdet.core.bbox', BaseBBoxCoder=BaseBBoxCoder)
+    _mod('mmdet.core.bbox.builder', BBOX_CODERS=BBOX_CODERS)
+    _mod('mmdet3d')
+    _mod('mmdet3d.core', LiDARInstance3DBoxes=LiDARInstance3DBoxes, circle_nms=_na,
+         draw_heatmap_gaussian=_na, gaussian_radius=_na, xywhr2xyxyr=_na, PseudoSampler=_Unused)
+    _mod('mmdet3d.models')
+    _mod('mmdet3d.models.fusion_layers', apply_3d_transformation=tp.apply_3d_transformation)
+    _mod('mmdet3d.models.builder', NECKS=NECKS, HEADS=HEADS, build_loss=build_loss)
+    _mod('mmdet3d.models.utils', clip_sigmoid=clip_sigmoid)
+    _mod('mmdet3d.ops')
+    _mod('mmdet3d.ops.iou3d')
+    _mod('mmdet3d.ops.iou3d.iou3d_utils', nms_gpu=_na)
+    _mod('detectron2')
+    _mod('detectron2.modeling')
+    _mod('detectron2.modeling.poolers', ROIPooler=ROIPooler)
+    _mod('detectron2.structures', Boxes=Boxes)
+    _mod('cv2', **_cv2_module())
+    if not hasattr(np, 'bool'):        # depth_map_utils.py:209,226 use the removed alias
+        np.bool = bool

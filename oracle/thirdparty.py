@@ -1,0 +1,235 @@
+"""Oracle restatements of third-party semantics (TEST INFRASTRUCTURE).
+
+Sources of these functions are NOT under /root/reference; they are restated
+from the published algorithms of the versions the reference pins
+(install.md): mmdet3d 0.17.1, detectron2 (ROIAlign aligned=True), OpenCV.
+PARITY UNPINNED at these boundaries (the reference holds no tests/vectors).
+"""
+import math
+
+import numpy as np
+import torch
+from scipy import ndimage
+
+
+# --------------------------------------------------------------------------
+# mmdet3d 0.17.1  models/fusion_layers/coord_transform.py
+# called at encoder_utils.py:156,189,280 and decoder_utils.py:692
+# --------------------------------------------------------------------------
+def apply_3d_transformation(pcd, coord_type, img_meta, reverse=False):
+    """Replay (or invert) the recorded 3-D augmentation flow on (n,3) points.
+
+    LiDAR conventions of mmdet3d 0.17.1: rotate = `p @ rot`, horizontal flip
+    negates y, vertical flip negates x.  Identity when the keys are absent.
+    """
+    assert coord_type == 'LIDAR'
+    dtype, device = pcd.dtype, pcd.device
+    rot = (torch.as_tensor(np.asarray(img_meta['pcd_rotation']), dtype=dtype, device=device)
+           if 'pcd_rotation' in img_meta else torch.eye(3, dtype=dtype, device=device))
+    scale = img_meta['pcd_scale_factor'] if 'pcd_scale_factor' in img_meta else 1.0
+    trans = (torch.as_tensor(np.asarray(img_meta['pcd_trans']), dtype=dtype, device=device)
+             if 'pcd_trans' in img_meta else torch.zeros(3, dtype=dtype, device=device))
+    hflip = img_meta.get('pcd_horizontal_flip', False)
+    vflip = img_meta.get('pcd_vertical_flip', False)
+    flow = list(img_meta.get('transformation_3d_flow', []))
+
+    p = pcd.clone()
+    if reverse:
+        scale_f, trans_v, rot_m = 1.0 / scale, -trans, rot.inverse()
+        flow = flow[::-1]
+    else:
+        scale_f, trans_v, rot_m = scale, trans, rot
+    for op in flow:
+        if op == 'T':
+            p[:, :3] = p[:, :3] + trans_v
+        elif op == 'S':
+            p[:, :3] = p[:, :3] * scale_f
+        elif op == 'R':
+            p[:, :3] = p[:, :3] @ rot_m
+        elif op == 'HF':
+            if hflip:
+                p[:, 1] = -p[:, 1]
+        elif op == 'VF':
+            if vflip:
+                p[:, 0] = -p[:, 0]
+        else:
+            raise AssertionError(f'This 3D data transformation op ({op}) is not supported')
+    return p
+
+
+def aug_affine(img_meta, reverse):
+    """The same flow composed into one affine `p' = p @ A + t` (float64).
+
+    Used by tests to check the composed form the HIP kernels consume."""
+    A = np.eye(3)
+    t = np.zeros(3)
+    rot = np.asarray(img_meta.get('pcd_rotation', np.eye(3)), dtype=np.float64)
+    scale = float(img_meta.get('pcd_scale_factor', 1.0))
+    trans = np.asarray(img_meta.get('pcd_trans', np.zeros(3)), dtype=np.float64)
+    hflip = img_meta.get('pcd_horizontal_flip', False)
+    vflip = img_meta.get('pcd_vertical_flip', False)
+    flow = list(img_meta.get('transformation_3d_flow', []))
+    if reverse:
+        scale, trans, rot = 1.0 / scale, -trans, np.linalg.inv(rot)
+        flow = flow[::-1]
+    for op in flow:
+        if op == 'T':
+            t = t + trans
+        elif op == 'S':
+            A, t = A * scale, t * scale
+        elif op == 'R':
+            A, t = A @ rot, t @ rot
+        elif op == 'HF' and hflip:
+            F = np.diag([1.0, -1.0, 1.0])
+            A, t = A @ F, t @ F
+        elif op == 'VF' and vflip:
+            F = np.diag([-1.0, 1.0, 1.0])
+            A, t = A @ F, t @ F
+    return A, t
+
+
+# --------------------------------------------------------------------------
+# mmdet3d 0.17.1  core/bbox/structures/lidar_box3d.py  LiDARInstance3DBoxes.corners
+# called at decoder_utils.py:690-691,808
+# --------------------------------------------------------------------------
+def lidar_box_corners(boxes):
+    """(Q,7) [x,y,z_bottom,dx,dy,dz,yaw] -> (Q,8,3), pre-v1.0 convention."""
+    dims = boxes[:, 3:6]
+    idx = np.stack(np.unravel_index(np.arange(8), [2, 2, 2]), axis=1)
+    corners_norm = torch.from_numpy(idx).to(device=dims.device, dtype=dims.dtype)
+    corners_norm = corners_norm[[0, 1, 3, 2, 4, 5, 7, 6]]
+    corners_norm = corners_norm - dims.new_tensor([0.5, 0.5, 0])
+    corners = dims.view(-1, 1, 3) * corners_norm.reshape(1, 8, 3)
+    ang = boxes[:, 6]
+    s, c = torch.sin(ang), torch.cos(ang)
+    o, z = torch.ones_like(c), torch.zeros_like(c)
+    rot_mat_T = torch.stack([torch.stack([c, -s, z]), torch.stack([s, c, z]), torch.stack([z, z, o])])
+    corners = torch.einsum('aij,jka->aik', corners, rot_mat_T)
+    corners = corners + boxes[:, :3].view(-1, 1, 3)
+    return corners
+
+
+# --------------------------------------------------------------------------
+# detectron2 ROIPooler(output_size=7, scales=[s], sampling_ratio=2, 'ROIAlignV2')
+# == ROIAlign(7, s, 2, aligned=True); decoder_utils.py:641-646,739-741,769-774,822-823
+# --------------------------------------------------------------------------
+def _roi_bilinear(feat, y, x):
+    """feat (C,H,W); y,x (...,) float -> (C, ...) with the detectron2 edge rules."""
+    C, H, W = feat.shape
+    oob = (y < -1.0) | (y > H) | (x < -1.0) | (x > W)
+    y = y.clamp(min=0)
+    x = x.clamp(min=0)
+    y_low = y.floor().long()
+    x_low = x.floor().long()
+    ycl = y_low >= H - 1
+    xcl = x_low >= W - 1
+    y_low = torch.where(ycl, torch.full_like(y_low, H - 1), y_low)
+    x_low = torch.where(xcl, torch.full_like(x_low, W - 1), x_low)
+    y_high = torch.where(ycl, y_low, y_low + 1)
+    x_high = torch.where(xcl, x_low, x_low + 1)
+    y = torch.where(ycl, y_low.to(y.dtype), y)
+    x = torch.where(xcl, x_low.to(x.dtype), x)
+    ly = y - y_low.to(y.dtype)
+    lx = x - x_low.to(x.dtype)
+    hy, hx = 1.0 - ly, 1.0 - lx
+    v1 = feat[:, y_low, x_low]
+    v2 = feat[:, y_low, x_high]
+    v3 = feat[:, y_high, x_low]
+    v4 = feat[:, y_high, x_high]
+    val = (hy * hx) * v1 + (hy * lx) * v2 + (ly * hx) * v3 + (ly * lx) * v4
+    return torch.where(oob, torch.zeros_like(val), val)
+
+
+def roi_align_v2(feat, boxes, output_size=7, spatial_scale=1.0, sampling_ratio=2):
+    """feat (1,C,H,W); boxes (q,4) xyxy in input pixels -> (q,C,7,7)."""
+    assert feat.shape[0] == 1 and sampling_ratio > 0
+    f = feat[0]
+    q = boxes.shape[0]
+    P, G = output_size, sampling_ratio
+    start_w = boxes[:, 0] * spatial_scale - 0.5
+    start_h = boxes[:, 1] * spatial_scale - 0.5
+    end_w = boxes[:, 2] * spatial_scale - 0.5
+    end_h = boxes[:, 3] * spatial_scale - 0.5
+    bin_w = (end_w - start_w) / P
+    bin_h = (end_h - start_h) / P
+    p = torch.arange(P, dtype=feat.dtype, device=feat.device)
+    g = torch.arange(G, dtype=feat.dtype, device=feat.device)
+    # (q, P, G)
+    ys = start_h[:, None, None] + p[None, :, None] * bin_h[:, None, None] + \
+        (g[None, None, :] + 0.5) * bin_h[:, None, None] / G
+    xs = start_w[:, None, None] + p[None, :, None] * bin_w[:, None, None] + \
+        (g[None, None, :] + 0.5) * bin_w[:, None, None] / G
+    # broadcast to (q, Ph, Gy, Pw, Gx)
+    Y = ys[:, :, :, None, None].expand(q, P, G, P, G)
+    X = xs[:, None, None, :, :].expand(q, P, G, P, G)
+    val = _roi_bilinear(f, Y, X)                      # (C,q,P,G,P,G)
+    out = val.sum(dim=(3, 5)) / float(G * G)          # (C,q,P,P)
+    return out.permute(1, 0, 2, 3).contiguous()
+
+
+# --------------------------------------------------------------------------
+# OpenCV calls of ip_basic/depth_map_utils.py:177-260, on float32 single-channel
+# --------------------------------------------------------------------------
+def cv_dilate(img, kernel):
+    """cv2.dilate, default anchor/border: max over the footprint, border ignored."""
+    return ndimage.maximum_filter(img, footprint=kernel.astype(bool), mode='constant',
+                                  cval=-np.inf).astype(np.float32)
+
+
+def cv_erode(img, kernel):
+    return ndimage.minimum_filter(img, footprint=kernel.astype(bool), mode='constant',
+                                  cval=np.inf).astype(np.float32)
+
+
+def cv_morph_close(img, kernel):
+    """cv2.morphologyEx(MORPH_CLOSE): dilate then erode."""
+    return cv_erode(cv_dilate(img, kernel), kernel)
+
+
+def cv_median_blur5(img):
+    """cv2.medianBlur(img, 5) for CV_32F: BORDER_REPLICATE."""
+    return ndimage.median_filter(img, size=5, mode='nearest').astype(np.float32)
+
+
+def cv_bilateral_filter(img, d, sigma_color, sigma_space):
+    """cv2.bilateralFilter for CV_32FC1 (bilateralFilter_32f): BORDER_REFLECT_101,
+    circular support r<=d/2, colour weight through the 4096-bin linearly
+    interpolated exp LUT spanning [min,max] of the image."""
+    src = np.asarray(img, dtype=np.float32)
+    radius = d // 2
+    gcc = np.float64(-0.5 / (sigma_color * sigma_color))
+    gsc = np.float64(-0.5 / (sigma_space * sigma_space))
+    mn, mx = float(src.min()), float(src.max())
+    if abs(mn - mx) < np.finfo(np.float32).eps:
+        return src.copy()
+    nbins = 1 << 12
+    scale_index = np.float32(nbins / (mx - mn))
+    lut = np.zeros(nbins + 2, dtype=np.float32)
+    last = 1.0
+    for i in range(nbins + 2):
+        if last > 0.0:
+            val = np.float64(i) / np.float64(scale_index)
+            lut[i] = np.float32(math.exp(val * val * gcc))
+            last = lut[i]
+        else:
+            lut[i] = 0.0
+    temp = np.pad(src, radius, mode='reflect')
+    H, W = src.shape
+    s = np.zeros((H, W), dtype=np.float32)
+    ws = np.zeros((H, W), dtype=np.float32)
+    for i in range(-radius, radius + 1):
+        for j in range(-radius, radius + 1):
+            r = math.sqrt(i * i + j * j)
+            if r > max(radius, 1):
+                continue
+            sw = np.float32(math.exp(r * r * gsc))
+            val = temp[radius + i:radius + i + H, radius + j:radius + j + W]
+            alpha = np.abs(val - src) * scale_index
+            idx = np.floor(alpha).astype(np.int64)
+            alpha = (alpha - idx.astype(np.float32)).astype(np.float32)
+            idx = np.clip(idx, 0, nbins)
+            w = sw * (lut[idx] + alpha * (lut[idx + 1] - lut[idx]))
+            w = w.astype(np.float32)
+            s += val * w
+            ws += w
+    return (s / ws).astype(np.float32)
