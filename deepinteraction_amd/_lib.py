@@ -1,0 +1,63 @@
+"""ctypes binding of libdeepinteraction_hip.so (the C ABI of include/deepinteraction_hip.h).
+
+There is NO fallback: if the HIP library is missing or an entry point fails, the
+product path raises.  (The CPU oracle under oracle/ is test infrastructure only.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdeepinteraction_hip.so')
+
+DI_F32, DI_F16 = 0, 1
+ABI_VERSION = 1
+
+_c_p, _c_i, _c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes, mirrors include/deepinteraction_hip.h one to one
+SIGNATURES = {
+    'di_local_attn_fwd': [_c_p] * 4 + [_c_i] * 6 + [_c_f, _c_i, _c_p],
+    'di_locatt_similar_fwd': [_c_p] * 3 + [_c_i] * 7 + [_c_p],
+    'di_locatt_similar_bwd': [_c_p] * 3 + [_c_i] * 8 + [_c_p],
+    'di_locatt_weighting_fwd': [_c_p] * 3 + [_c_i] * 7 + [_c_p],
+    'di_locatt_weighting_bwd_ori': [_c_p] * 3 + [_c_i] * 7 + [_c_p],
+    'di_locatt_weighting_bwd_weight': [_c_p] * 3 + [_c_i] * 7 + [_c_p],
+    'di_i2p_attn_fwd': [_c_p] * 9 + [_c_i] * 9 + [_c_f, _c_f, _c_i, _c_p],
+    'di_depth_scatter': [_c_p, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_p],
+    'di_depth_complete': [_c_p] * 4 + [_c_i] * 3 + [_c_p],
+    'di_bevwarp_gather_fwd': [_c_p] * 8 + [_c_i] * 7 + [_c_p],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises HipLibraryError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f'{LIB_PATH} is missing - build it with `python -m deepinteraction_amd.build` '
+                '(hipcc --offload-arch=gfx950).  There is no CPU fallback.')
+        L = ctypes.CDLL(LIB_PATH)
+        L.di_abi_version.restype = _c_i
+        L.di_last_error.restype = ctypes.c_char_p
+        if L.di_abi_version() != ABI_VERSION:
+            raise HipLibraryError(f'ABI version mismatch: library {L.di_abi_version()} != binding {ABI_VERSION}')
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = _c_i
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise HipLibraryError(f'{name} failed (rc={rc}): {L.di_last_error().decode()}')

@@ -1,0 +1,55 @@
+"""Build libdeepinteraction_hip.so (gfx950) in-tree with hipcc.
+
+`python -m deepinteraction_amd.build` or `__graft_entry__.build()`.  hipcc
+cross-compiles without a GPU; the resulting .so is git-ignored but travels with
+the tree to the GPU box.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libdeepinteraction_hip.so')
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-cuda-compat', '-Wno-unused-result',
+         f'--offload-arch={ARCH}']
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
+        glob.glob(os.path.join(HERE, '..', 'include', '*.h'))
+    return all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and up_to_date():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    for src in sources():      # one hipcc per translation unit, in parallel
+        obj = os.path.join(CSRC, os.path.basename(src)[:-4] + '.o')
+        objs.append(obj)
+        cmd = [hipcc] + [f for f in FLAGS if f != '-shared'] + ['-c', src, '-o', obj]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed: ' + ' '.join(cmd) + '\n' + out.decode())
+        if verbose and out.strip():
+            print(out.decode())
+    cmd = [hipcc, '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,274 @@
+// Sparse -> dense depth completion on the GPU (gfx950).
+//
+// Re-statement of ip_basic `fill_in_multiscale(extrapolate=False, blur_type='bilateral')`
+// (reference models/utils/ip_basic/depth_map_utils.py:134-287), which the reference
+// runs on the HOST with OpenCV in the middle of every encoder layer
+// (encoder_utils.py:175-182: GPU -> CPU -> 6 x cv2 pipelines -> GPU).  Here the whole
+// pipeline stays on the device as a chain of tiny stencil kernels over the
+// (n_views, Hi, Wi) maps (134k pixels at the Fusion_0075 shape - L2 resident), and the
+// caller runs it once per sample instead of once per layer (it does not depend on
+// features).  Exact float compare/min/max/median semantics; the bilateral weights follow
+// OpenCV's 4096-bin interpolated exp LUT.
+#include <float.h>
+
+#include "di_common.h"
+
+namespace di {
+
+__device__ __forceinline__ float inv_depth(float d) { return d > 0.1f ? 100.f - d : d; }  // :171-174
+
+// ---- stage 1 (:166-196): three depth-binned cross dilations of the inverted map
+template <int R>
+__device__ __forceinline__ float cross_dilate_bin(const float *__restrict__ d, int H, int W, int y,
+                                                  int x, float lo, float hi) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int o = -R; o <= R; ++o) {
+    const int yy = y + o;
+    if (yy >= 0 && yy < H) {
+      const float v = d[yy * W + x];
+      m = fmaxf(m, (v > lo && v <= hi) ? inv_depth(v) : 0.f);
+    }
+    const int xx = x + o;
+    if (o != 0 && xx >= 0 && xx < W) {
+      const float v = d[y * W + xx];
+      m = fmaxf(m, (v > lo && v <= hi) ? inv_depth(v) : 0.f);
+    }
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(256) void dc_multiscale_kernel(const float *__restrict__ in,
+                                                            float *__restrict__ out, int V, int H,
+                                                            int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * H * W) return;
+  const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
+  const float *d = in + (size_t)v * H * W;
+  const float far_ = cross_dilate_bin<1>(d, H, W, y, x, 30.0f, INFINITY);   // CROSS_KERNEL_3
+  const float med = cross_dilate_bin<2>(d, H, W, y, x, 15.0f, 30.0f);       // CROSS_KERNEL_5
+  const float near_ = cross_dilate_bin<3>(d, H, W, y, x, 0.1f, 15.0f);      // CROSS_KERNEL_7
+  float s2 = inv_depth(d[r]);
+  if (far_ > 0.1f) s2 = far_;
+  if (med > 0.1f) s2 = med;
+  if (near_ > 0.1f) s2 = near_;
+  out[i] = s2;
+}
+
+// ---- full-kernel dilate / erode with OpenCV's default border (ignored)
+template <int R, bool IS_MAX>
+__device__ __forceinline__ float box_extreme(const float *__restrict__ d, int H, int W, int y, int x) {
+  float m = IS_MAX ? -INFINITY : INFINITY;
+  for (int dy = -R; dy <= R; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= H) continue;
+#pragma unroll
+    for (int dx = -R; dx <= R; ++dx) {
+      const int xx = x + dx;
+      if (xx < 0 || xx >= W) continue;
+      const float v = d[yy * W + xx];
+      m = IS_MAX ? fmaxf(m, v) : fminf(m, v);
+    }
+  }
+  return m;
+}
+
+template <int R, bool IS_MAX>
+__global__ __launch_bounds__(256) void dc_box_kernel(const float *__restrict__ in,
+                                                     float *__restrict__ out, int V, int H, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * H * W) return;
+  const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
+  out[i] = box_extreme<R, IS_MAX>(in + (size_t)v * H * W, H, W, y, x);
+}
+
+// ---- 5x5 median, BORDER_REPLICATE (cv2.medianBlur for CV_32F)
+__device__ __forceinline__ float median25(const float *__restrict__ d, int H, int W, int y, int x) {
+  float a[25];
+#pragma unroll
+  for (int dy = -2; dy <= 2; ++dy) {
+    const int yy = min(max(y + dy, 0), H - 1);
+#pragma unroll
+    for (int dx = -2; dx <= 2; ++dx) {
+      const int xx = min(max(x + dx, 0), W - 1);
+      a[(dy + 2) * 5 + dx + 2] = d[yy * W + xx];
+    }
+  }
+  // 13 bubble passes: the 12 largest settle in a[13..24], a[12] is the median
+#pragma unroll
+  for (int p = 0; p < 13; ++p) {
+#pragma unroll
+    for (int j = 0; j < 24 - p; ++j) {
+      const float lo = fminf(a[j], a[j + 1]), hi = fmaxf(a[j], a[j + 1]);
+      a[j] = lo;
+      a[j + 1] = hi;
+    }
+  }
+  return a[12];
+}
+
+// :203-206  s4 = s3 > 0.1 ? median(s3) : s3
+__global__ __launch_bounds__(256) void dc_median_valid_kernel(const float *__restrict__ in,
+                                                              float *__restrict__ out, int V, int H,
+                                                              int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * H * W) return;
+  const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
+  const float c = in[i];
+  out[i] = c > 0.1f ? median25(in + (size_t)v * H * W, H, W, y, x) : c;
+}
+
+// first row with a valid pixel per column (np.argmax(col > 0.1): 0 when none)  :209-213, :228
+__global__ __launch_bounds__(256) void dc_col_first_kernel(const float *__restrict__ in,
+                                                           int32_t *__restrict__ first, int V, int H,
+                                                           int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * W) return;
+  const int v = i / W, x = i - v * W;
+  const float *d = in + (size_t)v * H * W;
+  int f = 0;
+  for (int y = 0; y < H; ++y)
+    if (d[y * W + x] > 0.1f) {
+      f = y;
+      break;
+    }
+  first[i] = f;
+}
+
+// :216-222  empty = !(s4 > 0.1) & top_mask ; s5 = empty ? dilate9x9(s4) : s4
+// :241-245  empty = (s7 < 0.1) & top_mask  ; s7 = empty ? dilate5x5(s7) : s7
+template <int R, bool STRICT_LT>
+__global__ __launch_bounds__(256) void dc_fill_kernel(const float *__restrict__ in,
+                                                      const int32_t *__restrict__ first,
+                                                      float *__restrict__ out, int V, int H, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * H * W) return;
+  const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
+  const float c = in[i];
+  const bool top = y >= first[v * W + x];
+  const bool empty = (STRICT_LT ? (c < 0.1f) : !(c > 0.1f)) && top;
+  out[i] = empty ? box_extreme<R, true>(in + (size_t)v * H * W, H, W, y, x) : c;
+}
+
+// :248-250  valid = (s7 > 0.1) & top_mask ; s7 = valid ? median(s7) : s7   (valid kept for :260)
+__global__ __launch_bounds__(256) void dc_median_top_kernel(const float *__restrict__ in,
+                                                            const int32_t *__restrict__ first,
+                                                            float *__restrict__ out,
+                                                            float *__restrict__ valid, int V, int H,
+                                                            int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * H * W) return;
+  const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
+  const float c = in[i];
+  const bool ok = c > 0.1f && y >= first[v * W + x];
+  valid[i] = ok ? 1.f : 0.f;
+  out[i] = ok ? median25(in + (size_t)v * H * W, H, W, y, x) : c;
+}
+
+// per-view min / max (cv::minMaxLoc inside bilateralFilter_32f)
+__global__ __launch_bounds__(1024) void dc_minmax_kernel(const float *__restrict__ in,
+                                                         float *__restrict__ mm, int H, int W) {
+  __shared__ float smin[16], smax[16];
+  const int v = blockIdx.x;
+  const float *d = in + (size_t)v * H * W;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
+    mn = fminf(mn, d[i]);
+    mx = fmaxf(mx, d[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smin[threadIdx.x >> 6] = mn;
+    smax[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+      mn = fminf(mn, smin[w]);
+      mx = fmaxf(mx, smax[w]);
+    }
+    mm[2 * v] = mn;
+    mm[2 * v + 1] = mx;
+  }
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return min(max(i, 0), n - 1);
+}
+
+// :259-266  blurred = bilateralFilter(s7, 5, 0.5, 2.0); s7[valid] = blurred[valid]; invert back.
+__global__ __launch_bounds__(256) void dc_bilateral_invert_kernel(const float *__restrict__ in,
+                                                                  const float *__restrict__ valid,
+                                                                  const float *__restrict__ mm,
+                                                                  float *__restrict__ out, int V,
+                                                                  int H, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * H * W) return;
+  const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
+  const float *d = in + (size_t)v * H * W;
+  const float c = d[r];
+  float res = c;
+  const float mn = mm[2 * v], mx = mm[2 * v + 1];
+  if (valid[i] != 0.f && !(fabsf(mn - mx) < FLT_EPSILON)) {
+    const double gcc = -0.5 / (0.5 * 0.5);   // sigma_color 0.5
+    const double gsc = -0.5 / (2.0 * 2.0);   // sigma_space 2.0
+    const float scale_index = (float)(4096.0 / ((double)mx - (double)mn));
+    float sum = 0.f, wsum = 0.f;
+    for (int dy = -2; dy <= 2; ++dy) {
+      for (int dx = -2; dx <= 2; ++dx) {
+        const int rr = dy * dy + dx * dx;
+        if (rr > 4) continue;  // circular support r <= 2
+        const float sw = (float)exp((double)rr * gsc);
+        const float val = d[reflect101(y + dy, H) * W + reflect101(x + dx, W)];
+        float alpha = fabsf(val - c) * scale_index;
+        int idx = (int)floorf(alpha);
+        alpha -= (float)idx;
+        idx = min(max(idx, 0), 4096);
+        const double v0 = (double)idx / (double)scale_index, v1 = (double)(idx + 1) / (double)scale_index;
+        const float e0 = (float)exp(v0 * v0 * gcc), e1 = (float)exp(v1 * v1 * gcc);
+        const float w = sw * (e0 + alpha * (e1 - e0));
+        sum += val * w;
+        wsum += w;
+      }
+    }
+    res = sum / wsum;
+  }
+  out[i] = res > 0.1f ? 100.f - res : res;  // :263-266
+}
+
+}  // namespace di
+
+extern "C" int di_depth_complete(const float *sparse, float *dense, float *scratch, int32_t *iscratch,
+                                 int n_views, int Hi, int Wi, void *stream) {
+  using namespace di;
+  DI_REQUIRE(n_views > 0 && Hi > 2 && Wi > 2, "bad depth map shape V=%d H=%d W=%d", n_views, Hi, Wi);
+  hipStream_t s = (hipStream_t)stream;
+  const int V = n_views, H = Hi, W = Wi;
+  const int n = V * H * W;
+  const dim3 g((n + 255) / 256), b(256), gc((V * W + 255) / 256);
+  float *A = scratch, *B = scratch + (size_t)n, *valid = scratch + 2 * (size_t)n;
+  float *mm = scratch + 3 * (size_t)n;
+  int32_t *first = iscratch;
+  hipLaunchKernelGGL(dc_multiscale_kernel, g, b, 0, s, sparse, A, V, H, W);              // s2
+  hipLaunchKernelGGL((dc_box_kernel<2, true>), g, b, 0, s, A, B, V, H, W);               // close: dilate
+  hipLaunchKernelGGL((dc_box_kernel<2, false>), g, b, 0, s, B, A, V, H, W);              //        erode -> s3
+  hipLaunchKernelGGL(dc_median_valid_kernel, g, b, 0, s, A, B, V, H, W);                 // s4
+  hipLaunchKernelGGL(dc_col_first_kernel, gc, b, 0, s, B, first, V, H, W);
+  hipLaunchKernelGGL((dc_fill_kernel<4, false>), g, b, 0, s, B, first, A, V, H, W);      // s5
+  hipLaunchKernelGGL(dc_col_first_kernel, gc, b, 0, s, A, first, V, H, W);               // top mask of s5
+  float *src = A, *dst = B;
+  for (int it = 0; it < 6; ++it) {                                                       // s7
+    hipLaunchKernelGGL((dc_fill_kernel<2, true>), g, b, 0, s, src, first, dst, V, H, W);
+    float *t = src; src = dst; dst = t;
+  }
+  hipLaunchKernelGGL(dc_median_top_kernel, g, b, 0, s, src, first, dst, valid, V, H, W);
+  hipLaunchKernelGGL(dc_minmax_kernel, dim3(V), dim3(1024), 0, s, dst, mm, H, W);
+  hipLaunchKernelGGL(dc_bilateral_invert_kernel, g, b, 0, s, dst, valid, mm, dense, V, H, W);
+  return check_launch("depth_complete");
+}

@@ -1,0 +1,29 @@
+// Host-side plumbing of libdeepinteraction_hip.so: thread-local error string, ABI version.
+#include <stdarg.h>
+
+#include "di_common.h"
+
+namespace di {
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return DI_ERR_LAUNCH;
+  }
+  return DI_OK;
+}
+}  // namespace di
+
+extern "C" {
+int di_abi_version(void) { return 1; }
+const char *di_last_error(void) { return di::g_err; }
+}

@@ -1,0 +1,83 @@
+"""Host-side preparation of the per-sample geometry constants the kernels consume.
+
+Everything here is tiny (six 4x4 matrices, two 3x4 affines, two pixel grids) and
+feature-independent; it is packed into one float32 buffer and uploaded with a single
+host->device copy per sample.
+"""
+import numpy as np
+import torch
+
+PC_RANGE = (-54.0, -54.0, -5.0, 54.0, 54.0, 3.0)   # hard-coded in the reference, encoder_utils.py:190
+
+
+def aug_affine(img_meta, reverse):
+    """mmdet3d 0.17.1 `apply_3d_transformation(pcd, 'LIDAR', img_meta, reverse)` (called at
+    reference encoder_utils.py:156,189,280, decoder_utils.py:692) composed into one affine
+    `p' = p @ A + t` (row vectors; LiDAR flips: HF negates y, VF negates x).  Identity when
+    the augmentation keys are absent.  Returns 12 float64: A row-major, then t."""
+    A = np.eye(3)
+    t = np.zeros(3)
+    rot = np.asarray(img_meta['pcd_rotation'], dtype=np.float64) if 'pcd_rotation' in img_meta else np.eye(3)
+    scale = float(img_meta.get('pcd_scale_factor', 1.0))
+    trans = (np.asarray(img_meta['pcd_trans'], dtype=np.float64) if 'pcd_trans' in img_meta
+             else np.zeros(3))
+    hflip = bool(img_meta.get('pcd_horizontal_flip', False))
+    vflip = bool(img_meta.get('pcd_vertical_flip', False))
+    flow = list(img_meta.get('transformation_3d_flow', []))
+    if reverse:
+        scale, trans, rot = 1.0 / scale, -trans, np.linalg.inv(rot)
+        flow = flow[::-1]
+    for op in flow:
+        if op == 'T':
+            t = t + trans
+        elif op == 'S':
+            A, t = A * scale, t * scale
+        elif op == 'R':
+            A, t = A @ rot, t @ rot
+        elif op == 'HF':
+            if hflip:
+                F = np.diag([1.0, -1.0, 1.0])
+                A, t = A @ F, t @ F
+        elif op == 'VF':
+            if vflip:
+                F = np.diag([-1.0, 1.0, 1.0])
+                A, t = A @ F, t @ F
+        else:
+            raise AssertionError(f'This 3D data transformation op ({op}) is not supported')
+    return np.concatenate([A.reshape(-1), t])
+
+
+class SampleGeometry:
+    """Device-resident constants of one sample: lidar2img, img2lidar, both affines, the
+    linspace pixel grids of encoder_utils.py:183-184 and the pc_range."""
+
+    def __init__(self, img_meta, img_hw, device):
+        Hi, Wi = img_hw
+        ori_H, ori_W = img_meta['input_shape'][:2]
+        l2i = torch.as_tensor(np.asarray(img_meta['lidar2img']), dtype=torch.float32)   # (V,4,4) :144-148
+        i2l = torch.inverse(l2i)                                                          # fp32, :149
+        V = l2i.shape[0]
+        xs = torch.linspace(0, ori_W - 1, Wi, dtype=torch.float32)
+        ys = torch.linspace(0, ori_H - 1, Hi, dtype=torch.float32)
+        parts = [l2i.reshape(-1), i2l.reshape(-1),
+                 torch.from_numpy(aug_affine(img_meta, True)).float(),
+                 torch.from_numpy(aug_affine(img_meta, False)).float(),
+                 torch.tensor(PC_RANGE, dtype=torch.float32), xs, ys]
+        buf = torch.cat(parts).to(device, non_blocking=True)
+        o = 0
+
+        def take(n):
+            nonlocal o
+            v = buf[o:o + n]
+            o += n
+            return v
+        self.n_views = V
+        self.ori_hw = (float(ori_H), float(ori_W))
+        self.img_hw = (Hi, Wi)
+        self.lidar2img = take(V * 16).view(V, 4, 4)
+        self.img2lidar = take(V * 16).view(V, 4, 4)
+        self.aug_rev = take(12)
+        self.aug_fwd = take(12)
+        self.pc_range = take(6)
+        self.xs = take(Wi)
+        self.ys = take(Hi)

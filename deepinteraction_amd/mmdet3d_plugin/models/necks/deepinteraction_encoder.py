@@ -1,0 +1,100 @@
+"""MMRI encoder (drop-in for reference `models/necks/deepinteraction_encoder.py`:
+DeepInteractionEncoderLayer :8-33, DeepInteractionEncoder :35-85).
+
+Same registry name, constructor kwargs, forward signature/returns and `state_dict` keys;
+channels-last + HIP execution (see models/utils/encoder_utils.py).  Per forward the
+feature-independent geometry (projection constants, sparse depth, depth completion) is built
+once per sample and shared by all layers through a private key in `pts_metas`.
+"""
+import torch
+from torch import nn
+
+from .... import ops
+from ....registry import NECKS
+from ..utils.encoder_utils import (GEOM_KEY, ConvBNReLU, LocalContextAttentionBlock, MMRI_I2P, MMRI_P2I,
+                                   pointwise)
+
+
+class DeepInteractionEncoderLayer(nn.Module):
+    def __init__(self, hidden_channel):
+        super().__init__()
+        self.I2P_block = MMRI_I2P(hidden_channel, hidden_channel, 0.1)
+        self.P_IML = LocalContextAttentionBlock(hidden_channel, hidden_channel, 9)
+        self.P_out_proj = ConvBNReLU(2 * hidden_channel, hidden_channel, kernel_size=1,
+                                     norm_layer=nn.BatchNorm2d, activation_layer=None)
+        self.P_integration = ConvBNReLU(2 * hidden_channel, hidden_channel, kernel_size=1,
+                                        norm_layer=nn.BatchNorm2d, activation_layer=None)
+        self.P2I_block = MMRI_P2I(hidden_channel, hidden_channel, 9)
+        self.I_IML = LocalContextAttentionBlock(hidden_channel, hidden_channel, 9)
+        self.I_out_proj = ConvBNReLU(2 * hidden_channel, hidden_channel, kernel_size=1,
+                                     norm_layer=nn.BatchNorm2d, activation_layer=None)
+        self.I_integration = ConvBNReLU(2 * hidden_channel, hidden_channel, kernel_size=1,
+                                        norm_layer=nn.BatchNorm2d, activation_layer=None)
+
+    @staticmethod
+    def _mix(proj, a, b):
+        """proj(cat((a, b), 1)); at inference the concat is folded into a split-K GEMM."""
+        if not proj.training and a.is_cuda:
+            return pointwise(proj, a, b)
+        return proj(torch.cat((a, b), dim=1))
+
+    def forward(self, img_feat, lidar_feat, img_metas, pts_metas):
+        batch_size = lidar_feat.shape[0]
+        BN, I_C, I_H, I_W = img_feat.shape
+        img5 = img_feat.view(batch_size, -1, I_C, I_H, I_W)
+        # BEV side
+        I2P_feat = self.I2P_block(lidar_feat, img5, img_metas, pts_metas)
+        P2P_feat = self.P_IML(lidar_feat, lidar_feat)
+        P_Aug_feat = self._mix(self.P_out_proj, I2P_feat, P2P_feat)
+        new_lidar_feat = self._mix(self.P_integration, P_Aug_feat, lidar_feat)
+        # image side (reads the same layer inputs; independent of the BEV side)
+        P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas)
+        I2I_feat = self.I_IML(img_feat, img_feat)
+        I_Aug_feat = self._mix(self.I_out_proj, P2I_feat.view(BN, -1, I_H, I_W), I2I_feat)
+        new_img_feat = self._mix(self.I_integration, I_Aug_feat, img_feat)
+        return new_img_feat, new_lidar_feat
+
+
+@NECKS.register_module()
+class DeepInteractionEncoder(nn.Module):
+    def __init__(self, num_layers=2, in_channels_img=64, in_channels_pts=128 * 3, hidden_channel=128,
+                 bn_momentum=0.1, bias='auto'):
+        super().__init__()
+        # mmcv build_conv_layer(dict(type='Conv2d'), ..., bias=bias): 'auto' is a truthy string
+        # -> both shared convs carry a bias (reference :45-62)
+        self.shared_conv_pts = nn.Conv2d(in_channels_pts, hidden_channel, kernel_size=3, padding=1,
+                                         bias=bool(bias))
+        self.shared_conv_img = nn.Conv2d(in_channels_img, hidden_channel, kernel_size=3, padding=1,
+                                         bias=bool(bias))
+        self.num_layers = num_layers
+        self.fusion_blocks = nn.ModuleList(
+            [DeepInteractionEncoderLayer(hidden_channel) for _ in range(num_layers)])
+        self.bn_momentum = bn_momentum
+        self.init_weights()
+
+    def init_weights(self):
+        self.init_bn_momentum()
+
+    def init_bn_momentum(self):
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                m.momentum = self.bn_momentum
+
+    def forward(self, img_feats, pts_feats, img_metas, pts_metas):
+        new_img_feat = self.shared_conv_img(ops.cl(img_feats))
+        new_pts_feat = self.shared_conv_pts(ops.cl(pts_feats))
+        pts_feat_conv = new_pts_feat.clone()
+        own_geom = GEOM_KEY not in pts_metas
+        own_bounds = 'pillar_batch_bounds' not in pts_metas
+        if own_geom:
+            pts_metas[GEOM_KEY] = [None] * len(img_metas)
+        try:
+            for i in range(self.num_layers):
+                new_img_feat, new_pts_feat = self.fusion_blocks[i](new_img_feat, new_pts_feat, img_metas,
+                                                                   pts_metas)
+        finally:
+            if own_geom:
+                pts_metas.pop(GEOM_KEY, None)
+                if own_bounds:
+                    pts_metas.pop('pillar_batch_bounds', None)
+        return new_img_feat, [pts_feat_conv, new_pts_feat]

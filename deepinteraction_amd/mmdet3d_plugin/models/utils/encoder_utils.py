@@ -1,0 +1,316 @@
+"""MI355X-native cross-modal operators of the MMRI encoder.
+
+Drop-in for the reference module of the same path
+(`projects/mmdet3d_plugin/models/utils/encoder_utils.py`): same class names, constructor
+arguments, `forward` signatures and `state_dict` keys -
+
+    ConvBNReLU :11-34, similarFunction :36-57, weightingFunction :60-81,
+    LocalContextAttentionBlock :84-135, BEVWarp :137-199, MMRI_P2I :202-213,
+    MMRI_I2P :216-320
+
+- but the execution is re-designed for CDNA4: channels-last feature maps end to end,
+hand-written HIP kernels (through the C ABI in include/deepinteraction_hip.h) for the
+window attention, the pillar attention and the BEV gather, depth completion on the device,
+BatchNorm folded into the 1x1 projections at inference, no per-sample host syncs and no
+GPU->CPU->GPU round trip.  Dense 1x1 projections are plain library GEMMs (hipBLASLt via
+torch) on the (pixels, C) view of the channels-last maps.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .... import ops
+from ....geometry import SampleGeometry
+
+GEOM_KEY = '_di_geometry'      # per-forward cache placed in pts_metas by DeepInteractionEncoder
+
+
+class ConvBNReLU(nn.Module):
+    """Reference encoder_utils.py:11-34."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, dilation=1, groups=1,
+                 norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU, bias='auto', inplace=True, affine=True):
+        super().__init__()
+        padding = dilation * (kernel_size - 1) // 2
+        self.use_norm = norm_layer is not None
+        self.use_activation = activation_layer is not None
+        if bias == 'auto':
+            bias = not self.use_norm
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation=dilation,
+                              groups=groups, bias=bias)
+        if self.use_norm:
+            self.bn = norm_layer(out_channels, affine=affine)
+        if self.use_activation:
+            self.activation = activation_layer(inplace=inplace)
+        self._fold_cache = None
+
+    def forward(self, x):
+        if not self.training and self.conv.kernel_size == (1, 1) and x.is_cuda:
+            return pointwise(self, x)
+        x = self.conv(x)
+        if self.use_norm:
+            x = self.bn(x)
+        if self.use_activation:
+            x = self.activation(x)
+        return x
+
+    def folded(self, dtype):
+        """Inference form `y = act(x W'^T + b')` with the BatchNorm folded in (fp32 math)."""
+        w, b = self.conv.weight, self.conv.bias
+        key = (dtype, w._version, w.device)
+        if self.use_norm:
+            bn = self.bn
+            key += (bn.running_mean._version, bn.running_var._version,
+                    None if bn.weight is None else bn.weight._version,
+                    None if bn.bias is None else bn.bias._version)
+        if self._fold_cache is not None and self._fold_cache[0] == key:
+            return self._fold_cache[1]
+        with torch.no_grad():
+            W = w.float().flatten(1)
+            bias = torch.zeros(W.shape[0], device=W.device) if b is None else b.float()
+            if self.use_norm:
+                inv = torch.rsqrt(self.bn.running_var.float() + self.bn.eps)
+                g = inv if self.bn.weight is None else inv * self.bn.weight.float()
+                beta = 0.0 if self.bn.bias is None else self.bn.bias.float()
+                W = W * g[:, None]
+                bias = (bias - self.bn.running_mean.float()) * g + beta
+            out = (W.to(dtype).contiguous(), bias.to(dtype).contiguous())
+        self._fold_cache = (key, out)
+        return out
+
+
+def pointwise(m, x, x2=None):
+    """Inference fast path of a 1x1 ConvBNReLU on channels-last maps: one GEMM on the
+    (pixels, C) view with folded BN.  `x2` = second half of a channel concat
+    (cat((x, x2), 1) is never materialised: split-K accumulate)."""
+    x = ops.cl(x)
+    n, C, H, W = x.shape
+    Wf, bf = m.folded(x.dtype)
+    xf = x.permute(0, 2, 3, 1).reshape(-1, C)
+    if x2 is None:
+        y = F.linear(xf, Wf, bf)
+    else:
+        x2f = ops.cl(x2).permute(0, 2, 3, 1).reshape(-1, x2.shape[1])
+        y = F.linear(xf, Wf[:, :C], bf)
+        y = torch.addmm(y, x2f, Wf[:, C:].t())
+    if m.use_activation:
+        y = torch.relu_(y)
+    return y.view(n, H, W, -1).permute(0, 3, 1, 2)
+
+
+class similarFunction(torch.autograd.Function):
+    """Reference encoder_utils.py:36-57, bound to the HIP window kernels."""
+
+    @staticmethod
+    def forward(ctx, x_ori, x_loc, kH, kW):
+        ctx.save_for_backward(x_ori, x_loc)
+        ctx.kHW = (kH, kW)
+        return ops.similar_forward(x_ori, x_loc, kH, kW)
+
+    @staticmethod
+    def backward(ctx, grad_outputs):
+        x_ori, x_loc = ctx.saved_tensors
+        kH, kW = ctx.kHW
+        grad_ori = ops.similar_backward(x_loc, grad_outputs, kH, kW, True)
+        grad_loc = ops.similar_backward(x_ori, grad_outputs, kH, kW, False)
+        return grad_ori, grad_loc, None, None
+
+
+class weightingFunction(torch.autograd.Function):
+    """Reference encoder_utils.py:60-81, bound to the HIP window kernels."""
+
+    @staticmethod
+    def forward(ctx, x_ori, x_weight, kH, kW):
+        ctx.save_for_backward(x_ori, x_weight)
+        ctx.kHW = (kH, kW)
+        return ops.weighting_forward(x_ori, x_weight, kH, kW)
+
+    @staticmethod
+    def backward(ctx, grad_outputs):
+        x_ori, x_weight = ctx.saved_tensors
+        kH, kW = ctx.kHW
+        grad_ori = ops.weighting_backward_ori(x_weight, grad_outputs, kH, kW)
+        grad_weight = ops.weighting_backward_weight(x_ori, grad_outputs, kH, kW)
+        return grad_ori, grad_weight, None, None
+
+
+class LocalContextAttentionBlock(nn.Module):
+    """Reference encoder_utils.py:84-135."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, last_affine=True):
+        super().__init__()
+        self.f_similar = similarFunction.apply
+        self.f_weighting = weightingFunction.apply
+        self.kernel_size = kernel_size
+        self.query_project = nn.Sequential(ConvBNReLU(in_channels, out_channels, kernel_size=1),
+                                           ConvBNReLU(out_channels, out_channels, kernel_size=1))
+        self.key_project = nn.Sequential(ConvBNReLU(in_channels, out_channels, kernel_size=1),
+                                         ConvBNReLU(out_channels, out_channels, kernel_size=1))
+        self.value_project = ConvBNReLU(in_channels, out_channels, kernel_size=1, affine=last_affine)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, target_feats, source_feats, **kwargs):
+        query = self.query_project(target_feats)
+        key = self.key_project(source_feats)
+        value = self.value_project(source_feats)
+        ks = self.kernel_size
+        scale = 1.0 / math.sqrt(key.size(1))
+        if not (torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)):
+            # inference: one fused kernel, the (n,H,W,81) weights stay in registers
+            return ops.local_attention(query, key, value, ks, ks, scale)
+        weight = self.f_similar(query, key, ks, ks)
+        weight = F.softmax(weight * scale, -1)
+        return self.f_weighting(value, weight, ks, ks)
+
+
+def sample_geometry(img_metas, pts_metas, b, img_hw, device):
+    cache = pts_metas.get(GEOM_KEY) if isinstance(pts_metas, dict) else None
+    if cache is not None and cache[b] is not None and cache[b].img_hw == tuple(img_hw):
+        return cache[b]
+    g = SampleGeometry(img_metas[b], tuple(img_hw), device)
+    if cache is not None:
+        cache[b] = g
+    return g
+
+
+class BEVWarp(nn.Module):
+    """Reference encoder_utils.py:137-199: BEV features gathered onto every image pixel
+    through a completed LiDAR depth map.  Depth scatter + completion depend only on the
+    points and metas; they are computed once per sample and cached in the geometry object
+    (the reference recomputes them in every layer, on the CPU)."""
+
+    def __init__(self):
+        super().__init__()
+
+    @staticmethod
+    def dense_depth(geom, pts, I_H, I_W, pts_metas, b):
+        if getattr(geom, 'dense_depth', None) is None:
+            if isinstance(pts_metas, dict) and 'dense_depth' in pts_metas:      # injected (tests)
+                geom.dense_depth = pts_metas['dense_depth'][b].to(pts.device, torch.float32).contiguous()
+            else:
+                p = pts if pts.dtype == torch.float32 else pts.float()
+                geom.sparse_depth = ops.depth_scatter(p, geom.lidar2img, geom.aug_rev, I_H, I_W, geom.ori_hw)
+                geom.dense_depth = ops.depth_complete(geom.sparse_depth)
+        return geom.dense_depth
+
+    def forward(self, lidar_feats, img_feats, img_metas, pts_metas, **kwargs):
+        B, V, C, I_H, I_W = img_feats.shape
+        out = []
+        for b in range(B):
+            geom = sample_geometry(img_metas, pts_metas, b, (I_H, I_W), lidar_feats.device)
+            depth = self.dense_depth(geom, pts_metas['pts'][b], I_H, I_W, pts_metas, b)
+            out.append(ops.bevwarp_gather(lidar_feats[b:b + 1], depth, geom.img2lidar, geom.aug_fwd,
+                                          geom.xs, geom.ys, geom.pc_range))
+        return out[0].unsqueeze(0) if B == 1 else torch.stack(out, 0)
+
+
+class MMRI_P2I(nn.Module):
+    """Reference encoder_utils.py:202-213."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, last_affine=True):
+        super().__init__()
+        self.Warp = BEVWarp()
+        self.Local = LocalContextAttentionBlock(in_channels, out_channels, kernel_size, last_affine=True)
+
+    def forward(self, lidar_feats, img_feats, img_metas, pts_metas, **kwargs):
+        warped = self.Warp(lidar_feats, img_feats, img_metas, pts_metas)        # B, N, C, H, W
+        B, N, C, H, W = warped.shape
+        out = self.Local(img_feats.reshape(B * N, C, H, W), warped.reshape(B * N, C, H, W))
+        return out.view(B, N, C, H, W)
+
+
+class MMRI_I2P(nn.Module):
+    """Reference encoder_utils.py:216-320: every non-empty pillar attends (single head) to the
+    image features under its <= 20 points x 6 cameras.
+
+    The reference materialises a (6,C,P*20) `grid_sample`, compacts it into 4 padding buckets
+    (`group_attn`, :226-255) and runs nn.MultiheadAttention per bucket.  Here one wavefront
+    per pillar projects, gathers and soft-maxes its own keys; the MHA projections are folded
+    around the kernel (exact in eval mode):
+        score_j = <Wk^T (Wq x + bq), s_j> / sqrt(C)      (the <q, bk> term is softmax-invariant)
+        out     = (Wo Wv) sum_j a_j s_j + (Wo bv + bo)
+    """
+
+    def __init__(self, pts_channels, img_channels, dropout):
+        super().__init__()
+        self.pts_channels = pts_channels
+        self.img_channels = img_channels
+        self.dropout = dropout
+        self.learnedAlign = nn.MultiheadAttention(pts_channels, 1, dropout=dropout, kdim=img_channels,
+                                                  vdim=img_channels, batch_first=True)
+        self._fold_cache = None
+
+    def folded(self, dtype):
+        la = self.learnedAlign
+        if la._qkv_same_embed_dim:
+            wq, wk, wv = la.in_proj_weight.chunk(3, 0)
+        else:
+            wq, wk, wv = la.q_proj_weight, la.k_proj_weight, la.v_proj_weight
+        key = (dtype, la.in_proj_bias._version, la.out_proj.weight._version, la.out_proj.bias._version,
+               wq._version if not la._qkv_same_embed_dim else la.in_proj_weight._version, wq.device)
+        if self._fold_cache is not None and self._fold_cache[0] == key:
+            return self._fold_cache[1]
+        with torch.no_grad():
+            E = self.pts_channels
+            bq, _, bv = la.in_proj_bias.float().chunk(3, 0)
+            wq, wk, wv = wq.float(), wk.float(), wv.float()
+            s = 1.0 / math.sqrt(E)
+            w_qk = (wk.t() @ wq) * s                       # (img_channels, pts_channels)
+            b_qk = (wk.t() @ bq) * s
+            w_ov = la.out_proj.weight.float() @ wv          # (pts_channels, img_channels)
+            b_ov = la.out_proj.weight.float() @ bv + la.out_proj.bias.float()
+            out = tuple(t.to(dtype).contiguous() for t in (w_qk, b_qk, w_ov, b_ov))
+        self._fold_cache = (key, out)
+        return out
+
+    def forward(self, lidar_feat, img_feat, img_metas, pts_metas, **kwargs):
+        if self.training and self.dropout > 0:
+            raise NotImplementedError('HIP MMRI_I2P implements the inference form (attention dropout inactive)')
+        B = len(img_metas)
+        lidar_feat = ops.cl(lidar_feat)
+        _, C, Hb, Wb = lidar_feat.shape
+        _, V, Ci, Hi, Wi = img_feat.shape
+        w_qk, b_qk, w_ov, b_ov = self.folded(lidar_feat.dtype)
+        flat = lidar_feat.permute(0, 2, 3, 1).reshape(-1, C)
+        qfold = F.linear(flat, w_qk, b_qk).view(B, Hb, Wb, Ci).permute(0, 3, 1, 2)   # channels-last
+        bounds = pillar_batch_bounds(pts_metas, B)
+        outs = []
+        for b in range(B):
+            s, e = bounds[b], bounds[b + 1]
+            geom = sample_geometry(img_metas, pts_metas, b, (Hi, Wi), lidar_feat.device)
+            ctx, valid = ops.i2p_attention(img_feat[b], qfold[b:b + 1], pts_metas['pillars'][s:e],
+                                           pts_metas['pillar_coors'][s:e], pts_metas['pillars_num_points'][s:e],
+                                           geom.lidar2img, geom.aug_rev, geom.ori_hw)
+            o = F.linear(ctx.permute(0, 2, 3, 1).reshape(-1, Ci), w_ov, b_ov)
+            o = o * valid.reshape(-1, 1)                                         # empty pillars / cells stay 0
+            outs.append(o.view(1, Hb, Wb, C).permute(0, 3, 1, 2))
+        return outs[0] if B == 1 else torch.cat(outs, 0)
+
+
+def pillar_batch_bounds(pts_metas, B):
+    """Start offsets of each sample's pillars (they are batch-sorted, reference :265-273).
+    The reference counts with B device->host syncs per layer; callers may pass the split
+    they already know as `pts_metas['pillar_batch_bounds']`, otherwise it is computed once
+    per forward and cached."""
+    if 'pillar_batch_bounds' in pts_metas:
+        return pts_metas['pillar_batch_bounds']
+    coors = pts_metas['pillar_coors']
+    if B == 1:
+        bounds = [0, coors.shape[0]]
+    else:
+        cnt = torch.bincount(coors[:, 0].long(), minlength=B).cpu().tolist()
+        bounds = [0]
+        for c in cnt:
+            bounds.append(bounds[-1] + c)
+    if GEOM_KEY in pts_metas:
+        pts_metas['pillar_batch_bounds'] = bounds
+    return bounds

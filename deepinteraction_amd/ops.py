@@ -1,0 +1,178 @@
+"""Tensor-level entry points of the HIP hot path.
+
+Thin plumbing: torch tensors in (device memory owned by PyTorch's allocator, the
+current HIP stream), raw pointers into `libdeepinteraction_hip.so` through its C ABI.
+Feature maps are logical (n,C,H,W) tensors in `torch.channels_last` memory format, i.e.
+physically (n,H,W,C) - the layout the kernels are written for.
+
+No CPU implementation lives here; CPU tensors are rejected.
+"""
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.DI_F32, torch.float16: _lib.DI_F16}
+
+
+def _code(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f'HIP hot path supports float32/float16 feature maps, got {t.dtype}')
+
+
+def _dev(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise _lib.HipLibraryError('HIP hot path called with a CPU tensor - there is no CPU fallback')
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def cl(t):
+    """(n,C,H,W) tensor physically channels-last (no copy when it already is)."""
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _is_cl(t):
+    return t.is_contiguous(memory_format=torch.channels_last)
+
+
+def empty_cl(n, C, H, W, like):
+    return torch.empty((n, C, H, W), dtype=like.dtype, device=like.device, memory_format=torch.channels_last)
+
+
+def zeros_cl(n, C, H, W, like):
+    return torch.zeros((n, C, H, W), dtype=like.dtype, device=like.device, memory_format=torch.channels_last)
+
+
+def _f32(t):
+    return t.contiguous().float() if t.dtype != torch.float32 or not t.is_contiguous() else t
+
+
+# ------------------------------------------------------------------ local-window attention
+def local_attention(q, k, v, kH, kW, scale):
+    """softmax_k(<q[p], k[p+off_k]> * scale) . v[p+off_k], fused (no (n,H,W,81) tensor)."""
+    _dev(q, k, v)
+    q, k, v = cl(q), cl(k), cl(v)
+    n, C, H, W = q.shape
+    out = empty_cl(n, C, H, W, q)
+    _lib.call('di_local_attn_fwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), n, H, W, C,
+              kH, kW, float(scale), _code(q), _stream())
+    return out
+
+
+def similar_forward(x_ori, x_loc, kH, kW):
+    _dev(x_ori, x_loc)
+    x_ori, x_loc = cl(x_ori), cl(x_loc)
+    n, C, H, W = x_ori.shape
+    out = torch.empty((n, H, W, kH * kW), dtype=torch.float32, device=x_ori.device)
+    _lib.call('di_locatt_similar_fwd', x_ori.data_ptr(), x_loc.data_ptr(), out.data_ptr(), n, H, W, C, kH,
+              kW, _code(x_ori), _stream())
+    return out
+
+
+def similar_backward(x, grad_out, kH, kW, is_ori):
+    _dev(x, grad_out)
+    x, grad_out = cl(x), _f32(grad_out)
+    n, C, H, W = x.shape
+    out = empty_cl(n, C, H, W, x)
+    _lib.call('di_locatt_similar_bwd', x.data_ptr(), grad_out.data_ptr(), out.data_ptr(), n, H, W, C, kH,
+              kW, int(bool(is_ori)), _code(x), _stream())
+    return out
+
+
+def weighting_forward(x_ori, x_weight, kH, kW):
+    _dev(x_ori, x_weight)
+    x_ori, x_weight = cl(x_ori), _f32(x_weight)
+    n, C, H, W = x_ori.shape
+    out = empty_cl(n, C, H, W, x_ori)
+    _lib.call('di_locatt_weighting_fwd', x_ori.data_ptr(), x_weight.data_ptr(), out.data_ptr(), n, H, W, C,
+              kH, kW, _code(x_ori), _stream())
+    return out
+
+
+def weighting_backward_ori(x_weight, grad_out, kH, kW):
+    _dev(x_weight, grad_out)
+    x_weight, grad_out = _f32(x_weight), cl(grad_out)
+    n, C, H, W = grad_out.shape
+    out = empty_cl(n, C, H, W, grad_out)
+    _lib.call('di_locatt_weighting_bwd_ori', x_weight.data_ptr(), grad_out.data_ptr(), out.data_ptr(), n, H,
+              W, C, kH, kW, _code(grad_out), _stream())
+    return out
+
+
+def weighting_backward_weight(x_ori, grad_out, kH, kW):
+    _dev(x_ori, grad_out)
+    x_ori = cl(x_ori)
+    grad_out = cl(grad_out.to(x_ori.dtype))
+    n, C, H, W = x_ori.shape
+    out = torch.empty((n, H, W, kH * kW), dtype=torch.float32, device=x_ori.device)
+    _lib.call('di_locatt_weighting_bwd_weight', x_ori.data_ptr(), grad_out.data_ptr(), out.data_ptr(), n, H,
+              W, C, kH, kW, _code(x_ori), _stream())
+    return out
+
+
+# ------------------------------------------------------------------ image -> BEV
+def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw):
+    """One sample.  img (V,C,Hi,Wi), qfold (1,C,Hb,Wb) channels-last; pillars (P,T,D) f32,
+    coors (P,4) i32, num_points (P,) i32, proj (V,4,4) f32, aug_rev (12,) f32.
+    Returns ctx (1,C,Hb,Wb) and valid (1,1,Hb,Wb) (same dtype as img)."""
+    _dev(img, qfold, pillars, coors, num_points, proj, aug_rev)
+    img, qfold = cl(img), cl(qfold)
+    V, C, Hi, Wi = img.shape
+    _, _, Hb, Wb = qfold.shape
+    P, T, D = pillars.shape
+    assert pillars.dtype == torch.float32 and pillars.is_contiguous()
+    assert coors.dtype == torch.int32 and coors.is_contiguous() and coors.shape[1] == 4
+    assert num_points.dtype == torch.int32 and num_points.is_contiguous()
+    assert proj.dtype == torch.float32 and proj.is_contiguous() and aug_rev.dtype == torch.float32
+    ctx = zeros_cl(1, C, Hb, Wb, img)
+    valid = torch.zeros((1, 1, Hb, Wb), dtype=img.dtype, device=img.device)
+    _lib.call('di_i2p_attn_fwd', img.data_ptr(), qfold.data_ptr(), pillars.data_ptr(), coors.data_ptr(),
+              num_points.data_ptr(), proj.data_ptr(), aug_rev.data_ptr(), ctx.data_ptr(), valid.data_ptr(),
+              P, T, D, V, Hi, Wi, Hb, Wb, C, float(ori_hw[0]), float(ori_hw[1]), _code(img), _stream())
+    return ctx, valid
+
+
+# ------------------------------------------------------------------ BEV -> image
+def depth_scatter(pts, proj, aug_rev, Hi, Wi, ori_hw):
+    """pts (Np,>=3) f32 -> sparse depth (V,Hi,Wi) f32; duplicates: highest point index wins."""
+    _dev(pts, proj, aug_rev)
+    assert pts.dtype == torch.float32 and pts.dim() == 2 and pts.stride(1) == 1
+    V = proj.shape[0]
+    packed = torch.zeros((V, Hi, Wi), dtype=torch.int64, device=pts.device)
+    depth = torch.empty((V, Hi, Wi), dtype=torch.float32, device=pts.device)
+    _lib.call('di_depth_scatter', pts.data_ptr(), pts.shape[0], pts.stride(0), proj.data_ptr(),
+              aug_rev.data_ptr(), packed.data_ptr(), depth.data_ptr(), V, Hi, Wi, float(ori_hw[0]),
+              float(ori_hw[1]), _stream())
+    return depth
+
+
+def depth_complete(sparse):
+    """ip_basic fill_in_multiscale per view on the GPU: (V,H,W) f32 -> (V,H,W) f32."""
+    _dev(sparse)
+    assert sparse.dtype == torch.float32 and sparse.is_contiguous() and sparse.dim() == 3
+    V, H, W = sparse.shape
+    dense = torch.empty_like(sparse)
+    scratch = torch.empty(3 * V * H * W + 2 * V, dtype=torch.float32, device=sparse.device)
+    iscratch = torch.empty(V * W, dtype=torch.int32, device=sparse.device)
+    _lib.call('di_depth_complete', sparse.data_ptr(), dense.data_ptr(), scratch.data_ptr(),
+              iscratch.data_ptr(), V, H, W, _stream())
+    return dense
+
+
+def bevwarp_gather(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range):
+    """bev (1,C,Hb,Wb) channels-last, depth (V,Hi,Wi) f32 -> warped (V,C,Hi,Wi) channels-last."""
+    _dev(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range)
+    bev = cl(bev)
+    _, C, Hb, Wb = bev.shape
+    V, Hi, Wi = depth.shape
+    assert depth.dtype == torch.float32 and depth.is_contiguous()
+    out = empty_cl(V, C, Hi, Wi, bev)
+    _lib.call('di_bevwarp_gather_fwd', bev.data_ptr(), depth.data_ptr(), img2lidar.data_ptr(),
+              aug_fwd.data_ptr(), xs.data_ptr(), ys.data_ptr(), pc_range.data_ptr(), out.data_ptr(), V, Hi,
+              Wi, Hb, Wb, C, _code(bev), _stream())
+    return out

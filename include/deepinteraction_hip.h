@@ -1,0 +1,123 @@
+/* deepinteraction_hip.h - C ABI of libdeepinteraction_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the DeepInteraction interaction hot path
+ * (SURVEY.md 8(b)).  It replaces, for the reference at /root/reference
+ * (paths relative to projects/mmdet3d_plugin/):
+ *
+ *   - the pybind11 module `locatt_ops.localattention`
+ *       models/utils/ops/locatt_ops/localAttention.h:11-40, localAttention.cpp:61-73
+ *   - the torch / OpenCV call sequences inside
+ *       models/utils/encoder_utils.py:127-135 (LocalContextAttentionBlock.forward)
+ *       models/utils/encoder_utils.py:142-199 (BEVWarp.forward + ip_basic fill_in_multiscale)
+ *       models/utils/encoder_utils.py:257-320 (MMRI_I2P.forward / group_attn)
+ *       models/utils/decoder_utils.py:660-761, 788-841 (RoI blocks: projection, rects, ROIAlignV2)
+ *       models/utils/decoder_utils.py:96-103 (200 x 32400 cross attention)
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; no torch types.  All pointers are
+ *     DEVICE pointers unless the parameter name ends in `_host`.
+ *   - the CALLER owns every buffer (outputs and scratch); nothing is allocated,
+ *     freed or synchronised inside; every launch goes to `stream` (a hipStream_t).
+ *   - re-entrant and callable from any host thread (autograd worker threads).
+ *   - return 0 on success, a negative DI_ERR_* code on failure; no exceptions
+ *     cross the ABI; `di_last_error()` returns a thread-local message.
+ *   - feature maps are CHANNELS-LAST: (n, H, W, C) with C contiguous
+ *     (the physical layout of a torch tensor of logical shape (n,C,H,W) and
+ *     memory_format=torch.channels_last).  C must be a multiple of 8, <= 128.
+ *   - `dtype`: DI_F32 or DI_F16 = element type of the feature maps.  Arithmetic
+ *     accumulates in fp32 in both cases.  Geometry (points, matrices, depth,
+ *     window weights of the unfused ops) is always float32.
+ */
+#ifndef DEEPINTERACTION_HIP_H
+#define DEEPINTERACTION_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { DI_F32 = 0, DI_F16 = 1 };
+enum {
+  DI_OK = 0,
+  DI_ERR_ARG = -1,      /* unsupported shape / window / dtype */
+  DI_ERR_LAUNCH = -2,   /* hipGetLastError() after a launch    */
+  DI_ERR_LDS = -3       /* tile does not fit the 160 KiB LDS   */
+};
+
+int di_abi_version(void);
+const char *di_last_error(void);
+
+/* ---------------------------------------------------------------- local-window attention
+ * Fused forward of LocalContextAttentionBlock.forward (encoder_utils.py:132-134):
+ *   w = softmax_k( <q[p], k[p+off_k]> * scale ),  out[p] = sum_k w_k * v[p+off_k]
+ * window slot k <-> (dy,dx) = (k / kW - kH/2, k % kW - kW/2) (kernels.cuh:22-27);
+ * out-of-image slots score 0 AND stay in the softmax (kernels.cuh:28-39), their
+ * value contribution is 0 (kernels.cuh:71-75).  `scale` = 1/sqrt(C) in the reference.
+ * Supported windows: kH,kW odd in {3,5,7,9}. */
+int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
+                      int C, int kH, int kW, float scale, int dtype, void *stream);
+
+/* The five entry points of locatt_ops (localAttention.h:11-40), channels-last features,
+ * float32 window tensors of shape (n,H,W,kH*kW):
+ *   similar_forward(x_ori,x_loc)            -> di_locatt_similar_fwd
+ *   similar_backward(x,grad,is_ori)         -> di_locatt_similar_bwd
+ *   weighting_forward(x_ori,x_weight)       -> di_locatt_weighting_fwd
+ *   weighting_backward_ori(x_weight,grad)   -> di_locatt_weighting_bwd_ori
+ *   weighting_backward_weight(x_ori,grad)   -> di_locatt_weighting_bwd_weight */
+int di_locatt_similar_fwd(const void *x_ori, const void *x_loc, float *out_w, int n, int H, int W,
+                          int C, int kH, int kW, int dtype, void *stream);
+int di_locatt_similar_bwd(const void *x, const float *grad_w, void *grad_in, int n, int H, int W,
+                          int C, int kH, int kW, int is_ori, int dtype, void *stream);
+int di_locatt_weighting_fwd(const void *x_ori, const float *x_weight, void *out, int n, int H, int W,
+                            int C, int kH, int kW, int dtype, void *stream);
+int di_locatt_weighting_bwd_ori(const float *x_weight, const void *grad_out, void *grad_ori, int n,
+                                int H, int W, int C, int kH, int kW, int dtype, void *stream);
+int di_locatt_weighting_bwd_weight(const void *x_ori, const void *grad_out, float *grad_w, int n,
+                                   int H, int W, int C, int kH, int kW, int dtype, void *stream);
+
+/* ---------------------------------------------------------------- image -> BEV pillar attention
+ * MMRI_I2P.forward for ONE sample (encoder_utils.py:270-319), with the single-head
+ * attention folded algebraically: the caller passes
+ *   qfold[y,x,:] = Wk^T (Wq bev[y,x,:] + bq) / sqrt(C)    (Hb,Wb,C)
+ * and receives ctx[y,x,:] = sum_j softmax_j(<qfold, s_j>) s_j over the valid keys
+ * s_j = bilinear(img[cam_j], uv_j) of the pillar at cell (y,x) (slot = point*6+cam,
+ * :298,:309-310; points >= num_points masked, :303-307) and valid[y,x] = 1 where the
+ * pillar has at least one valid key (:314).  ctx/valid must be zero-filled by the caller;
+ * cells without a pillar are not touched (:259).
+ *   pillars (P,T,D) float32 xyz in the first 3 of D; coors (P,4) int32 [b,z,y,x];
+ *   proj (n_views,4,4) float32 row-major lidar2img; aug_rev 12 floats = A(3x3),t(3)
+ *   of the REVERSE augmentation flow as `p' = p @ A + t` (apply_3d_transformation,
+ *   reverse=True, :280); ori_H/ori_W = img_metas['input_shape'] (:288-290). */
+int di_i2p_attn_fwd(const void *img, const void *qfold, const float *pillars, const int32_t *coors,
+                    const int32_t *num_points, const float *proj, const float *aug_rev, void *ctx,
+                    void *valid, int P, int T, int D, int n_views, int Hi, int Wi, int Hb, int Wb,
+                    int C, float ori_H, float ori_W, int dtype, void *stream);
+
+/* ---------------------------------------------------------------- BEV -> image gather
+ * BEVWarp.forward (encoder_utils.py:142-199) in three steps per sample.
+ * (1) project all raw points and scatter camera-z into the feature-resolution sparse
+ *     depth maps (:155-174).  INT scatter; duplicate pixels: HIGHEST POINT INDEX WINS
+ *     (deterministic form of the reference's last-writer-wins).  `packed` is
+ *     (n_views,Hi,Wi) uint64 scratch, zero-filled by the caller; `depth` receives float32. */
+int di_depth_scatter(const float *pts, int n_pts, int pt_stride, const float *proj,
+                     const float *aug_rev, unsigned long long *packed, float *depth, int n_views,
+                     int Hi, int Wi, float ori_H, float ori_W, void *stream);
+/* (2) ip_basic fill_in_multiscale(extrapolate=False, blur='bilateral') per view
+ *     (depth_map_utils.py:134-287) on the GPU.  scratch: 3*n_views*Hi*Wi + 2*n_views floats;
+ *     iscratch: n_views*Wi int32. */
+int di_depth_complete(const float *sparse, float *dense, float *scratch, int32_t *iscratch,
+                      int n_views, int Hi, int Wi, void *stream);
+/* (3) un-project every feature pixel through its depth, mask by pc_range, bilinear-gather
+ *     the BEV map (:183-196).  xs (Wi), ys (Hi): the linspace pixel grids of :183-184;
+ *     img2lidar (n_views,4,4) row-major; aug_fwd: forward flow as p' = p @ A + t (:189);
+ *     pc_range 6 floats (:190).  out (n_views,Hi,Wi,C). */
+int di_bevwarp_gather_fwd(const void *bev, const float *depth, const float *img2lidar,
+                          const float *aug_fwd, const float *xs, const float *ys,
+                          const float *pc_range, void *out, int n_views, int Hi, int Wi, int Hb,
+                          int Wb, int C, int dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPINTERACTION_HIP_H */

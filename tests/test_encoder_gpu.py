@@ -1,0 +1,294 @@
+"""GPU parity: HIP hot path (through the C ABI) vs the CPU oracle, same seeded inputs.
+
+Tolerances (stated per test): bit-exact for INT/index work; fp32 kernels within float32
+round-off of the differently-ordered sums (1e-5 relative to the value scale); fp16 feature
+maps within 1e-3 of the value scale (BASELINE.json north_star) on fp16-rounded inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from deepinteraction_amd import ops, synth
+from deepinteraction_amd.geometry import SampleGeometry
+from oracle import encoder as oenc
+from oracle.locatt import TorchLocatt, local_attention
+
+DEV = 'cuda'
+
+
+def _require_gpu():
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+
+
+def _q(t, dtype):
+    """Round to the kernel's storage dtype and return (device tensor, oracle fp32 copy)."""
+    d = t.to(dtype)
+    return d.to(DEV), d.float()
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.float16, 1e-3)])
+@pytest.mark.parametrize('shape', [(2, 128, 13, 37, 9, 9), (1, 128, 8, 16, 9, 9), (1, 32, 9, 21, 3, 5),
+                                   (1, 64, 6, 18, 7, 7), (1, 8, 5, 5, 5, 5)])
+def test_local_attention_fused(dtype, tol, shape):
+    _require_gpu()
+    n, C, H, W, kh, kw = shape
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(n, C, H, W, generator=g).relu() for _ in range(3))   # post-ReLU like the block
+    (qd, qo), (kd, ko), (vd, vo) = _q(q, dtype), _q(k, dtype), _q(v, dtype)
+    out = ops.local_attention(qd, kd, vd, kh, kw, 1.0 / math.sqrt(C)).float().cpu()
+    ref = local_attention(qo, ko, vo, kh, kw)
+    scale = ref.abs().max().item()
+    err = (out - ref).abs().max().item()
+    assert err <= tol * max(scale, 1.0), (err, scale)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.float16, 1e-3)])
+@pytest.mark.parametrize('shape', [(2, 128, 13, 37, 9, 9), (1, 32, 9, 21, 3, 5)])
+def test_locatt_five_entry_points(dtype, tol, shape):
+    """The drop-in `locatt_ops.localattention` module vs the oracle of the same five ops."""
+    _require_gpu()
+    from deepinteraction_amd.mmdet3d_plugin.models.utils.ops import locatt_ops
+    la = locatt_ops.localattention
+    n, C, H, W, kh, kw = shape
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(n, C, H, W, generator=g), torch.randn(n, C, H, W, generator=g)
+    w = torch.randn(n, H, W, kh * kw, generator=g)
+    (ad, ao), (bd, bo) = _q(a, dtype), _q(b, dtype)
+    wd = w.to(DEV)
+    cases = [
+        (la.similar_forward(ad, bd, kh, kw), TorchLocatt.similar_forward(ao, bo, kh, kw)),
+        (la.weighting_forward(ad, wd, kh, kw), TorchLocatt.weighting_forward(ao, w, kh, kw)),
+        (la.similar_backward(ad, wd, kh, kw, True), TorchLocatt.similar_backward(ao, w, kh, kw, True)),
+        (la.similar_backward(ad, wd, kh, kw, False), TorchLocatt.similar_backward(ao, w, kh, kw, False)),
+        (la.weighting_backward_ori(wd, ad, kh, kw), TorchLocatt.weighting_backward_ori(w, ao, kh, kw)),
+        (la.weighting_backward_weight(ad, bd, kh, kw), TorchLocatt.weighting_backward_weight(ao, bo, kh, kw)),
+    ]
+    for i, (got, ref) in enumerate(cases):
+        got = got.float().cpu()
+        assert got.shape == ref.shape, i
+        scale = max(ref.abs().max().item(), 1.0)
+        # fp16 outputs carry an extra half-ulp of output rounding on top of the 1e-3 budget
+        extra = 2 ** -11 if (dtype == torch.float16 and got.shape[1] == C and got.dim() == 4 and i not in (0, 5)) else 0
+        err = (got - ref).abs().max().item()
+        assert err <= (tol + extra) * scale, (i, err, scale)
+
+
+def test_locatt_autograd_block():
+    """similarFunction / weightingFunction autograd wrappers (training path of the block)."""
+    _require_gpu()
+    from deepinteraction_amd.mmdet3d_plugin.models.utils.encoder_utils import similarFunction, weightingFunction
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(1, 16, 7, 9, generator=g)
+    b = torch.randn(1, 16, 7, 9, generator=g)
+    ad, bd = a.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    w = similarFunction.apply(ad, bd, 3, 3)
+    p = torch.softmax(w / 4.0, -1)
+    o = weightingFunction.apply(bd, p, 3, 3)
+    o.square().sum().backward()
+    ao, bo = a.clone().requires_grad_(), b.clone().requires_grad_()
+    wo = TorchLocatt.similar_forward(ao, bo, 3, 3)
+    oo = TorchLocatt.weighting_forward(bo, torch.softmax(wo / 4.0, -1), 3, 3)
+    oo.square().sum().backward()
+    assert torch.allclose(ad.grad.cpu(), ao.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(bd.grad.cpu(), bo.grad, rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- geometry
+def _tiny(seed=0, aug=None, hidden=128):
+    shape = dict(synth.SHAPE_TINY)
+    return shape, synth.make_inputs(1, shape, seed=seed, aug=aug)
+
+
+def test_depth_scatter_exact_on_pixel_centres():
+    """INT op, bit-exact: points un-projected from pixel centres land mid-pixel, so the index
+    arithmetic has no rounding ambiguity; duplicates -> the highest point index must win."""
+    _require_gpu()
+    shape, inp = _tiny()
+    meta = inp['img_metas'][0]
+    Hi, Wi = shape['img_hw']
+    ori_H, ori_W = meta['input_shape']
+    l2i = torch.as_tensor(np.asarray(meta['lidar2img']), dtype=torch.float64)
+    i2l = torch.inverse(l2i)
+    g = torch.Generator().manual_seed(0)
+    pts = []
+    for v in range(6):
+        rr = torch.randint(0, Hi, (300,), generator=g)
+        cc = torch.randint(0, Wi, (300,), generator=g)
+        d = torch.rand(300, generator=g, dtype=torch.float64) * 40 + 2
+        u = (cc.double() + 0.5) * ori_W / Wi
+        w_ = (rr.double() + 0.5) * ori_H / Hi
+        xyd = torch.stack([u * d, w_ * d, d, torch.ones_like(d)], -1)
+        pts.append((i2l[v] @ xyd.T).T[:, :3])
+    pts = torch.cat(pts).float()
+    pts = torch.cat([pts, pts[:200] * 1.0], 0)            # exact duplicates with higher indices
+    geom = SampleGeometry(meta, (Hi, Wi), DEV)
+    got = ops.depth_scatter(pts.to(DEV), geom.lidar2img, geom.aug_rev, Hi, Wi, geom.ori_hw).cpu()
+    depth, uv, _, mask = oenc.project_to_views(pts, oenc.lidar2img_tensor([meta], pts)[0], ori_H, ori_W)
+    ref = oenc.scatter_depth(uv, depth, mask, ori_H, ori_W, Hi, Wi)
+    assert torch.equal(got != 0, ref != 0)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5)     # the stored depth is a float sum
+
+
+def test_depth_scatter_random_cloud():
+    """Random cloud: a projected coordinate can sit within float round-off of a pixel boundary,
+    where the CPU matmul and the GPU FMA chain may floor differently; allow <= 0.2% of pixels."""
+    _require_gpu()
+    shape, inp = _tiny(seed=3)
+    meta, pts = inp['img_metas'][0], inp['pts_metas']['pts'][0]
+    Hi, Wi = shape['img_hw']
+    ori_H, ori_W = meta['input_shape']
+    geom = SampleGeometry(meta, (Hi, Wi), DEV)
+    got = ops.depth_scatter(pts.to(DEV), geom.lidar2img, geom.aug_rev, Hi, Wi, geom.ori_hw).cpu()
+    ref = oenc.BEVWarp().sparse_depth(pts, meta, oenc.lidar2img_tensor([meta], pts)[0], Hi, Wi)
+    bad = ((got - ref).abs() > 1e-4 * ref.abs().clamp(min=1)).float().mean().item()
+    assert bad <= 2e-3, bad
+    assert (ref != 0).float().mean() > 0.2
+
+
+def test_depth_completion_matches_oracle():
+    """fill_in_multiscale on the device vs the scipy oracle on the SAME sparse map.  All stages
+    are compare/min/max/median selections (exact); only the bilateral weights involve exp."""
+    _require_gpu()
+    shape, inp = _tiny(seed=1)
+    meta, pts = inp['img_metas'][0], inp['pts_metas']['pts'][0]
+    Hi, Wi = shape['img_hw']
+    geom = SampleGeometry(meta, (Hi, Wi), DEV)
+    sparse = ops.depth_scatter(pts.to(DEV), geom.lidar2img, geom.aug_rev, Hi, Wi, geom.ori_hw)
+    # thin the map so the hole-filling stages have work to do
+    g = torch.Generator().manual_seed(0)
+    keep = (torch.rand(sparse.shape, generator=g) < 0.25).to(DEV)
+    sparse = sparse * keep
+    got = ops.depth_complete(sparse.contiguous()).cpu()
+    ref = oenc.complete_depth(sparse.cpu())
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-4), (got - ref).abs().max()
+    assert (got != sparse.cpu()).float().mean() > 0.3
+
+
+@pytest.mark.parametrize('aug', [None, 'aug'])
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.float16, 1e-3)])
+def test_bevwarp_module(dtype, tol, aug):
+    """Product BEVWarp vs oracle BEVWarp with an injected dense depth (kernel parity must not
+    hinge on the completion)."""
+    _require_gpu()
+    from deepinteraction_amd.mmdet3d_plugin.models.utils.encoder_utils import BEVWarp
+    a = synth.example_aug(0) if aug else None
+    shape, inp = _tiny(seed=2, aug=a)
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    g = torch.Generator().manual_seed(0)
+    bev = torch.randn(1, 128, Hb, Wb, generator=g)
+    dense = torch.rand(1, 6, Hi, Wi, generator=g) * 50 + 1
+    dense[0, :, :3] = 0                               # unfilled pixels un-project to the camera centre
+    img5 = torch.zeros(1, 6, 128, Hi, Wi)
+    pm = dict(inp['pts_metas'], dense_depth=dense)
+    bd, bo = _q(bev, dtype)
+    ref = oenc.BEVWarp()(bo, img5, inp['img_metas'], pm)
+    pm_dev = dict(pm, pts=[p.to(DEV) for p in pm['pts']])
+    got = BEVWarp()(bd, img5.to(DEV, dtype), inp['img_metas'], pm_dev).float().cpu()
+    # a pixel whose un-projected point sits on the pc_range boundary or a texel edge may flip
+    diff = (got - ref).abs().amax(2)                   # (1,6,H,W)
+    frac_bad = (diff > tol * max(ref.abs().max().item(), 1)).float().mean().item()
+    assert frac_bad <= 2e-3, frac_bad
+    assert ref.abs().sum() > 0
+
+
+@pytest.mark.parametrize('aug', [None, 'aug'])
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.float16, 2e-3)])
+def test_i2p_module(dtype, tol, aug):
+    """Product MMRI_I2P (folded projections + wave-per-pillar kernel) vs oracle MMRI_I2P
+    (torch MHA on the gathered keys) with a shared state_dict."""
+    _require_gpu()
+    from deepinteraction_amd.mmdet3d_plugin.models.utils.encoder_utils import MMRI_I2P
+    a = synth.example_aug(1) if aug else None
+    shape, inp = _tiny(seed=4, aug=a)
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    torch.manual_seed(0)
+    ref_m = oenc.MMRI_I2P(128, 128, 0.1).eval()
+    ref_m.learnedAlign.in_proj_bias.data.normal_(0, 0.1)
+    ref_m.learnedAlign.out_proj.bias.data.normal_(0, 0.1)
+    m = MMRI_I2P(128, 128, 0.1).eval()
+    m.load_state_dict(ref_m.state_dict())
+    g = torch.Generator().manual_seed(0)
+    bev = torch.randn(1, 128, Hb, Wb, generator=g)
+    img = torch.randn(1, 6, 128, Hi, Wi, generator=g)
+    (bd, bo), (idv, io) = _q(bev, dtype), _q(img, dtype)
+    with torch.no_grad():
+        ref = ref_m(bo, io, inp['img_metas'], inp['pts_metas'])
+        pm = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
+        got = m.to(DEV, dtype)(bd, idv, inp['img_metas'], pm).float().cpu()
+    scale = max(ref.abs().max().item(), 1.0)
+    diff = (got - ref).abs().amax(1)
+    # points projecting within round-off of the image border may flip their mask: allow 0.5% of pillars
+    frac_bad = (diff > tol * scale).float().sum().item() / max((ref.abs().amax(1) > 0).float().sum().item(), 1)
+    assert frac_bad <= 5e-3, frac_bad
+    # cells without a pillar are exactly zero; pillars exist
+    occupied = torch.zeros(Hb, Wb, dtype=torch.bool)
+    c = inp['pts_metas']['pillar_coors'].long()
+    occupied[c[:, 2], c[:, 3]] = True
+    assert torch.all(got[0][:, ~occupied] == 0)
+    assert (ref != 0).any()
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 5e-4), (torch.float16, 2e-2)])
+def test_encoder_forward(dtype, tol):
+    """Whole DeepInteractionEncoder (2 layers): product on the GPU vs oracle on the CPU, shared
+    state_dict, injected dense depth.  fp32: GEMM/conv summation-order noise through ~12 stacked
+    projections per layer.  fp16: every intermediate map is stored in fp16 (2^-11 relative per
+    store) and the 1x1/3x3 GEMMs run in fp16 with fp32 accumulation; measured ~5e-3, bound 2e-2."""
+    _require_gpu()
+    from deepinteraction_amd.mmdet3d_plugin.models.necks.deepinteraction_encoder import DeepInteractionEncoder
+    shape, inp = _tiny(seed=5)
+    torch.manual_seed(1234)
+    O = oenc.DeepInteractionEncoder(2, shape['c_img'], shape['c_pts'], 128).eval()
+    for mod in O.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+    M = DeepInteractionEncoder(2, shape['c_img'], shape['c_pts'], 128).eval()
+    M.load_state_dict(O.state_dict())
+    with torch.no_grad():
+        sparse = oenc.BEVWarp().sparse_depth(inp['pts_metas']['pts'][0], inp['img_metas'][0],
+                                             oenc.lidar2img_tensor(inp['img_metas'], inp['img_feats'])[0],
+                                             *shape['img_hw'])
+        dense = oenc.complete_depth(sparse).unsqueeze(0)
+        pm = dict(inp['pts_metas'], dense_depth=dense)
+        (imd, imo), (ptd, pto) = _q(inp['img_feats'], dtype), _q(inp['pts_feats'], dtype)
+        ri, (rp0, rp1) = O(imo, pto, inp['img_metas'], pm)
+        pmd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in pm.items()}
+        pmd['pts'] = [p.to(DEV) for p in pm['pts']]
+        gi, (gp0, gp1) = M.to(DEV, dtype)(imd, ptd, inp['img_metas'], pmd)
+    assert '_di_geometry' not in pmd
+    for name, got, ref in [('img', gi, ri), ('pts_conv', gp0, rp0), ('pts', gp1, rp1)]:
+        got = got.float().cpu()
+        scale = max(ref.abs().max().item(), 1.0)
+        d = (got - ref).abs()
+        frac_bad = (d > tol * scale).float().mean().item()
+        assert frac_bad <= 2e-3, (name, frac_bad, d.max().item(), scale)
+
+
+def test_encoder_full_depth_path_runs():
+    """End to end with the on-device scatter + completion (no injection): finite, right shapes."""
+    _require_gpu()
+    from deepinteraction_amd.mmdet3d_plugin.models.necks.deepinteraction_encoder import DeepInteractionEncoder
+    shape, inp = _tiny(seed=6)
+    torch.manual_seed(0)
+    M = DeepInteractionEncoder(2, shape['c_img'], shape['c_pts'], 128).eval().to(DEV, torch.float16)
+    pm = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
+    pm['pts'] = [p.to(DEV) for p in inp['pts_metas']['pts']]
+    with torch.no_grad():
+        gi, (gp0, gp1) = M(inp['img_feats'].to(DEV, torch.float16), inp['pts_feats'].to(DEV, torch.float16),
+                           inp['img_metas'], pm)
+    assert gi.shape == (6, 128) + tuple(shape['img_hw']) and gp1.shape == (1, 128) + tuple(shape['bev_hw'])
+    assert torch.isfinite(gi).all() and torch.isfinite(gp1).all()
+
+
+def test_cpu_tensor_is_rejected():
+    """The product path has no CPU fallback."""
+    from deepinteraction_amd import _lib
+    x = torch.zeros(1, 128, 8, 8)
+    with pytest.raises(_lib.HipLibraryError):
+        ops.local_attention(x, x, x, 9, 9, 1.0)
