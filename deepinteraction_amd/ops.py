@@ -45,7 +45,7 @@ def empty_cl(n, C, H, W, like):
 
 
 def zeros_cl(n, C, H, W, like):
-    return torch.zeros((n, C, H, W), dtype=like.dtype, device=like.device, memory_format=torch.channels_last)
+    return empty_cl(n, C, H, W, like).zero_()
 
 
 def _f32(t):
