@@ -1,0 +1,64 @@
+"""Oracle vs the committed golden vectors, which were produced by the REFERENCE'S OWN code
+(oracle/refpin/make_golden.py).  CPU only; runs everywhere (also on the GPU box, where
+/root/reference does not exist)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder as odec, depth_completion, encoder as oenc
+from oracle.locatt import CLocatt, TorchLocatt
+from oracle.refpin import make_golden as mg
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_locatt_port_matches_reference_kernels_bitwise(oracle_libs):
+    g = np.load(os.path.join(GOLD, 'locatt.npz'))
+    a, b, w = mg.locatt_inputs()
+    port = CLocatt('port')
+    got = dict(similar_forward=port.similar_forward(a, b, 9, 9),
+               weighting_forward=port.weighting_forward(a, w, 9, 9),
+               similar_backward_ori=port.similar_backward(a, w, 9, 9, True),
+               similar_backward_loc=port.similar_backward(a, w, 9, 9, False),
+               weighting_backward_ori=port.weighting_backward_ori(w, a, 9, 9),
+               weighting_backward_weight=port.weighting_backward_weight(a, b, 9, 9))
+    for k, v in got.items():
+        assert np.array_equal(v.numpy(), g[k]), k                       # bit-exact (double accumulation)
+        t = getattr(TorchLocatt, k.replace('_ori', '').replace('_loc', '')) if False else None
+    # the vectorised torch form, to float32 round-off
+    assert np.allclose(TorchLocatt.similar_forward(a, b, 9, 9).numpy(), g['similar_forward'], atol=2e-5)
+    assert np.allclose(TorchLocatt.weighting_forward(a, w, 9, 9).numpy(), g['weighting_forward'], atol=2e-5)
+
+
+def test_depth_completion_matches_reference_bitwise():
+    g = np.load(os.path.join(GOLD, 'depth_completion.npz'))['dense']
+    sparse = mg.sparse_depth_input()
+    for v in range(sparse.shape[0]):
+        assert np.array_equal(depth_completion.fill_in_multiscale(sparse[v].copy()), g[v])
+
+
+@pytest.mark.parametrize('aug', [False, True])
+def test_encoder_matches_reference_golden(aug):
+    g = np.load(os.path.join(GOLD, 'modules.npz'))
+    m, inp = mg.encoder_case(oenc.DeepInteractionEncoder, aug)
+    with torch.no_grad():
+        img, (p0, p1) = m(inp['img_feats'], inp['pts_feats'], inp['img_metas'], inp['pts_metas'])
+    for name, t in (('img', img), ('pts_conv', p0), ('pts', p1)):
+        s = mg.summarize(t)
+        pre = f'enc{int(aug)}_{name}_'
+        assert np.allclose(s['sample'], g[pre + 'sample'], rtol=0, atol=5e-6), name
+        for k in ('sum', 'abssum', 'possum'):
+            assert abs(s[k] - g[pre + k]) <= 1e-5 * max(1.0, abs(g[pre + 'abssum'])), (name, k)
+
+
+def test_decoder_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, 'modules.npz'))
+    m, (pts, img, metas) = mg.decoder_case(odec.DeepInteractionDecoder)
+    with torch.no_grad():
+        r = m(pts, img, metas)[0][0]
+    for k, v in r.items():
+        assert np.allclose(v.numpy(), g['dec_' + k], rtol=0, atol=2e-5), k
+    assert np.array_equal(m.query_labels.numpy(), g['dec_query_labels'])              # INT: bit-exact
+    assert np.array_equal(torch.stack(m.on_the_image_mask).numpy(), g['dec_on_the_image_mask'])
