@@ -26,7 +26,13 @@ SIGNATURES = {
     'di_depth_scatter': [_c_p, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_p],
     'di_depth_complete': [_c_p] * 4 + [_c_i] * 3 + [_c_p],
     'di_bevwarp_gather_fwd': [_c_p] * 8 + [_c_i] * 7 + [_c_p],
+    'di_heatmap_nms': [_c_p] * 3 + [_c_i] * 5 + [ctypes.c_uint, _c_i, _c_p],
+    'di_query_geometry': [_c_p] * 10 + [_c_i] * 3 + [_c_f] * 5 + [_c_p],
+    'di_roi_align_fwd': [_c_p] * 3 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
+    'di_mha_decode_fwd': [_c_p] * 4 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
 }
+# helpers that return a value instead of an error code
+VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4}
 
 _lib = None
 
@@ -48,7 +54,7 @@ def lib():
         L.di_last_error.restype = ctypes.c_char_p
         if L.di_abi_version() != ABI_VERSION:
             raise HipLibraryError(f'ABI version mismatch: library {L.di_abi_version()} != binding {ABI_VERSION}')
-        for name, argtypes in SIGNATURES.items():
+        for name, argtypes in list(SIGNATURES.items()) + list(VALUE_FUNCS.items()):
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = _c_i

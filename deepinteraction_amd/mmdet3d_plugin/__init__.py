@@ -1,5 +1,7 @@
 """Host-side mirror of the reference plugin surface for the interaction hot path
 (`projects/mmdet3d_plugin/__init__.py:1-10`), limited to the hot path's modules."""
+from .core.bbox.coders.transfusion_bbox_coder import TransFusionBBoxCoder  # noqa: F401
+from .models.dense_heads.deepinteraction_decoder import DeepInteractionDecoder  # noqa: F401
 from .models.necks.deepinteraction_encoder import DeepInteractionEncoder  # noqa: F401
 
-__all__ = ['DeepInteractionEncoder']
+__all__ = ['DeepInteractionEncoder', 'DeepInteractionDecoder', 'TransFusionBBoxCoder']

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from .... import ops
 from ....geometry import SampleGeometry
+from ....utils import param_key
 
 GEOM_KEY = '_di_geometry'      # per-forward cache placed in pts_metas by DeepInteractionEncoder
 
@@ -59,12 +60,7 @@ class ConvBNReLU(nn.Module):
     def folded(self, dtype):
         """Inference form `y = act(x W'^T + b')` with the BatchNorm folded in (fp32 math)."""
         w, b = self.conv.weight, self.conv.bias
-        key = (dtype, w._version, w.device)
-        if self.use_norm:
-            bn = self.bn
-            key += (bn.running_mean._version, bn.running_var._version,
-                    None if bn.weight is None else bn.weight._version,
-                    None if bn.bias is None else bn.bias._version)
+        key = (dtype, param_key(self))
         if self._fold_cache is not None and self._fold_cache[0] == key:
             return self._fold_cache[1]
         with torch.no_grad():
@@ -76,7 +72,7 @@ class ConvBNReLU(nn.Module):
                 beta = 0.0 if self.bn.bias is None else self.bn.bias.float()
                 W = W * g[:, None]
                 bias = (bias - self.bn.running_mean.float()) * g + beta
-            out = (W.to(dtype).contiguous(), bias.to(dtype).contiguous())
+            out = (W.to(dtype, copy=True).contiguous(), bias.to(dtype, copy=True).contiguous())
         self._fold_cache = (key, out)
         return out
 
@@ -255,8 +251,7 @@ class MMRI_I2P(nn.Module):
             wq, wk, wv = la.in_proj_weight.chunk(3, 0)
         else:
             wq, wk, wv = la.q_proj_weight, la.k_proj_weight, la.v_proj_weight
-        key = (dtype, la.in_proj_bias._version, la.out_proj.weight._version, la.out_proj.bias._version,
-               wq._version if not la._qkv_same_embed_dim else la.in_proj_weight._version, wq.device)
+        key = (dtype, param_key(la))
         if self._fold_cache is not None and self._fold_cache[0] == key:
             return self._fold_cache[1]
         with torch.no_grad():

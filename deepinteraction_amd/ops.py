@@ -176,3 +176,66 @@ def bevwarp_gather(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range):
               aug_fwd.data_ptr(), xs.data_ptr(), ys.data_ptr(), pc_range.data_ptr(), out.data_ptr(), V, Hi,
               Wi, Hb, Wb, C, _code(bev), _stream())
     return out
+
+
+# ------------------------------------------------------------------ MMPI decoder
+def heatmap_nms(dense_a, dense_b, nms_kernel, k1_classes):
+    """(sigmoid(a)+sigmoid(b))/2 masked to its local maxima; float32 (B,Cc,H,W)."""
+    _dev(dense_a, dense_b)
+    a, b = dense_a.contiguous(), dense_b.contiguous()
+    B, Cc, H, W = a.shape
+    out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=a.device)
+    mask = 0
+    for c in k1_classes:
+        mask |= 1 << c
+    _lib.call('di_heatmap_nms', a.data_ptr(), b.data_ptr(), out.data_ptr(), B, Cc, H, W, nms_kernel, mask,
+              _code(a), _stream())
+    return out
+
+
+def query_geometry(res, proj, aug_rev, per_sample, cell, pc_xy, bev_cell, dim_scale, want_img, want_bev):
+    """res: dict of float32 (B,k,Q) tensors (center, height, dim, rot).  Returns
+    (on_img (B,V,Q) int32, rect_img (B,V,Q,4), rect_bev (B,Q,4)); absent groups are None."""
+    c, h, d, r = (res[k].contiguous() for k in ('center', 'height', 'dim', 'rot'))
+    _dev(c, h, d, r)
+    assert c.dtype == torch.float32 and h.dtype == torch.float32
+    B, _, Q = c.shape
+    V = proj.shape[1] if proj is not None else 0
+    dev = c.device
+    on = torch.empty((B, V, Q), dtype=torch.int32, device=dev) if want_img else None
+    ri = torch.empty((B, V, Q, 4), dtype=torch.float32, device=dev) if want_img else None
+    rb = torch.empty((B, Q, 4), dtype=torch.float32, device=dev) if want_bev else None
+    p = lambda t: 0 if t is None else t.data_ptr()
+    _lib.call('di_query_geometry', c.data_ptr(), h.data_ptr(), d.data_ptr(), r.data_ptr(), p(proj), p(aug_rev),
+              p(per_sample), p(on), p(ri), p(rb), B, Q, V, float(cell), float(pc_xy[0]), float(pc_xy[1]),
+              float(bev_cell), float(dim_scale), _stream())
+    return on, ri, rb
+
+
+def roi_align(feat, rois, spatial_scale):
+    """feat (N,C,H,W) channels-last; rois (R,5) f32 [n,x0,y0,x1,y1] -> (R,49,C)."""
+    _dev(feat, rois)
+    feat = cl(feat)
+    N, C, H, W = feat.shape
+    rois = rois.contiguous()
+    assert rois.dtype == torch.float32 and rois.shape[1] == 5
+    R = rois.shape[0]
+    out = torch.empty((R, 49, C), dtype=feat.dtype, device=feat.device)
+    _lib.call('di_roi_align_fwd', feat.data_ptr(), rois.data_ptr(), out.data_ptr(), R, N, H, W, C,
+              float(spatial_scale), _code(feat), _stream())
+    return out
+
+
+def mha_decode(q, kv, num_heads, scale):
+    """q (B,Q,E), kv (B,S,2E) = [K|V] -> softmax(q k^T scale) v, (B,Q,E)."""
+    _dev(q, kv)
+    q, kv = q.contiguous(), kv.contiguous()
+    B, Q, E = q.shape
+    S = kv.shape[1]
+    assert kv.shape[2] == 2 * E and kv.dtype == q.dtype
+    n = _lib.lib().di_mha_decode_scratch_floats(B, Q, S, num_heads)
+    scratch = torch.empty(n, dtype=torch.float32, device=q.device)
+    out = torch.empty_like(q)
+    _lib.call('di_mha_decode_fwd', q.data_ptr(), kv.data_ptr(), out.data_ptr(), scratch.data_ptr(), B, Q, S,
+              num_heads, E // num_heads, float(scale), _code(q), _stream())
+    return out

@@ -117,6 +117,42 @@ int di_bevwarp_gather_fwd(const void *bev, const float *depth, const float *img2
                           const float *pc_range, void *out, int n_views, int Hi, int Wi, int Hb,
                           int Wb, int C, int dtype, void *stream);
 
+/* ---------------------------------------------------------------- MMPI decoder
+ * (1) query initialisation heat map (deepinteraction_decoder.py:225-238):
+ *     out = h * (h == local_max(h)),  h = (sigmoid(a) + sigmoid(b)) / 2, float32 (B,Cc,H,W).
+ *     a, b: the two dense heat-map logits, (B,Cc,H,W) CONTIGUOUS (NCHW, Cc is 10).  Classes
+ *     whose bit is set in k1_class_mask use kernel 1 (:232-237); the others use `nms_kernel`
+ *     with the outermost pad ring forced to 0 (local_max is filled in the interior only). */
+int di_heatmap_nms(const void *a, const void *b, float *out, int B, int num_classes, int H, int W,
+                   int nms_kernel, unsigned k1_class_mask, int dtype, void *stream);
+
+/* (2) per-query geometry for the RoI blocks (decoder_utils.py:666-738, :804-819;
+ *     TransFusionBBoxCoder.decode, transfusion_bbox_coder.py:57-70; LiDARInstance3DBoxes.corners).
+ *     center (B,2,Q) in BEV cells, height (B,1,Q), dim (B,3,Q) log-size, rot (B,2,Q) sin/cos,
+ *     all float32.  proj (B,V,4,4), aug_rev (B,12), per_sample (B,6) = [input_w, input_h,
+ *     flip, orig_w, crop_x, crop_y].  Outputs: on_img (B,V,Q) int32 (centre strictly inside),
+ *     rect_img (B,V,Q,4) and rect_bev (B,Q,4) xyxy (input pixels / BEV cells).  Either output
+ *     group may be NULL.  dim_scale: 1 for the image block, 2 for the point block (:807). */
+int di_query_geometry(const float *center, const float *height, const float *dim, const float *rot,
+                      const float *proj, const float *aug_rev, const float *per_sample, int32_t *on_img,
+                      float *rect_img, float *rect_bev, int B, int Q, int n_views, float cell, float pc_x0,
+                      float pc_y0, float bev_cell, float dim_scale, void *stream);
+
+/* (3) detectron2 ROIAlign(output 7x7, sampling_ratio 2, aligned=True) (decoder_utils.py:641-646,
+ *     739-741, 769-774, 822-823).  feat (N,H,W,C) channels-last; rois (R,5) float32 =
+ *     [map index, x0, y0, x1, y1]; out (R,49,C) (bin-major: the (49,q,128) operand of
+ *     DynamicConv without the reference's flatten/permute). */
+int di_roi_align_fwd(const void *feat, const float *rois, void *out, int R, int N, int H, int W, int C,
+                     float spatial_scale, int dtype, void *stream);
+
+/* (4) multi-head attention core of the decoder layer's 200 x 32400 cross attention
+ *     (decoder_utils.py:101-103, :471-485): out = softmax(q k^T * scale) v per head, head_dim 16.
+ *     q (B,Q,E), kv (B,S,2E) = [K | V] (already projected), out (B,Q,E);
+ *     scratch: di_mha_decode_scratch_floats(B,Q,S,num_heads) floats. */
+int di_mha_decode_scratch_floats(int B, int Q, int S, int num_heads);
+int di_mha_decode_fwd(const void *q, const void *kv, void *out, float *scratch, int B, int Q, int S,
+                      int num_heads, int head_dim, float scale, int dtype, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -325,7 +325,9 @@ class DeepInteractionDecoder(nn.Module):
         base = torch.cat([(bx + 0.5)[None], (by + 0.5)[None]], 0)[None]
         return base.view(1, 2, -1).permute(0, 2, 1)
 
-    def forward(self, pts_inputs, img_inputs, img_metas):
+    def forward(self, pts_inputs, img_inputs, img_metas, top_override=None):
+        """`top_override` (B,Q) flattened (class*HW + cell) picks replaces the arg-sort (tests of
+        the continuous part with an fp16 product whose near-tied proposals may reorder)."""
         lidar_feat, new_lidar_feat = pts_inputs[0], pts_inputs[1]
         B, C = lidar_feat.shape[:2]
         flat = lidar_feat.view(B, C, -1)
@@ -343,6 +345,8 @@ class DeepInteractionDecoder(nn.Module):
         heat = heat * (heat == local_max)
         heat = heat.view(B, heat.shape[1], -1)
         top = heat.view(B, -1).argsort(dim=-1, descending=True)[..., :self.num_proposals]     # :242
+        if top_override is not None:
+            top = top_override
         top_class = top // heat.shape[-1]
         top_index = top % heat.shape[-1]
         query_feat = flat.gather(-1, top_index[:, None, :].expand(-1, C, -1))
