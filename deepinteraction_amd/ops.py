@@ -13,6 +13,20 @@ from . import _lib
 
 _DT = {torch.float32: _lib.DI_F32, torch.float16: _lib.DI_F16}
 
+# When a list, every profiled launch appends (kernel name, n, start_event, end_event): HIP events
+# recorded on the launch stream right around the kernel (bench.py's live roofline measurement).
+PROFILE = None
+
+
+def _profiled(name, n, launch):
+    if PROFILE is None:
+        return launch()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    launch()
+    e.record()
+    PROFILE.append((name, n, s, e))
+
 
 def _code(t):
     try:
@@ -59,8 +73,9 @@ def local_attention(q, k, v, kH, kW, scale):
     q, k, v = cl(q), cl(k), cl(v)
     n, C, H, W = q.shape
     out = empty_cl(n, C, H, W, q)
-    _lib.call('di_local_attn_fwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), n, H, W, C,
-              kH, kW, float(scale), _code(q), _stream())
+    _profiled('local_attn_fwd', n, lambda: _lib.call(
+        'di_local_attn_fwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), n, H, W, C, kH, kW,
+        float(scale), _code(q), _stream()))
     return out
 
 

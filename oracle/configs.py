@@ -1,27 +1,2 @@
-"""Head/neck constructor kwargs used by tests, smoke and bench (TEST INFRASTRUCTURE helper;
-values of reference projects/configs/nuscenes/Fusion_0075_refactor.py:185-224,243-251)."""
-import copy
-
-POINT_CLOUD_RANGE = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]
-
-
-def decoder_cfg(bev=180, num_proposals=200, voxel=None, num_views=6):
-    """`bev` = BEV cells per side; the reference has 180 (= 1440 / 8, voxel 0.075)."""
-    osf = 8
-    voxel = 108.0 / (bev * osf) if voxel is None else voxel
-    return copy.deepcopy(dict(
-        num_views=num_views, out_size_factor_img=4, num_proposals=num_proposals, auxiliary=True,
-        hidden_channel=128, num_classes=10, num_mmpi=4, num_heads=8, learnable_query_pos=False,
-        initialize_by_heatmap=True, nms_kernel_size=3, ffn_channel=256, dropout=0.1, bn_momentum=0.1,
-        activation='relu',
-        common_heads=dict(center=(2, 2), height=(1, 2), dim=(3, 2), rot=(2, 2), vel=(2, 2)),
-        bbox_coder=dict(type='TransFusionBBoxCoder', pc_range=POINT_CLOUD_RANGE[:2], voxel_size=[voxel, voxel],
-                        out_size_factor=osf, post_center_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
-                        score_threshold=0.0, code_size=10),
-        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2, alpha=0.25, reduction='mean', loss_weight=1.0),
-        loss_bbox=dict(type='L1Loss', reduction='mean', loss_weight=0.25),
-        loss_heatmap=dict(type='GaussianFocalLoss', reduction='mean', loss_weight=1.0),
-        train_cfg=None,
-        test_cfg=dict(dataset='nuScenes', grid_size=[bev * osf, bev * osf, 40], out_size_factor=osf,
-                      pc_range=POINT_CLOUD_RANGE[0:2], voxel_size=[voxel, voxel], nms_type=None),
-    ))
+"""Re-export of the reference config values (see deepinteraction_amd/configs.py)."""
+from deepinteraction_amd.configs import POINT_CLOUD_RANGE, decoder_cfg  # noqa: F401
