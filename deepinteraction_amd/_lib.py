@@ -17,6 +17,7 @@ _c_p, _c_i, _c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 # name -> argtypes, mirrors include/deepinteraction_hip.h one to one
 SIGNATURES = {
     'di_local_attn_fwd': [_c_p] * 4 + [_c_i] * 6 + [_c_f, _c_i, _c_p],
+    'di_local_attn_fwd_ex': [_c_p] * 4 + [_c_i] * 6 + [_c_f, _c_i, _c_i, _c_p],
     'di_locatt_similar_fwd': [_c_p] * 3 + [_c_i] * 7 + [_c_p],
     'di_locatt_similar_bwd': [_c_p] * 3 + [_c_i] * 8 + [_c_p],
     'di_locatt_weighting_fwd': [_c_p] * 3 + [_c_i] * 7 + [_c_p],

@@ -363,6 +363,9 @@ static int dispatch_window(LaOp op, int kH, int kW, const LaArgs &A) {
   return DI_ERR_ARG;
 }
 
+int launch_local_attn_mfma(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
+                           float scale, hipStream_t stream);   // local_attn_mfma.hip
+
 static int run_la(LaOp op, int dtype, int kH, int kW, const LaArgs &A) {
   DI_REQUIRE(A.n > 0 && A.H > 0 && A.W > 0, "empty feature map n=%d H=%d W=%d", A.n, A.H, A.W);
   DI_REQUIRE(A.C > 0 && A.C % 8 == 0 && A.C <= 128, "C=%d must be a multiple of 8, <= 128", A.C);
@@ -378,10 +381,22 @@ static int run_la(LaOp op, int dtype, int kH, int kW, const LaArgs &A) {
 
 extern "C" {
 
+int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
+                         int C, int kH, int kW, float scale, int dtype, int variant, void *stream) {
+  di::LaArgs A{q, k, v, out, n, H, W, C, scale, (hipStream_t)stream};
+  const bool mfma_ok = dtype == DI_F16 && C == 128 && kH == 9 && kW == 9 && n > 0 && H > 0 && W > 0;
+  if (variant == DI_LA_MFMA && !mfma_ok) {
+    di::set_error("MFMA local attention needs fp16, C=128, 9x9 (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
+    return DI_ERR_ARG;
+  }
+  if (mfma_ok && variant != DI_LA_VALU)
+    return di::launch_local_attn_mfma(q, k, v, out, n, H, W, scale, (hipStream_t)stream);
+  return di::run_la(di::OP_FUSED, dtype, kH, kW, A);
+}
+
 int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                       int C, int kH, int kW, float scale, int dtype, void *stream) {
-  di::LaArgs A{q, k, v, out, n, H, W, C, scale, (hipStream_t)stream};
-  return di::run_la(di::OP_FUSED, dtype, kH, kW, A);
+  return di_local_attn_fwd_ex(q, k, v, out, n, H, W, C, kH, kW, scale, dtype, DI_LA_AUTO, stream);
 }
 
 int di_locatt_similar_fwd(const void *x_ori, const void *x_loc, float *out_w, int n, int H, int W,

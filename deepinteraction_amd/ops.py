@@ -67,15 +67,18 @@ def _f32(t):
 
 
 # ------------------------------------------------------------------ local-window attention
-def local_attention(q, k, v, kH, kW, scale):
+LA_AUTO, LA_VALU, LA_MFMA = 0, 1, 2
+
+
+def local_attention(q, k, v, kH, kW, scale, variant=LA_AUTO):
     """softmax_k(<q[p], k[p+off_k]> * scale) . v[p+off_k], fused (no (n,H,W,81) tensor)."""
     _dev(q, k, v)
     q, k, v = cl(q), cl(k), cl(v)
     n, C, H, W = q.shape
     out = empty_cl(n, C, H, W, q)
     _profiled('local_attn_fwd', n, lambda: _lib.call(
-        'di_local_attn_fwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), n, H, W, C, kH, kW,
-        float(scale), _code(q), _stream()))
+        'di_local_attn_fwd_ex', q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), n, H, W, C, kH, kW,
+        float(scale), _code(q), variant, _stream()))
     return out
 
 

@@ -57,6 +57,11 @@ const char *di_last_error(void);
  * Supported windows: kH,kW odd in {3,5,7,9}. */
 int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                       int C, int kH, int kW, float scale, int dtype, void *stream);
+/* Same op with an explicit kernel choice: DI_LA_AUTO picks the matrix-core kernel (fp16, C=128,
+ * 9x9: banded 16x16x32 MFMA tiles) when it applies, else the generic LDS-tiled VALU kernel. */
+enum { DI_LA_AUTO = 0, DI_LA_VALU = 1, DI_LA_MFMA = 2 };
+int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
+                         int C, int kH, int kW, float scale, int dtype, int variant, void *stream);
 
 /* The five entry points of locatt_ops (localAttention.h:11-40), channels-last features,
  * float32 window tensors of shape (n,H,W,kH*kW):

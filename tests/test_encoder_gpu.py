@@ -45,6 +45,32 @@ def test_local_attention_fused(dtype, tol, shape):
     assert err <= tol * max(scale, 1.0), (err, scale)
 
 
+@pytest.mark.parametrize('variant', [ops.LA_VALU, ops.LA_MFMA])
+@pytest.mark.parametrize('shape', [(2, 13, 37), (1, 4, 16), (3, 9, 200), (1, 180, 180), (1, 1, 5)])
+def test_local_attention_fp16_kernel_variants(variant, shape):
+    """Both fp16 kernels of the fused op (LDS-tiled VALU; banded 16x16x32 MFMA) against the
+    oracle: ragged tiles (W % 16, H % 4), image borders, several images, tiny maps.  The MFMA
+    path rounds the softmax weights to fp16 (rel 2^-11) before the PV product: 1e-3 budget."""
+    _require_gpu()
+    n, H, W = shape
+    C = 128
+    g = torch.Generator().manual_seed(7)
+    q, k, v = (torch.randn(n, C, H, W, generator=g).relu() for _ in range(3))
+    k[0, :, H // 2, W // 2] *= 4.0                      # a dominant key: peaky softmax rows
+    (qd, qo), (kd, ko), (vd, vo) = _q(q, torch.float16), _q(k, torch.float16), _q(v, torch.float16)
+    out = ops.local_attention(qd, kd, vd, 9, 9, 1.0 / math.sqrt(C), variant=variant).float().cpu()
+    ref = local_attention(qo, ko, vo, 9, 9)
+    err = (out - ref).abs().max().item()
+    assert err <= 1e-3 * max(ref.abs().max().item(), 1.0), err
+
+
+def test_local_attention_mfma_rejects_unsupported():
+    from deepinteraction_amd import _lib
+    x = torch.zeros(1, 64, 8, 16, device=DEV, dtype=torch.float16)
+    with pytest.raises(_lib.HipLibraryError):
+        ops.local_attention(x, x, x, 9, 9, 1.0, variant=ops.LA_MFMA)       # C != 128
+
+
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.float16, 1e-3)])
 @pytest.mark.parametrize('shape', [(2, 128, 13, 37, 9, 9), (1, 32, 9, 21, 3, 5)])
 def test_locatt_five_entry_points(dtype, tol, shape):

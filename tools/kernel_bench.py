@@ -41,10 +41,13 @@ def main():
         return torch.randn(*sh, device=dev, generator=g).relu().to(dt).contiguous(memory_format=torch.channels_last)
     for name, (n, H, W) in dict(image=(6, Hi, Wi), bev=(1, Hb, Wb)).items():
         q, k, v = rnd(n, C, H, W), rnd(n, C, H, W), rnd(n, C, H, W)
-        us = timeit(lambda: ops.local_attention(q, k, v, 9, 9, 1 / math.sqrt(C)))
         byt = 4 * n * C * H * W * s
-        print(f'local_attn_fwd {name:5s} {a.dtype}: {us:8.1f} us  algorithmic {byt/1e6:7.1f} MB  -> {byt/us/1e6:6.3f} TB/s'
-              f'  ({byt/us/1e6/8.0*100:4.1f}% of 8 TB/s)')
+        for vname, var in (('valu', ops.LA_VALU), ('mfma', ops.LA_MFMA)):
+            if var == ops.LA_MFMA and dt != torch.float16:
+                continue
+            us = timeit(lambda: ops.local_attention(q, k, v, 9, 9, 1 / math.sqrt(C), variant=var))
+            print(f'local_attn_fwd[{vname}] {name:5s} {a.dtype}: {us:8.1f} us  algorithmic {byt/1e6:7.1f} MB  -> {byt/us/1e6:6.3f} TB/s'
+                  f'  ({byt/us/1e6/8.0*100:4.1f}% of 8 TB/s)')
         us = timeit(lambda: ops.similar_forward(q, k, 9, 9))
         print(f'  similar_fwd   {name:5s}: {us:8.1f} us')
         w = torch.softmax(ops.similar_forward(q, k, 9, 9), -1)
