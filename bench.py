@@ -162,7 +162,7 @@ def main():
     durs = [s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name == 'local_attn_fwd' and n == n_img]
     avg = sum(durs) / max(len(durs), 1)
     achieved = alg_bytes / avg / 1e9 if durs else None
-    roofline = dict(bound='hbm', kernel='local_attn_fwd (image side, 9x9, C=128)',
+    roofline = dict(bound='hbm', kernel='di_local_attn_fwd, image side 6x112x200, 9x9, C=128 (local_attn_m2_kernel, 16x4 tiles)',
                     achieved=None if achieved is None else round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                     traffic=None, avg_launch_us=round(avg * 1e6, 2), launches=len(durs),

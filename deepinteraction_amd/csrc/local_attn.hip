@@ -365,6 +365,10 @@ static int dispatch_window(LaOp op, int kH, int kW, const LaArgs &A) {
 
 int launch_local_attn_mfma(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                            float scale, hipStream_t stream);   // local_attn_mfma.hip
+int launch_local_attn_mfma2(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
+                            float scale, int cfg, hipStream_t stream);   // local_attn_mfma2.hip
+int launch_local_attn_mfma3(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
+                            float scale, int cfg, hipStream_t stream);   // local_attn_mfma3.hip
 
 static int run_la(LaOp op, int dtype, int kH, int kW, const LaArgs &A) {
   DI_REQUIRE(A.n > 0 && A.H > 0 && A.W > 0, "empty feature map n=%d H=%d W=%d", A.n, A.H, A.W);
@@ -389,7 +393,25 @@ int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out,
     di::set_error("MFMA local attention needs fp16, C=128, 9x9 (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
     return DI_ERR_ARG;
   }
-  if (mfma_ok && variant != DI_LA_VALU)
+  if (variant >= DI_LA_MFMA3 && variant < DI_LA_MFMA3 + 4) {
+    if (!mfma_ok) {
+      di::set_error("MFMA local attention needs fp16, C=128, 9x9 (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
+      return DI_ERR_ARG;
+    }
+    return di::launch_local_attn_mfma3(q, k, v, out, n, H, W, scale, variant - DI_LA_MFMA3, (hipStream_t)stream);
+  }
+  if (variant >= DI_LA_MFMA2 && variant < DI_LA_MFMA2 + 5) {
+    if (!mfma_ok) {
+      di::set_error("MFMA local attention needs fp16, C=128, 9x9 (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
+      return DI_ERR_ARG;
+    }
+    return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, variant - DI_LA_MFMA2, (hipStream_t)stream);
+  }
+  if (mfma_ok && variant == DI_LA_MFMA)
+    return di::launch_local_attn_mfma(q, k, v, out, n, H, W, scale, (hipStream_t)stream);
+  if (mfma_ok && variant == DI_LA_AUTO && (long long)n * H * W * 256 < (1ll << 31))   // fastest measured: 16x4 tiles, 2 workgroups per CU
+    return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, 2, (hipStream_t)stream);
+  if (mfma_ok && variant == DI_LA_AUTO)
     return di::launch_local_attn_mfma(q, k, v, out, n, H, W, scale, (hipStream_t)stream);
   return di::run_la(di::OP_FUSED, dtype, kH, kW, A);
 }

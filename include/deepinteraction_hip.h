@@ -57,9 +57,12 @@ const char *di_last_error(void);
  * Supported windows: kH,kW odd in {3,5,7,9}. */
 int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                       int C, int kH, int kW, float scale, int dtype, void *stream);
-/* Same op with an explicit kernel choice: DI_LA_AUTO picks the matrix-core kernel (fp16, C=128,
- * 9x9: banded 16x16x32 MFMA tiles) when it applies, else the generic LDS-tiled VALU kernel. */
-enum { DI_LA_AUTO = 0, DI_LA_VALU = 1, DI_LA_MFMA = 2 };
+/* Same op with an explicit kernel choice.  DI_LA_AUTO picks, for fp16 / C=128 / 9x9, the persistent
+ * software-pipelined matrix-core kernel (row-pair 16x16x32 MFMA tiles, local_attn_mfma2.hip), else the
+ * generic LDS-tiled VALU kernel.  The other codes select one implementation (tests, measurements). */
+enum { DI_LA_AUTO = 0, DI_LA_VALU = 1, DI_LA_MFMA = 2,
+       DI_LA_MFMA2 = 3 /* + configuration: 3 = 16x8 tiles, 5 = 16x4 tiles (the AUTO choice), 7 = timestamps */,
+       DI_LA_MFMA3 = 8 /* producer/consumer wavefronts + direct-to-LDS loads; 11 = with 8 producer waves */ };
 int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                          int C, int kH, int kW, float scale, int dtype, int variant, void *stream);
 

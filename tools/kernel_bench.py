@@ -42,8 +42,9 @@ def main():
     for name, (n, H, W) in dict(image=(6, Hi, Wi), bev=(1, Hb, Wb)).items():
         q, k, v = rnd(n, C, H, W), rnd(n, C, H, W), rnd(n, C, H, W)
         byt = 4 * n * C * H * W * s
-        for vname, var in (('valu', ops.LA_VALU), ('mfma', ops.LA_MFMA)):
-            if var == ops.LA_MFMA and dt != torch.float16:
+        for vname, var in (('valu', ops.LA_VALU), ('auto', ops.LA_AUTO), ('mfma', ops.LA_MFMA), ('m2c0', ops.LA_MFMA2),
+                           ('m2c2', ops.LA_MFMA2 + 2), ('m3c0', ops.LA_MFMA3), ('m3c3', ops.LA_MFMA3 + 3)):
+            if var != ops.LA_VALU and dt != torch.float16:
                 continue
             us = timeit(lambda: ops.local_attention(q, k, v, 9, 9, 1 / math.sqrt(C), variant=var))
             print(f'local_attn_fwd[{vname}] {name:5s} {a.dtype}: {us:8.1f} us  algorithmic {byt/1e6:7.1f} MB  -> {byt/us/1e6:6.3f} TB/s'
