@@ -113,47 +113,50 @@ def main():
     ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
     ap.add_argument('--shape', default='R', choices=['R', 'A', 'TINY'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true',
+                    help='launch every kernel from the host each step instead of replaying the captured hipGraph')
+    ap.add_argument('--roofline-steps', type=int, default=5,
+                    help='eager forwards run after the timed region to time the dominant kernel with HIP events')
     args = ap.parse_args()
 
-    from deepinteraction_amd import ops, synth
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    from deepinteraction_amd import ops, parallel, synth
+    rank, local, world = parallel.env_rank()
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+    parallel.init('nccl', device)                 # RCCL over xGMI; only the timing protocol uses it
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     shape = dict(R=synth.SHAPE_R, A=synth.SHAPE_A, TINY=synth.SHAPE_TINY)[args.shape]
     dtype = dict(f16=torch.float16, f32=torch.float32)[args.dtype]
     enc, dec = build_models(shape, args.proposals, dtype, device)
-    data = to_device(synth.make_inputs(args.batch, shape, seed=1000 * rank), device, dtype)
+    # weak scaling: rank r owns samples [r*batch, (r+1)*batch) of the global batch (deepinteraction_amd/parallel.py)
+    ids = parallel.sample_ids(0, args.batch, rank, world)
+    data = to_device(synth.make_inputs(args.batch, shape, seed=parallel.sample_seed(ids[0])), device, dtype)
     n_pillars = int(data['pts_metas']['pillars'].shape[0])
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    # One step = one forward of encoder + decoder on the resident batch.  Default: the forward is captured
+    # once into a hipGraph (deepinteraction_amd/graphed.py) and every step replays it - all ~600 kernels
+    # run each step, only the host-side launch work is gone.  --eager launches them from Python instead.
     with torch.no_grad():
+        if args.eager:
+            step = lambda: forward(enc, dec, data)
+        else:
+            from deepinteraction_amd.graphed import GraphedHotPath
+            step = GraphedHotPath(enc, dec, data)
         for _ in range(args.warmup):
+            step()
+        # barrier + synchronize | K steps | barrier + synchronize, MAX over ranks
+        elapsed = parallel.timed_region(step, args.steps, device)
+        # dominant-kernel timing: HIP events right around the launch, on the launch stream, in eager
+        # forwards of the same model and data (events cannot bracket one kernel inside a graph replay)
+        forward(enc, dec, data)
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        for _ in range(args.roofline_steps):
             forward(enc, dec, data)
-        sync()
-        ops.PROFILE = []                               # HIP-event pairs around the local-attention launches
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            forward(enc, dec, data)
-        sync()
-        elapsed = time.perf_counter() - t0
+        torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     # roofline of the dominant kernel: fused local-window attention on the image maps
     Hi, Wi = shape['img_hw']
     n_img = 6 * args.batch
@@ -166,14 +169,15 @@ def main():
                     achieved=None if achieved is None else round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                     traffic=None, avg_launch_us=round(avg * 1e6, 2), launches=len(durs),
-                    algorithmic_bytes=alg_bytes)
+                    algorithmic_bytes=alg_bytes,
+                    timed_in=f'{args.roofline_steps} eager forwards right after the timed region, HIP events on the launch stream')
     pmc = os.path.join(ROOT, 'profiles', 'pmc_local_attn.json')
     if os.path.exists(pmc):                            # HBM bytes per launch from a separate rocprofv3 --pmc pass
         roofline['traffic'] = json.load(open(pmc)).get('hbm_bytes_per_launch')
 
     if rank == 0:
-        total = args.gpus * args.batch * args.steps
-        out = dict(metric='samples/sec forward (Fusion_0075 synthetic)', value=round(total / elapsed, 3),
+        out = dict(metric='samples/sec forward (Fusion_0075 synthetic)',
+                   value=round(parallel.throughput(args.batch, args.steps, elapsed, world), 3),
                    unit='samples/s', n_gpus=args.gpus, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='f16' if dtype == torch.float16 else 'f32', data='synthetic',
@@ -181,13 +185,14 @@ def main():
                                         f'Fusion_0075_refactor shapes (shape {args.shape}), random-init weights',
                                batch_per_gpu=args.batch, global_batch=args.batch * args.gpus,
                                num_proposals=args.proposals, pillars=n_pillars,
+                               launch='eager' if args.eager else 'hipGraph replay of the captured forward',
                                parallelism=f'{args.gpus} independent replicas, sharded by sample'),
                    roofline=roofline)
         if args.gpus == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(shape, args.proposals)
         print(json.dumps(out))
     if world > 1:
-        dist.destroy_process_group()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -53,17 +53,11 @@ class SampleGeometry:
 
     def __init__(self, img_meta, img_hw, device):
         Hi, Wi = img_hw
+        host = self._pack(img_meta, img_hw)
+        V = int(np.asarray(img_meta['lidar2img']).shape[0])
         ori_H, ori_W = img_meta['input_shape'][:2]
-        l2i = torch.as_tensor(np.asarray(img_meta['lidar2img']), dtype=torch.float32)   # (V,4,4) :144-148
-        i2l = torch.inverse(l2i)                                                          # fp32, :149
-        V = l2i.shape[0]
-        xs = torch.linspace(0, ori_W - 1, Wi, dtype=torch.float32)
-        ys = torch.linspace(0, ori_H - 1, Hi, dtype=torch.float32)
-        parts = [l2i.reshape(-1), i2l.reshape(-1),
-                 torch.from_numpy(aug_affine(img_meta, True)).float(),
-                 torch.from_numpy(aug_affine(img_meta, False)).float(),
-                 torch.tensor(PC_RANGE, dtype=torch.float32), xs, ys]
-        buf = torch.cat(parts).to(device, non_blocking=True)
+        buf = host.to(device, non_blocking=True)
+        self._buf = buf
         o = 0
 
         def take(n):
@@ -81,3 +75,27 @@ class SampleGeometry:
         self.pc_range = take(6)
         self.xs = take(Wi)
         self.ys = take(Hi)
+
+    @staticmethod
+    def _pack(img_meta, img_hw):
+        Hi, Wi = img_hw
+        ori_H, ori_W = img_meta['input_shape'][:2]
+        l2i = torch.as_tensor(np.asarray(img_meta['lidar2img']), dtype=torch.float32)   # (V,4,4) :144-148
+        i2l = torch.inverse(l2i)                                                          # fp32, :149
+        xs = torch.linspace(0, ori_W - 1, Wi, dtype=torch.float32)
+        ys = torch.linspace(0, ori_H - 1, Hi, dtype=torch.float32)
+        return torch.cat([l2i.reshape(-1), i2l.reshape(-1),
+                          torch.from_numpy(aug_affine(img_meta, True)).float(),
+                          torch.from_numpy(aug_affine(img_meta, False)).float(),
+                          torch.tensor(PC_RANGE, dtype=torch.float32), xs, ys])
+
+    def update(self, img_meta):
+        """Refresh the constants IN PLACE for a new sample (same view count / input_shape): the
+        device addresses stay valid, so a captured hipGraph that reads them can simply be replayed.
+        Also forgets the cached depth maps of the previous sample."""
+        ori_H, ori_W = img_meta['input_shape'][:2]
+        assert (float(ori_H), float(ori_W)) == self.ori_hw, 'input_shape changed: rebuild the geometry'
+        host = self._pack(img_meta, self.img_hw)
+        assert host.numel() == self._buf.numel(), 'view count changed: rebuild the geometry'
+        self._buf.copy_(host, non_blocking=True)
+        self.sparse_depth = self.dense_depth = None

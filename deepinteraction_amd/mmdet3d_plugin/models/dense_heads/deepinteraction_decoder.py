@@ -85,6 +85,7 @@ class DeepInteractionDecoder(nn.Module):
         self.query_labels = None
         self.on_the_image_mask = []
         self.ret_idx = ret_idx
+        self.static_geometry = None       # optional persistent QueryGeometry (deepinteraction_amd.graphed)
         self.init_weights()
 
     def create_2D_grid(self, x_size, y_size):
@@ -148,7 +149,8 @@ class DeepInteractionDecoder(nn.Module):
             query_pos = res_layer['center'].detach().permute(0, 2, 1)
 
         img_feat_flatten = img_feat.view(B, self.num_views, I_C, -1)
-        geom = QueryGeometry(img_metas, dev)
+        # a caller that replays a captured graph keeps ONE geometry object alive and refreshes it in place
+        geom = self.static_geometry if self.static_geometry is not None else QueryGeometry(img_metas, dev)
         self.on_the_image_mask = []
         ret_dicts = []
         for layer_idx in range(self.num_mmpi):

@@ -308,6 +308,16 @@ class QueryGeometry:
     affine (B,12) and [w, h, flip, orig_w, crop_x, crop_y] (B,6) - one host->device copy."""
 
     def __init__(self, img_metas, device):
+        host, B, V = self._pack(img_metas)
+        buf = host.to(device, non_blocking=True)
+        self._buf = buf
+        self.B, self.V = B, V
+        self.proj = buf[:B * V * 16].view(B, V, 4, 4)
+        self.aug_rev = buf[B * V * 16:B * V * 16 + B * 12].view(B, 12)
+        self.per_sample = buf[B * V * 16 + B * 12:].view(B, 6)
+
+    @staticmethod
+    def _pack(img_metas):
         l2i = np.stack([np.asarray(m['lidar2img'], dtype=np.float32) for m in img_metas])
         aug = np.stack([aug_affine(m, True) for m in img_metas]).astype(np.float32)
         ps = []
@@ -318,12 +328,16 @@ class QueryGeometry:
             crop = m.get('img_crop_offset', (0.0, 0.0))
             ps.append([float(w), float(h), flip, orig_w, float(crop[0]), float(crop[1])])
         B, V = l2i.shape[:2]
-        buf = torch.from_numpy(np.concatenate([l2i.reshape(-1), aug.reshape(-1),
-                                               np.asarray(ps, np.float32).reshape(-1)])).to(device, non_blocking=True)
-        self.B, self.V = B, V
-        self.proj = buf[:B * V * 16].view(B, V, 4, 4)
-        self.aug_rev = buf[B * V * 16:B * V * 16 + B * 12].view(B, 12)
-        self.per_sample = buf[B * V * 16 + B * 12:].view(B, 6)
+        host = torch.from_numpy(np.concatenate([l2i.reshape(-1), aug.reshape(-1),
+                                                np.asarray(ps, np.float32).reshape(-1)]))
+        return host, B, V
+
+    def update(self, img_metas):
+        """Refresh IN PLACE for new samples (same batch / view count): addresses stay valid for a
+        captured hipGraph."""
+        host, B, V = self._pack(img_metas)
+        assert (B, V) == (self.B, self.V), 'batch or view count changed: rebuild the geometry'
+        self._buf.copy_(host, non_blocking=True)
 
 
 class _RCNNBase(nn.Module):

@@ -1,0 +1,80 @@
+"""N > 1 host logic of the sample-sharded path on CPU: two `gloo` processes (world_size 2)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import time
+    import torch.distributed as dist
+    from deepinteraction_amd import parallel, synth
+    assert parallel.init('gloo')
+    # (i) sample assignment: disjoint, contiguous, independent of which rank generates a sample
+    ids = [parallel.sample_ids(step, 2, rank, world) for step in range(3)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, ids)
+    flat = sorted(i for r in gathered for step in r for i in step)
+    assert flat == list(range(3 * world * 2)), flat
+    shape = synth.SHAPE_TINY
+    mine = synth.make_inputs(1, shape, seed=parallel.sample_seed(ids[0][0]))['img_feats']
+    other = synth.make_inputs(1, shape, seed=parallel.sample_seed(gathered[1 - rank][0][0]))['img_feats']
+    sums = [None] * world
+    dist.all_gather_object(sums, float(mine.double().sum()))
+    assert abs(sums[1 - rank] - float(other.double().sum())) < 1e-9      # same global sample, same tensor
+    assert abs(sums[0] - sums[1]) > 1e-6                                   # different samples on the two ranks
+    # (ii) timing protocol: the slow rank sets the time on every rank
+    el = parallel.timed_region(lambda: time.sleep(0.02 if rank == 0 else 0.06), steps=3)
+    assert 0.17 <= el < 1.0, el
+    thr = parallel.throughput(2, 3, el, world)
+    assert abs(thr - 12 / el) < 1e-9
+    # (iii) bucketed gradient averaging, with a parameter that has no gradient on one rank
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)),
+          torch.nn.Parameter(torch.zeros(2, 2), requires_grad=False), torch.nn.Parameter(torch.zeros(4))]
+    ps[0].grad = torch.full((5, 3), float(rank + 1))
+    ps[1].grad = torch.arange(7.0) * (rank + 1)
+    if rank == 0:
+        ps[3].grad = torch.ones(4)
+    parallel.allreduce_gradients(ps, world, bucket_bytes=64)              # tiny buckets: several flushes
+    assert torch.allclose(ps[0].grad, torch.full((5, 3), 1.5))
+    assert torch.allclose(ps[1].grad, torch.arange(7.0) * 1.5)
+    assert ps[2].grad is None
+    assert torch.allclose(ps[3].grad, torch.full((4,), 0.5))
+    out.put((rank, el))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, p.exitcode
+    res = dict(out.get(timeout=5) for _ in range(2))
+    assert abs(res[0] - res[1]) < 1e-12            # MAX over ranks: identical on both
+
+
+def test_single_process_defaults():
+    sys.path.insert(0, ROOT)
+    from deepinteraction_amd import parallel
+    assert parallel.sample_ids(2, 3, 0, 1) == [6, 7, 8]
+    assert parallel.max_over_ranks(1.25) == 1.25
+    assert parallel.throughput(2, 10, 4.0, 1) == 5.0
