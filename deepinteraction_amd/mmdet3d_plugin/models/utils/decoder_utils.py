@@ -114,8 +114,9 @@ class MultiheadAttention(nn.Module):
 
 def mha_tokens(q_in, k_in, v_in, w, b, out_proj, H, dropout_p=0.0, key_allowed=None):
     """Batch-first multi-head attention on small token sets with library GEMMs.
-    q_in (B,L,E), k_in/v_in (B,S,E); key_allowed: optional bool (B,G,S) -> one attention per
-    group g with the other keys masked out; returns (B,L,E) or (B,G,L,E)."""
+    q_in (B,L,E), k_in/v_in (B,S,E); key_allowed: optional bool (B,L,S) - query l attends only to the
+    keys s with key_allowed[b,l,s] (a row without any allowed key yields NaN; callers drop it).
+    Returns (B,L,E)."""
     B, L, E = q_in.shape
     S = k_in.shape[1]
     D = E // H
@@ -129,19 +130,13 @@ def mha_tokens(q_in, k_in, v_in, w, b, out_proj, H, dropout_p=0.0, key_allowed=N
     q = q.view(B, L, H, D).transpose(1, 2) * (float(D) ** -0.5)
     k = k.view(B, S, H, D).transpose(1, 2)
     v = v.view(B, S, H, D).transpose(1, 2)
-    sc = torch.matmul(q, k.transpose(-1, -2))                              # (B,H,L,S)
-    if key_allowed is None:
-        a = torch.softmax(sc.float(), -1).to(v.dtype)
-        if dropout_p > 0:
-            a = F.dropout(a, dropout_p)
-        o = torch.matmul(a, v).transpose(1, 2).reshape(B, L, E)
-    else:
-        G = key_allowed.shape[1]
-        sc = sc.float().unsqueeze(1).masked_fill(~key_allowed.view(B, G, 1, 1, S), float('-inf'))
-        a = torch.softmax(sc, -1).to(v.dtype)                              # rows of empty groups: NaN, dropped later
-        if dropout_p > 0:
-            a = F.dropout(a, dropout_p)
-        o = torch.matmul(a, v.unsqueeze(1)).transpose(2, 3).reshape(B, G, L, E)
+    sc = torch.matmul(q, k.transpose(-1, -2)).float()                      # (B,H,L,S)
+    if key_allowed is not None:
+        sc = sc.masked_fill(~key_allowed.view(B, 1, L, S), float('-inf'))
+    a = torch.softmax(sc, -1).to(v.dtype)
+    if dropout_p > 0:
+        a = F.dropout(a, dropout_p)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(B, L, E)
     return out_proj(o)
 
 
@@ -343,13 +338,11 @@ class QueryGeometry:
 class _RCNNBase(nn.Module):
     def _stack(self, x, roi, sfx, key_allowed=None):
         """decoder_utils.py:743-756 / :824-837 on tokens x (B,Q,C): self-attn + LN, DynamicConv + LN,
-        FFN(GELU) + LN.  With key_allowed (B,G,Q) the result is (B,G,Q,C) (one refinement per group)."""
+        FFN(GELU) + LN.  key_allowed (B,Q,Q): the keys each query may attend to."""
         g = lambda n: getattr(self, n + sfx)
         sa = g('dyconv_pre_self_attn')
         p = sa.dropout if self.training else 0.0
         a = mha_tokens(x, x, x, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj, sa.num_heads, p, key_allowed)
-        if key_allowed is not None:
-            x = x.unsqueeze(1)
         x = g('norm1')(x + g('dropout1')(a))
         shp = x.shape
         dy = g('dyconv').forward_nk(x.reshape(-1, shp[-1]), roi)
@@ -386,18 +379,26 @@ class ImageRCNNBlock(_RCNNBase):
         on, rect, _ = ops.query_geometry(res32, geom.proj, geom.aug_rev, geom.per_sample,
                                          cfg['out_size_factor'] * cfg['voxel_size'][0], cfg['pc_range'][:2],
                                          1.0, 1.0, True, False)
-        maps = img_feat_flatten.reshape(B * V, C, img_h, img_w)
-        idx = torch.arange(B * V, device=rect.device, dtype=torch.float32).view(B, V, 1, 1).expand(B, V, Q, 1)
-        rois = torch.cat([idx, rect], -1).view(-1, 5)
-        roi = ops.roi_align(maps, rois, 1.0 / self.out_size_factor_img)        # (B*V*Q, 49, C)
+        # Which (view, query) results survive in the reference?  A view with <= 1 centre on it is
+        # skipped (:726) and a later view overwrites an earlier one (:728,:759): query q keeps the output
+        # of its LAST valid view v*(q) only.  That output depends on the other queries only through the
+        # self-attention among the queries of view v*(q) (:745), so the whole block is evaluated for the
+        # <= Q surviving (v*(q), q) pairs instead of all V*Q - same results, 1/V of the RoI work - with
+        # the per-view query subsets expressed as an attention mask.  No host synchronisation.
         onb = on.bool()
-        x = self._stack(query_feat.transpose(1, 2), roi, '', key_allowed=onb)    # (B,V,Q,C)
-        view_ok = on.sum(-1, keepdim=True) > 1                                   # "<= 1 query: skip" (:726)
-        sel = onb & view_ok
+        view_ok = on.sum(-1, keepdim=True) > 1                                   # (B,V,1)
+        sel = onb & view_ok                                                      # (B,V,Q)
         vid = torch.arange(V, device=on.device).view(1, V, 1)
-        last = torch.where(sel, vid, torch.full_like(vid, -1)).max(1).values     # later view overwrites (:759)
-        picked = x.gather(1, last.clamp(min=0).view(B, 1, Q, 1).expand(B, 1, Q, C)).squeeze(1)
-        out = torch.where((last >= 0).unsqueeze(-1), picked, torch.zeros_like(picked))
+        last = torch.where(sel, vid, torch.full_like(vid, -1)).max(1).values     # (B,Q): v*(q) or -1
+        lastc = last.clamp(min=0)
+        rect_q = rect.gather(1, lastc.view(B, 1, Q, 1).expand(B, 1, Q, 4)).squeeze(1)        # (B,Q,4)
+        maps = img_feat_flatten.reshape(B * V, C, img_h, img_w)
+        idx = (torch.arange(B, device=rect.device).view(B, 1) * V + lastc).to(torch.float32).unsqueeze(-1)
+        rois = torch.cat([idx, rect_q], -1).view(-1, 5)
+        roi = ops.roi_align(maps, rois, 1.0 / self.out_size_factor_img)          # (B*Q, 49, C)
+        key_allowed = sel.gather(1, lastc.view(B, Q, 1).expand(B, Q, Q))         # [b,q,k] = sel[b, v*(q), k]
+        x = self._stack(query_feat.transpose(1, 2), roi, '', key_allowed=key_allowed)        # (B,Q,C)
+        out = torch.where((last >= 0).unsqueeze(-1), x, torch.zeros_like(x))     # unseen queries: 0 (:665)
         return out.transpose(1, 2), last.to(torch.float32)
 
 
