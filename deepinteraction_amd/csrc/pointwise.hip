@@ -1,0 +1,245 @@
+// Fused chains of 1x1 convolutions (+ folded BatchNorm, + ReLU, + channel concat) on channels-last fp16
+// maps, on the gfx950 matrix cores.
+//
+// The MMRI encoder is full of them (reference encoder_utils.py:92-117 query/key/value projections of
+// LocalContextAttentionBlock = 2 or 1 x {Conv1x1 + BN + ReLU}; deepinteraction_encoder.py:13-19,26-32
+// the out_proj / integration pairs = Conv1x1(cat(a, b)) + BN twice).  As library GEMMs each link of a
+// chain reads and writes a whole 34 MB map (and a separate ReLU pass re-reads it); here a chain is one
+// pass over the pixels:
+//
+//     h = act1( W1 . [x1 ; x2] + b1 )          (x2 optional: the concat is never materialised)
+//     y = act2( W2 . [h  ; x3] + b2 )          (second link optional; x3 optional)
+//
+// One wavefront owns 32 pixels at a time.  Everything is computed TRANSPOSED - H^T = W1 . X^T - so
+// that (i) the B operand of the 16x16x32 MFMA is 8 consecutive channels of one pixel = one 16-B global
+// load per lane straight from the channels-last map, (ii) the accumulator of link 1 (lane = pixel,
+// registers = 4 consecutive output channels) IS, after ReLU and conversion to fp16, the B operand of
+// link 2, with the MFMA k index mapped to hidden channel 32kk + 16t + 4g + r (k = 8g + 4t + r): the
+// hidden activations never leave registers, and W2's columns are permuted accordingly when it is staged.
+// Weights live in LDS (XOR-swizzled 16-B chunks: conflict-free ds_read_b128 fragments), staged once per
+// persistent workgroup.  fp32 accumulation, bias add in fp32.
+#include "di_common.h"
+
+namespace di {
+namespace pw {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int NW = 8, NT = NW * 64;   // wavefronts / threads per workgroup
+constexpr int PG = 2;                 // pixel groups of 16 per wavefront pass
+
+// LDS image of a (128 x K) fp16 weight matrix: row r at r*K*2 bytes, 16-B chunk c of the row stored at
+// position (c & ~15) | ((c & 15) ^ (r & 15)).
+template <int K>
+__device__ __forceinline__ int w_off(int r, int c) {
+  return r * K * 2 + (((c & ~15) | ((c & 15) ^ (r & 15))) << 4);
+}
+
+// stage W (128 x K, row-major fp16 in global) into LDS; PERM: the first 128 columns are re-ordered for
+// the register-resident hidden operand: LDS column 32kk + 8g + 4t + r <- global column 32kk + 16t + 4g + r
+template <int K, bool PERM>
+__device__ __forceinline__ void stage_w(const __half *__restrict__ w, unsigned char *lds, int tid) {
+  constexpr int CH = K / 8;            // 16-B chunks per row
+  for (int e = tid; e < 128 * CH; e += NT) {
+    const int r = e / CH, c = e - r * CH;
+    uint4 val;
+    if (PERM && c < 16) {
+      // destination chunk c = 4kk + g holds columns 32kk + 8g + (4t + r'), i.e. two 8-B pieces of the source
+      const int kk = c >> 2, g = c & 3;
+      const uint2 lo = *reinterpret_cast<const uint2 *>(w + (size_t)r * K + 32 * kk + 4 * g);        // t = 0
+      const uint2 hi = *reinterpret_cast<const uint2 *>(w + (size_t)r * K + 32 * kk + 16 + 4 * g);   // t = 1
+      val = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    } else {
+      val = *reinterpret_cast<const uint4 *>(w + (size_t)r * K + c * 8);
+    }
+    *reinterpret_cast<uint4 *>(lds + w_off<K>(r, c)) = val;
+  }
+}
+
+template <int K1, int K2>
+__global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
+    const __half *__restrict__ x1, const __half *__restrict__ x2, const __half *__restrict__ x3,
+    const __half *__restrict__ w1, const float *__restrict__ b1, const __half *__restrict__ w2,
+    const float *__restrict__ b2, __half *__restrict__ y, long long M, int relu1, int relu2) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  unsigned char *lw1 = lds;
+  unsigned char *lw2 = lds + 128 * K1 * 2;
+  float *lb = reinterpret_cast<float *>(lds + 128 * K1 * 2 + 128 * K2 * 2);   // b1[128], b2[128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+
+  stage_w<K1, false>(w1, lw1, tid);
+  if (K2 > 0) stage_w<(K2 > 0 ? K2 : 128), true>(w2, lw2, tid);
+  if (tid < 128) {
+    lb[tid] = b1[tid];
+    lb[128 + tid] = K2 > 0 ? b2[tid] : 0.f;
+  }
+  __syncthreads();
+
+  constexpr int KK1 = K1 / 32;
+  const long long nchunk = (M + 16 * PG - 1) / (16 * PG);
+  for (long long ch = (long long)blockIdx.x * NW + wave; ch < nchunk; ch += (long long)gridDim.x * NW) {
+    const long long p0 = ch * (16 * PG);
+    // ---- B operands of link 1: pixel i of each group, channels 32kk + 8g .. +7 (x1 then x2)
+    h8 xb[PG][KK1];
+    long long pix[PG];
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      pix[pg] = p0 + pg * 16 + i;
+      const long long pc = pix[pg] < M ? pix[pg] : M - 1;       // ragged tail: clamped read, no store
+#pragma unroll
+      for (int kk = 0; kk < KK1; ++kk) {
+        const __half *src = kk < 4 ? x1 : x2;
+        xb[pg][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(src + pc * 128 + (kk & 3) * 32 + g * 8));
+      }
+    }
+    // ---- link 1: H^T[oc][px] = W1 . X^T
+    f4 acc[PG][8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) acc[pg][nb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK1; ++kk) {
+        const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<K1>(16 * nb + i, 4 * kk + g)));
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) acc[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[pg][kk], acc[pg][nb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the weight fragments of one output block live at a time
+    }
+    // bias + activation: lane holds output channels 16nb + 4g + r of pixel i
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const f4 bias = *reinterpret_cast<const f4 *>(lb + 16 * nb + 4 * g);
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) {
+        f4 t = acc[pg][nb] + bias;
+        if (relu1) t = __builtin_elementwise_max(t, f4{0.f, 0.f, 0.f, 0.f});
+        acc[pg][nb] = t;
+      }
+    }
+    if (K2 == 0) {
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg)
+        if (pix[pg] < M) {
+#pragma unroll
+          for (int nb = 0; nb < 8; ++nb) {
+            h4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (_Float16)acc[pg][nb][r];
+            *reinterpret_cast<h4 *>(y + pix[pg] * 128 + 16 * nb + 4 * g) = o;
+          }
+        }
+      continue;
+    }
+    // ---- link 2: B operand = the hidden activations in registers (k = 8g + 4t + r <-> channel 32kk + 16t + 4g + r),
+    // then (K2 = 256) the channels of x3
+    constexpr int KK2 = (K2 > 0 ? K2 : 128) / 32;
+    h8 hb[PG][4];
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        h8 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          t[r] = (_Float16)acc[pg][2 * kk][r];
+          t[4 + r] = (_Float16)acc[pg][2 * kk + 1][r];
+        }
+        hb[pg][kk] = t;
+      }
+    if (K2 == 256) {
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) {
+        const long long pc = pix[pg] < M ? pix[pg] : M - 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)   // xb is dead: reuse its registers for x3
+          xb[pg][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(x3 + pc * 128 + kk * 32 + g * 8));
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      f4 o2[PG];
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) o2[pg] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK2; ++kk) {
+        const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<(K2 > 0 ? K2 : 128)>(16 * nb + i, 4 * kk + g)));
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg)
+          o2[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, kk < 4 ? hb[pg][kk] : xb[pg][kk & 3], o2[pg], 0, 0, 0);
+      }
+      const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg) {
+        f4 t = o2[pg] + bias;
+        if (relu2) t = __builtin_elementwise_max(t, f4{0.f, 0.f, 0.f, 0.f});
+        if (pix[pg] < M) {
+          h4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (_Float16)t[r];
+          *reinterpret_cast<h4 *>(y + pix[pg] * 128 + 16 * nb + 4 * g) = o;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int K1, int K2>
+static int launch(const void *x1, const void *x2, const void *x3, const void *w1, const float *b1,
+                  const void *w2, const float *b2, void *y, long long M, int relu1, int relu2,
+                  hipStream_t stream) {
+  constexpr int LDS = 128 * K1 * 2 + 128 * K2 * 2 + 1024;
+  static int n_cu = 0;   // idempotent initialisation; a race only repeats the queries
+  if (n_cu == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+      set_error("cannot query the CU count");
+      return DI_ERR_LAUNCH;
+    }
+    hipError_t e = hipFuncSetAttribute((const void *)pointwise_chain_kernel<K1, K2>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DI_ERR_LAUNCH;
+    }
+    n_cu = cus;
+  }
+  const long long nchunk = (M + 16 * PG - 1) / (16 * PG);
+  const int per_cu = LDS <= 80 * 1024 ? 2 : 1;
+  long long grid = (long long)n_cu * per_cu;
+  if (grid * NW > nchunk) grid = (nchunk + NW - 1) / NW;
+  hipLaunchKernelGGL((pointwise_chain_kernel<K1, K2>), dim3((unsigned)grid), dim3(NT), LDS, stream,
+                     (const __half *)x1, (const __half *)x2, (const __half *)x3, (const __half *)w1, b1,
+                     (const __half *)w2, b2, (__half *)y, M, relu1, relu2);
+  return check_launch("pointwise_chain");
+}
+
+}  // namespace pw
+}  // namespace di
+
+extern "C" int di_pointwise_chain_fwd(const void *x1, const void *x2, const void *x3, const void *w1,
+                                      const float *b1, const void *w2, const float *b2, void *y,
+                                      long long n_pixels, int k1, int k2, int relu1, int relu2, void *stream) {
+  DI_REQUIRE(n_pixels > 0, "empty map");
+  DI_REQUIRE(x1 && w1 && b1 && y, "x1, w1, b1, y are required");
+  DI_REQUIRE((k1 == 128 && !x2) || (k1 == 256 && x2), "k1 = 128 (x1) or 256 (x1 ; x2), got %d", k1);
+  DI_REQUIRE(k2 == 0 || (w2 && b2), "second link needs w2 and b2");
+  DI_REQUIRE((k2 == 0 && !x3) || (k2 == 128 && !x3) || (k2 == 256 && x3), "k2 = 0, 128 (h) or 256 (h ; x3), got %d", k2);
+  hipStream_t s = (hipStream_t)stream;
+#define DI_PW(A, B) \
+  if (k1 == A && k2 == B) return di::pw::launch<A, B>(x1, x2, x3, w1, b1, w2, b2, y, n_pixels, relu1, relu2, s)
+  DI_PW(128, 0);
+  DI_PW(128, 128);
+  DI_PW(256, 0);
+  DI_PW(256, 256);
+  DI_PW(128, 256);
+  DI_PW(256, 128);
+#undef DI_PW
+  di::set_error("unsupported chain k1=%d k2=%d", k1, k2);
+  return DI_ERR_ARG;
+}

@@ -12,7 +12,7 @@ from torch import nn
 from .... import ops
 from ....registry import NECKS
 from ..utils.encoder_utils import (GEOM_KEY, ConvBNReLU, LocalContextAttentionBlock, MMRI_I2P, MMRI_P2I,
-                                   pointwise)
+                                   mix2)
 
 
 class DeepInteractionEncoderLayer(nn.Module):
@@ -31,13 +31,6 @@ class DeepInteractionEncoderLayer(nn.Module):
         self.I_integration = ConvBNReLU(2 * hidden_channel, hidden_channel, kernel_size=1,
                                         norm_layer=nn.BatchNorm2d, activation_layer=None)
 
-    @staticmethod
-    def _mix(proj, a, b):
-        """proj(cat((a, b), 1)); at inference the concat is folded into a split-K GEMM."""
-        if not proj.training and a.is_cuda:
-            return pointwise(proj, a, b)
-        return proj(torch.cat((a, b), dim=1))
-
     def forward(self, img_feat, lidar_feat, img_metas, pts_metas):
         batch_size = lidar_feat.shape[0]
         BN, I_C, I_H, I_W = img_feat.shape
@@ -45,13 +38,12 @@ class DeepInteractionEncoderLayer(nn.Module):
         # BEV side
         I2P_feat = self.I2P_block(lidar_feat, img5, img_metas, pts_metas)
         P2P_feat = self.P_IML(lidar_feat, lidar_feat)
-        P_Aug_feat = self._mix(self.P_out_proj, I2P_feat, P2P_feat)
-        new_lidar_feat = self._mix(self.P_integration, P_Aug_feat, lidar_feat)
+        # P_integration(cat(P_out_proj(cat(I2P, P2P)), lidar)) (:26-27): one fused kernel at inference
+        new_lidar_feat = mix2(self.P_out_proj, I2P_feat, P2P_feat, self.P_integration, lidar_feat)
         # image side (reads the same layer inputs; independent of the BEV side)
         P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas)
         I2I_feat = self.I_IML(img_feat, img_feat)
-        I_Aug_feat = self._mix(self.I_out_proj, P2I_feat.view(BN, -1, I_H, I_W), I2I_feat)
-        new_img_feat = self._mix(self.I_integration, I_Aug_feat, img_feat)
+        new_img_feat = mix2(self.I_out_proj, P2I_feat.view(BN, -1, I_H, I_W), I2I_feat, self.I_integration, img_feat)
         return new_img_feat, new_lidar_feat
 
 

@@ -72,7 +72,8 @@ class ConvBNReLU(nn.Module):
                 beta = 0.0 if self.bn.bias is None else self.bn.bias.float()
                 W = W * g[:, None]
                 bias = (bias - self.bn.running_mean.float()) * g + beta
-            out = (W.to(dtype, copy=True).contiguous(), bias.to(dtype, copy=True).contiguous())
+            out = (W.to(dtype, copy=True).contiguous(), bias.to(dtype, copy=True).contiguous(),
+                   bias.to(torch.float32, copy=True).contiguous())
         self._fold_cache = (key, out)
         return out
 
@@ -83,7 +84,7 @@ def pointwise(m, x, x2=None):
     (cat((x, x2), 1) is never materialised: split-K accumulate)."""
     x = ops.cl(x)
     n, C, H, W = x.shape
-    Wf, bf = m.folded(x.dtype)
+    Wf, bf, _ = m.folded(x.dtype)
     xf = x.permute(0, 2, 3, 1).reshape(-1, C)
     if x2 is None:
         y = F.linear(xf, Wf, bf)
@@ -94,6 +95,40 @@ def pointwise(m, x, x2=None):
     if m.use_activation:
         y = torch.relu_(y)
     return y.view(n, H, W, -1).permute(0, 3, 1, 2)
+
+
+def _fusable(x, *mods):
+    """fp16 HIP maps with 128 channels through 1x1 ConvBNReLU links of 128 outputs, inference form."""
+    return (x.is_cuda and x.dtype == torch.float16 and x.shape[1] == 128 and not torch.is_grad_enabled()
+            and all(isinstance(m, ConvBNReLU) and not m.training and m.conv.kernel_size == (1, 1)
+                    and m.conv.out_channels == 128 and m.conv.groups == 1 for m in mods))
+
+
+def project(seq, x):
+    """A query/key/value projection (one ConvBNReLU or a Sequential of two) as ONE fused kernel when it
+    is a 128-channel fp16 inference chain (ops.pointwise_chain), else link by link."""
+    mods = list(seq) if isinstance(seq, nn.Sequential) else [seq]
+    if len(mods) in (1, 2) and _fusable(x, *mods) and all(m.conv.in_channels == 128 for m in mods):
+        w1, _, b1 = mods[0].folded(x.dtype)
+        if len(mods) == 1:
+            return ops.pointwise_chain(x, w1, b1, mods[0].use_activation)
+        w2, _, b2 = mods[1].folded(x.dtype)
+        return ops.pointwise_chain(x, w1, b1, mods[0].use_activation, w2=w2, b2=b2, relu2=mods[1].use_activation)
+    return seq(x)
+
+
+def mix2(proj1, a, b, proj2, c):
+    """proj2(cat(proj1(cat(a, b)), c)) - the out_proj / integration pair of an encoder layer
+    (deepinteraction_encoder.py:26-27, 31-32) - as ONE fused kernel when possible."""
+    if _fusable(a, proj1, proj2) and proj1.conv.in_channels == 256 and proj2.conv.in_channels == 256 \
+            and b.shape == a.shape and c.shape == a.shape and b.dtype == a.dtype and c.dtype == a.dtype:
+        w1, _, b1 = proj1.folded(a.dtype)
+        w2, _, b2 = proj2.folded(a.dtype)
+        return ops.pointwise_chain(a, w1, b1, proj1.use_activation, x2=b, w2=w2, b2=b2,
+                                   relu2=proj2.use_activation, x3=c)
+    if not proj1.training and a.is_cuda:
+        return pointwise(proj2, pointwise(proj1, a, b), c)
+    return proj2(torch.cat((proj1(torch.cat((a, b), dim=1)), c), dim=1))
 
 
 class similarFunction(torch.autograd.Function):
@@ -155,9 +190,9 @@ class LocalContextAttentionBlock(nn.Module):
                     nn.init.constant_(m.bias, 0)
 
     def forward(self, target_feats, source_feats, **kwargs):
-        query = self.query_project(target_feats)
-        key = self.key_project(source_feats)
-        value = self.value_project(source_feats)
+        query = project(self.query_project, target_feats)
+        key = project(self.key_project, source_feats)
+        value = project(self.value_project, source_feats)
         ks = self.kernel_size
         scale = 1.0 / math.sqrt(key.size(1))
         if not (torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)):

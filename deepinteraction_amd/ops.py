@@ -135,6 +135,34 @@ def weighting_backward_weight(x_ori, grad_out, kH, kW):
     return out
 
 
+# ------------------------------------------------------------------ fused 1x1-convolution chains
+def pointwise_chain(x1, w1, b1, relu1, x2=None, w2=None, b2=None, relu2=False, x3=None):
+    """y = act2(W2 . [act1(W1 . [x1 ; x2] + b1) ; x3] + b2) over the pixels of fp16 channels-last maps
+    (C = 128); the second link is optional.  w* fp16 (128, 128 or 256), b* float32 (128)."""
+    _dev(x1, w1, b1)
+    x1 = cl(x1)
+    n, C, H, W = x1.shape
+    assert C == 128 and x1.dtype == torch.float16, 'fused chains are fp16, 128 channels'
+    k1 = 128 if x2 is None else 256
+    k2 = 0 if w2 is None else (128 if x3 is None else 256)
+    assert w1.shape == (128, k1) and w1.dtype == torch.float16 and w1.is_contiguous()
+    assert b1.dtype == torch.float32 and b1.numel() == 128
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    if x2 is not None:
+        x2 = cl(x2)
+        assert x2.shape == x1.shape and x2.dtype == x1.dtype
+    if x3 is not None:
+        x3 = cl(x3)
+        assert x3.shape == x1.shape and x3.dtype == x1.dtype
+    if w2 is not None:
+        assert w2.shape == (128, k2) and w2.dtype == torch.float16 and w2.is_contiguous()
+        assert b2.dtype == torch.float32 and b2.numel() == 128
+    y = empty_cl(n, 128, H, W, x1)
+    _lib.call('di_pointwise_chain_fwd', x1.data_ptr(), ptr(x2), ptr(x3), w1.data_ptr(), b1.data_ptr(), ptr(w2),
+              ptr(b2), y.data_ptr(), n * H * W, k1, k2, int(bool(relu1)), int(bool(relu2)), _stream())
+    return y
+
+
 # ------------------------------------------------------------------ image -> BEV
 def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw):
     """One sample.  img (V,C,Hi,Wi), qfold (1,C,Hb,Wb) channels-last; pillars (P,T,D) f32,

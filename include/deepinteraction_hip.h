@@ -84,6 +84,18 @@ int di_locatt_weighting_bwd_ori(const float *x_weight, const void *grad_out, voi
 int di_locatt_weighting_bwd_weight(const void *x_ori, const void *grad_out, float *grad_w, int n,
                                    int H, int W, int C, int kH, int kW, int dtype, void *stream);
 
+/* ---------------------------------------------------------------- fused 1x1-convolution chains
+ * The Conv1x1 + BN (+ ReLU) projections of LocalContextAttentionBlock (encoder_utils.py:92-117) and the
+ * out_proj / integration pairs of the encoder layer (deepinteraction_encoder.py:13-19, 26-32), with
+ * BatchNorm folded by the caller, as ONE pass over the pixels of channels-last fp16 maps (C = 128):
+ *     h = act1(W1 . [x1 ; x2] + b1)        k1 = 128 (x2 = NULL) or 256
+ *     y = act2(W2 . [h  ; x3] + b2)        k2 = 0 (no second link: y = h), 128 (x3 = NULL) or 256
+ * w1 (128,k1), w2 (128,k2) row-major fp16 (natural column order); b1, b2 (128) float32; relu* 0/1.
+ * x*, y: (n_pixels, 128) fp16.  fp32 accumulation; the hidden map h never touches memory. */
+int di_pointwise_chain_fwd(const void *x1, const void *x2, const void *x3, const void *w1, const float *b1,
+                           const void *w2, const float *b2, void *y, long long n_pixels, int k1, int k2,
+                           int relu1, int relu2, void *stream);
+
 /* ---------------------------------------------------------------- image -> BEV pillar attention
  * MMRI_I2P.forward for ONE sample (encoder_utils.py:270-319), with the single-head
  * attention folded algebraically: the caller passes

@@ -322,3 +322,39 @@ def test_cpu_tensor_is_rejected():
     x = torch.zeros(1, 128, 8, 8)
     with pytest.raises(_lib.HipLibraryError):
         ops.local_attention(x, x, x, 9, 9, 1.0)
+
+
+@pytest.mark.parametrize('k1,k2,relu', [(128, 0, True), (128, 128, True), (256, 0, False), (256, 256, False),
+                                        (128, 256, True), (256, 128, False)])
+@pytest.mark.parametrize('npix', [(1, 7, 5), (2, 33, 61), (6, 112, 200)])
+def test_pointwise_chain(k1, k2, relu, npix):
+    """Fused 1x1-conv chains (ops.pointwise_chain, MFMA) against the same chain in float64 on the same
+    fp16 operands; the kernel keeps the hidden map in registers as fp16, so does the reference.
+    Ragged pixel counts (not a multiple of 32) included.  fp32 accumulation: 1e-3 of the value scale."""
+    _require_gpu()
+    n, H, W = npix
+    g = torch.Generator().manual_seed(11)
+    mk = lambda: (torch.randn(n, 128, H, W, generator=g)).half()
+    x1, x2, x3 = mk(), (mk() if k1 == 256 else None), (mk() if k2 == 256 else None)
+    w1 = (torch.randn(128, k1, generator=g) / math.sqrt(k1)).half()
+    b1 = torch.randn(128, generator=g) * 0.1
+    w2 = (torch.randn(128, k2, generator=g) / math.sqrt(k2)).half() if k2 else None
+    b2 = torch.randn(128, generator=g) * 0.1 if k2 else None
+    dev = lambda t: None if t is None else t.to(DEV)
+    cl = lambda t: None if t is None else t.to(DEV).contiguous(memory_format=torch.channels_last)
+    out = ops.pointwise_chain(cl(x1), dev(w1), dev(b1), relu, x2=cl(x2), w2=dev(w2), b2=dev(b2), relu2=relu,
+                              x3=cl(x3)).float().cpu()
+    flat = lambda t: t.permute(0, 2, 3, 1).reshape(-1, 128).double()
+    xin = flat(x1) if x2 is None else torch.cat([flat(x1), flat(x2)], 1)
+    h = xin @ w1.double().t() + b1.double()
+    if relu:
+        h = h.relu()
+    if k2:
+        h = h.half().double()
+        hin = h if x3 is None else torch.cat([h, flat(x3)], 1)
+        h = hin @ w2.double().t() + b2.double()
+        if relu:
+            h = h.relu()
+    ref = h.float().view(n, H, W, 128).permute(0, 3, 1, 2)
+    err = (out - ref).abs().max().item()
+    assert err <= 1e-3 * max(ref.abs().max().item(), 1.0), err
