@@ -393,7 +393,7 @@ int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out,
     di::set_error("MFMA local attention needs fp16, C=128, 9x9 (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
     return DI_ERR_ARG;
   }
-  if (variant >= DI_LA_MFMA3 && variant < DI_LA_MFMA3 + 4) {
+  if (variant >= DI_LA_MFMA3 && variant < DI_LA_MFMA3 + 3) {
     if (!mfma_ok) {
       di::set_error("MFMA local attention needs fp16, C=128, 9x9 (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
       return DI_ERR_ARG;

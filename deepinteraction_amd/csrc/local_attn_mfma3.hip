@@ -277,15 +277,23 @@ __global__ __launch_bounds__(G::NT, G::WPS) void local_attn_m3_kernel(
     static_for<0, 2>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       const unsigned char *buf = lds + mod3(b0 + u) * G::UNITB;
-      static_for<0, 10>([&](auto rc) {
-        constexpr int rr = decltype(rc)::value;
-        if constexpr (u == 0 && rr < G::NN) st_pend(rr);     // stores left over from the previous tile
-#pragma unroll
-        for (int kl = 0; kl < G::KK; ++kl) {
-          const uint4 raw = *reinterpret_cast<const uint4 *>(buf + koff[kl] + rr * ROWB);
-          s[rr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, raw), qf[u * G::KK + kl], s[rr], 0, 0, 0);
-        }
-        pin_vmem();
+      // explicit software pipeline: the K fragment of MFMA step j + PFK is requested before step j runs
+      // (20 steps = 10 key rows x 2 channel halves); the order is pinned, the compiler would otherwise
+      // sink the LDS reads next to their uses and expose their latency with only two waves per SIMD
+      constexpr int PFK = 8;
+      uint4 kf[20];
+      static_for<0, PFK>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        kf[j] = *reinterpret_cast<const uint4 *>(buf + koff[j & 1] + (j >> 1) * ROWB);
+      });
+      static_for<0, 20>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int rr = j >> 1, kl = j & 1;
+        if constexpr (j + PFK < 20)
+          kf[j + PFK] = *reinterpret_cast<const uint4 *>(buf + koff[(j + PFK) & 1] + ((j + PFK) >> 1) * ROWB);
+        if constexpr (u == 0 && kl == 0 && rr < G::NN) st_pend(rr);     // stores left over from the previous tile
+        s[rr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, kf[j]), qf[u * G::KK + kl], s[rr], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       });
       DI_TS();
       if constexpr (u == 1) {
@@ -337,24 +345,34 @@ __global__ __launch_bounds__(G::NT, G::WPS) void local_attn_m3_kernel(
       f4 acc[G::NN];
 #pragma unroll
       for (int nl = 0; nl < G::NN; ++nl) acc[nl] = f4{0.f, 0.f, 0.f, 0.f};
-      static_for<0, 5>([&](auto pc) {
-        constexpr int pr = decltype(pc)::value;
-        if constexpr (u == 0) {
-          if (pr < 4 && has_next) ld_q(pr);          // qf is dead since the last K unit
-        } else if constexpr (pr < G::NN) {
-          st_pend(pr);                                // output channels of V unit 0
+      // same explicit pipeline for the transposed V fragments (20 steps = 5 row pairs x 4 channel blocks,
+      // two ds_read_b64_tr_b16 each)
+      constexpr int PFV = 8;
+      hv4 va[20], vb[20];
+      auto rd_v = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int pr = j >> 2, nl = j & 3;
+        const unsigned char *p0 = buf + vbase + ((nl ^ vsw) << 5) + 2 * pr * ROWB;
+        va[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(p0));
+        vb[j] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(p0 + ROWB));
+      };
+      static_for<0, PFV>(rd_v);
+      static_for<0, 20>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int pr = j >> 2, nl = j & 3;
+        if constexpr (j + PFV < 20) rd_v(std::integral_constant<int, j + PFV>{});
+        if constexpr (nl == 0) {
+          if constexpr (u == 0) {
+            if (pr < 4 && has_next) ld_q(pr);          // qf is dead since the last K unit
+          } else if constexpr (pr < G::NN) {
+            st_pend(pr);                                // output channels of V unit 0
+          }
         }
-#pragma unroll
-        for (int nl = 0; nl < G::NN; ++nl) {
-          const unsigned char *p0 = buf + vbase + ((nl ^ vsw) << 5) + 2 * pr * ROWB;
-          const hv4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(p0));
-          const hv4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(p0 + ROWB));
-          h8 a;
-          a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3];
-          a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
-          acc[nl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[pr], acc[nl], 0, 0, 0);
-        }
-        pin_vmem();
+        h8 a;
+        a[0] = va[j][0]; a[1] = va[j][1]; a[2] = va[j][2]; a[3] = va[j][3];
+        a[4] = vb[j][0]; a[5] = vb[j][1]; a[6] = vb[j][2]; a[7] = vb[j][3];
+        acc[nl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[pr], acc[nl], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       });
       DI_TS();
 #pragma unroll
@@ -429,7 +447,6 @@ int launch_local_attn_mfma3(const void *q, const void *k, const void *v, void *o
     case 0: return m3::launch<m3::Cfg<2, 4, 4, 3>>(q, k, v, out, n, H, W, scale, 1, stream);
     case 1: return m3::launch<m3::Cfg<2, 4, 4, 3, 6>>(q, k, v, out, n, H, W, scale, 1, stream);
     case 2: return m3::launch<m3::Cfg<2, 4, 4, 3, 4>>(q, k, v, out, n, H, W, scale, 1, stream);
-    case 3: return m3::launch<m3::Cfg<2, 4, 8, 4>>(q, k, v, out, n, H, W, scale, 1, stream);
   }
   set_error("unknown local_attn_mfma3 configuration %d", cfg);
   return DI_ERR_ARG;
