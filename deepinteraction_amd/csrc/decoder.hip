@@ -304,6 +304,131 @@ __global__ __launch_bounds__(256) void mha_decode_combine_kernel(const float *__
   out[((size_t)b * Q + qi) * Hh * kHD + h * kHD + d] = (T)(O / L);
 }
 
+
+// ---------------------------------------------------------------------------------
+// fp16 matrix-core form of pass 1 (head dim 16): grid (chunks of 256 keys, B); the workgroup stages the
+// chunk's K and V rows of ALL heads in LDS ([head][key][K16 | V16], 64 B rows, coalesced 512-B key rows
+// from HBM); wavefront w owns head w and walks the query groups of 16:
+//   S^T = K . Q^T   one 16x16x16 MFMA per 16-key tile (A = K rows from LDS, B = Q^T from global),
+//   softmax state of the chunk per query = per lane column (two cross-row exchanges),
+//   O^T = V^T . P^T with the exp registers as B operand and V^T from ds_read_b64_tr_b16.
+// Same partial-state layout as the scalar kernel; pass 2 (combine4) spreads a query's chunks over the 64
+// lanes of a wavefront.
+namespace mh {
+constexpr int KC = 256;       // keys per workgroup
+constexpr int NT16 = KC / 16; // 16-key tiles
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float f4 __attribute__((ext_vector_type(4)));
+}  // namespace mh
+
+__global__ __launch_bounds__(512) void mha_decode_mfma_kernel(const __half *__restrict__ q,
+                                                              const __half *__restrict__ kv,
+                                                              float *__restrict__ part, int B, int Q, int S,
+                                                              int Hh, float scale) {
+  using namespace mh;
+  extern __shared__ __align__(16) unsigned char lds[];   // Hh * KC * 64 bytes
+  // grid (chunks, query splits, B): the splits of a chunk stage the same keys (second one hits L2) and
+  // share its query groups, so that the launch fills all CUs
+  const int chunk = blockIdx.x, b = blockIdx.z, nchunk = gridDim.x;
+  const int E = Hh * kHD;
+  const int s0 = chunk * KC;
+  const int ns = min(KC, S - s0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  // stage: 16-B piece p of a key row: p>>4 = K|V, (p>>1)&(Hh-1)... = head, p&1 = half of the head's 16 dims
+  const int ppk = 4 * Hh;                                // pieces per key row (2E halfs / 8)
+  for (int e = tid; e < KC * ppk; e += blockDim.x) {
+    const int key = e / ppk, p = e - key * ppk;
+    const int isv = p / (2 * Hh), hh = (p >> 1) % Hh, half8 = p & 1;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (key < ns) val = *reinterpret_cast<const uint4 *>(kv + ((size_t)b * S + s0 + key) * 2 * E + p * 8);
+    *reinterpret_cast<uint4 *>(lds + ((hh * KC + key) * 64 + isv * 32 + half8 * 16)) = val;
+  }
+  __syncthreads();
+  const int nqg = (Q + 15) / 16;
+  for (int h = wave; h < Hh; h += (int)(blockDim.x >> 6)) {
+    const unsigned char *hb = lds + (size_t)h * KC * 64;
+    for (int qg = blockIdx.y; qg < nqg; qg += gridDim.y) {
+      const int qi = qg * 16 + i;
+      const int qc = qi < Q ? qi : Q - 1;
+      const h4 qf = *reinterpret_cast<const h4 *>(q + ((size_t)b * Q + qc) * E + h * kHD + 4 * g);
+      f4 sc[NT16];
+      float m = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < NT16; ++t) {
+        const h4 kf = *reinterpret_cast<const h4 *>(hb + (16 * t + i) * 64 + g * 8);
+        f4 c = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = (16 * t + 4 * g + r < ns) ? c[r] * scale : -INFINITY;   // key row 4g + r of the tile
+          c[r] = x;
+          m = fmaxf(m, x);
+        }
+        sc[t] = c;
+      }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float l = 0.f;
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < NT16; ++t) {
+        h4 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(sc[t][r] - m);
+          l += e;
+          pf[r] = (_Float16)e;
+        }
+        const hv4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (hv4 __attribute__((address_space(3))) *)(hb + (16 * t + 4 * g + (i >> 2)) * 64 + 32 + (i & 3) * 8));
+        h4 vf;
+        vf[0] = vt[0]; vf[1] = vt[1]; vf[2] = vt[2]; vf[3] = vt[3];
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, acc, 0, 0, 0);
+      }
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      if (qi < Q) {
+        float *dst = part + ((((size_t)b * Hh + h) * nchunk + chunk) * Q + qi) * (kHD + 2);
+        if (g == 0) {
+          dst[0] = m;
+          dst[1] = l;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[2 + 4 * g + r] = acc[r];   // O^T[dim 4g + r][query i]
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mha_decode_combine4_kernel(const float *__restrict__ part,
+                                                                  T *__restrict__ out, int B, int Q, int Hh,
+                                                                  int nchunk) {
+  // one wavefront per (b, h, q): lane = (chunk slice cs of 4, head channel d)
+  const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= B * Hh * Q) return;
+  const int lane = threadIdx.x & 63, d = lane & 15, cs = lane >> 4;
+  const int qi = w % Q, h = (w / Q) % Hh, b = w / (Q * Hh);
+  const float *base = part + (((size_t)b * Hh + h) * nchunk) * Q * (kHD + 2) + (size_t)qi * (kHD + 2);
+  float M = -INFINITY;
+  for (int c = cs; c < nchunk; c += 4) M = fmaxf(M, base[(size_t)c * Q * (kHD + 2)]);
+  M = fmaxf(M, __shfl_xor(M, 16));
+  M = fmaxf(M, __shfl_xor(M, 32));
+  float L = 0.f, O = 0.f;
+  for (int c = cs; c < nchunk; c += 4) {
+    const float *p = base + (size_t)c * Q * (kHD + 2);
+    const float wgt = __expf(p[0] - M);
+    L += p[1] * wgt;
+    O += p[2 + d] * wgt;
+  }
+  L += __shfl_xor(L, 16);
+  L += __shfl_xor(L, 32);
+  O += __shfl_xor(O, 16);
+  O += __shfl_xor(O, 32);
+  if (cs == 0) out[((size_t)b * Q + qi) * Hh * kHD + h * kHD + d] = (T)(O / L);
+}
+
 }  // namespace di
 
 extern "C" {
@@ -359,7 +484,7 @@ int di_roi_align_fwd(const void *feat, const float *rois, void *out, int R, int 
 }
 
 int di_mha_decode_scratch_floats(int B, int Q, int S, int num_heads) {
-  const int nchunk = (S + di::kChunk - 1) / di::kChunk;
+  const int nchunk = (S + di::mh::KC - 1) / di::mh::KC;   // the smaller of the two kernels' chunk sizes
   return B * num_heads * nchunk * Q * (di::kHD + 2);
 }
 
@@ -371,7 +496,26 @@ int di_mha_decode_fwd(const void *q, const void *kv, void *out, float *scratch, 
   const dim3 g1(nchunk, num_heads, B), blk(256);
   const dim3 g2((B * num_heads * Q + 15) / 16);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == DI_F16) {
+  if (dtype == DI_F16 && num_heads * di::mh::KC * 64 <= 160 * 1024) {
+    // matrix-core path: all heads of a 256-key chunk per workgroup
+    const int nc = (S + di::mh::KC - 1) / di::mh::KC;
+    const int lds = num_heads * di::mh::KC * 64;
+    static bool attr_set = false;   // idempotent; a race only repeats the call
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void *)di::mha_decode_mfma_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) {
+        di::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return DI_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+    const int qsplit = nc * B >= 200 ? 1 : (nc * B >= 100 ? 2 : 4);
+    hipLaunchKernelGGL(di::mha_decode_mfma_kernel, dim3(nc, qsplit, B), dim3(512), lds, s, (const __half *)q,
+                       (const __half *)kv, scratch, B, Q, S, num_heads, scale);
+    hipLaunchKernelGGL(di::mha_decode_combine4_kernel<__half>, dim3((B * num_heads * Q + 3) / 4), blk, 0, s,
+                       scratch, (__half *)out, B, Q, num_heads, nc);
+  } else if (dtype == DI_F16) {
     hipLaunchKernelGGL(di::mha_decode_partial_kernel<__half>, g1, blk, 0, s, (const __half *)q,
                        (const __half *)kv, scratch, B, Q, S, num_heads, scale);
     hipLaunchKernelGGL(di::mha_decode_combine_kernel<__half>, g2, blk, 0, s, scratch, (__half *)out, B, Q,
