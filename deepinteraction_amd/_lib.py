@@ -25,6 +25,10 @@ SIGNATURES = {
     'di_locatt_weighting_bwd_weight': [_c_p] * 3 + [_c_i] * 7 + [_c_p],
     'di_pointwise_chain_fwd': [_c_p] * 8 + [ctypes.c_longlong] + [_c_i] * 4 + [_c_p],
     'di_i2p_attn_fwd': [_c_p] * 9 + [_c_i] * 9 + [_c_f, _c_f, _c_i, _c_p],
+    'di_i2p_attn_fwd_ex': [_c_p] * 9 + [_c_i] * 9 + [_c_f, _c_f, _c_f, ctypes.c_ulonglong, _c_i, _c_p],
+    'di_i2p_attn_bwd': [_c_p] * 10 + [_c_i] * 9 + [_c_f, _c_f, _c_f, ctypes.c_ulonglong, _c_i, _c_p],
+    'di_bevwarp_gather_bwd': [_c_p] * 8 + [_c_i] * 7 + [_c_p],
+    'di_roi_align_bwd': [_c_p] * 3 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
     'di_depth_scatter': [_c_p, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_p],
     'di_depth_complete': [_c_p] * 4 + [_c_i] * 3 + [_c_p],
     'di_bevwarp_gather_fwd': [_c_p] * 8 + [_c_i] * 7 + [_c_p],

@@ -1,0 +1,62 @@
+"""torch.autograd bindings of the gather operators (training step).
+
+Forward = the inference kernels; backward = the float32-atomic scatter kernels of csrc/backward.hip.  Only
+feature maps receive gradients: sampling coordinates are functions of points, metas and detached box
+predictions, exactly as in the reference (F.grid_sample's grid at encoder_utils.py:195,:297 is built from
+data; the RoI boxes come from deep-copied, decoded predictions, decoder_utils.py:672-679)."""
+import torch
+
+from . import ops
+
+
+class BEVWarpGather(torch.autograd.Function):
+    """warped = bilinear(bev, unproject(depth)) masked to pc_range  (encoder_utils.py:183-196)."""
+
+    @staticmethod
+    def forward(ctx, bev, depth, img2lidar, aug_fwd, xs, ys, pc_range):
+        ctx.save_for_backward(depth, img2lidar, aug_fwd, xs, ys, pc_range)
+        ctx.bev_hw, ctx.bev_dtype = tuple(bev.shape[-2:]), bev.dtype
+        return ops.bevwarp_gather(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        depth, img2lidar, aug_fwd, xs, ys, pc_range = ctx.saved_tensors
+        g = ops.bevwarp_gather_bwd(grad_out, depth, img2lidar, aug_fwd, xs, ys, pc_range, ctx.bev_hw)
+        return g.to(ctx.bev_dtype), None, None, None, None, None, None
+
+
+class RoIAlign(torch.autograd.Function):
+    """detectron2 ROIAlign(7x7, ratio 2, aligned) on channels-last maps, output (R,49,C)."""
+
+    @staticmethod
+    def forward(ctx, feat, rois, spatial_scale):
+        ctx.save_for_backward(rois)
+        ctx.shape, ctx.dtype, ctx.scale = tuple(feat.shape), feat.dtype, float(spatial_scale)
+        return ops.roi_align(feat, rois, spatial_scale)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (rois,) = ctx.saved_tensors
+        g = ops.roi_align_bwd(grad_out, rois, ctx.shape, ctx.scale)
+        return g.to(ctx.dtype), None, None
+
+
+class I2PAttention(torch.autograd.Function):
+    """ctx[cell] = sum_j softmax_j(<qfold[cell], s_j>) s_j over the pillar's valid image keys
+    (encoder_utils.py:257-320 with the single-head attention folded, see MMRI_I2P)."""
+
+    @staticmethod
+    def forward(ctx, img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p, seed):
+        ctx.save_for_backward(img, qfold, pillars, coors, num_points, proj, aug_rev)
+        ctx.ori_hw, ctx.dropout_p, ctx.seed = ori_hw, float(dropout_p), int(seed)
+        out, valid = ops.i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p,
+                                       seed)
+        ctx.mark_non_differentiable(valid)
+        return out, valid
+
+    @staticmethod
+    def backward(ctx, grad_ctx, _grad_valid):
+        img, qfold, pillars, coors, num_points, proj, aug_rev = ctx.saved_tensors
+        g_img, g_q = ops.i2p_attention_bwd(img, qfold, grad_ctx, pillars, coors, num_points, proj, aug_rev,
+                                           ctx.ori_hw, ctx.dropout_p, ctx.seed)
+        return g_img.to(img.dtype), g_q.to(qfold.dtype), None, None, None, None, None, None, None, None

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void i2p_attn_fwd_kernel(
     const int32_t *__restrict__ coors, const int32_t *__restrict__ num_points,
     const float *__restrict__ proj, const float *__restrict__ aug, T *__restrict__ ctx,
     T *__restrict__ valid_out, int P, int Tp, int D, int V, int Hi, int Wi, int Hb, int Wb, int C,
-    float ori_H, float ori_W) {
+    float ori_H, float ori_W, float drop_p, unsigned long long seed) {
   __shared__ KeyEnt s_list[4][kMaxSlots];
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
   const int l16 = lane & 15, sub = lane >> 4;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void i2p_attn_fwd_kernel(
         const int rank = count + __popcll(mask & ((1ull << lane) - 1ull));
         list[rank].ix = ix;
         list[rank].iy = iy;
-        list[rank].cam = cam;
+        list[rank].cam = slot;          // the slot id: camera = slot % V, and the dropout hash key
       }
       count += __popcll(mask);
     }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void i2p_attn_fwd_kernel(
       float s8[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) s8[i] = 0.f;
-      if (ch_ok) bilinear8(img + (size_t)k.cam * Hi * Wi * C, Hi, Wi, C, k.ix, k.iy, ch0, s8);
+      if (ch_ok) bilinear8(img + (size_t)(k.cam % V) * Hi * Wi * C, Hi, Wi, C, k.ix, k.iy, ch0, s8);
       float part = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) part = fmaf(qf[i], s8[i], part);
@@ -167,8 +167,11 @@ __global__ __launch_bounds__(256) void i2p_attn_fwd_kernel(
       const float a = __expf(m - mn);  // first key: exp(-inf) = 0
       const float pe = __expf(sc - mn);
       l = l * a + pe;
+      // attention dropout (training, nn.MultiheadAttention dropout on the probabilities): a dropped key
+      // stays in the softmax denominator, its value term vanishes, kept ones are scaled by 1 / (1 - p)
+      const float pv = drop_p > 0.f ? (di_keep(seed, p, k.cam, drop_p) ? pe / (1.f - drop_p) : 0.f) : pe;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pe * s8[i];
+      for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pv * s8[i];
       m = mn;
     }
     // merge the four groups' online-softmax states (lanes with equal l16)
@@ -277,13 +280,13 @@ template <typename T>
 static int run_i2p(const void *img, const void *qfold, const float *pillars, const int32_t *coors,
                    const int32_t *num_points, const float *proj, const float *aug_rev, void *ctx,
                    void *valid, int P, int Tp, int D, int V, int Hi, int Wi, int Hb, int Wb, int C,
-                   float ori_H, float ori_W, hipStream_t stream) {
+                   float ori_H, float ori_W, float drop_p, unsigned long long seed, hipStream_t stream) {
   if (P == 0) return DI_OK;
   const int blocks = min((P + 3) / 4, 256 * 8);
 #define DI_I2P(FULL)                                                                              \
   hipLaunchKernelGGL((i2p_attn_fwd_kernel<T, FULL>), dim3(blocks), dim3(256), 0, stream,          \
                      (const T *)img, (const T *)qfold, pillars, coors, num_points, proj, aug_rev, \
-                     (T *)ctx, (T *)valid, P, Tp, D, V, Hi, Wi, Hb, Wb, C, ori_H, ori_W)
+                     (T *)ctx, (T *)valid, P, Tp, D, V, Hi, Wi, Hb, Wb, C, ori_H, ori_W, drop_p, seed)
   if (C == 128) DI_I2P(true); else DI_I2P(false);
 #undef DI_I2P
   return check_launch("i2p_attn_fwd");
@@ -308,21 +311,31 @@ static int run_gather(const void *bev, const float *depth, const float *img2lida
 
 extern "C" {
 
+int di_i2p_attn_fwd_ex(const void *img, const void *qfold, const float *pillars, const int32_t *coors,
+                       const int32_t *num_points, const float *proj, const float *aug_rev, void *ctx,
+                       void *valid, int P, int T, int D, int n_views, int Hi, int Wi, int Hb, int Wb,
+                       int C, float ori_H, float ori_W, float dropout_p, unsigned long long seed, int dtype,
+                       void *stream) {
+  DI_REQUIRE(P >= 0 && T > 0 && D >= 3 && n_views > 0, "bad pillar shape P=%d T=%d D=%d V=%d", P, T, D, n_views);
+  DI_REQUIRE(T * n_views <= di::kMaxSlots, "T*n_views=%d exceeds %d key slots", T * n_views, di::kMaxSlots);
+  DI_REQUIRE(C > 0 && C % 8 == 0 && C <= 128, "C=%d must be a multiple of 8, <= 128", C);
+  DI_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p=%f out of [0,1)", (double)dropout_p);
+  if (dtype == DI_F16)
+    return di::run_i2p<__half>(img, qfold, pillars, coors, num_points, proj, aug_rev, ctx, valid, P, T,
+                               D, n_views, Hi, Wi, Hb, Wb, C, ori_H, ori_W, dropout_p, seed, (hipStream_t)stream);
+  if (dtype == DI_F32)
+    return di::run_i2p<float>(img, qfold, pillars, coors, num_points, proj, aug_rev, ctx, valid, P, T,
+                              D, n_views, Hi, Wi, Hb, Wb, C, ori_H, ori_W, dropout_p, seed, (hipStream_t)stream);
+  di::set_error("unsupported dtype %d", dtype);
+  return DI_ERR_ARG;
+}
+
 int di_i2p_attn_fwd(const void *img, const void *qfold, const float *pillars, const int32_t *coors,
                     const int32_t *num_points, const float *proj, const float *aug_rev, void *ctx,
                     void *valid, int P, int T, int D, int n_views, int Hi, int Wi, int Hb, int Wb,
                     int C, float ori_H, float ori_W, int dtype, void *stream) {
-  DI_REQUIRE(P >= 0 && T > 0 && D >= 3 && n_views > 0, "bad pillar shape P=%d T=%d D=%d V=%d", P, T, D, n_views);
-  DI_REQUIRE(T * n_views <= di::kMaxSlots, "T*n_views=%d exceeds %d key slots", T * n_views, di::kMaxSlots);
-  DI_REQUIRE(C > 0 && C % 8 == 0 && C <= 128, "C=%d must be a multiple of 8, <= 128", C);
-  if (dtype == DI_F16)
-    return di::run_i2p<__half>(img, qfold, pillars, coors, num_points, proj, aug_rev, ctx, valid, P, T,
-                               D, n_views, Hi, Wi, Hb, Wb, C, ori_H, ori_W, (hipStream_t)stream);
-  if (dtype == DI_F32)
-    return di::run_i2p<float>(img, qfold, pillars, coors, num_points, proj, aug_rev, ctx, valid, P, T,
-                              D, n_views, Hi, Wi, Hb, Wb, C, ori_H, ori_W, (hipStream_t)stream);
-  di::set_error("unsupported dtype %d", dtype);
-  return DI_ERR_ARG;
+  return di_i2p_attn_fwd_ex(img, qfold, pillars, coors, num_points, proj, aug_rev, ctx, valid, P, T, D, n_views,
+                            Hi, Wi, Hb, Wb, C, ori_H, ori_W, 0.f, 0ull, dtype, stream);
 }
 
 int di_depth_scatter(const float *pts, int n_pts, int pt_stride, const float *proj,

@@ -139,6 +139,16 @@ __device__ __forceinline__ float row16_max(float x) {
   return x;
 }
 
+// Attention dropout of the pillar attention (training): keep/drop decision of key slot `slot` of pillar `p`,
+// a counter-based hash of (seed, p, slot) so that forward and backward regenerate the same mask.
+__device__ __forceinline__ bool di_keep(unsigned long long seed, int p, int slot, float drop_p) {
+  unsigned long long x = seed + (((unsigned long long)(unsigned)p << 8) | (unsigned)slot);
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27; x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return (float)(x >> 40) * (1.f / 16777216.f) >= drop_p;
+}
+
 // XCD-aware block remap: the dispatcher round-robins consecutive block ids over the
 // 8 XCDs (private L2 each); give every XCD one contiguous chunk of the tile list so
 // neighbouring tiles (which share halo texels) hit the same L2.  Bijective for any n.

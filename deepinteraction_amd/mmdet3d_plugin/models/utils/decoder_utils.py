@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import ops
+from ....autograd import RoIAlign
 from ....geometry import aug_affine
 from ....utils import param_key
 
@@ -75,7 +76,7 @@ class PositionEmbeddingLearned(nn.Module):
 
     def tokens(self, xyz, out_dtype):
         """xyz (B,P,k) -> (B,P,C) in `out_dtype`."""
-        if self.training:
+        if self.training or torch.is_grad_enabled():
             return self.forward(xyz.to(self.position_embedding_head[0].weight.dtype)).transpose(1, 2).to(out_dtype)
         c1, bn, _, c2 = self.position_embedding_head
         key = param_key(self)
@@ -163,7 +164,7 @@ class TransformerDecoderLayer(nn.Module):
         """cross_posembed(key_pos) as tokens (B,Pk,C).  The BEV grid is constant, so at
         inference the embedding is computed once and reused (the reference recomputes the
         32 400-token Conv1d stack on every call)."""
-        if self.training:
+        if self.training or torch.is_grad_enabled():
             return self.cross_posembed.tokens(key_pos, dtype)
         key = (key_pos.data_ptr(), key_pos.shape, dtype, param_key(self.cross_posembed))
         if self._kpe_cache is None or self._kpe_cache[0] != key:
@@ -192,7 +193,17 @@ class TransformerDecoderLayer(nn.Module):
         if x.is_cuda and not (torch.is_grad_enabled() and (q.requires_grad or kv.requires_grad)):
             o = ops.mha_decode(q, kv, ca.num_heads, float(ca.head_dim) ** -0.5)
         else:
-            raise NotImplementedError('HIP cross attention implements the inference form only')
+            # training: the (B,H,Q,32400) score tensor is materialised, as in the reference (:471-485),
+            # through library GEMMs and their autograd
+            Bq, Lq, _ = q.shape
+            H, D = ca.num_heads, ca.head_dim
+            qh = q.view(Bq, Lq, H, D).transpose(1, 2) * (float(D) ** -0.5)
+            kh = kv[..., :E].reshape(Bq, -1, H, D).transpose(1, 2)
+            vh = kv[..., E:].reshape(Bq, -1, H, D).transpose(1, 2)
+            a = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)).float(), -1).to(vh.dtype)
+            if self.training and ca.dropout > 0:
+                a = F.dropout(a, ca.dropout)
+            o = torch.matmul(a, vh).transpose(1, 2).reshape(Bq, Lq, E)
         x = self.norm2(x + self.dropout2(ca.out_proj(o)))
         x = self.norm3(x + self.dropout3(self.linear2(self.dropout(self.activation(self.linear1(x))))))
         return x.transpose(1, 2)
@@ -258,7 +269,7 @@ class FFN(nn.Module):
         return out
 
     def forward(self, x):
-        if self.training or not self._fusable():
+        if self.training or torch.is_grad_enabled() or not self._fusable():
             return {h: self.__getattr__(h)(x) for h in self.heads}
         W1, b1, W2, b2, sizes = self.folded()
         t = x.float().transpose(1, 2)                                      # (B,Q,Cin)
@@ -335,6 +346,13 @@ class QueryGeometry:
         self._buf.copy_(host, non_blocking=True)
 
 
+def _roi_align(feat, rois, scale):
+    """RoIAlign; with autograd w.r.t. the feature maps when they need a gradient (training)."""
+    if torch.is_grad_enabled() and feat.requires_grad:
+        return RoIAlign.apply(feat, rois.detach(), scale)
+    return ops.roi_align(feat, rois, scale)
+
+
 class _RCNNBase(nn.Module):
     def _stack(self, x, roi, sfx, key_allowed=None):
         """decoder_utils.py:743-756 / :824-837 on tokens x (B,Q,C): self-attn + LN, DynamicConv + LN,
@@ -395,8 +413,11 @@ class ImageRCNNBlock(_RCNNBase):
         maps = img_feat_flatten.reshape(B * V, C, img_h, img_w)
         idx = (torch.arange(B, device=rect.device).view(B, 1) * V + lastc).to(torch.float32).unsqueeze(-1)
         rois = torch.cat([idx, rect_q], -1).view(-1, 5)
-        roi = ops.roi_align(maps, rois, 1.0 / self.out_size_factor_img)          # (B*Q, 49, C)
+        roi = _roi_align(maps, rois, 1.0 / self.out_size_factor_img)             # (B*Q, 49, C)
         key_allowed = sel.gather(1, lastc.view(B, Q, 1).expand(B, Q, Q))         # [b,q,k] = sel[b, v*(q), k]
+        # queries no camera sees are discarded below; give them every key so that their softmax rows (and
+        # the gradients flowing through the shared GEMMs in training) stay finite
+        key_allowed = key_allowed | (last < 0).unsqueeze(-1)
         x = self._stack(query_feat.transpose(1, 2), roi, '', key_allowed=key_allowed)        # (B,Q,C)
         out = torch.where((last >= 0).unsqueeze(-1), x, torch.zeros_like(x))     # unseen queries: 0 (:665)
         return out.transpose(1, 2), last.to(torch.float32)
@@ -427,6 +448,6 @@ class PointRCNNBlock(_RCNNBase):
         _, _, rect = ops.query_geometry(res32, None, None, None, cell, bc.pc_range[:2], cell, 2.0, False, True)
         idx = torch.arange(B, device=rect.device, dtype=torch.float32).view(B, 1, 1).expand(B, Q, 1)
         rois = torch.cat([idx, rect], -1).view(-1, 5)
-        roi = ops.roi_align(new_lidar_feat, rois, 1.0)                          # (B*Q, 49, C)
+        roi = _roi_align(new_lidar_feat, rois, 1.0)                             # (B*Q, 49, C)
         x = self._stack(query_feat.transpose(1, 2), roi, '_pts')
         return x.transpose(1, 2), None

@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import ops
+from ....autograd import BEVWarpGather, I2PAttention
 from ....geometry import SampleGeometry
 from ....utils import param_key
 
@@ -48,7 +49,7 @@ class ConvBNReLU(nn.Module):
         self._fold_cache = None
 
     def forward(self, x):
-        if not self.training and self.conv.kernel_size == (1, 1) and x.is_cuda:
+        if not self.training and not torch.is_grad_enabled() and self.conv.kernel_size == (1, 1) and x.is_cuda:
             return pointwise(self, x)
         x = self.conv(x)
         if self.use_norm:
@@ -126,7 +127,7 @@ def mix2(proj1, a, b, proj2, c):
         w2, _, b2 = proj2.folded(a.dtype)
         return ops.pointwise_chain(a, w1, b1, proj1.use_activation, x2=b, w2=w2, b2=b2,
                                    relu2=proj2.use_activation, x3=c)
-    if not proj1.training and a.is_cuda:
+    if not proj1.training and not torch.is_grad_enabled() and a.is_cuda:
         return pointwise(proj2, pointwise(proj1, a, b), c)
     return proj2(torch.cat((proj1(torch.cat((a, b), dim=1)), c), dim=1))
 
@@ -239,8 +240,12 @@ class BEVWarp(nn.Module):
         for b in range(B):
             geom = sample_geometry(img_metas, pts_metas, b, (I_H, I_W), lidar_feats.device)
             depth = self.dense_depth(geom, pts_metas['pts'][b], I_H, I_W, pts_metas, b)
-            out.append(ops.bevwarp_gather(lidar_feats[b:b + 1], depth, geom.img2lidar, geom.aug_fwd,
-                                          geom.xs, geom.ys, geom.pc_range))
+            if torch.is_grad_enabled() and lidar_feats.requires_grad:       # training: d(warped)/d(bev)
+                out.append(BEVWarpGather.apply(lidar_feats[b:b + 1], depth, geom.img2lidar, geom.aug_fwd,
+                                               geom.xs, geom.ys, geom.pc_range))
+            else:
+                out.append(ops.bevwarp_gather(lidar_feats[b:b + 1], depth, geom.img2lidar, geom.aug_fwd,
+                                              geom.xs, geom.ys, geom.pc_range))
         return out[0].unsqueeze(0) if B == 1 else torch.stack(out, 0)
 
 
@@ -302,14 +307,34 @@ class MMRI_I2P(nn.Module):
         self._fold_cache = (key, out)
         return out
 
+    def folded_live(self, dtype):
+        """The same folding as `folded`, inside autograd (training: gradients reach the MHA parameters).
+        The dropped <q, bk> term shifts all scores of a pillar equally: its gradient is exactly zero in
+        the reference too."""
+        la = self.learnedAlign
+        if la._qkv_same_embed_dim:
+            wq, wk, wv = la.in_proj_weight.chunk(3, 0)
+        else:
+            wq, wk, wv = la.q_proj_weight, la.k_proj_weight, la.v_proj_weight
+        bq, _, bv = la.in_proj_bias.chunk(3, 0)
+        s = 1.0 / math.sqrt(self.pts_channels)
+        w_qk = (wk.t() @ wq) * s
+        b_qk = (wk.t() @ bq) * s
+        w_ov = la.out_proj.weight @ wv
+        b_ov = la.out_proj.weight @ bv + la.out_proj.bias
+        return tuple(t.to(dtype) for t in (w_qk, b_qk, w_ov, b_ov))
+
     def forward(self, lidar_feat, img_feat, img_metas, pts_metas, **kwargs):
-        if self.training and self.dropout > 0:
-            raise NotImplementedError('HIP MMRI_I2P implements the inference form (attention dropout inactive)')
         B = len(img_metas)
         lidar_feat = ops.cl(lidar_feat)
         _, C, Hb, Wb = lidar_feat.shape
         _, V, Ci, Hi, Wi = img_feat.shape
-        w_qk, b_qk, w_ov, b_ov = self.folded(lidar_feat.dtype)
+        live = torch.is_grad_enabled()
+        w_qk, b_qk, w_ov, b_ov = self.folded_live(lidar_feat.dtype) if live else self.folded(lidar_feat.dtype)
+        # attention dropout (nn.MultiheadAttention(dropout) acts on the probabilities, training only):
+        # decided per (pillar, key slot) by a counter-based hash of a fresh seed, regenerated in backward
+        drop = float(self.dropout) if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop > 0 else 0
         flat = lidar_feat.permute(0, 2, 3, 1).reshape(-1, C)
         qfold = F.linear(flat, w_qk, b_qk).view(B, Hb, Wb, Ci).permute(0, 3, 1, 2)   # channels-last
         bounds = pillar_batch_bounds(pts_metas, B)
@@ -317,9 +342,9 @@ class MMRI_I2P(nn.Module):
         for b in range(B):
             s, e = bounds[b], bounds[b + 1]
             geom = sample_geometry(img_metas, pts_metas, b, (Hi, Wi), lidar_feat.device)
-            ctx, valid = ops.i2p_attention(img_feat[b], qfold[b:b + 1], pts_metas['pillars'][s:e],
-                                           pts_metas['pillar_coors'][s:e], pts_metas['pillars_num_points'][s:e],
-                                           geom.lidar2img, geom.aug_rev, geom.ori_hw)
+            args = (img_feat[b], qfold[b:b + 1], pts_metas['pillars'][s:e], pts_metas['pillar_coors'][s:e],
+                    pts_metas['pillars_num_points'][s:e], geom.lidar2img, geom.aug_rev, geom.ori_hw, drop, seed + b)
+            ctx, valid = I2PAttention.apply(*args) if live else ops.i2p_attention(*args)
             o = F.linear(ctx.permute(0, 2, 3, 1).reshape(-1, Ci), w_ov, b_ov)
             o = o * valid.reshape(-1, 1)                                         # empty pillars / cells stay 0
             outs.append(o.view(1, Hb, Wb, C).permute(0, 3, 1, 2))

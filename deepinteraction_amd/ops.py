@@ -164,7 +164,7 @@ def pointwise_chain(x1, w1, b1, relu1, x2=None, w2=None, b2=None, relu2=False, x
 
 
 # ------------------------------------------------------------------ image -> BEV
-def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw):
+def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p=0.0, seed=0):
     """One sample.  img (V,C,Hi,Wi), qfold (1,C,Hb,Wb) channels-last; pillars (P,T,D) f32,
     coors (P,4) i32, num_points (P,) i32, proj (V,4,4) f32, aug_rev (12,) f32.
     Returns ctx (1,C,Hb,Wb) and valid (1,1,Hb,Wb) (same dtype as img)."""
@@ -179,10 +179,31 @@ def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw)
     assert proj.dtype == torch.float32 and proj.is_contiguous() and aug_rev.dtype == torch.float32
     ctx = zeros_cl(1, C, Hb, Wb, img)
     valid = torch.zeros((1, 1, Hb, Wb), dtype=img.dtype, device=img.device)
-    _lib.call('di_i2p_attn_fwd', img.data_ptr(), qfold.data_ptr(), pillars.data_ptr(), coors.data_ptr(),
+    _lib.call('di_i2p_attn_fwd_ex', img.data_ptr(), qfold.data_ptr(), pillars.data_ptr(), coors.data_ptr(),
               num_points.data_ptr(), proj.data_ptr(), aug_rev.data_ptr(), ctx.data_ptr(), valid.data_ptr(),
-              P, T, D, V, Hi, Wi, Hb, Wb, C, float(ori_hw[0]), float(ori_hw[1]), _code(img), _stream())
+              P, T, D, V, Hi, Wi, Hb, Wb, C, float(ori_hw[0]), float(ori_hw[1]), float(dropout_p), int(seed),
+              _code(img), _stream())
     return ctx, valid
+
+
+def i2p_attention_bwd(img, qfold, grad_ctx, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p=0.0,
+                      seed=0):
+    """Gradients of i2p_attention w.r.t. img (V,C,Hi,Wi) and qfold (1,C,Hb,Wb): float32, channels-last."""
+    _dev(img, qfold, grad_ctx)
+    img, qfold = cl(img), cl(qfold)
+    grad_ctx = cl(grad_ctx.to(img.dtype))
+    V, C, Hi, Wi = img.shape
+    _, _, Hb, Wb = qfold.shape
+    P, T, D = pillars.shape
+    g_img = torch.zeros((V, C, Hi, Wi), dtype=torch.float32, device=img.device).contiguous(
+        memory_format=torch.channels_last)
+    g_q = torch.zeros((1, C, Hb, Wb), dtype=torch.float32, device=img.device).contiguous(
+        memory_format=torch.channels_last)
+    _lib.call('di_i2p_attn_bwd', img.data_ptr(), qfold.data_ptr(), grad_ctx.data_ptr(), pillars.data_ptr(),
+              coors.data_ptr(), num_points.data_ptr(), proj.data_ptr(), aug_rev.data_ptr(), g_img.data_ptr(),
+              g_q.data_ptr(), P, T, D, V, Hi, Wi, Hb, Wb, C, float(ori_hw[0]), float(ori_hw[1]), float(dropout_p),
+              int(seed), _code(img), _stream())
+    return g_img, g_q
 
 
 # ------------------------------------------------------------------ BEV -> image
@@ -224,6 +245,20 @@ def bevwarp_gather(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range):
               aug_fwd.data_ptr(), xs.data_ptr(), ys.data_ptr(), pc_range.data_ptr(), out.data_ptr(), V, Hi,
               Wi, Hb, Wb, C, _code(bev), _stream())
     return out
+
+
+def bevwarp_gather_bwd(grad_out, depth, img2lidar, aug_fwd, xs, ys, pc_range, bev_hw):
+    """Gradient of bevwarp_gather w.r.t. the BEV map: (1,C,Hb,Wb) float32, channels-last."""
+    _dev(grad_out, depth)
+    grad_out = cl(grad_out)
+    V, C, Hi, Wi = grad_out.shape
+    Hb, Wb = bev_hw
+    g = torch.zeros((1, C, Hb, Wb), dtype=torch.float32, device=grad_out.device).contiguous(
+        memory_format=torch.channels_last)
+    _lib.call('di_bevwarp_gather_bwd', grad_out.data_ptr(), depth.data_ptr(), img2lidar.data_ptr(),
+              aug_fwd.data_ptr(), xs.data_ptr(), ys.data_ptr(), pc_range.data_ptr(), g.data_ptr(), V, Hi, Wi, Hb,
+              Wb, C, _code(grad_out), _stream())
+    return g
 
 
 # ------------------------------------------------------------------ MMPI decoder
@@ -272,6 +307,19 @@ def roi_align(feat, rois, spatial_scale):
     _lib.call('di_roi_align_fwd', feat.data_ptr(), rois.data_ptr(), out.data_ptr(), R, N, H, W, C,
               float(spatial_scale), _code(feat), _stream())
     return out
+
+
+def roi_align_bwd(grad_out, rois, feat_shape, spatial_scale):
+    """Gradient of roi_align w.r.t. the feature maps: grad_out (R,49,C) -> (N,C,H,W) float32, channels-last."""
+    _dev(grad_out, rois)
+    grad_out = grad_out.contiguous()
+    N, C, H, W = feat_shape
+    R = rois.shape[0]
+    g = torch.zeros((N, C, H, W), dtype=torch.float32, device=grad_out.device).contiguous(
+        memory_format=torch.channels_last)
+    _lib.call('di_roi_align_bwd', grad_out.data_ptr(), rois.contiguous().data_ptr(), g.data_ptr(), R, N, H, W, C,
+              float(spatial_scale), _code(grad_out), _stream())
+    return g
 
 
 def mha_decode(q, kv, num_heads, scale):

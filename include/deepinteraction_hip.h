@@ -114,6 +114,23 @@ int di_i2p_attn_fwd(const void *img, const void *qfold, const float *pillars, co
                     void *valid, int P, int T, int D, int n_views, int Hi, int Wi, int Hb, int Wb,
                     int C, float ori_H, float ori_W, int dtype, void *stream);
 
+/* Training form: attention dropout on the probabilities (nn.MultiheadAttention(dropout=0.1), encoder_utils.py:
+ * 223-224): key (pillar, slot) is dropped with probability dropout_p, decided by a counter-based hash of
+ * (seed, pillar, slot) that the backward regenerates; dropped keys stay in the softmax denominator. */
+int di_i2p_attn_fwd_ex(const void *img, const void *qfold, const float *pillars, const int32_t *coors,
+                       const int32_t *num_points, const float *proj, const float *aug_rev, void *ctx,
+                       void *valid, int P, int T, int D, int n_views, int Hi, int Wi, int Hb, int Wb,
+                       int C, float ori_H, float ori_W, float dropout_p, unsigned long long seed, int dtype,
+                       void *stream);
+/* Backward of the above: grad_ctx (Hb,Wb,C) -> grad_img (n_views,Hi,Wi,C) and grad_qfold (Hb,Wb,C), both
+ * float32, zero-filled by the caller (grad_img is accumulated with atomics).  The sampling coordinates carry
+ * no gradient (points and metas are data). */
+int di_i2p_attn_bwd(const void *img, const void *qfold, const void *grad_ctx, const float *pillars,
+                    const int32_t *coors, const int32_t *num_points, const float *proj, const float *aug_rev,
+                    float *grad_img, float *grad_qfold, int P, int T, int D, int n_views, int Hi, int Wi, int Hb,
+                    int Wb, int C, float ori_H, float ori_W, float dropout_p, unsigned long long seed, int dtype,
+                    void *stream);
+
 /* ---------------------------------------------------------------- BEV -> image gather
  * BEVWarp.forward (encoder_utils.py:142-199) in three steps per sample.
  * (1) project all raw points and scatter camera-z into the feature-resolution sparse
@@ -136,6 +153,12 @@ int di_bevwarp_gather_fwd(const void *bev, const float *depth, const float *img2
                           const float *aug_fwd, const float *xs, const float *ys,
                           const float *pc_range, void *out, int n_views, int Hi, int Wi, int Hb,
                           int Wb, int C, int dtype, void *stream);
+
+/* Backward of (3): grad_out (n_views,Hi,Wi,C) -> grad_bev (Hb,Wb,C) float32, zero-filled by the caller,
+ * accumulated with atomics (the autograd of F.grid_sample at encoder_utils.py:195 w.r.t. its input). */
+int di_bevwarp_gather_bwd(const void *grad_out, const float *depth, const float *img2lidar, const float *aug_fwd,
+                          const float *xs, const float *ys, const float *pc_range, float *grad_bev, int n_views,
+                          int Hi, int Wi, int Hb, int Wb, int C, int dtype, void *stream);
 
 /* ---------------------------------------------------------------- MMPI decoder
  * (1) query initialisation heat map (deepinteraction_decoder.py:225-238):
@@ -163,6 +186,12 @@ int di_query_geometry(const float *center, const float *height, const float *dim
  *     [map index, x0, y0, x1, y1]; out (R,49,C) (bin-major: the (49,q,128) operand of
  *     DynamicConv without the reference's flatten/permute). */
 int di_roi_align_fwd(const void *feat, const float *rois, void *out, int R, int N, int H, int W, int C,
+                     float spatial_scale, int dtype, void *stream);
+
+/* Backward of (3) w.r.t. the feature maps: grad_out (R,49,C) -> grad_feat (N,H,W,C) float32, zero-filled by
+ * the caller, accumulated with atomics (the boxes carry no gradient: they come from detached predictions,
+ * decoder_utils.py:672-679). */
+int di_roi_align_bwd(const void *grad_out, const float *rois, float *grad_feat, int R, int N, int H, int W, int C,
                      float spatial_scale, int dtype, void *stream);
 
 /* (4) multi-head attention core of the decoder layer's 200 x 32400 cross attention

@@ -206,6 +206,9 @@ class ImageRCNNBlock(_RCNNBase):
         prev = query_feat
         out = torch.zeros_like(query_feat)                                                   # :665
         cfg = self.test_cfg
+        # the geometry is built from DETACHED copies of the predictions (:662, :667-679): no gradient
+        # reaches the heads through RoI coordinates
+        res_layer = {k: v.detach() for k, v in res_layer.items()}
         pos = res_layer['center'] * cfg['out_size_factor'] * cfg['voxel_size'][0] + cfg['pc_range'][0]
         pos3d = torch.cat([pos, res_layer['height']], 1)                                     # (B,3,Q) :666-667
         boxes = self.bbox_coder.decode(res_layer['heatmap'], res_layer['rot'], res_layer['dim'],
@@ -259,6 +262,7 @@ class PointRCNNBlock(_RCNNBase):
     def forward(self, query_feat, res_layer, new_lidar_feat, img_feat_flatten, img_metas, img_h, img_w):
         B = query_feat.shape[0]
         out = torch.zeros_like(query_feat)
+        res_layer = {k: v.detach() for k, v in res_layer.items()}                            # :792-803 deep copies of .detach()
         boxes = self.bbox_coder.decode(res_layer['heatmap'], res_layer['rot'], res_layer['dim'],
                                        res_layer['center'], res_layer['height'], res_layer.get('vel'))
         bc = self.bbox_coder
@@ -335,7 +339,7 @@ class DeepInteractionDecoder(nn.Module):
         BN, I_C, I_H, I_W = img_inputs.shape
         dense = self.heatmap_head(lidar_feat)
         dense_img = self.heatmap_head_img(new_lidar_feat)
-        heat = (dense.sigmoid() + dense_img.sigmoid()) / 2                                    # :225
+        heat = (dense.detach().sigmoid() + dense_img.detach().sigmoid()) / 2                  # :225 (detached there too)
         pad = self.nms_kernel_size // 2
         local_max = torch.zeros_like(heat)
         local_max[:, :, pad:-pad, pad:-pad] = F.max_pool2d(heat, self.nms_kernel_size, 1, 0)   # :229-230
@@ -359,12 +363,12 @@ class DeepInteractionDecoder(nn.Module):
             res = self.prediction_heads[i](query_feat)
             res['center'] = res['center'] + query_pos.permute(0, 2, 1)
             first = res
-            query_pos = res['center'].permute(0, 2, 1)
+            query_pos = res['center'].detach().permute(0, 2, 1)                              # :268 .detach().clone()
         img_flat = img_inputs.view(B, self.num_views, I_C, -1)
         self.on_the_image_mask, rets = [], []
         for l in range(self.num_mmpi):
             prev = query_feat.clone()
-            query_pos = res['center'].permute(0, 2, 1)
+            query_pos = res['center'].detach().permute(0, 2, 1)                              # :281 .detach().clone()
             query_feat, on = self.decode_head[l](prev, res, new_lidar_feat, img_flat, img_metas, I_H, I_W)
             res = self.pred_head[l](torch.cat([query_feat, prev], 1))                          # :289
             res['center'] = res['center'] + query_pos.permute(0, 2, 1)

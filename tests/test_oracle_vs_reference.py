@@ -144,3 +144,82 @@ def test_decoder_matches_reference(ref, narrow):
         assert torch.equal(a, b)
     if narrow:
         assert (~R.on_the_image_mask[0]).any()                   # the fallback path was exercised
+
+
+def test_decoder_gradients_match_reference(ref):
+    """Pins the oracle's GRADIENT semantics (where the reference detaches: heat-map proposals :225,
+    next-level query positions :268,:281, RoI geometry decoder_utils.py:662-679,792-803) to the reference's
+    own Python: same random linear functional of all outputs, autograd on both, eval-mode modules
+    (the RoI blocks' stubs are differentiable restatements)."""
+    shape = synth.SHAPE_TINY
+    cfg = configs.decoder_cfg(bev=36, num_proposals=24)
+    torch.manual_seed(7)
+    R = ref.decoder.DeepInteractionDecoder(**cfg)
+    _randomize_bn(R)
+    O = odec.DeepInteractionDecoder(**cfg)
+    O.load_state_dict(R.state_dict())
+    R.eval(), O.eval()
+    g = torch.Generator().manual_seed(0)
+    Hi, Wi = shape['img_hw']
+    base = [torch.randn(1, 128, 36, 36, generator=g), torch.randn(1, 128, 36, 36, generator=g),
+            torch.randn(6, 128, Hi, Wi, generator=g)]
+    metas = synth.make_inputs(1, shape, seed=0)['img_metas']
+    grads = []
+    for M in (R, O):
+        p0, p1, img = (t.clone().requires_grad_(True) for t in base)
+        out = M([p0, p1], img, metas)[0][0]
+        gen = torch.Generator().manual_seed(3)
+        loss = sum((out[k] * torch.randn(out[k].shape, generator=gen)).sum() for k in sorted(out))
+        M.zero_grad()
+        loss.backward()
+        grads.append(([p0.grad, p1.grad, img.grad], {n: p.grad for n, p in M.named_parameters()}))
+    for a, b in zip(*[gr[0] for gr in grads]):
+        assert torch.allclose(a, b, rtol=0, atol=1e-4 * max(1.0, a.abs().max().item())), (a - b).abs().max()
+    n = 0
+    for name, gr in grads[0][1].items():
+        go = grads[1][1][name]
+        if gr is None:
+            assert go is None or go.abs().max().item() == 0.0, name
+            continue
+        assert go is not None, name
+        assert torch.allclose(gr, go, rtol=0, atol=1e-4 * max(1.0, gr.abs().max().item())), (name, (gr - go).abs().max())
+        n += 1
+    assert n > 100
+
+
+def test_encoder_gradients_match_reference(ref):
+    """Gradient pin of the oracle's MMRI encoder: the reference's own Python (its autograd Functions
+    around the compiled reference locatt kernels, F.grid_sample, nn.MultiheadAttention through group_attn)
+    vs the oracle's autograd, eval mode (dropout off), one layer."""
+    shape = synth.SHAPE_TINY
+    inp = synth.make_inputs(1, shape, seed=0)
+    torch.manual_seed(1234)
+    R = ref.encoder.DeepInteractionEncoder(num_layers=1, in_channels_img=shape['c_img'],
+                                           in_channels_pts=shape['c_pts'], hidden_channel=128)
+    _randomize_bn(R)
+    O = oenc.DeepInteractionEncoder(1, shape['c_img'], shape['c_pts'], 128)
+    O.load_state_dict(R.state_dict())
+    R.eval(), O.eval()
+    sparse = oenc.BEVWarp().sparse_depth(inp['pts_metas']['pts'][0], inp['img_metas'][0],
+                                         oenc.lidar2img_tensor(inp['img_metas'], inp['img_feats'])[0], *shape['img_hw'])
+    grads = []
+    for M in (R, O):
+        img = inp['img_feats'].clone().requires_grad_(True)
+        pts = inp['pts_feats'].clone().requires_grad_(True)
+        im, (p0, p1) = M(img, pts, inp['img_metas'], inp['pts_metas'])
+        gen = torch.Generator().manual_seed(4)
+        loss = sum((t * torch.randn(t.shape, generator=gen)).sum() for t in (im, p0, p1))
+        M.zero_grad()
+        loss.backward()
+        grads.append(([img.grad, pts.grad], {n: p.grad for n, p in M.named_parameters()}))
+    for a, b in zip(*[gr[0] for gr in grads]):
+        assert torch.allclose(a, b, rtol=0, atol=2e-5 * max(1.0, a.abs().max().item())), (a - b).abs().max()
+    n = 0
+    for name, gr in grads[0][1].items():
+        go = grads[1][1][name]
+        assert (gr is None) == (go is None), name
+        if gr is None:
+            continue
+        assert torch.allclose(gr, go, rtol=0, atol=5e-5 * max(1.0, gr.abs().max().item())), (name, (gr - go).abs().max())
+        n += 1
+    assert n > 60

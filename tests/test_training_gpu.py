@@ -1,0 +1,279 @@
+"""GPU: the training step of the hot path - gradients of the HIP path against
+torch autograd of the CPU oracle on the same seeded inputs, float32.
+
+  * operator level: BEV gather, RoIAlign and pillar attention backward kernels (float32 atomics:
+    summation order differs, 1e-4 of the gradient scale);
+  * module level: encoder + decoder in train() mode (BatchNorm batch statistics, dropout 0) - gradients of
+    a random linear functional of all head outputs w.r.t. both input feature maps and every parameter
+    (2e-3 of each tensor's gradient scale: ~60 stacked fp32 stages with different reduction orders);
+  * attention dropout of the pillar attention: forward and backward regenerate the same mask
+    (directional derivative vs finite difference) and drop the expected fraction.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from deepinteraction_amd import ops, synth
+from deepinteraction_amd.autograd import BEVWarpGather, I2PAttention, RoIAlign
+from deepinteraction_amd.geometry import SampleGeometry
+from oracle import configs, decoder as odec, encoder as oenc
+from oracle.refpin import make_golden as mg
+from oracle.thirdparty import roi_align_v2
+
+DEV = 'cuda'
+
+
+def _cl(t):
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def test_bevwarp_gather_backward():
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+    shape = synth.SHAPE_TINY
+    inp = synth.make_inputs(1, shape, seed=3)
+    meta = inp['img_metas'][0]
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    g = torch.Generator().manual_seed(1)
+    dense = torch.rand(6, Hi, Wi, generator=g) * 60.0
+    dense[torch.rand(6, Hi, Wi, generator=g) < 0.2] = 0.0
+    bev = torch.randn(1, 128, Hb, Wb, generator=g, requires_grad=True)
+    w = torch.randn(6, 128, Hi, Wi, generator=g)
+    # oracle: grid_sample autograd
+    l2i = oenc.lidar2img_tensor([meta], bev)[0]
+    grid, lift = oenc.bev_sample_grid(dense, torch.inverse(l2i), meta, *meta['input_shape'])
+    warped = F.grid_sample(bev.expand(6, -1, -1, -1), grid, mode='bilinear', padding_mode='zeros',
+                           align_corners=False) * lift.unsqueeze(1)
+    (warped * w).sum().backward()
+    # HIP
+    geom = SampleGeometry(meta, (Hi, Wi), DEV)
+    bev_d = _cl(bev.detach()).requires_grad_(True)
+    out = BEVWarpGather.apply(bev_d, dense.to(DEV), geom.img2lidar, geom.aug_fwd, geom.xs, geom.ys, geom.pc_range)
+    (out * w.to(DEV)).sum().backward()
+    err = (bev_d.grad.cpu() - bev.grad).abs().max().item()
+    assert err <= 1e-4 * bev.grad.abs().max().item(), err
+
+
+def test_roi_align_backward():
+    g = torch.Generator().manual_seed(2)
+    N, C, H, W = 3, 128, 20, 31
+    feat = torch.randn(N, C, H, W, generator=g)
+    R = 17
+    xy = torch.rand(R, 2, generator=g) * torch.tensor([W * 4.0, H * 4.0]) - 8.0        # some boxes hang over the edge
+    wh = torch.rand(R, 2, generator=g) * 40.0 + 1.0
+    idx = torch.randint(0, N, (R, 1), generator=g).float()
+    rois = torch.cat([idx, xy, xy + wh], 1)
+    wgt = torch.randn(R, 49, C, generator=g)
+    ref = torch.zeros_like(feat)
+    for n in range(N):
+        sel = (idx[:, 0] == n).nonzero().flatten()
+        if sel.numel() == 0:
+            continue
+        f = feat[n:n + 1].clone().requires_grad_(True)
+        o = roi_align_v2(f, rois[sel, 1:], 7, 0.25, 2)                                  # (q,C,7,7)
+        (o.flatten(2).transpose(1, 2) * wgt[sel]).sum().backward()
+        ref[n] = f.grad[0]
+    fd = _cl(feat).requires_grad_(True)
+    out = RoIAlign.apply(fd, rois.to(DEV), 0.25)
+    (out * wgt.to(DEV)).sum().backward()
+    err = (fd.grad.cpu() - ref).abs().max().item()
+    assert err <= 1e-4 * ref.abs().max().item(), err
+
+
+def _i2p_pair(dropout):
+    from deepinteraction_amd.mmdet3d_plugin.models.utils.encoder_utils import MMRI_I2P
+    torch.manual_seed(5)
+    O = oenc.MMRI_I2P(128, 128, dropout)
+    mg.randomize(O, 4)
+    M = MMRI_I2P(128, 128, dropout)
+    M.load_state_dict(O.state_dict())
+    return O, M
+
+
+def test_i2p_attention_backward_vs_oracle():
+    shape = synth.SHAPE_TINY
+    inp = synth.make_inputs(1, shape, seed=6)
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    O, M = _i2p_pair(0.0)
+    O.train(), M.train()
+    g = torch.Generator().manual_seed(8)
+    bev = torch.randn(1, 128, Hb, Wb, generator=g)
+    img = torch.randn(1, 6, 128, Hi, Wi, generator=g)
+    w = torch.randn(1, 128, Hb, Wb, generator=g)
+    bo, io = bev.clone().requires_grad_(True), img.clone().requires_grad_(True)
+    (O(bo, io, inp['img_metas'], inp['pts_metas']) * w).sum().backward()
+    pm = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
+    M = M.to(DEV)
+    bd = _cl(bev).requires_grad_(True)
+    idv = img.to(DEV).requires_grad_(True)
+    (M(bd, idv, inp['img_metas'], pm) * w.to(DEV)).sum().backward()
+    for name, got, ref in (('bev', bd.grad, bo.grad), ('img', idv.grad, io.grad)):
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 2e-4 * ref.abs().max().item(), (name, err)
+    ref_p = dict(O.named_parameters())
+    for name, p in M.named_parameters():
+        if ref_p[name].grad is None:          # e.g. nothing: all MHA parameters are used
+            continue
+        # the key bias only shifts all scores of a pillar: its exact gradient is 0; the oracle's is round-off
+        ref = ref_p[name].grad
+        err = (p.grad.cpu() - ref).abs().max().item()
+        assert err <= 5e-4 * max(ref.abs().max().item(), 1e-3), (name, err)
+
+
+def test_i2p_attention_dropout_is_consistent():
+    """Same (seed, p): forward twice is identical, ~p of the keys are dropped, and the backward matches a
+    finite difference of the forward along a random direction (i.e. it regenerates the same mask)."""
+    shape = synth.SHAPE_TINY
+    inp = synth.make_inputs(1, shape, seed=6)
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    geom = SampleGeometry(inp['img_metas'][0], (Hi, Wi), DEV)
+    pm = inp['pts_metas']
+    args = (pm['pillars'].to(DEV), pm['pillar_coors'].to(DEV), pm['pillars_num_points'].to(DEV), geom.lidar2img,
+            geom.aug_rev, geom.ori_hw)
+    g = torch.Generator().manual_seed(9)
+    img = _cl(torch.randn(6, 128, Hi, Wi, generator=g).double().float())
+    qf = _cl(torch.randn(1, 128, Hb, Wb, generator=g) * 0.05)
+    a, _ = ops.i2p_attention(img, qf, *args, dropout_p=0.5, seed=77)
+    b, _ = ops.i2p_attention(img, qf, *args, dropout_p=0.5, seed=77)
+    c, _ = ops.i2p_attention(img, qf, *args, dropout_p=0.5, seed=78)
+    z, valid = ops.i2p_attention(img, qf, *args)
+    assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, z)
+    # constant image => context = (kept mass) / (1 - p): the kept fraction of the softmax mass averages 1 - p
+    ones = torch.ones_like(img)
+    d, _ = ops.i2p_attention(ones, torch.zeros_like(qf), *args, dropout_p=0.5, seed=5)
+    kept = (d[:, 0] * 0.5)[valid[:, 0] > 0]
+    assert 0.45 <= kept.mean().item() <= 0.55, kept.mean().item()
+    # directional derivative
+    w = torch.randn(a.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    imr = img.clone().requires_grad_(True)
+    qr = qf.clone().requires_grad_(True)
+    out, _ = I2PAttention.apply(imr, qr, *args, 0.5, 77)
+    (out * w).sum().backward()
+    di = torch.randn(img.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    dq = torch.randn(qf.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) * 0.05
+    eps = 1e-2
+    fp = (ops.i2p_attention(_cl(img + eps * di), _cl(qf + eps * dq), *args, dropout_p=0.5, seed=77)[0] * w).sum()
+    fm = (ops.i2p_attention(_cl(img - eps * di), _cl(qf - eps * dq), *args, dropout_p=0.5, seed=77)[0] * w).sum()
+    fd = ((fp - fm) / (2 * eps)).item()
+    an = ((imr.grad * di).sum() + (qr.grad * dq).sum()).item()
+    assert abs(fd - an) <= 2e-2 * max(abs(an), 1.0), (fd, an)
+
+
+def test_training_step_gradients_match_oracle():
+    from deepinteraction_amd.mmdet3d_plugin import DeepInteractionDecoder, DeepInteractionEncoder
+    shape = synth.SHAPE_TINY
+    cfg = configs.decoder_cfg(bev=shape['bev_hw'][0], num_proposals=24)
+    cfg['dropout'] = 0.0
+    torch.manual_seed(11)
+    OE = oenc.DeepInteractionEncoder(1, shape['c_img'], shape['c_pts'], 128)
+    OD = odec.DeepInteractionDecoder(**cfg)
+    mg.randomize(OE, 21)
+    mg.randomize(OD, 22)
+    ME = DeepInteractionEncoder(1, shape['c_img'], shape['c_pts'], 128)
+    MD = DeepInteractionDecoder(**cfg)
+    ME.load_state_dict(OE.state_dict())
+    MD.load_state_dict(OD.state_dict())
+    for blk_o, blk_m in zip(OE.fusion_blocks, ME.fusion_blocks):       # attention dropout off on both sides
+        blk_o.I2P_block.learnedAlign.dropout = 0.0
+        blk_m.I2P_block.dropout = 0.0
+    for m in (OE, OD, ME, MD):
+        m.train()
+    inp = synth.make_inputs(1, shape, seed=12)
+    metas = inp['img_metas']
+    # the completed depth is injected so that both sides unproject through identical depth maps
+    sparse = oenc.BEVWarp().sparse_depth(inp['pts_metas']['pts'][0], metas[0],
+                                         oenc.lidar2img_tensor(metas, inp['img_feats'])[0], *shape['img_hw'])
+    pm = dict(inp['pts_metas'], dense_depth=oenc.complete_depth(sparse).unsqueeze(0))
+
+    def run(E, D, img, pts, pmetas, dev, top=None):
+        im, (p0, p1) = E(img, pts, metas, pmetas)
+        out = D([p0, p1], im, metas, **({} if top is None else {'top_override': top}))[0][0]
+        gen = torch.Generator().manual_seed(33)
+        loss = 0.0
+        for k in sorted(out):
+            loss = loss + (out[k].float() * torch.randn(out[k].shape, generator=gen).to(dev)).sum()
+        return loss
+
+    ME, MD = ME.to(DEV), MD.to(DEV)
+    pmd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in pm.items()}
+    pmd['pts'] = [p.to(DEV) for p in pm['pts']]
+
+    def check(name, got, ref, tol):
+        scale = ref.abs().max().item()
+        err = (got.cpu() - ref).abs().max().item()
+        # + 2e-4 absolute: parameters whose exact gradient is 0 (a BatchNorm bias feeding a 1x1 conv that is
+        # batch-normalised again; the key bias of a softmax) carry only round-off on both sides
+        assert err <= tol * scale + 2e-4, (name, err, scale)
+
+    def check_params(mod_m, mod_o, tag, tol):
+        ref, n = dict(mod_o.named_parameters()), 0
+        for name, p in mod_m.named_parameters():
+            r = ref[name].grad
+            if r is None:
+                assert p.grad is None or p.grad.abs().max().item() == 0.0, (tag, name)
+                continue
+            assert p.grad is not None and torch.isfinite(p.grad).all(), (tag, name)
+            if r.abs().max().item() < 1e-7:
+                continue                              # e.g. the key bias of a softmax: exact zero
+            check(f'{tag}.{name}', p.grad, r, tol)
+            n += 1
+        return n
+
+    def functional(outs, dev, seed):
+        gen = torch.Generator().manual_seed(seed)
+        return sum((t.float() * torch.randn(t.shape, generator=gen).to(dev)).sum() for t in outs)
+
+    # ---- A. encoder: gradients of a random functional of its three outputs
+    img_d = inp['img_feats'].to(DEV).requires_grad_(True)
+    pts_d = inp['pts_feats'].to(DEV).requires_grad_(True)
+    im_d, (p0_d, p1_d) = ME(img_d, pts_d, metas, pmd)
+    functional((im_d, p0_d, p1_d), DEV, 31).backward()
+    img_o = inp['img_feats'].clone().requires_grad_(True)
+    pts_o = inp['pts_feats'].clone().requires_grad_(True)
+    im_o, (p0_o, p1_o) = OE(img_o, pts_o, metas, pm)
+    functional((im_o, p0_o, p1_o), 'cpu', 31).backward()
+    check('encoder d img_feats', img_d.grad, img_o.grad, 2e-4)
+    check('encoder d pts_feats', pts_d.grad, pts_o.grad, 2e-4)
+    n_enc = check_params(ME, OE, 'encoder', 5e-4)
+    assert n_enc > 60, n_enc
+
+    # ---- B. decoder on IDENTICAL inputs (the oracle encoder's outputs): gradients w.r.t. the three
+    # feature maps and every parameter.  (Fed with its own encoder's outputs, which differ by ~2e-6, the
+    # decoder gradient moves by ~0.5 %: RoIs hanging over the map edge pool all-zero bins, and the
+    # LayerNorm of a constant row (DynamicConv, decoder_utils.py:614-621) amplifies round-off of that
+    # row by 1/sqrt(eps) in backward - in the reference just as here.  Stage-wise parity on identical
+    # inputs plus the chain rule (part C) is the well-conditioned statement.)
+    feats_o = [t.detach().clone().requires_grad_(True) for t in (im_o, p0_o, p1_o)]
+    feats_d = [t.detach().to(DEV).requires_grad_(True) for t in (im_o, p0_o, p1_o)]
+    out_d = MD([feats_d[1], feats_d[2]], feats_d[0], metas)[0][0]
+    functional([out_d[k] for k in sorted(out_d)], DEV, 33).backward()
+    out_o = OD([feats_o[1], feats_o[2]], feats_o[0], metas, top_override=MD.top_proposals.cpu())[0][0]
+    functional([out_o[k] for k in sorted(out_o)], 'cpu', 33).backward()
+    for name, a, b in zip(('img', 'pts_conv', 'pts'), feats_d, feats_o):
+        check(f'decoder d {name}', a.grad, b.grad, 1e-3)
+    n_dec = check_params(MD, OD, 'decoder', 2e-3)
+    assert n_dec > 100, n_dec
+
+    # ---- C. end to end: the chain rule through both modules agrees with feeding the decoder's input
+    # gradients (B-style leaves of OUR encoder outputs) through OUR encoder backward, everything finite
+    for m in (ME, MD):
+        m.zero_grad()
+    img_e = inp['img_feats'].to(DEV).requires_grad_(True)
+    pts_e = inp['pts_feats'].to(DEV).requires_grad_(True)
+    im_e, (p0_e, p1_e) = ME(img_e, pts_e, metas, pmd)
+    out_e = MD([p0_e, p1_e], im_e, metas)[0][0]
+    loss = functional([out_e[k] for k in sorted(out_e)], DEV, 33)
+    g_feats = torch.autograd.grad(loss, [im_e, p0_e, p1_e], retain_graph=True)
+    loss.backward(retain_graph=True)
+    g_in = torch.autograd.grad([im_e, p0_e, p1_e], [img_e, pts_e], g_feats)
+    check('e2e d img_feats', img_e.grad, g_in[0].cpu(), 1e-5)
+    check('e2e d pts_feats', pts_e.grad, g_in[1].cpu(), 1e-5)
+    for mod in (ME, MD):
+        for name, p in mod.named_parameters():
+            assert p.grad is None or torch.isfinite(p.grad).all(), name
