@@ -12,6 +12,8 @@
 // All three re-derive the geometry exactly as their forward kernels do (same code, same rounding) and
 // accumulate with float32 atomics into float32 gradient maps (the caller casts); 16 lanes own one texel
 // (8 channels each), as in the forward kernels.
+#include <limits.h>
+
 #include "di_common.h"
 
 namespace di {
@@ -124,6 +126,13 @@ __device__ __forceinline__ void scatter8(float *__restrict__ gmap, int Wm, int C
 }
 
 // ---------------------------------------------------------------- BEV -> image gather, backward
+// One 16-lane group walks a RUN of consecutive pixels of one image row and keeps the four corner sums of
+// the BEV cell it is currently hitting in registers, flushing them with atomics only when the cell
+// changes: neighbouring pixels un-project to the same 0.6 m cell most of the time, and every pixel without
+// depth un-projects to the camera centre - tens of thousands of texels on ONE cell (15 ms of serialised
+// atomics per launch when every pixel adds on its own).
+constexpr int kRunB = 16;
+
 template <typename T>
 __global__ __launch_bounds__(256) void bevwarp_gather_bwd_kernel(
     const T *__restrict__ grad_out, const float *__restrict__ depth, const float *__restrict__ img2lidar,
@@ -136,29 +145,65 @@ __global__ __launch_bounds__(256) void bevwarp_gather_bwd_kernel(
   const AffineB A = load_affine_b(aug);
   const float r0 = pc_range[0], r1 = pc_range[1], r2 = pc_range[2];
   const float r3 = pc_range[3], r4 = pc_range[4], r5 = pc_range[5];
-  const int total = V * Hi * Wi;
+  const int runs_per_row = (Wi + kRunB - 1) / kRunB;
+  const int total = V * Hi * runs_per_row;
   const int ngrp = gridDim.x * (blockDim.x >> 4);
-  for (int pix = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); pix < total; pix += ngrp) {
-    const int v = pix / (Hi * Wi);
-    const int rem = pix - v * Hi * Wi;
-    const int yy = rem / Wi, xx = rem - yy * Wi;
-    const float d = depth[pix];
-    const float X = xs[xx] * d, Y = ys[yy] * d;
+  for (int run = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); run < total; run += ngrp) {
+    const int row = run / runs_per_row, x_beg = (run - row * runs_per_row) * kRunB;
+    const int v = row / Hi, yy = row - v * Hi;
     const float *M = img2lidar + v * 16;
-    float x = M[0] * X + M[1] * Y + M[2] * d + M[3];
-    float y = M[4] * X + M[5] * Y + M[6] * d + M[7];
-    float z = M[8] * X + M[9] * Y + M[10] * d + M[11];
-    apply_affine_b(A, x, y, z);
-    const bool lift = x > r0 && y > r1 && z > r2 && x < r3 && y < r4 && z < r5;
-    if (!lift || !ch_ok) continue;
-    const float gx = ((x - r0) / (r3 - r0) - 0.5f) * 2.f;
-    const float gy = ((y - r1) / (r4 - r1) - 0.5f) * 2.f;
-    const float ix = ((gx + 1.f) * Wb - 1.f) * 0.5f;
-    const float iy = ((gy + 1.f) * Hb - 1.f) * 0.5f;
-    const Bilin b = bilin_setup(ix, iy, Hb, Wb);
-    float g[8];
-    unpack8(ld8(grad_out + (size_t)pix * C + ch0), g);
-    scatter8(grad_bev, Wb, C, b, ch0, g);
+    int cx0 = INT_MIN, cy0 = INT_MIN;
+    float a00[8], a01[8], a10[8], a11[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a00[i] = a01[i] = a10[i] = a11[i] = 0.f;
+    auto flush = [&]() {
+      if (cx0 == INT_MIN || !ch_ok) return;
+      const bool xl = cx0 >= 0 && cx0 < Wb, xh = cx0 + 1 >= 0 && cx0 + 1 < Wb;
+      const bool yl = cy0 >= 0 && cy0 < Hb, yh = cy0 + 1 >= 0 && cy0 + 1 < Hb;
+      float *p = grad_bev + ((long long)cy0 * Wb + cx0) * C + ch0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (yl && xl) atomicAdd(p + i, a00[i]);
+        if (yl && xh) atomicAdd(p + C + i, a01[i]);
+        if (yh && xl) atomicAdd(p + (long long)Wb * C + i, a10[i]);
+        if (yh && xh) atomicAdd(p + (long long)Wb * C + C + i, a11[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a00[i] = a01[i] = a10[i] = a11[i] = 0.f;
+    };
+    for (int xx = x_beg; xx < min(x_beg + kRunB, Wi); ++xx) {
+      const int pix = (v * Hi + yy) * Wi + xx;
+      const float d = depth[pix];
+      const float X = xs[xx] * d, Y = ys[yy] * d;
+      float x = M[0] * X + M[1] * Y + M[2] * d + M[3];
+      float y = M[4] * X + M[5] * Y + M[6] * d + M[7];
+      float z = M[8] * X + M[9] * Y + M[10] * d + M[11];
+      apply_affine_b(A, x, y, z);
+      const bool lift = x > r0 && y > r1 && z > r2 && x < r3 && y < r4 && z < r5;
+      if (!lift) continue;
+      const float gx = ((x - r0) / (r3 - r0) - 0.5f) * 2.f;
+      const float gy = ((y - r1) / (r4 - r1) - 0.5f) * 2.f;
+      const float ix = ((gx + 1.f) * Wb - 1.f) * 0.5f;
+      const float iy = ((gy + 1.f) * Hb - 1.f) * 0.5f;
+      const Bilin b = bilin_setup(ix, iy, Hb, Wb);
+      if (b.x0 != cx0 || b.y0 != cy0) {
+        flush();
+        cx0 = b.x0;
+        cy0 = b.y0;
+      }
+      float g[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] = 0.f;
+      if (ch_ok) unpack8(ld8(grad_out + (size_t)pix * C + ch0), g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        a00[i] = fmaf(b.w00, g[i], a00[i]);
+        a01[i] = fmaf(b.w01, g[i], a01[i]);
+        a10[i] = fmaf(b.w10, g[i], a10[i]);
+        a11[i] = fmaf(b.w11, g[i], a11[i]);
+      }
+    }
+    flush();
   }
 }
 
@@ -376,7 +421,7 @@ int di_bevwarp_gather_bwd(const void *grad_out, const float *depth, const float 
                           int Hi, int Wi, int Hb, int Wb, int C, int dtype, void *stream) {
   DI_REQUIRE(n_views > 0 && Hi > 0 && Wi > 0 && Hb > 0 && Wb > 0, "bad gather shape");
   DI_REQUIRE(C > 0 && C % 8 == 0 && C <= 128, "C=%d must be a multiple of 8, <= 128", C);
-  const int total = n_views * Hi * Wi;
+  const int total = n_views * Hi * ((Wi + di::kRunB - 1) / di::kRunB);   // one 16-lane group per run of pixels
   const int blocks = min((total + 15) / 16, 256 * 16);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DI_F16)
