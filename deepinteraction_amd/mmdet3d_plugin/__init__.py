@@ -1,7 +1,10 @@
 """Host-side mirror of the reference plugin surface for the interaction hot path
 (`projects/mmdet3d_plugin/__init__.py:1-10`), limited to the hot path's modules."""
+from .core.bbox.assigners import (BBox3DL1Cost, BBoxBEVL1Cost, HeuristicAssigner3D, HungarianAssigner3D,  # noqa: F401
+                                  IoU3DCost)
 from .core.bbox.coders.transfusion_bbox_coder import TransFusionBBoxCoder  # noqa: F401
 from .models.dense_heads.deepinteraction_decoder import DeepInteractionDecoder  # noqa: F401
 from .models.necks.deepinteraction_encoder import DeepInteractionEncoder  # noqa: F401
 
-__all__ = ['DeepInteractionEncoder', 'DeepInteractionDecoder', 'TransFusionBBoxCoder']
+__all__ = ['DeepInteractionEncoder', 'DeepInteractionDecoder', 'TransFusionBBoxCoder', 'HungarianAssigner3D',
+           'HeuristicAssigner3D', 'BBox3DL1Cost', 'BBoxBEVL1Cost', 'IoU3DCost']

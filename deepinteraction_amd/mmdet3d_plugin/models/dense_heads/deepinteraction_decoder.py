@@ -2,18 +2,24 @@
 `DeepInteractionDecoder` :19-313: same registry name, constructor kwargs, forward signature /
 return structure, side attributes `query_labels` / `on_the_image_mask`, `state_dict` keys).
 
-Forward only in this round (loss / get_targets / get_bboxes are SURVEY 8(f) "next" rows).
-Shape-static, sync-free execution: fused heat-map NMS kernel, library top-k, batched RoI blocks
-(see models/utils/decoder_utils.py), prediction heads in float32.
+`forward` is the hot path: shape-static, sync-free execution (fused heat-map NMS kernel, library top-k,
+batched RoI blocks - see models/utils/decoder_utils.py - prediction heads in float32).
+`get_targets` / `get_targets_single` / `loss` / `get_bboxes` (reference :315-638) are host logic on torch
+tensors: they mirror the reference line by line, with the mmdet / mmdet3d helpers they call restated in
+deepinteraction_amd/det3d_compat.py (parity unpinned at that third-party boundary).
 """
 import copy
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from .... import ops
+from ....det3d_compat import (AssignResult, LiDARBoxes, build_loss, circle_nms, clip_sigmoid, draw_heatmap_gaussian,
+                              gaussian_radius, pseudo_sample)
 from ....registry import HEADS, build_bbox_coder
+from ...core.bbox.assigners import build_assigner
 from ..utils.decoder_utils import (FFN, ConvModule, ImageRCNNBlock, PointRCNNBlock, PositionEmbeddingLearned,
                                    QueryGeometry, TransformerDecoderLayer, build_conv_layer)
 
@@ -43,6 +49,10 @@ class DeepInteractionDecoder(nn.Module):
         if loss_cls is not None and not self.use_sigmoid_cls:
             self.num_classes += 1
         self.loss_cfg = dict(loss_cls=loss_cls, loss_bbox=loss_bbox, loss_heatmap=loss_heatmap)
+        if loss_cls is not None:                       # reference :75-77 (mmdet build_loss)
+            self.loss_cls, self.loss_bbox = build_loss(loss_cls), build_loss(loss_bbox)
+            self.loss_heatmap = build_loss(loss_heatmap)
+        self.sampling = False
         self.bbox_coder = build_bbox_coder(bbox_coder)
 
         self.heatmap_head = nn.Sequential(
@@ -87,6 +97,15 @@ class DeepInteractionDecoder(nn.Module):
         self.ret_idx = ret_idx
         self.static_geometry = None       # optional persistent QueryGeometry (deepinteraction_amd.graphed)
         self.init_weights()
+        self._init_assigner_sampler()
+
+    def _init_assigner_sampler(self):
+        """Reference :185-200: PseudoSampler + the assigner(s) named by train_cfg."""
+        if self.train_cfg is None:
+            return
+        assigner = self.train_cfg['assigner']
+        self.bbox_assigner = ([build_assigner(a) for a in assigner] if isinstance(assigner, list)
+                              else build_assigner(assigner))
 
     def create_2D_grid(self, x_size, y_size):
         """Reference :162-169: BEV cell centres (col + 0.5, row + 0.5), row-major."""
@@ -179,3 +198,172 @@ class DeepInteractionDecoder(nn.Module):
             else:
                 new_res[key] = ret_dicts[0][key]
         return [[new_res]]
+
+    # ------------------------------------------------------------------ targets (reference :315-482)
+    def get_targets(self, gt_bboxes_3d, gt_labels_3d, preds_dict):
+        """gt_bboxes_3d: list of LiDARInstance3DBoxes-like (`.tensor`, `.gravity_center`); preds_dict: the
+        `[dict]` of one forward.  Returns (labels, label_weights, bbox_targets, bbox_weights, ious, num_pos,
+        matched_ious, heatmap) as the reference."""
+        res = [self.get_targets_single(gt_bboxes_3d[b], gt_labels_3d[b],
+                                       {k: v[b:b + 1] for k, v in preds_dict[0].items()}, b)
+               for b in range(len(gt_bboxes_3d))]
+        cat = lambda i: torch.cat([r[i] for r in res], dim=0)
+        num_pos = int(np.sum([r[5] for r in res]))
+        matched_ious = float(np.mean([r[6] for r in res]))
+        return cat(0), cat(1), cat(2), cat(3), cat(4), num_pos, matched_ious, cat(7)
+
+    def get_targets_single(self, gt_bboxes_3d, gt_labels_3d, preds_dict, batch_idx):
+        num_proposals = preds_dict['center'].shape[-1]
+        dev = preds_dict['center'].device
+        det = lambda k: preds_dict[k].detach().clone()          # "carefully! do not change the network outputs"
+        vel = det('vel') if 'vel' in preds_dict else None
+        boxes_dict = self.bbox_coder.decode(det('heatmap'), det('rot'), det('dim'), det('center'), det('height'), vel)
+        bboxes_tensor = boxes_dict[0]['bboxes']
+        score = preds_dict['heatmap'].detach()
+        gt_bboxes_tensor = gt_bboxes_3d.tensor.to(dev)
+        gt_labels_3d = gt_labels_3d.to(dev)
+        num_layer = self.num_mmpi if self.auxiliary else 1
+        Q = self.num_proposals
+        tc = self.train_cfg
+        assign_result_list = []
+        for l in range(num_layer):                              # every layer is assigned separately
+            boxes_l = bboxes_tensor[Q * l:Q * (l + 1), :]
+            score_l = score[..., Q * l:Q * (l + 1)]
+            if tc['assigner']['type'] == 'HungarianAssigner3D':
+                r = self.bbox_assigner.assign(boxes_l, gt_bboxes_tensor, gt_labels_3d, score_l, tc)
+            elif tc['assigner']['type'] == 'HeuristicAssigner':
+                r = self.bbox_assigner.assign(boxes_l, gt_bboxes_tensor, None, gt_labels_3d,
+                                              self.query_labels[batch_idx])
+            else:
+                raise NotImplementedError
+            assign_result_list.append(r)
+        zeros = lambda: bboxes_tensor.new_zeros(Q)
+        ens = AssignResult(
+            num_gts=sum(r.num_gts for r in assign_result_list),
+            gt_inds=torch.cat([r.gt_inds for r in assign_result_list]),
+            max_overlaps=torch.cat([zeros() if r.max_overlaps is None else r.max_overlaps
+                                    for r in assign_result_list]),
+            labels=torch.cat([r.labels for r in assign_result_list]))
+        sampling = pseudo_sample(ens, bboxes_tensor, gt_bboxes_tensor)
+        pos_inds, neg_inds = sampling.pos_inds, sampling.neg_inds
+        assert len(pos_inds) + len(neg_inds) == num_proposals
+
+        code = self.bbox_coder.code_size
+        bbox_targets = torch.zeros([num_proposals, code], device=dev)
+        bbox_weights = torch.zeros([num_proposals, code], device=dev)
+        ious = torch.clamp(ens.max_overlaps, min=0.0, max=1.0)
+        labels = bboxes_tensor.new_zeros(num_proposals, dtype=torch.long)
+        label_weights = bboxes_tensor.new_zeros(num_proposals, dtype=torch.long)
+        if gt_labels_3d is not None:                            # default label = background
+            labels += self.num_classes
+        if len(pos_inds) > 0:                                   # only positives regress
+            bbox_targets[pos_inds, :] = self.bbox_coder.encode(sampling.pos_gt_bboxes)
+            bbox_weights[pos_inds, :] = 1.0
+            labels[pos_inds] = 1 if gt_labels_3d is None else gt_labels_3d[sampling.pos_assigned_gt_inds]
+            label_weights[pos_inds] = 1.0 if tc['pos_weight'] <= 0 else tc['pos_weight']
+        if len(neg_inds) > 0:
+            label_weights[neg_inds] = 1.0
+
+        # dense heat-map target: one Gaussian per GT box on the BEV grid (:450-475)
+        gt = torch.cat([gt_bboxes_3d.gravity_center, gt_bboxes_3d.tensor[:, 3:]], dim=1).to(dev)
+        grid_size = torch.tensor(tc['grid_size'])
+        pc_range = torch.tensor(tc['point_cloud_range'])
+        voxel_size = torch.tensor(tc['voxel_size'])
+        fmap = grid_size[:2] // tc['out_size_factor']           # [x_len, y_len]
+        heatmap = gt.new_zeros(self.num_classes, int(fmap[1]), int(fmap[0]))
+        for idx in range(len(gt)):
+            width = gt[idx][3] / voxel_size[0] / tc['out_size_factor']
+            length = gt[idx][4] / voxel_size[1] / tc['out_size_factor']
+            if width > 0 and length > 0:
+                radius = gaussian_radius((length, width), min_overlap=tc['gaussian_overlap'])
+                radius = max(tc['min_radius'], int(radius))
+                coor_x = (gt[idx][0] - pc_range[0]) / voxel_size[0] / tc['out_size_factor']
+                coor_y = (gt[idx][1] - pc_range[1]) / voxel_size[1] / tc['out_size_factor']
+                center_int = torch.tensor([coor_x, coor_y], dtype=torch.float32, device=dev).to(torch.int32)
+                draw_heatmap_gaussian(heatmap[gt_labels_3d[idx]], center_int, radius)
+        mean_iou = ious[pos_inds].sum() / max(len(pos_inds), 1)
+        return (labels[None], label_weights[None], bbox_targets[None], bbox_weights[None], ious[None],
+                int(pos_inds.shape[0]), float(mean_iou), heatmap[None])
+
+    # ------------------------------------------------------------------ loss (reference :484-547)
+    def loss(self, gt_bboxes_3d, gt_labels_3d, preds_dicts, **kwargs):
+        (labels, label_weights, bbox_targets, bbox_weights, ious, _num_pos, matched_ious,
+         heatmap) = self.get_targets(gt_bboxes_3d, gt_labels_3d, preds_dicts[0])
+        Q = self.num_proposals
+        num_pos = []
+        for l in range(self.num_mmpi):
+            sl = slice(l * Q, (l + 1) * Q)
+            if l % 2 == 0:                                      # image layers: only queries some camera sees
+                m = self.on_the_image_mask[l // 2]
+                label_weights[..., sl] = label_weights[..., sl] * m
+                bbox_weights[:, sl, :] = bbox_weights[:, sl, :] * m[:, :, None]
+            num_pos.append(bbox_weights.max(-1).values[..., sl].sum())
+        preds_dict = preds_dicts[0][0]
+        loss_dict = dict()
+        loss_dict['loss_heatmap'] = self.loss_heatmap(clip_sigmoid(preds_dict['dense_heatmap'].float()), heatmap,
+                                                      avg_factor=max(heatmap.eq(1).float().sum().item(), 1))
+        code_weights = self.train_cfg.get('code_weights', None)
+        for l in range(self.num_mmpi):
+            sl = slice(l * Q, (l + 1) * Q)
+            layer_cls_score = preds_dict['heatmap'][..., sl].permute(0, 2, 1).reshape(-1, self.num_classes)
+            layer_loss_cls = self.loss_cls(layer_cls_score.float(), labels[..., sl].reshape(-1),
+                                           label_weights[..., sl].reshape(-1), avg_factor=max(num_pos[l], 1))
+            parts = [preds_dict[k][..., sl] for k in ('center', 'height', 'dim', 'rot')]
+            if 'vel' in preds_dict:
+                parts.append(preds_dict['vel'][..., sl])
+            preds = torch.cat(parts, dim=1).permute(0, 2, 1).float()     # (B, Q, code_size)
+            reg_w = bbox_weights[:, sl, :] * bbox_weights.new_tensor(code_weights)
+            layer_loss_bbox = self.loss_bbox(preds, bbox_targets[:, sl, :], reg_w, avg_factor=max(num_pos[l], 1))
+            loss_dict[f'layer_{l}_loss_cls'] = layer_loss_cls
+            loss_dict[f'layer_{l}_loss_bbox'] = layer_loss_bbox
+        loss_dict['matched_ious'] = layer_loss_cls.new_tensor(matched_ious)
+        return loss_dict
+
+    # ------------------------------------------------------------------ boxes (reference :549-638)
+    def get_bboxes(self, preds_dicts, img_metas, img=None, rescale=False, for_roi=False):
+        """Last layer's Q queries -> [[boxes, scores, labels]] (batch size 1, as the reference asserts)."""
+        rets = []
+        Q = self.num_proposals
+        for preds_dict in preds_dicts:
+            pd = preds_dict[0]
+            batch_size = pd['heatmap'].shape[0]
+            one_hot = F.one_hot(self.query_labels, num_classes=self.num_classes).permute(0, 2, 1)
+            batch_score = pd['heatmap'][..., -Q:].sigmoid() * pd['query_heatmap_score'] * one_hot
+            vel = pd['vel'][..., -Q:] if 'vel' in pd else None
+            temp = self.bbox_coder.decode(batch_score, pd['rot'][..., -Q:], pd['dim'][..., -Q:],
+                                          pd['center'][..., -Q:], pd['height'][..., -Q:], vel, filter=True)
+            if self.test_cfg['dataset'] == 'nuScenes':
+                tasks = [dict(indices=[0, 1, 2, 3, 4, 5, 6, 7], radius=-1), dict(indices=[8], radius=0.175),
+                         dict(indices=[9], radius=0.175)]
+            elif self.test_cfg['dataset'] == 'Waymo':
+                tasks = [dict(indices=[0], radius=0.7), dict(indices=[1], radius=0.7), dict(indices=[2], radius=0.7)]
+            ret_layer = []
+            for i in range(batch_size):
+                boxes3d, scores, labels = temp[i]['bboxes'], temp[i]['scores'], temp[i]['labels']
+                if self.test_cfg['nms_type'] is not None:
+                    if self.test_cfg['nms_type'] != 'circle':
+                        raise NotImplementedError('rotated NMS (mmdet3d nms_gpu) is outside this port')
+                    keep_mask = torch.zeros_like(scores)
+                    for task in tasks:
+                        task_mask = torch.zeros_like(scores)
+                        for cls_idx in task['indices']:
+                            task_mask += labels == cls_idx
+                        task_mask = task_mask.bool()
+                        if task['radius'] > 0:
+                            dets = torch.cat([boxes3d[task_mask][:, :2], scores[:, None][task_mask]], dim=1)
+                            keep = torch.tensor(circle_nms(dets.detach().cpu().numpy(), task['radius']),
+                                                dtype=torch.long, device=scores.device)
+                        else:
+                            keep = torch.arange(int(task_mask.sum()), device=scores.device)
+                        if keep.shape[0] != 0:
+                            keep_mask[torch.where(task_mask != 0)[0][keep]] = 1
+                    keep_mask = keep_mask.bool()
+                    ret = dict(bboxes=boxes3d[keep_mask], scores=scores[keep_mask], labels=labels[keep_mask])
+                else:
+                    ret = dict(bboxes=boxes3d, scores=scores, labels=labels)
+                ret_layer.append(ret)
+            rets.append(ret_layer)
+        assert len(rets) == 1 and len(rets[0]) == 1
+        box_type = img_metas[0].get('box_type_3d', LiDARBoxes)
+        r = rets[0][0]
+        return [[box_type(r['bboxes'], box_dim=r['bboxes'].shape[-1]), r['scores'], r['labels'].int()]]

@@ -27,6 +27,7 @@ _HOT_MODULES = {
     'decoder_utils': 'projects.mmdet3d_plugin.models.utils.decoder_utils',
     'decoder': 'projects.mmdet3d_plugin.models.dense_heads.deepinteraction_decoder',
     'bbox_coder': 'projects.mmdet3d_plugin.core.bbox.coders.transfusion_bbox_coder',
+    'assigner': 'projects.mmdet3d_plugin.core.bbox.assigners.hungarian_assigner',
 }
 
 _PKGS = [
@@ -35,6 +36,7 @@ _PKGS = [
     'projects.mmdet3d_plugin.models.utils.ip_basic', 'projects.mmdet3d_plugin.models.necks',
     'projects.mmdet3d_plugin.models.dense_heads', 'projects.mmdet3d_plugin.core',
     'projects.mmdet3d_plugin.core.bbox', 'projects.mmdet3d_plugin.core.bbox.coders',
+    'projects.mmdet3d_plugin.core.bbox.assigners',
 ]
 
 
