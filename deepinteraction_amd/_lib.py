@@ -32,6 +32,9 @@ SIGNATURES = {
     'di_depth_scatter': [_c_p, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_p],
     'di_depth_complete': [_c_p] * 4 + [_c_i] * 3 + [_c_p],
     'di_bevwarp_gather_fwd': [_c_p] * 8 + [_c_i] * 7 + [_c_p],
+    'di_voxel_keys': [_c_p, _c_i, _c_i, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p],
+    'di_voxel_heads': [_c_p, _c_i, _c_p, _c_p, _c_p],
+    'di_voxel_scatter': [_c_p, _c_i, _c_i, _c_i] + [_c_p] * 5 + [_c_i] * 4 + [_c_p] * 4,
     'di_heatmap_nms': [_c_p] * 3 + [_c_i] * 5 + [ctypes.c_uint, _c_i, _c_p],
     'di_query_geometry': [_c_p] * 10 + [_c_i] * 3 + [_c_f] * 5 + [_c_p],
     'di_roi_align_fwd': [_c_p] * 3 + [_c_i] * 5 + [_c_f, _c_i, _c_p],

@@ -335,3 +335,38 @@ def mha_decode(q, kv, num_heads, scale):
     _lib.call('di_mha_decode_fwd', q.data_ptr(), kv.data_ptr(), out.data_ptr(), scratch.data_ptr(), B, Q, S,
               num_heads, E // num_heads, float(scale), _code(q), _stream())
     return out
+
+
+# ------------------------------------------------------------------ pillar / voxel producer
+def voxelize(points, voxel_size, pc_range, max_points, max_voxels, n_feat=None):
+    """Hard voxelisation (spconv PointToVoxel semantics, first-come order).  points (N,D') float32 on the device
+    -> voxels (max_voxels, max_points, n_feat), coords (max_voxels, 3) int32 [z,y,x], num_points (max_voxels,)
+    int32, n_voxels (0-dim int64 tensor on the device: no host synchronisation here).  Rows >= n_voxels are zero."""
+    _dev(points)
+    assert points.dtype == torch.float32 and points.dim() == 2 and (points.shape[0] == 0 or points.stride(1) == 1)
+    N, stride = points.shape[0], points.stride(0)
+    D = n_feat or points.shape[1]
+    dev = points.device
+    grid = [int(round((pc_range[3 + a] - pc_range[a]) / voxel_size[a])) for a in range(3)]
+    geo = torch.tensor(list(pc_range) + list(voxel_size), dtype=torch.float32, device=dev)
+    voxels = torch.zeros((max_voxels, max_points, D), dtype=torch.float32, device=dev)
+    coords = torch.zeros((max_voxels, 3), dtype=torch.int32, device=dev)
+    num = torch.zeros((max_voxels,), dtype=torch.int32, device=dev)
+    if N == 0:
+        return voxels, coords, num, torch.zeros((), dtype=torch.int64, device=dev)
+    keys = torch.empty(N, dtype=torch.int64, device=dev)
+    _lib.call('di_voxel_keys', points.data_ptr(), N, stride, geo.data_ptr(), grid[0], grid[1], grid[2],
+              keys.data_ptr(), _stream())
+    skeys = torch.sort(keys).values
+    head = torch.empty(N, dtype=torch.int32, device=dev)
+    first = torch.empty(N, dtype=torch.int64, device=dev)
+    _lib.call('di_voxel_heads', skeys.data_ptr(), N, head.data_ptr(), first.data_ptr(), _stream())
+    seg = (torch.cumsum(head, 0, dtype=torch.int32) - 1).contiguous()
+    sfirst = torch.sort(first).values
+    slot_of_seg = torch.empty(N, dtype=torch.int32, device=dev)
+    head_of_seg = torch.empty(N, dtype=torch.int32, device=dev)
+    _lib.call('di_voxel_scatter', points.data_ptr(), N, stride, D, skeys.data_ptr(), sfirst.data_ptr(),
+              seg.data_ptr(), slot_of_seg.data_ptr(), head_of_seg.data_ptr(), grid[0], grid[1], max_points,
+              max_voxels, voxels.data_ptr(), coords.data_ptr(), num.data_ptr(), _stream())
+    n_vox = torch.clamp(head.sum(dtype=torch.int64), max=max_voxels)
+    return voxels, coords, num, n_vox

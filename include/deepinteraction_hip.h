@@ -202,6 +202,25 @@ int di_mha_decode_scratch_floats(int B, int Q, int S, int num_heads);
 int di_mha_decode_fwd(const void *q, const void *kv, void *out, float *scratch, int B, int Q, int S,
                       int num_heads, int head_dim, float scale, int dtype, void *stream);
 
+/* ---------------------------------------------------------------- pillar / voxel producer
+ * Hard voxelisation (spconv PointToVoxel as wrapped by models/updated_modules/sparse_voxelize.py:9-70), three
+ * kernels around two key sorts the caller runs (any stable 64-bit sort):
+ *   di_voxel_keys     keys[i] = voxel_id << 32 | i, INT64_MAX for points outside `geo` = [range(6), vsize(3)]
+ *   (sort keys)       -> sorted_keys
+ *   di_voxel_heads    head[i] = 1 at the first point of every voxel; first_key[i] = first point index << 32 | i
+ *   (seg_id = cumsum(head) - 1; sort first_key) -> sorted_first
+ *   di_voxel_scatter  voxels (max_voxels, max_points, n_feat) float32, coords (max_voxels, 3) int32 [z,y,x],
+ *                     num_points (max_voxels,) int32, all zero-filled by the caller; slot_of_seg / head_of_seg:
+ *                     n_pts int32 of scratch.  Voxels in the order of their first point, the first max_points
+ *                     points of a voxel in point order (the CPU semantics; spconv's GPU order is unspecified). */
+int di_voxel_keys(const float *pts, int n_pts, int pt_stride, const float *geo, int gx, int gy, int gz,
+                  long long *keys, void *stream);
+int di_voxel_heads(const long long *sorted_keys, int n_pts, int32_t *head, long long *first_key, void *stream);
+int di_voxel_scatter(const float *pts, int n_pts, int pt_stride, int n_feat, const long long *sorted_keys,
+                     const long long *sorted_first, const int32_t *seg_id, int32_t *slot_of_seg, int32_t *head_of_seg,
+                     int gx, int gy, int max_points, int max_voxels, float *voxels, int32_t *coords,
+                     int32_t *num_points, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

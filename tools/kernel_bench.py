@@ -75,6 +75,13 @@ def main():
     us = timeit(lambda: ops.i2p_attention(img, bev, pil, coo, num, geom.lidar2img, geom.aug_rev, geom.ori_hw))
     byt = 6 * C * Hi * Wi * s + P * 20 * 12 + P * 20 + P * C * s + C * Hb * Wb * s
     print(f'i2p_attention (P={P}): {us:8.1f} us  algorithmic {byt/1e6:.1f} MB -> {byt/us/1e6:.3f} TB/s')
+    Hb_, Wb_ = shape['bev_hw']
+    rng = list(synth.PC_RANGE)
+    vs = [(rng[3] - rng[0]) / Wb_, (rng[4] - rng[1]) / Hb_, rng[5] - rng[2]]
+    p32 = pts.float().contiguous()
+    us = timeit(lambda: ops.voxelize(p32, vs, rng, 20, 60000))
+    byt = pts.shape[0] * (20 + 16 + 8 + 16) + 60000 * 20 * 5 * 4 * 2
+    print(f'voxelize ({pts.shape[0]} pts -> pillars, cap 60000): {us:8.1f} us  (~{byt/1e6:.1f} MB incl. zero fill)')
 
 
 if __name__ == '__main__':
