@@ -25,3 +25,26 @@ def decoder_cfg(bev=180, num_proposals=200, voxel=None, num_views=6):
         test_cfg=dict(dataset='nuScenes', grid_size=[bev * osf, bev * osf, 40], out_size_factor=osf,
                       pc_range=POINT_CLOUD_RANGE[0:2], voxel_size=[voxel, voxel], nms_type=None),
     ))
+
+
+def encoder_pp_cfg(in_channels_img=256, in_channels_pts=256, num_layers=2):
+    """`imgpts_neck` of reference projects/configs/nuscenes/Fusion_0075_plusplus.py:210-267."""
+    ffn = dict(type='FFN', embed_dims=128, feedforward_channels=512, num_fcs=2, ffn_drop=0.1,
+               act_cfg=dict(type='ReLU', inplace=True))
+    msda = dict(type='MultiScaleDeformableAttention', embed_dims=128, num_levels=2, batch_first=True)
+    return copy.deepcopy(dict(
+        num_layers=num_layers, in_channels_img=in_channels_img, in_channels_pts=in_channels_pts, hidden_channel=128,
+        bn_momentum=0.1, bias='auto',
+        img_transformerlayers=dict(
+            type='DeepInteractionLayer',
+            attn_cfgs=[msda, dict(type='MMRI_P2I', embed_dims=128, batch_first=True)],
+            ffn_cfgs=ffn,
+            operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm', 'ffn', 'norm')),
+        pts_transformerlayers=dict(
+            type='DeepInteractionLayer',
+            attn_cfgs=[msda, dict(type='MMRI_I2P_Polar', embed_dims=128, dropout=0.1, batch_first=True),
+                       dict(type='MMRI_I2P', embed_dims=128, dropout=0.1, batch_first=True, fp16_enabled=True,
+                            group_attn_enabled=True)],
+            ffn_cfgs=ffn,
+            operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')),
+    ))

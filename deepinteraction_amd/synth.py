@@ -27,8 +27,14 @@ def make_lidar2img(input_shape, raw_hw=(900, 1600), fx=1266.0, fy=1266.0, cx=800
                    cam_height=1.5):
     """Six 4x4 float64 `lidar2img` matrices: `viewpad @ lidar2cam` (nuscenes_dataset.py:58-67)
     then rescaled to `input_shape` as ScaleImageMultiViewImage does (transform_3d.py:125-134)."""
+    return make_cameras(input_shape, raw_hw, fx, fy, cx, cy, cam_height)[0]
+
+
+def make_cameras(input_shape, raw_hw=(900, 1600), fx=1266.0, fy=1266.0, cx=800.0, cy=450.0, cam_height=1.5):
+    """(lidar2img, cam2lidar, cam_intrinsic): six 4x4 float64 each; the last two are what the ++ data pipeline adds
+    (nuscenes_dataset.py:70-83): `cam2lidar` = inverse of `lidar2cam`, `cam_intrinsic` = the 4x4 viewpad."""
     H_in, W_in = input_shape
-    out = []
+    out, c2l, intr = [], [], []
     for yaw in CAM_YAWS_DEG:
         a = math.radians(yaw)
         fwd = np.array([math.cos(a), math.sin(a), 0.0])
@@ -45,7 +51,9 @@ def make_lidar2img(input_shape, raw_hw=(900, 1600), fx=1266.0, fy=1266.0, cx=800
         scale[0, 0] = W_in / raw_hw[1]
         scale[1, 1] = H_in / raw_hw[0]
         out.append(scale @ (viewpad @ l2c))
-    return out
+        c2l.append(np.linalg.inv(l2c))
+        intr.append(viewpad.copy())
+    return out, c2l, intr
 
 
 def make_points(n, seed):
@@ -148,3 +156,30 @@ def example_aug(seed=0):
                 pcd_trans=rng.normal(0, 0.5, 3).astype(np.float32),
                 pcd_horizontal_flip=True, pcd_vertical_flip=False,
                 transformation_3d_flow=['R', 'S', 'T', 'HF'])
+
+
+SHAPE_PP = dict(SHAPE_R, c_img=256, c_pts=256)
+SHAPE_PP_TINY = dict(SHAPE_TINY, img_hw=(16, 28), c_img=24, c_pts=40)
+
+
+def make_inputs_pp(batch=1, shape=SHAPE_PP, seed=0, device='cpu', dtype=torch.float32, aug=None):
+    """Inputs of the DeepInteraction++ neck `FusionTransformerv4.forward(img_feats, pts_feats, img_metas, pts_metas)`
+    (config 5): `img_feats` = 2 image levels (stride 4 and 8), `pts_feats` = [the two BEV maps stacked on the channel
+    axis, BEV level 0, BEV level 1] (all at the BEV resolution); metas carry `cam2lidar` and `cam_intrinsic` too."""
+    base = make_inputs(batch, shape, seed, device, dtype, aug)
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    img_feats, bev0, bev1 = [base['img_feats']], [], []
+    lvl1 = []
+    for b in range(batch):
+        g = torch.Generator().manual_seed(10_000 + seed + b)
+        lvl1.append((torch.randn(6, shape['c_img'], Hi // 2, Wi // 2, generator=g) * 0.5).clamp_(min=0))
+        bev0.append((torch.randn(1, shape['c_pts'], Hb, Wb, generator=g) * 0.5).clamp_(min=0))
+        bev1.append((torch.randn(1, shape['c_pts'], Hb, Wb, generator=g) * 0.5).clamp_(min=0))
+    img_feats.append(torch.cat(lvl1).to(device=device, dtype=dtype))
+    bev0, bev1 = torch.cat(bev0).to(device=device, dtype=dtype), torch.cat(bev1).to(device=device, dtype=dtype)
+    _, c2l, intr = make_cameras(shape['input_shape'])
+    for meta in base['img_metas']:
+        meta['cam2lidar'], meta['cam_intrinsic'] = c2l, intr
+    return dict(img_feats=img_feats, pts_feats=[torch.cat([bev0, bev1], 1), bev0, bev1],
+                img_metas=base['img_metas'], pts_metas=base['pts_metas'])

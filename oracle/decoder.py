@@ -329,6 +329,23 @@ class DeepInteractionDecoder(nn.Module):
         base = torch.cat([(bx + 0.5)[None], (by + 0.5)[None]], 0)[None]
         return base.view(1, 2, -1).permute(0, 2, 1)
 
+    def mmpi(self, query_feat, res, first, new_lidar_feat, img_flat, img_metas, I_H, I_W):
+        """:279-297: the alternating image / point RoI refinement."""
+        self.on_the_image_mask, rets = [], []
+        for l in range(self.num_mmpi):
+            prev = query_feat.clone()
+            query_pos = res['center'].detach().permute(0, 2, 1)                              # :281 .detach().clone()
+            query_feat, on = self.decode_head[l](prev, res, new_lidar_feat, img_flat, img_metas, I_H, I_W)
+            res = self.pred_head[l](torch.cat([query_feat, prev], 1))                          # :289
+            res['center'] = res['center'] + query_pos.permute(0, 2, 1)
+            if l % 2 == 0:
+                m = on != -1
+                self.on_the_image_mask.append(m)
+                for k in res:                                                                  # :293-295
+                    res[k] = torch.where(m.unsqueeze(1), res[k], first[k])
+            rets.append(res)
+        return rets
+
     def forward(self, pts_inputs, img_inputs, img_metas, top_override=None):
         """`top_override` (B,Q) flattened (class*HW + cell) picks replaces the arg-sort (tests of
         the continuous part with an fp16 product whose near-tied proposals may reorder)."""
@@ -365,19 +382,7 @@ class DeepInteractionDecoder(nn.Module):
             first = res
             query_pos = res['center'].detach().permute(0, 2, 1)                              # :268 .detach().clone()
         img_flat = img_inputs.view(B, self.num_views, I_C, -1)
-        self.on_the_image_mask, rets = [], []
-        for l in range(self.num_mmpi):
-            prev = query_feat.clone()
-            query_pos = res['center'].detach().permute(0, 2, 1)                              # :281 .detach().clone()
-            query_feat, on = self.decode_head[l](prev, res, new_lidar_feat, img_flat, img_metas, I_H, I_W)
-            res = self.pred_head[l](torch.cat([query_feat, prev], 1))                          # :289
-            res['center'] = res['center'] + query_pos.permute(0, 2, 1)
-            if l % 2 == 0:
-                m = on != -1
-                self.on_the_image_mask.append(m)
-                for k in res:                                                                  # :293-295
-                    res[k] = torch.where(m.unsqueeze(1), res[k], first[k])
-            rets.append(res)
+        rets = self.mmpi(query_feat, res, first, new_lidar_feat, img_flat, img_metas, I_H, I_W)
         rets[0]['query_heatmap_score'] = heat.gather(-1, top_index[:, None, :].expand(-1, self.num_classes, -1))
         rets[0]['dense_heatmap'] = dense_img
         if not self.auxiliary:

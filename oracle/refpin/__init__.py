@@ -28,6 +28,8 @@ _HOT_MODULES = {
     'decoder': 'projects.mmdet3d_plugin.models.dense_heads.deepinteraction_decoder',
     'bbox_coder': 'projects.mmdet3d_plugin.core.bbox.coders.transfusion_bbox_coder',
     'assigner': 'projects.mmdet3d_plugin.core.bbox.assigners.hungarian_assigner',
+    'encoder_pp': 'projects.mmdet3d_plugin.models.necks.fusion_transformerv4',
+    'decoder_pp': 'projects.mmdet3d_plugin.models.dense_heads.deepinteractionplusplus_decoder',
 }
 
 _PKGS = [
@@ -38,6 +40,69 @@ _PKGS = [
     'projects.mmdet3d_plugin.core.bbox', 'projects.mmdet3d_plugin.core.bbox.coders',
     'projects.mmdet3d_plugin.core.bbox.assigners',
 ]
+
+
+def fix_zero_layer_encoders(model):
+    """torch 1.9.1 (the reference's pin) runs `nn.TransformerEncoder` with zero layers as `norm(src)`; torch >= 2.0
+    indexes `self.layers[0]` and raises.  Restores the 1.9.1 behaviour on the instances of a reference model
+    (MMRI_I2P_Polar builds nn.Transformer(num_encoder_layers=0), fusion_transformerv4.py:490-492)."""
+    import torch
+    for m in model.modules():
+        if isinstance(m, torch.nn.TransformerEncoder) and len(m.layers) == 0:
+            m.forward = (lambda norm: (lambda src, *a, **k: norm(src)))(m.norm)
+        if isinstance(m, torch.nn.TransformerDecoder):
+            # 1.9.1: `for mod in layers: out = mod(out, memory, ...)`, then norm; 2.x first probes
+            # `layers[0].self_attn.batch_first`, which FlashMultiheadAttention does not have
+            def dec(tgt, memory, *a, _m=m, **k):
+                for layer in _m.layers:
+                    tgt = layer(tgt, memory)
+                return _m.norm(tgt) if _m.norm is not None else tgt
+            m.forward = dec
+    return model
+
+
+def _patch_pp(ns):
+    """Three shims around the reference's ++ classes so they run on CPU under torch 2.x (nothing else is changed):
+      * FlashAttention.forward (fusion_transformerv4.py:672-712) asserts CUDA + half: replaced by the same
+        (b s) flattening around the stubbed flash-attn function, in fp32;
+      * FlashMultiheadAttention.forward (:748-760) gains **kwargs: torch >= 2.0's TransformerDecoderLayer passes
+        `is_causal=`, torch 1.9.1 (the reference's pin) did not;
+      * PointRCNNBlockV2.forward ends without `return` (decoder_utils.py:1089): the local `query_feat` at exit is
+        captured and returned as `(query_feat, None)`, the v1 contract the ++ decoder unpacks (:286)."""
+    import torch
+    pp, du = ns.encoder_pp, ns.decoder_utils
+    flash = ns.stubs.flash_attn_unpadded_kvpacked_func
+
+    def fa_forward(self, q, kv, causal=False, key_padding_mask=None):
+        assert key_padding_mask is None
+        B, T, S = q.shape[0], q.shape[1], kv.shape[1]
+        cq = torch.arange(0, (B + 1) * T, step=T, dtype=torch.int32)
+        ck = torch.arange(0, (B + 1) * S, step=S, dtype=torch.int32)
+        out = flash(q.flatten(0, 1), kv.flatten(0, 1), cq, ck, T, S, 0.0, softmax_scale=self.softmax_scale,
+                    causal=causal)
+        return out.view(B, T, *out.shape[1:]), None
+    pp.FlashAttention.forward = fa_forward
+    orig = pp.FlashMultiheadAttention.forward
+    pp.FlashMultiheadAttention.forward = (
+        lambda self, q, k, v, key_padding_mask=None, need_weights=None, attn_mask=None, **kw:
+        orig(self, q, k, v, key_padding_mask=key_padding_mask, need_weights=need_weights, attn_mask=attn_mask))
+    inner = du.PointRCNNBlockV2.forward
+    code = inner.__code__
+
+    def with_return(self, *a, **k):
+        box = {}
+
+        def prof(frame, event, arg):
+            if event == 'return' and frame.f_code is code:
+                box['q'] = frame.f_locals.get('query_feat')
+        old = sys.getprofile()
+        sys.setprofile(prof)
+        try:
+            r = inner(self, *a, **k)
+        finally:
+            sys.setprofile(old)
+        return r if r is not None else (box['q'], None)
+    du.PointRCNNBlockV2.forward = with_return
 
 
 def reference_available():
@@ -65,6 +130,8 @@ def load_reference(locatt_kind='reference'):
         for short, full in _HOT_MODULES.items():
             setattr(ns, short, importlib.import_module(full))
         ns.stubs = stubs
+        _patch_pp(ns)
+        ns.fix_zero_layer_encoders = fix_zero_layer_encoders
         return ns
     finally:
         for k in [k for k in sys.modules

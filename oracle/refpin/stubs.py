@@ -11,7 +11,7 @@ import torch.nn as nn
 from .. import thirdparty as tp
 from ..locatt import CLocatt, TorchLocatt
 
-STUB_ROOTS = ('mmcv', 'mmdet', 'mmdet3d', 'detectron2', 'cv2')
+STUB_ROOTS = ('mmcv', 'mmdet', 'mmdet3d', 'detectron2', 'cv2', 'flash_attn')
 
 
 def _mod(name, **attrs):
@@ -88,9 +88,69 @@ class ConvModule(nn.Module):
         return x
 
 
-class _Unused(nn.Module):
-    def __init__(self, *a, **k):
+class BaseModule(nn.Module):
+    def __init__(self, init_cfg=None):
         super().__init__()
+
+
+def make_transformer_bricks():
+    """mmcv 1.3.18 registries + `BaseTransformerLayer.__init__` (attentions / ffns / norms from
+    `operation_order`); the reference's DeepInteractionLayer only inherits the constructor."""
+    import copy
+    TRANSFORMER_LAYER, ATTENTION = Registry('transformer layer'), Registry('attention')
+    ATTENTION.register_module(module=tp.MultiScaleDeformableAttention)
+
+    class BaseTransformerLayer(BaseModule):
+        def __init__(self, attn_cfgs=None, ffn_cfgs=None, operation_order=None, norm_cfg=dict(type='LN'),
+                     init_cfg=None, batch_first=False, **kwargs):
+            super().__init__(init_cfg)
+            self.batch_first = batch_first
+            n_attn = operation_order.count('self_attn') + operation_order.count('cross_attn')
+            if isinstance(attn_cfgs, dict):
+                attn_cfgs = [copy.deepcopy(attn_cfgs) for _ in range(n_attn)]
+            assert n_attn == len(attn_cfgs)
+            self.num_attn, self.operation_order, self.norm_cfg = n_attn, operation_order, norm_cfg
+            self.pre_norm = operation_order[0] == 'norm'
+            self.attentions = nn.ModuleList()
+            index = 0
+            for name in operation_order:
+                if name in ('self_attn', 'cross_attn'):
+                    cfg = dict(attn_cfgs[index])
+                    cfg.setdefault('batch_first', batch_first)
+                    att = ATTENTION.build(cfg)
+                    att.operation_name = name
+                    self.attentions.append(att)
+                    index += 1
+            self.embed_dims = self.attentions[0].embed_dims
+            n_ffn = operation_order.count('ffn')
+            if isinstance(ffn_cfgs, dict):
+                ffn_cfgs = [copy.deepcopy(ffn_cfgs) for _ in range(n_ffn)]
+            self.ffns = nn.ModuleList()
+            for i in range(n_ffn):
+                cfg = dict(ffn_cfgs[i])
+                cfg.pop('type', None)
+                cfg.setdefault('embed_dims', self.embed_dims)
+                self.ffns.append(tp.TransFFN(**cfg))
+            assert norm_cfg['type'] == 'LN'
+            self.norms = nn.ModuleList([nn.LayerNorm(self.embed_dims) for _ in range(operation_order.count('norm'))])
+
+    return dict(FFN=tp.TransFFN, BaseTransformerLayer=BaseTransformerLayer,
+                MultiScaleDeformableAttention=tp.MultiScaleDeformableAttention,
+                build_transformer_layer=TRANSFORMER_LAYER.build), TRANSFORMER_LAYER, ATTENTION
+
+
+def flash_attn_unpadded_kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_sq, max_sk, dropout_p,
+                                      softmax_scale=None, causal=False):
+    """flash-attn 0.2.2 semantics for equal-length sequences: q (B*T,h,d), kv (B*S,2,h,d) -> (B*T,h,d)."""
+    assert not causal and dropout_p == 0.0
+    B = cu_seqlens_q.numel() - 1
+    h, d = q.shape[-2:]
+    qq = q.view(B, max_sq, h, d).transpose(1, 2).float()
+    k = kv[:, 0].view(B, max_sk, h, d).transpose(1, 2).float()
+    v = kv[:, 1].view(B, max_sk, h, d).transpose(1, 2).float()
+    scale = softmax_scale if softmax_scale is not None else d ** -0.5
+    out = torch.softmax(qq @ k.transpose(-1, -2) * scale, -1) @ v
+    return out.transpose(1, 2).reshape(B * max_sq, h, d).to(q.dtype)
 
 
 # ---- mmdet3d.core ----------------------------------------------------------
@@ -191,8 +251,14 @@ def install(locatt_kind='reference'):
     _mod('mmcv')
     _mod('mmcv.cnn', ConvModule=ConvModule, build_conv_layer=build_conv_layer, kaiming_init=kaiming_init)
     _mod('mmcv.cnn.bricks')
-    _mod('mmcv.cnn.bricks.transformer', FFN=_Unused)
-    _mod('mmcv.runner', force_fp32=force_fp32)
+    bricks, TRANSFORMER_LAYER, ATTENTION = make_transformer_bricks()
+    _mod('mmcv.cnn.bricks.registry', TRANSFORMER_LAYER=TRANSFORMER_LAYER, ATTENTION=ATTENTION)
+    _mod('mmcv.cnn.bricks.transformer', **bricks)
+    # auto_fp16 is the identity here: the pin runs the reference's structure in fp32
+    _mod('mmcv.runner', force_fp32=force_fp32, auto_fp16=force_fp32, BaseModule=BaseModule)
+    _mod('flash_attn')
+    _mod('flash_attn.flash_attn_interface', flash_attn_unpadded_kvpacked_func=flash_attn_unpadded_kvpacked_func)
+    _mod('flash_attn.bert_padding', unpad_input=_na, pad_input=_na, index_first_axis=_na)
     # loss / targets / post-processing helpers of mmdet + mmdet3d: the SAME restatements the product uses
     # (deepinteraction_amd/det3d_compat.py) - what this pins is the reference's own control flow around them
     from deepinteraction_amd import det3d_compat as dc

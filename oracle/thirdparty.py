@@ -9,6 +9,7 @@ import math
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 from scipy import ndimage
 
 
@@ -233,3 +234,118 @@ def cv_bilateral_filter(img, d, sigma_color, sigma_space):
             s += val * w
             ws += w
     return (s / ws).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# mmcv-full 1.3.18 transformer bricks used by DeepInteraction++ (mmcv/cnn/bricks/transformer.py,
+# mmcv/ops/multi_scale_deform_attn.py).  Sources are not under /root/reference: restated from the
+# published algorithm, PARITY UNPINNED at this boundary.
+def ms_deform_attn_core(value, spatial_shapes, sampling_locations, attention_weights):
+    """value (bs, sum HW, heads, d); spatial_shapes list of (H, W); sampling_locations
+    (bs, nq, heads, L, P, 2) in [0,1] (x, y); attention_weights (bs, nq, heads, L, P) -> (bs, nq, heads*d).
+    Bilinear, zero padding, align_corners=False (the `grid_sample` formulation mmcv ships as its CPU path)."""
+    bs, _, nh, d = value.shape
+    _, nq, _, L, P, _ = sampling_locations.shape
+    sizes = [int(h) * int(w) for h, w in spatial_shapes]
+    grids = 2 * sampling_locations - 1
+    sampled = []
+    for lvl, (v, (h, w)) in enumerate(zip(value.split(sizes, dim=1), spatial_shapes)):
+        v = v.flatten(2).transpose(1, 2).reshape(bs * nh, d, int(h), int(w))
+        g = grids[:, :, :, lvl].transpose(1, 2).flatten(0, 1)                     # (bs*nh, nq, P, 2)
+        sampled.append(F.grid_sample(v, g, mode='bilinear', padding_mode='zeros', align_corners=False))
+    w_ = attention_weights.transpose(1, 2).reshape(bs * nh, 1, nq, L * P)
+    out = (torch.stack(sampled, dim=-2).flatten(-2) * w_).sum(-1).view(bs, nh * d, nq)
+    return out.transpose(1, 2).contiguous()
+
+
+class MultiScaleDeformableAttention(torch.nn.Module):
+    """mmcv 1.3.18 `MultiScaleDeformableAttention` (defaults num_heads=8, num_points=4, dropout=0.1)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64, dropout=0.1,
+                 batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__()
+        nn = torch.nn
+        self.embed_dims, self.num_heads, self.num_levels, self.num_points = embed_dims, num_heads, num_levels, num_points
+        self.batch_first = batch_first
+        self.dropout = nn.Dropout(dropout)
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        nn = torch.nn
+        nn.init.constant_(self.sampling_offsets.weight, 0.)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.num_heads, 1, 1, 2).repeat(
+            1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid[:, :, i, :] *= i + 1
+        self.sampling_offsets.bias.data = grid.view(-1)
+        nn.init.constant_(self.attention_weights.weight, 0.)
+        nn.init.constant_(self.attention_weights.bias, 0.)
+        nn.init.xavier_uniform_(self.value_proj.weight)
+        nn.init.constant_(self.value_proj.bias, 0.)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.constant_(self.output_proj.bias, 0.)
+
+    def sampling(self, query, reference_points, spatial_shapes):
+        """Projected offsets + softmax weights -> (locations (bs,nq,h,L,P,2), weights (bs,nq,h,L,P))."""
+        bs, nq, _ = query.shape
+        off = self.sampling_offsets(query).view(bs, nq, self.num_heads, self.num_levels, self.num_points, 2)
+        w = self.attention_weights(query).view(bs, nq, self.num_heads, self.num_levels * self.num_points)
+        w = w.softmax(-1).view(bs, nq, self.num_heads, self.num_levels, self.num_points)
+        assert reference_points.shape[-1] == 2
+        shapes = torch.as_tensor([[int(h), int(w_)] for h, w_ in spatial_shapes], device=query.device)
+        normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1).to(query.dtype)
+        loc = reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+        return loc, w
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
+        bs, nv, _ = value.shape
+        shapes = [(int(h), int(w)) for h, w in spatial_shapes]
+        assert sum(h * w for h, w in shapes) == nv
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        value = value.view(bs, nv, self.num_heads, -1)
+        loc, w = self.sampling(query, reference_points, shapes)
+        out = self.output_proj(ms_deform_attn_core(value, shapes, loc, w))
+        if not self.batch_first:
+            out = out.permute(1, 0, 2)
+        return self.dropout(out) + identity
+
+
+class TransFFN(torch.nn.Module):
+    """mmcv 1.3.18 `FFN`: identity + Dropout(Linear(Dropout(act(Linear(x))))); keys `layers.0.0.*`, `layers.1.*`."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2, act_cfg=dict(type='ReLU', inplace=True),
+                 ffn_drop=0., dropout_layer=None, add_identity=True, init_cfg=None, **kwargs):
+        super().__init__()
+        nn = torch.nn
+        assert num_fcs >= 2 and act_cfg['type'] == 'ReLU' and dropout_layer is None
+        self.embed_dims = embed_dims
+        layers, cin = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(nn.Linear(cin, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(ffn_drop)))
+            cin = feedforward_channels
+        layers += [nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop)]
+        self.layers = nn.Sequential(*layers)
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return out
+        return (x if identity is None else identity) + out

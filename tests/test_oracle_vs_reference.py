@@ -223,3 +223,87 @@ def test_encoder_gradients_match_reference(ref):
         assert torch.allclose(gr, go, rtol=0, atol=5e-5 * max(1.0, gr.abs().max().item())), (name, (gr - go).abs().max())
         n += 1
     assert n > 60
+
+
+# ---------------------------------------------------------------------------------- DeepInteraction++ (row a20)
+from oracle import plusplus as opp  # noqa: E402
+
+
+def _perturb(m, seed=7, scale=0.05):
+    """The mmcv default inits zero the deformable-attention projections: move every parameter off its init so
+    the pin sees all paths."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize('aug', [False, True])
+def test_pp_encoder_matches_reference(ref, aug):
+    shape = synth.SHAPE_PP_TINY
+    inp = synth.make_inputs_pp(1, shape, seed=0, aug=synth.example_aug(1) if aug else None)
+    torch.manual_seed(1234)
+    cfg = configs.encoder_pp_cfg(shape['c_img'], shape['c_pts'])
+    R = ref.fix_zero_layer_encoders(ref.encoder_pp.FusionTransformerv4(**cfg))
+    _perturb(R)
+    O = opp.FusionTransformerv4(**cfg)
+    O.load_state_dict(R.state_dict())
+    assert set(O.state_dict()) == set(R.state_dict())
+    R.eval(), O.eval()
+    with torch.no_grad():
+        ri, (rp0, rp1) = R(list(inp['img_feats']), list(inp['pts_feats']), inp['img_metas'], inp['pts_metas'])
+        oi, (op0, op1) = O(list(inp['img_feats']), list(inp['pts_feats']), inp['img_metas'], inp['pts_metas'])
+    for a, b in ((ri, oi), (rp0, op0), (rp1, op1)):
+        assert a.shape == b.shape
+        assert torch.allclose(a, b, rtol=0, atol=5e-5), (a - b).abs().max()
+    assert ri.abs().max() > 0.1 and rp1.abs().max() > 0.1
+
+
+def test_pp_polar_attention_matches_reference(ref):
+    """MMRI_I2P_Polar alone, two samples with different augmentation records."""
+    shape = synth.SHAPE_PP_TINY
+    inp = synth.make_inputs_pp(2, shape, seed=4, aug=synth.example_aug(2))
+    torch.manual_seed(3)
+    R = ref.fix_zero_layer_encoders(ref.encoder_pp.MMRI_I2P_Polar(128, 0.1)).eval()
+    O = opp.MMRI_I2P_Polar(128, 0.1).eval()
+    O.load_state_dict(R.state_dict())
+    assert set(O.state_dict()) == set(R.state_dict())
+    g = torch.Generator().manual_seed(1)
+    bev = torch.randn(2, 128, *shape['bev_hw'], generator=g)
+    img = torch.randn(12, 128, *shape['img_hw'], generator=g)
+    with torch.no_grad():
+        a = R(bev, img, inp['img_metas'], inp['pts_metas'])
+        b = O(bev, img, inp['img_metas'], inp['pts_metas'])
+    assert torch.allclose(a, b, atol=2e-5), (a - b).abs().max()
+    assert (a - bev).abs().max() > 0.1
+
+
+def _decoder_pp_pair(ref, bev, Q):
+    cfg = configs.decoder_cfg(bev=bev, num_proposals=Q)
+    torch.manual_seed(11)
+    R = ref.decoder_pp.DeepInteractionPlusPlusDecoder(**cfg)
+    _randomize_bn(R)
+    O = opp.DeepInteractionPlusPlusDecoder(**cfg)
+    O.load_state_dict(R.state_dict())
+    assert set(O.state_dict()) == set(R.state_dict())
+    return R.eval(), O.eval()
+
+
+@pytest.mark.parametrize('aug', [False, True])
+def test_pp_decoder_matches_reference(ref, aug):
+    shape = synth.SHAPE_TINY
+    Hb = shape['bev_hw'][0]
+    R, O = _decoder_pp_pair(ref, Hb, 24)
+    inp = synth.make_inputs(1, shape, seed=5, aug=synth.example_aug(3) if aug else None)
+    g = torch.Generator().manual_seed(2)
+    pts = [torch.randn(1, 128, Hb, Hb, generator=g), torch.randn(1, 128, Hb, Hb, generator=g)]
+    img = torch.randn(6, 128, *shape['img_hw'], generator=g)
+    with torch.no_grad():
+        r = R(pts, img, inp['img_metas'])[0][0]
+        o = O(pts, img, inp['img_metas'])[0][0]
+    assert set(r) == set(o)
+    for k in r:
+        assert torch.allclose(r[k], o[k], atol=3e-5), (k, (r[k] - o[k]).abs().max())
+    assert len(R.on_the_image_mask) == len(O.on_the_image_mask) == 4
+    for a, b in zip(R.on_the_image_mask, O.on_the_image_mask):
+        assert torch.equal(a.cpu(), b.cpu())
