@@ -86,6 +86,21 @@ def decoder_case(cls_decoder):
     return m.eval(), ([p0, p1], img, metas)
 
 
+def encoder_pp_case(cls_encoder, aug, fix=lambda m: m):
+    shape = synth.SHAPE_PP_TINY
+    inp = synth.make_inputs_pp(1, shape, seed=0, aug=synth.example_aug(1) if aug else None)
+    torch.manual_seed(1234)
+    m = fix(cls_encoder(**configs.encoder_pp_cfg(shape['c_img'], shape['c_pts'])))
+    randomize(m, 15)
+    return m.eval(), inp
+
+
+def decoder_pp_case(cls_decoder):
+    m, args = decoder_case(cls_decoder)
+    randomize(m, 19)
+    return m, args
+
+
 def summarize(t):
     """A strided sample plus moments: small fixture, still position-sensitive."""
     t = t.detach().float()
@@ -129,6 +144,21 @@ def main():
         out['dec_query_labels'] = m.query_labels.numpy()
         out['dec_on_the_image_mask'] = torch.stack(m.on_the_image_mask).numpy()
     np.savez_compressed(os.path.join(OUT, 'modules.npz'), **out)
+    out = {}
+    with torch.no_grad():                              # DeepInteraction++
+        for aug in (False, True):
+            m, inp = encoder_pp_case(ref.encoder_pp.FusionTransformerv4, aug, ref.fix_zero_layer_encoders)
+            img, (p0, p1) = m(list(inp['img_feats']), list(inp['pts_feats']), inp['img_metas'], inp['pts_metas'])
+            for name, t in (('img', img), ('pts_conv', p0), ('pts', p1)):
+                for k, v in summarize(t).items():
+                    out[f'enc{int(aug)}_{name}_{k}'] = v
+        m, (pts, img, metas) = decoder_pp_case(ref.decoder_pp.DeepInteractionPlusPlusDecoder)
+        r = m(pts, img, metas)[0][0]
+        for k, v in r.items():
+            out[f'dec_{k}'] = v.numpy()
+        out['dec_query_labels'] = m.query_labels.numpy()
+        out['dec_on_the_image_mask'] = torch.stack(m.on_the_image_mask).numpy()
+    np.savez_compressed(os.path.join(OUT, 'modules_pp.npz'), **out)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

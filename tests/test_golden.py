@@ -62,3 +62,32 @@ def test_decoder_matches_reference_golden():
         assert np.allclose(v.numpy(), g['dec_' + k], rtol=0, atol=2e-5), k
     assert np.array_equal(m.query_labels.numpy(), g['dec_query_labels'])              # INT: bit-exact
     assert np.array_equal(torch.stack(m.on_the_image_mask).numpy(), g['dec_on_the_image_mask'])
+
+
+# ---------------------------------------------------------------------------------- DeepInteraction++ (row a20)
+from oracle import plusplus as opp  # noqa: E402
+
+
+@pytest.mark.parametrize('aug', [False, True])
+def test_pp_encoder_matches_reference_golden(aug):
+    g = np.load(os.path.join(GOLD, 'modules_pp.npz'))
+    m, inp = mg.encoder_pp_case(opp.FusionTransformerv4, aug)
+    with torch.no_grad():
+        img, (p0, p1) = m(list(inp['img_feats']), list(inp['pts_feats']), inp['img_metas'], inp['pts_metas'])
+    for name, t in (('img', img), ('pts_conv', p0), ('pts', p1)):
+        s = mg.summarize(t)
+        pre = f'enc{int(aug)}_{name}_'
+        assert np.allclose(s['sample'], g[pre + 'sample'], rtol=0, atol=2e-5), name
+        for k in ('sum', 'abssum', 'possum'):
+            assert abs(s[k] - g[pre + k]) <= 1e-5 * max(1.0, abs(g[pre + 'abssum'])), (name, k)
+
+
+def test_pp_decoder_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, 'modules_pp.npz'))
+    m, (pts, img, metas) = mg.decoder_pp_case(opp.DeepInteractionPlusPlusDecoder)
+    with torch.no_grad():
+        r = m(pts, img, metas)[0][0]
+    for k, v in r.items():
+        assert np.allclose(v.numpy(), g['dec_' + k], rtol=0, atol=3e-5), k
+    assert np.array_equal(m.query_labels.numpy(), g['dec_query_labels'])              # INT: bit-exact
+    assert np.array_equal(torch.stack(m.on_the_image_mask).numpy(), g['dec_on_the_image_mask'])
