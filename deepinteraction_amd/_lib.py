@@ -32,6 +32,10 @@ SIGNATURES = {
     'di_depth_scatter': [_c_p, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_p],
     'di_depth_complete': [_c_p] * 4 + [_c_i] * 3 + [_c_p],
     'di_bevwarp_gather_fwd': [_c_p] * 8 + [_c_i] * 7 + [_c_p],
+    'di_ms_deform_attn_fwd': [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_i, _c_p],
+    'di_grid_gather_fwd': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p],
+    'di_polar_bev_sample_fwd': [_c_p] * 7 + [_c_i] * 8 + [_c_p],
+    'di_mha_small_fwd': [_c_p, _c_i, _c_p, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_i, _c_p],
     'di_voxel_keys': [_c_p, _c_i, _c_i, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p],
     'di_voxel_heads': [_c_p, _c_i, _c_p, _c_p, _c_p],
     'di_voxel_scatter': [_c_p, _c_i, _c_i, _c_i] + [_c_p] * 5 + [_c_i] * 4 + [_c_p] * 4,

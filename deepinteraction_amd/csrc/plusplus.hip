@@ -1,0 +1,392 @@
+// DeepInteraction++ operators for gfx950: multi-scale deformable attention, the polar
+// ray attention's two samplers, and a small multi-head attention for short sequences.
+//
+//   di_ms_deform_attn_fwd     mmcv `MultiScaleDeformableAttention` core (8 heads x 16 ch) with the softmax over the
+//                             L*P logits and the offset -> sampling location arithmetic fused in; replaces the
+//                             mmcv CUDA op `ms_deform_attn` reached from fusion_transformerv4.py:170-178 (self
+//                             attention over 2 levels) and :238 (MMRI_P2I over the warped BEV map)
+//   di_grid_gather_fwd        bilinear `grid_sample` of a channels-last map at an explicit normalised grid (+ an
+//                             additive term): the polar ray queries, fusion_transformerv4.py:574-575
+//   di_polar_bev_sample_fwd   fusion_transformerv4.py:581-640 for ALL cameras in one launch: every BEV cell lifts
+//                             its 10 height samples into each camera, averages the sampling location, reads the
+//                             camera's polar map, averages over the cameras that see it and adds the residual
+//   di_mha_small_fwd          softmax(QK^T/sqrt(16))V for many short sequences (rays x image columns),
+//                             flash-attn's role at fusion_transformerv4.py:697-700
+//
+// All are gather / HBM-bound: 16 lanes own one 128-channel texel row (16 B per lane), fp32 accumulation.
+#include "di_common.h"
+
+namespace di {
+namespace pp {
+
+constexpr int kMaxLevels = 4;
+struct Levels {
+  int n;
+  int h[kMaxLevels], w[kMaxLevels], start[kMaxLevels];
+};
+
+// One corner of a bilinear footprint, zero outside the map.
+template <typename T>
+__device__ __forceinline__ void corner8(const T *__restrict__ map, int H, int W, int sy, int sx, int y, int x,
+                                        float wgt, float (&acc)[8]) {
+  if (y < 0 || y >= H || x < 0 || x >= W) return;
+  float f[8];
+  unpack8(ld8(map + (size_t)y * sy + (size_t)x * sx), f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = fmaf(wgt, f[i], acc[i]);
+}
+
+// Bilinear sample at pixel coordinates (px, py) (texel centres at integers), zeros padding; `map` already points
+// at the lane's 8 channels; (sy, sx) = elements between vertically / horizontally neighbouring texels.
+template <typename T>
+__device__ __forceinline__ void bilinear8(const T *__restrict__ map, int H, int W, int sy, int sx, float px, float py,
+                                          float wgt, float (&acc)[8]) {
+  if (!(px > -1.f && px < (float)W && py > -1.f && py < (float)H)) return;      // also rejects NaN / huge
+  const float fx = floorf(px), fy = floorf(py);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float ax = px - fx, ay = py - fy;
+  corner8(map, H, W, sy, sx, y0, x0, wgt * (1.f - ay) * (1.f - ax), acc);
+  corner8(map, H, W, sy, sx, y0, x0 + 1, wgt * (1.f - ay) * ax, acc);
+  corner8(map, H, W, sy, sx, y0 + 1, x0, wgt * ay * (1.f - ax), acc);
+  corner8(map, H, W, sy, sx, y0 + 1, x0 + 1, wgt * ay * ax, acc);
+}
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T *p) { return (float)*p; }
+
+// ------------------------------------------------------------------------------------------------
+// Deformable attention.  value (bs, S, 128) [S = sum H_l W_l, 8 heads x 16 ch]; off (bs*nq rows, row stride
+// off_rs) holding (8, L, P, 2) raw offsets; logit (rows, stride logit_rs) holding (8, L*P); ref (ref_bs in {1,bs},
+// nq, L, 2) fp32 in [0,1]; out (bs, nq, 128).  lane = (query, head, half of the head's 16 channels).
+template <typename T, int L, int P>
+__global__ __launch_bounds__(256) void ms_deform_attn_kernel(const T *__restrict__ value, const T *__restrict__ off,
+                                                             int off_rs, const T *__restrict__ logit, int logit_rs,
+                                                             const float *__restrict__ ref, int ref_shared,
+                                                             T *__restrict__ out, int bs, int nq, int S, Levels lv) {
+  constexpr int LP = L * P;
+  const int l16 = threadIdx.x & 15;
+  const int head = l16 >> 1, half = l16 & 1;
+  const long long total = (long long)bs * nq;
+  const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (row >= total) return;
+  const int b = (int)(row / nq), q = (int)(row - (long long)b * nq);
+  // softmax over the head's L*P logits
+  float w[LP];
+  const T *lg = logit + (size_t)row * logit_rs + head * LP;
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) {
+    w[i] = ldf(lg + i);
+    m = fmaxf(m, w[i]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) {
+    w[i] = __expf(w[i] - m);
+    sum += w[i];
+  }
+  const float inv = 1.f / sum;
+  const T *of = off + (size_t)row * off_rs + head * LP * 2;
+  const float *rf = ref + ((size_t)(ref_shared ? 0 : b) * nq + q) * L * 2;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const T *vb = value + (size_t)b * S * 128 + head * 16 + half * 8;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int H = lv.h[l], W = lv.w[l];
+    const T *map = vb + (size_t)lv.start[l] * 128;
+    const float rx = rf[l * 2], ry = rf[l * 2 + 1];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const float ox = ldf(of + (l * P + p) * 2), oy = ldf(of + (l * P + p) * 2 + 1);
+      // loc = ref + off / (W, H);  pixel = loc * size - 0.5   (grid_sample, align_corners=False)
+      const float px = (rx + ox / (float)W) * (float)W - 0.5f;
+      const float py = (ry + oy / (float)H) * (float)H - 0.5f;
+      bilinear8(map, H, W, W * 128, 128, px, py, w[l * P + p] * inv, acc);
+    }
+  }
+  st8(out + (size_t)row * 128 + head * 16 + half * 8, pack8f(acc, T()));
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[g, n, :] = bilinear(feat[g / per_feat], grid[g, n]) (+ add[n, :]);  feat (Bf,H,W,C), grid (Bg,N,2) in [-1,1].
+template <typename T>
+__global__ __launch_bounds__(256) void grid_gather_kernel(const T *__restrict__ feat, const float *__restrict__ grid,
+                                                          const T *__restrict__ add, T *__restrict__ out, int Bg,
+                                                          int N, int per_feat, int H, int W, int C) {
+  const int l16 = threadIdx.x & 15, ch0 = l16 * kChPerLane;
+  const long long total = (long long)Bg * N;
+  const long long idx = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (idx >= total || ch0 >= C) return;
+  const int g = (int)(idx / N), n = (int)(idx - (long long)g * N);
+  const float gx = grid[idx * 2], gy = grid[idx * 2 + 1];
+  const float px = ((gx + 1.f) * (float)W - 1.f) * 0.5f, py = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  bilinear8(feat + (size_t)(g / per_feat) * H * W * C + ch0, H, W, W * C, C, px, py, 1.f, acc);
+  if (add != nullptr) {
+    float a[8];
+    unpack8(ld8(add + (size_t)n * C + ch0), a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += a[i];
+  }
+  st8(out + (size_t)idx * C + ch0, pack8f(acc, T()));
+}
+
+// ------------------------------------------------------------------------------------------------
+// polar (B, V, Wp, R, C) polar maps, RAY-major (texel (r, w) at (w*R + r)*C: the layout the ray transformer emits); bev (B, Hb, Wb, C) residual; proj (B, V, 4, 4); aug_rev (B, 12)
+// [A row-major, t: p' = p A + t]; cam_xy (B, V, 2); par = pc_range(6), input H, input W, r0, R.
+// One 16-lane group per BEV cell; the geometry is recomputed by every lane of the group (a few hundred flops).
+template <typename T>
+__global__ __launch_bounds__(256) void polar_bev_sample_kernel(const T *__restrict__ polar, const T *__restrict__ bev,
+                                                               const float *__restrict__ proj,
+                                                               const float *__restrict__ aug_rev,
+                                                               const float *__restrict__ cam_xy,
+                                                               const float *__restrict__ par, T *__restrict__ out,
+                                                               int B, int V, int R, int Wp, int Hb, int Wb, int C) {
+  constexpr int ZS = 10;
+  const int l16 = threadIdx.x & 15, ch0 = l16 * kChPerLane;
+  const long long total = (long long)B * Hb * Wb;
+  const long long cell = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (cell >= total || ch0 >= C) return;
+  const int b = (int)(cell / (Hb * Wb)), ij = (int)(cell - (long long)b * Hb * Wb);
+  const int i = ij / Wb, j = ij - i * Wb;
+  const float x0 = par[0], y0 = par[1], z0 = par[2], x1 = par[3], y1 = par[4], z1 = par[5];
+  const float in_h = par[6], in_w = par[7], r0 = par[8], Rf = par[9];
+  // cell centre: the reference divides the column index by the ROW count and vice versa (:585-586); square maps
+  const float bx = ((float)j + 0.5f) / (float)Hb * (x1 - x0) + x0;
+  const float by = ((float)i + 0.5f) / (float)Wb * (y1 - y0) + y0;
+  const float *A = aug_rev + b * 12;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  int vis = 0;
+  for (int v = 0; v < V; ++v) {
+    const float *M = proj + ((size_t)b * V + v) * 16;
+    const float cx = cam_xy[((size_t)b * V + v) * 2], cy = cam_xy[((size_t)b * V + v) * 2 + 1];
+    float su = 0.f, sr = 0.f;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < ZS; ++k) {
+      const float bz = ((float)k + 0.5f) / (float)ZS * (z1 - z0) + z0;
+      const float px = bx * A[0] + by * A[3] + bz * A[6] + A[9];
+      const float py = bx * A[1] + by * A[4] + bz * A[7] + A[10];
+      const float pz = bx * A[2] + by * A[5] + bz * A[8] + A[11];
+      const float xc = M[0] * px + M[1] * py + M[2] * pz + M[3];
+      const float yc = M[4] * px + M[5] * py + M[6] * pz + M[7];
+      const float zc = M[8] * px + M[9] * py + M[10] * pz + M[11];
+      const float zd = fmaxf(zc, 1e-5f);
+      const float u = 2.f * (xc / zd / in_w) - 1.f, vv = 2.f * (yc / zd / in_h) - 1.f;
+      any |= (zc > 1e-5f) && u > -1.f && u < 1.f && vv > -1.f && vv < 1.f;
+      su += u;
+      const float dx = px - cx, dy = py - cy;
+      const float rad = sqrtf(dx * dx + dy * dy);
+      sr += fminf(fmaxf(2.f * (rad - r0) / Rf - 1.f, -1.f), 1.f);
+    }
+    if (!any) continue;
+    ++vis;
+    const float lx = su / (float)ZS, ly = sr / (float)ZS;
+    const float fx = ((lx + 1.f) * (float)Wp - 1.f) * 0.5f, fy = ((ly + 1.f) * (float)R - 1.f) * 0.5f;
+    bilinear8(polar + ((size_t)b * V + v) * R * Wp * C + ch0, R, Wp, C, R * C, fx, fy, 1.f, acc);   // ray-major
+  }
+  const float inv = 1.f / (float)(vis > 0 ? vis : 1);
+  float res[8];
+  unpack8(ld8(bev + (size_t)cell * C + ch0), res);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = fmaf(acc[c], inv, res[c]);
+  st8(out + (size_t)cell * C + ch0, pack8f(acc, T()));
+}
+
+// ------------------------------------------------------------------------------------------------
+// q (N, Tq, q_rs) / k, v (N, S, kv_rs) / out (N, Tq, E): E = heads*16 columns starting at the given pointers (so a
+// packed [Q|K|V] GEMM output can be passed with strides).  Workgroup = (sequence, group of 4 heads); a wave owns one
+// head, its K/V rows sit in LDS (every lane reads the same row: broadcast) and a lane runs the online softmax of
+// one query row, 4 keys per rescale.
+template <typename T>
+__global__ __launch_bounds__(256) void mha_small_kernel(const T *__restrict__ q, int q_rs, const T *__restrict__ k,
+                                                        const T *__restrict__ v, int kv_rs, T *__restrict__ out,
+                                                        int out_rs, int Tq, int S, int heads, float scale_log2) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const int n = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int head = blockIdx.y * 4 + wave;
+  if (head >= heads) return;
+  T *ks = smem + (size_t)wave * S * 32, *vs = ks + (size_t)S * 16;
+  const T *kb = k + (size_t)n * S * kv_rs + head * 16, *vb = v + (size_t)n * S * kv_rs + head * 16;
+  for (int t = lane; t < S * 2; t += 64) {                       // S rows x two 8-channel halves
+    const int s = t >> 1, h8 = (t & 1) * 8;
+    st8(ks + s * 16 + h8, ld8(kb + (size_t)s * kv_rs + h8));
+    st8(vs + s * 16 + h8, ld8(vb + (size_t)s * kv_rs + h8));
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();                               // the wave only reads what it wrote itself
+  for (int t0 = 0; t0 < Tq; t0 += 64) {
+    const int t = t0 + lane;
+    if (t >= Tq) break;
+    float qv[16], acc[16];
+    {
+      float a[8], b8[8];
+      const T *qp = q + ((size_t)n * Tq + t) * q_rs + head * 16;
+      unpack8(ld8(qp), a);
+      unpack8(ld8(qp + 8), b8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        qv[i] = a[i] * scale_log2;
+        qv[8 + i] = b8[i] * scale_log2;
+        acc[i] = acc[8 + i] = 0.f;
+      }
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 4) {
+      float sc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = min(s0 + u, S - 1);
+        float a[8], b8[8];
+        unpack8(ld8(ks + s * 16), a);
+        unpack8(ld8(ks + s * 16 + 8), b8);
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d = fmaf(qv[i], a[i], fmaf(qv[8 + i], b8[i], d));
+        sc[u] = (s0 + u < S) ? d : -INFINITY;
+      }
+      const float mn = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), m);
+      const float corr = exp2f(m - mn);
+      l *= corr;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] *= corr;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = min(s0 + u, S - 1);
+        const float p = exp2f(sc[u] - mn);
+        l += p;
+        float a[8], b8[8];
+        unpack8(ld8(vs + s * 16), a);
+        unpack8(ld8(vs + s * 16 + 8), b8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[i] = fmaf(p, a[i], acc[i]);
+          acc[8 + i] = fmaf(p, b8[i], acc[8 + i]);
+        }
+      }
+      m = mn;
+    }
+    const float inv = 1.f / l;
+    float o0[8], o1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      o0[i] = acc[i] * inv;
+      o1[i] = acc[8 + i] * inv;
+    }
+    T *op = out + ((size_t)n * Tq + t) * out_rs + head * 16;
+    st8(op, pack8f(o0, T()));
+    st8(op + 8, pack8f(o1, T()));
+  }
+}
+
+}  // namespace pp
+}  // namespace di
+
+extern "C" {
+
+int di_ms_deform_attn_fwd(const void *value, const void *offsets, int off_row_stride, const void *logits,
+                          int logit_row_stride, const float *ref, int ref_shared, void *out, int bs, int nq,
+                          int n_levels, int n_points, const int32_t *level_hw, int dtype, void *stream) {
+  DI_REQUIRE(bs > 0 && nq > 0, "bad deformable attention shape");
+  DI_REQUIRE((n_levels == 1 || n_levels == 2) && n_points == 4, "levels %d / points %d unsupported (1|2 levels, 4 points)",
+             n_levels, n_points);
+  di::pp::Levels lv;
+  lv.n = n_levels;
+  int S = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    lv.h[l] = level_hw[2 * l];
+    lv.w[l] = level_hw[2 * l + 1];
+    DI_REQUIRE(lv.h[l] > 0 && lv.w[l] > 0, "bad level shape");
+    lv.start[l] = S;
+    S += lv.h[l] * lv.w[l];
+  }
+  const long long rows = (long long)bs * nq;
+  const dim3 grid((unsigned)((rows + 15) / 16)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DI_MSDA(TT, LL)                                                                                              \
+  hipLaunchKernelGGL((di::pp::ms_deform_attn_kernel<TT, LL, 4>), grid, blk, 0, s, (const TT *)value,                 \
+                     (const TT *)offsets, off_row_stride, (const TT *)logits, logit_row_stride, ref, ref_shared,     \
+                     (TT *)out, bs, nq, S, lv)
+  if (dtype == DI_F16) { if (n_levels == 1) DI_MSDA(__half, 1); else DI_MSDA(__half, 2); }
+  else if (dtype == DI_F32) { if (n_levels == 1) DI_MSDA(float, 1); else DI_MSDA(float, 2); }
+  else { di::set_error("unsupported dtype %d", dtype); return DI_ERR_ARG; }
+#undef DI_MSDA
+  return di::check_launch("ms_deform_attn_fwd");
+}
+
+int di_grid_gather_fwd(const void *feat, const float *grid, const void *add, void *out, int n_grids, int n_points,
+                       int grids_per_feat, int H, int W, int C, int dtype, void *stream) {
+  DI_REQUIRE(n_grids > 0 && n_points > 0 && grids_per_feat > 0 && H > 0 && W > 0, "bad grid gather shape");
+  DI_REQUIRE(C > 0 && C % 8 == 0 && C <= 128, "C=%d must be a multiple of 8, <= 128", C);
+  const long long total = (long long)n_grids * n_points;
+  const dim3 g((unsigned)((total + 15) / 16)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DI_F16)
+    hipLaunchKernelGGL((di::pp::grid_gather_kernel<__half>), g, blk, 0, s, (const __half *)feat, grid,
+                       (const __half *)add, (__half *)out, n_grids, n_points, grids_per_feat, H, W, C);
+  else if (dtype == DI_F32)
+    hipLaunchKernelGGL((di::pp::grid_gather_kernel<float>), g, blk, 0, s, (const float *)feat, grid,
+                       (const float *)add, (float *)out, n_grids, n_points, grids_per_feat, H, W, C);
+  else { di::set_error("unsupported dtype %d", dtype); return DI_ERR_ARG; }
+  return di::check_launch("grid_gather_fwd");
+}
+
+int di_polar_bev_sample_fwd(const void *polar, const void *bev, const float *proj, const float *aug_rev,
+                            const float *cam_xy, const float *params, void *out, int B, int V, int R, int Wp, int Hb,
+                            int Wb, int C, int dtype, void *stream) {
+  DI_REQUIRE(B > 0 && V > 0 && R > 0 && Wp > 0 && Hb > 0 && Wb > 0, "bad polar sample shape");
+  DI_REQUIRE(Hb == Wb, "square BEV maps only (the reference swaps the axis sizes, fusion_transformerv4.py:585-586)");
+  DI_REQUIRE(C > 0 && C % 8 == 0 && C <= 128, "C=%d must be a multiple of 8, <= 128", C);
+  const long long total = (long long)B * Hb * Wb;
+  const dim3 g((unsigned)((total + 15) / 16)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DI_F16)
+    hipLaunchKernelGGL((di::pp::polar_bev_sample_kernel<__half>), g, blk, 0, s, (const __half *)polar,
+                       (const __half *)bev, proj, aug_rev, cam_xy, params, (__half *)out, B, V, R, Wp, Hb, Wb, C);
+  else if (dtype == DI_F32)
+    hipLaunchKernelGGL((di::pp::polar_bev_sample_kernel<float>), g, blk, 0, s, (const float *)polar,
+                       (const float *)bev, proj, aug_rev, cam_xy, params, (float *)out, B, V, R, Wp, Hb, Wb, C);
+  else { di::set_error("unsupported dtype %d", dtype); return DI_ERR_ARG; }
+  return di::check_launch("polar_bev_sample_fwd");
+}
+
+int di_mha_small_fwd(const void *q, int q_row_stride, const void *k, const void *v, int kv_row_stride, void *out,
+                     int out_row_stride, int n_seq, int Tq, int S, int num_heads, int head_dim, float scale, int dtype,
+                     void *stream) {
+  DI_REQUIRE(head_dim == 16, "head_dim %d unsupported (16 only)", head_dim);
+  DI_REQUIRE(n_seq > 0 && Tq > 0 && S > 0 && num_heads > 0, "bad attention shape");
+  DI_REQUIRE(q_row_stride % 8 == 0 && kv_row_stride % 8 == 0 && out_row_stride % 8 == 0, "row strides must be 16-B aligned");
+  const size_t esz = dtype == DI_F16 ? 2 : 4;
+  const size_t lds = (size_t)4 * S * 32 * esz;
+  DI_REQUIRE(lds <= 160 * 1024, "S=%d too long for the short-sequence kernel (K/V of 4 heads must fit the 160 KB LDS)", S);
+  if (lds > 64 * 1024) {   // above the default dynamic-LDS cap: opt in (idempotent, no stream interaction)
+    const void *fn = dtype == DI_F16 ? (const void *)di::pp::mha_small_kernel<__half>
+                                     : (const void *)di::pp::mha_small_kernel<float>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      di::set_error("cannot reserve %zu B of LDS", lds);
+      return DI_ERR_ARG;
+    }
+  }
+  const dim3 g(n_seq, (num_heads + 3) / 4), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  const float sl2 = scale * 1.4426950408889634f;
+  if (dtype == DI_F16)
+    hipLaunchKernelGGL((di::pp::mha_small_kernel<__half>), g, blk, lds, s, (const __half *)q, q_row_stride,
+                       (const __half *)k, (const __half *)v, kv_row_stride, (__half *)out, out_row_stride, Tq, S,
+                       num_heads, sl2);
+  else if (dtype == DI_F32)
+    hipLaunchKernelGGL((di::pp::mha_small_kernel<float>), g, blk, lds, s, (const float *)q, q_row_stride,
+                       (const float *)k, (const float *)v, kv_row_stride, (float *)out, out_row_stride, Tq, S,
+                       num_heads, sl2);
+  else { di::set_error("unsupported dtype %d", dtype); return DI_ERR_ARG; }
+  return di::check_launch("mha_small_fwd");
+}
+
+}  // extern "C"

@@ -81,11 +81,7 @@ class DeepInteractionDecoder(nn.Module):
         for _ in range(num_mmpi // 2):
             heads = copy.deepcopy(common_heads)
             heads.update(dict(heatmap=(self.num_classes, num_heatmap_convs)))
-            self.decode_head.append(ImageRCNNBlock(num_views, num_proposals, out_size_factor_img, test_cfg,
-                                                   self.bbox_coder, hidden_channel, num_heads, dropout))
-            self.pred_head.append(FFN(hidden_channel * 2, heads, conv_cfg=conv_cfg, norm_cfg=norm_cfg, bias=bias))
-            self.decode_head.append(PointRCNNBlock(hidden_channel, num_heads, dropout, self.bbox_coder))
-            self.pred_head.append(FFN(hidden_channel * 2, heads, conv_cfg=conv_cfg, norm_cfg=norm_cfg, bias=bias))
+            self._add_mmpi_pair(heads, num_proposals, hidden_channel, num_heads, dropout, conv_cfg, norm_cfg, bias)
 
         x_size = test_cfg['grid_size'][0] // test_cfg['out_size_factor']
         y_size = test_cfg['grid_size'][1] // test_cfg['out_size_factor']
@@ -98,6 +94,14 @@ class DeepInteractionDecoder(nn.Module):
         self.static_geometry = None       # optional persistent QueryGeometry (deepinteraction_amd.graphed)
         self.init_weights()
         self._init_assigner_sampler()
+
+    def _add_mmpi_pair(self, heads, num_proposals, hidden_channel, num_heads, dropout, conv_cfg, norm_cfg, bias):
+        """One image RoI block + one point RoI block with their prediction heads (reference :131-147)."""
+        self.decode_head.append(ImageRCNNBlock(self.num_views, num_proposals, self.out_size_factor_img, self.test_cfg,
+                                               self.bbox_coder, hidden_channel, num_heads, dropout))
+        self.pred_head.append(FFN(hidden_channel * 2, heads, conv_cfg=conv_cfg, norm_cfg=norm_cfg, bias=bias))
+        self.decode_head.append(PointRCNNBlock(hidden_channel, num_heads, dropout, self.bbox_coder))
+        self.pred_head.append(FFN(hidden_channel * 2, heads, conv_cfg=conv_cfg, norm_cfg=norm_cfg, bias=bias))
 
     def _init_assigner_sampler(self):
         """Reference :185-200: PseudoSampler + the assigner(s) named by train_cfg."""
@@ -170,6 +174,25 @@ class DeepInteractionDecoder(nn.Module):
         img_feat_flatten = img_feat.view(B, self.num_views, I_C, -1)
         # a caller that replays a captured graph keeps ONE geometry object alive and refreshes it in place
         geom = self.static_geometry if self.static_geometry is not None else QueryGeometry(img_metas, dev)
+        ret_dicts = self._mmpi(query_feat, res_layer, first_res_layer, new_lidar_feat, img_feat_flatten, img_metas,
+                               I_H, I_W, geom)
+
+        ret_dicts[0]['query_heatmap_score'] = heatmap.gather(
+            index=top_index[:, None, :].expand(-1, self.num_classes, -1), dim=-1)
+        ret_dicts[0]['dense_heatmap'] = dense_heatmap_img
+        if self.auxiliary is False:
+            return [ret_dicts[-1]]
+        new_res = {}
+        for key in ret_dicts[0].keys():
+            if key not in ['dense_heatmap', 'dense_heatmap_old', 'query_heatmap_score']:
+                new_res[key] = torch.cat([ret_dict[key] for ret_dict in ret_dicts], dim=-1)
+            else:
+                new_res[key] = ret_dicts[0][key]
+        return [[new_res]]
+
+    def _mmpi(self, query_feat, res_layer, first_res_layer, new_lidar_feat, img_feat_flatten, img_metas, I_H, I_W,
+              geom):
+        """Reference :279-297: the alternating image / point RoI refinement; returns the per-layer dicts."""
         self.on_the_image_mask = []
         ret_dicts = []
         for layer_idx in range(self.num_mmpi):
@@ -185,19 +208,11 @@ class DeepInteractionDecoder(nn.Module):
                 self.on_the_image_mask.append(mask)
                 res_layer = {k: torch.where(mask.unsqueeze(1), v, first_res_layer[k]) for k, v in res_layer.items()}
             ret_dicts.append(res_layer)
+        return ret_dicts
 
-        ret_dicts[0]['query_heatmap_score'] = heatmap.gather(
-            index=top_index[:, None, :].expand(-1, self.num_classes, -1), dim=-1)
-        ret_dicts[0]['dense_heatmap'] = dense_heatmap_img
-        if self.auxiliary is False:
-            return [ret_dicts[-1]]
-        new_res = {}
-        for key in ret_dicts[0].keys():
-            if key not in ['dense_heatmap', 'dense_heatmap_old', 'query_heatmap_score']:
-                new_res[key] = torch.cat([ret_dict[key] for ret_dict in ret_dicts], dim=-1)
-            else:
-                new_res[key] = ret_dicts[0][key]
-        return [[new_res]]
+    def _layer_mask(self, l):
+        """The on-the-image mask that weights the targets of MMPI layer `l` (reference :506-508), or None."""
+        return self.on_the_image_mask[l // 2] if l % 2 == 0 else None
 
     # ------------------------------------------------------------------ targets (reference :315-482)
     def get_targets(self, gt_bboxes_3d, gt_labels_3d, preds_dict):
@@ -293,8 +308,8 @@ class DeepInteractionDecoder(nn.Module):
         num_pos = []
         for l in range(self.num_mmpi):
             sl = slice(l * Q, (l + 1) * Q)
-            if l % 2 == 0:                                      # image layers: only queries some camera sees
-                m = self.on_the_image_mask[l // 2]
+            m = self._layer_mask(l)
+            if m is not None:                                   # image layers: only queries some camera sees
                 label_weights[..., sl] = label_weights[..., sl] * m
                 bbox_weights[:, sl, :] = bbox_weights[:, sl, :] * m[:, :, None]
             num_pos.append(bbox_weights.max(-1).values[..., sl].sum())

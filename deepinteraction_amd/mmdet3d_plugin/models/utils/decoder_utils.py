@@ -414,13 +414,20 @@ class ImageRCNNBlock(_RCNNBase):
         idx = (torch.arange(B, device=rect.device).view(B, 1) * V + lastc).to(torch.float32).unsqueeze(-1)
         rois = torch.cat([idx, rect_q], -1).view(-1, 5)
         roi = _roi_align(maps, rois, 1.0 / self.out_size_factor_img)             # (B*Q, 49, C)
-        key_allowed = sel.gather(1, lastc.view(B, Q, 1).expand(B, Q, Q))         # [b,q,k] = sel[b, v*(q), k]
-        # queries no camera sees are discarded below; give them every key so that their softmax rows (and
-        # the gradients flowing through the shared GEMMs in training) stay finite
-        key_allowed = key_allowed | (last < 0).unsqueeze(-1)
-        x = self._stack(query_feat.transpose(1, 2), roi, '', key_allowed=key_allowed)        # (B,Q,C)
+        x = self._refine_views(query_feat.transpose(1, 2), roi, sel, last, lastc)            # (B,Q,C)
         out = torch.where((last >= 0).unsqueeze(-1), x, torch.zeros_like(x))     # unseen queries: 0 (:665)
         return out.transpose(1, 2), last.to(torch.float32)
+
+
+    def _refine_views(self, x, roi, sel, last, lastc):
+        """The attention / DynamicConv / FFN stack on tokens x (B,Q,C), every query inside the query set of its
+        last valid view: sel (B,V,Q) membership, last (B,Q) = v*(q) or -1, lastc = last clamped to >= 0."""
+        B, Q, _ = x.shape
+        key_allowed = sel.gather(1, lastc.view(B, Q, 1).expand(B, Q, Q))         # [b,q,k] = sel[b, v*(q), k]
+        # queries no camera sees are discarded by the caller; give them every key so that their softmax rows
+        # (and the gradients flowing through the shared GEMMs in training) stay finite
+        key_allowed = key_allowed | (last < 0).unsqueeze(-1)
+        return self._stack(x, roi, '', key_allowed=key_allowed)
 
 
 class PointRCNNBlock(_RCNNBase):
@@ -449,5 +456,86 @@ class PointRCNNBlock(_RCNNBase):
         idx = torch.arange(B, device=rect.device, dtype=torch.float32).view(B, 1, 1).expand(B, Q, 1)
         rois = torch.cat([idx, rect], -1).view(-1, 5)
         roi = _roi_align(new_lidar_feat, rois, 1.0)                             # (B*Q, 49, C)
-        x = self._stack(query_feat.transpose(1, 2), roi, '_pts')
+        x = self._refine_all(query_feat.transpose(1, 2), roi)
         return x.transpose(1, 2), None
+
+    def _refine_all(self, x, roi):
+        return self._stack(x, roi, '_pts')
+
+
+# ---------------------------------------------------------------------------------- DeepInteraction++ (V2 blocks)
+class _V2Mix:
+    """What `ImageRCNNBlockV2` / `PointRCNNBlockV2` (reference :844-1089) change in the refinement stack: the FFN
+    becomes an mmcv `FFN` (ReLU, identity inside), and a parallel "self" branch (FFN + LayerNorm on the
+    post-self-attention feature) is mixed in with the learnable `scale` / `self_scale` (both 0.5).
+
+    Reproduced as published: the mix `query (1,n,C) * scale + self_feat (n,1,C) * self_scale` broadcasts to
+    (n,n,C) and row 0 is kept (:986-990, :1086-1089), i.e. EVERY query of a group receives the self-branch feature
+    of the group's FIRST query (lowest query index)."""
+
+    def _v2_init(self, hidden, dropout, sfx):
+        from .transformer_bricks import TransFFN
+        for n in ('linear1', 'linear2', 'dropout', 'activation'):
+            delattr(self, n + sfx)
+        setattr(self, 'self_norm' + sfx, nn.LayerNorm(hidden))
+        self.ffn = TransFFN(embed_dims=hidden, feedforward_channels=hidden * 4, num_fcs=2, ffn_drop=dropout,
+                            act_cfg=dict(type='ReLU', inplace=True))
+        self.self_ffn = TransFFN(embed_dims=hidden, feedforward_channels=hidden * 4, num_fcs=2, ffn_drop=dropout,
+                                 act_cfg=dict(type='ReLU', inplace=True))
+        self.scale = nn.Parameter(torch.ones(1) * 0.5)
+        self.self_scale = nn.Parameter(torch.ones(1) * 0.5)
+
+    def _attend(self, q_tok, x, sfx, key_allowed):
+        g = lambda n: getattr(self, n + sfx)
+        sa = g('dyconv_pre_self_attn')
+        p = sa.dropout if self.training else 0.0
+        a = mha_tokens(q_tok, x, x, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj, sa.num_heads, p, key_allowed)
+        return g('norm1')(q_tok + g('dropout1')(a))
+
+    def _main_branch(self, y, roi, sfx):
+        g = lambda n: getattr(self, n + sfx)
+        shp = y.shape
+        dy = g('dyconv').forward_nk(y.reshape(-1, shp[-1]), roi)
+        z = g('norm2')(y + g('dropout2')(dy.view(shp)))
+        return g('norm3')(self.ffn(z))
+
+
+class ImageRCNNBlockV2(_V2Mix, ImageRCNNBlock):
+    """Reference decoder_utils.py:844-993."""
+
+    def __init__(self, num_views, num_proposals, out_size_factor_img, test_cfg, bbox_coder, hidden_channel,
+                 num_heads, dropout):
+        ImageRCNNBlock.__init__(self, num_views, num_proposals, out_size_factor_img, test_cfg, bbox_coder,
+                                hidden_channel, num_heads, dropout)
+        self._v2_init(hidden_channel, dropout, '')
+
+    def _refine_views(self, x, roi, sel, last, lastc):
+        B, Q, C = x.shape
+        V = sel.shape[1]
+        key_allowed = sel.gather(1, lastc.view(B, Q, 1).expand(B, Q, Q)) | (last < 0).unsqueeze(-1)
+        y = self._attend(x, x, '', key_allowed)                                  # x is also the key / value set
+        z = self._main_branch(y, roi, '')
+        # self branch of the first query of every view, evaluated among that view's queries
+        ar = torch.arange(Q, device=x.device).view(1, 1, Q)
+        first = torch.where(sel, ar, torch.full_like(ar, Q)).min(-1).values      # (B,V); Q when the view is unused
+        firstc = first.clamp(max=Q - 1)
+        xf = x.gather(1, firstc.unsqueeze(-1).expand(B, V, C))
+        yf = self._attend(xf, x, '', sel | (first >= Q).unsqueeze(-1))           # (B,V,C)
+        sf = self.self_norm(self.self_ffn(yf))
+        s = sf.gather(1, lastc.unsqueeze(-1).expand(B, Q, C))                    # self feature of view v*(q)
+        return z * self.scale + s * self.self_scale
+
+
+class PointRCNNBlockV2(_V2Mix, PointRCNNBlock):
+    """Reference decoder_utils.py:997-1089.  The published `forward` has no `return` (:1089); `(query_feat, None)`
+    - the v1 contract the ++ head unpacks (deepinteractionplusplus_decoder.py:286) - is returned here."""
+
+    def __init__(self, hidden_channel, num_heads, dropout, bbox_coder):
+        PointRCNNBlock.__init__(self, hidden_channel, num_heads, dropout, bbox_coder)
+        self._v2_init(hidden_channel, dropout, '_pts')
+
+    def _refine_all(self, x, roi):
+        y = self._attend(x, x, '_pts', None)
+        z = self._main_branch(y, roi, '_pts')
+        s0 = self.self_norm_pts(self.self_ffn(y[:, 0:1]))                        # query 0's self feature, for all
+        return z * self.scale + s0 * self.self_scale

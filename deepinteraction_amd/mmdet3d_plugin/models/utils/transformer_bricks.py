@@ -1,0 +1,115 @@
+"""The two mmcv-full 1.3.18 transformer bricks DeepInteraction++ builds on (reference imports them at
+necks/fusion_transformerv4.py:21-22 and models/utils/decoder_utils.py:14), MI355X-native: same constructor
+arguments, parameter names and maths, token-major (bs, N, C) execution with the deformable sampling in one HIP
+kernel (csrc/plusplus.hip) instead of mmcv's CUDA op.  mmcv is not a dependency."""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .... import ops
+from ....utils import param_key
+
+
+class TransFFN(nn.Module):
+    """mmcv `FFN`: identity + Dropout(Linear(Dropout(act(Linear(x))))); keys `layers.0.0.*`, `layers.1.*`."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2, act_cfg=dict(type='ReLU', inplace=True),
+                 ffn_drop=0., dropout_layer=None, add_identity=True, init_cfg=None, **kwargs):
+        super().__init__()
+        assert num_fcs >= 2 and act_cfg.get('type', 'ReLU') == 'ReLU' and dropout_layer is None
+        self.embed_dims, self.feedforward_channels, self.num_fcs = embed_dims, feedforward_channels, num_fcs
+        layers, cin = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(nn.Linear(cin, feedforward_channels), nn.ReLU(inplace=True),
+                                        nn.Dropout(ffn_drop)))
+            cin = feedforward_channels
+        layers += [nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop)]
+        self.layers = nn.Sequential(*layers)
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return out
+        return (x if identity is None else identity) + out
+
+
+class MultiScaleDeformableAttention(nn.Module):
+    """mmcv `MultiScaleDeformableAttention` (defaults: 8 heads, 4 points, dropout 0.1); parameters
+    `sampling_offsets`, `attention_weights`, `value_proj`, `output_proj`.
+
+    Inference on the GPU: ONE packed GEMM produces offsets and logits, `ops.ms_deform_attn` does softmax, location
+    arithmetic, bilinear gathers and the weighted sum."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64, dropout=0.1,
+                 batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__()
+        assert embed_dims % num_heads == 0
+        self.embed_dims, self.num_heads, self.num_levels, self.num_points = embed_dims, num_heads, num_levels, num_points
+        self.batch_first, self.im2col_step = batch_first, im2col_step
+        self.dropout = nn.Dropout(dropout)
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self._pack_cache = None
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.constant_(self.sampling_offsets.weight, 0.)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.num_heads, 1, 1, 2).repeat(
+            1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias.copy_(grid.view(-1))
+        nn.init.constant_(self.attention_weights.weight, 0.)
+        nn.init.constant_(self.attention_weights.bias, 0.)
+        nn.init.xavier_uniform_(self.value_proj.weight)
+        nn.init.constant_(self.value_proj.bias, 0.)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.constant_(self.output_proj.bias, 0.)
+
+    def packed(self):
+        """[sampling_offsets ; attention_weights] as one (heads*L*P*3, C) projection (inference cache)."""
+        if torch.is_grad_enabled():
+            return (torch.cat([self.sampling_offsets.weight, self.attention_weights.weight]),
+                    torch.cat([self.sampling_offsets.bias, self.attention_weights.bias]))
+        key = param_key(self)
+        if self._pack_cache is None or self._pack_cache[0] != key:
+            with torch.no_grad():
+                self._pack_cache = (key, (torch.cat([self.sampling_offsets.weight, self.attention_weights.weight]).contiguous(),
+                                          torch.cat([self.sampling_offsets.bias, self.attention_weights.bias]).contiguous()))
+        return self._pack_cache[1]
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('deformable-attention backward is not built yet: run DeepInteraction++ under '
+                                      'torch.no_grad() (forward path); training is the v1 model')
+        shapes = [(int(h), int(w)) for h, w in spatial_shapes]
+        bs, nq, _ = query.shape
+        v = self.value_proj(value)
+        if key_padding_mask is not None:
+            v = v.masked_fill(key_padding_mask[..., None], 0.0)
+        n_off = self.num_heads * self.num_levels * self.num_points * 2
+        w, b = self.packed()
+        proj = F.linear(query, w, b)                                           # (bs, nq, heads*L*P*3)
+        ref = reference_points.to(torch.float32).contiguous()
+        out = ops.ms_deform_attn(v.contiguous(), proj[..., :n_off], proj[..., n_off:], ref, shapes, self.num_points)
+        out = self.output_proj(out)
+        if not self.batch_first:
+            out = out.permute(1, 0, 2)
+        return self.dropout(out) + identity

@@ -370,3 +370,85 @@ def voxelize(points, voxel_size, pc_range, max_points, max_voxels, n_feat=None):
               max_voxels, voxels.data_ptr(), coords.data_ptr(), num.data_ptr(), _stream())
     n_vox = torch.clamp(head.sum(dtype=torch.int64), max=max_voxels)
     return voxels, coords, num, n_vox
+
+
+# ------------------------------------------------------------------ DeepInteraction++ operators
+def _rows(t):
+    """(rows.., cols) view with unit column stride and uniform row stride -> (data_ptr, row stride in elements)."""
+    assert t.stride(-1) == 1
+    rs = t.stride(-2)
+    for d in range(t.dim() - 2):
+        assert t.stride(d) == t.stride(d + 1) * t.shape[d + 1], 'rows must be uniformly strided'
+    return t.data_ptr(), rs
+
+
+def ms_deform_attn(value, offsets, logits, ref, level_hw, n_points=4):
+    """mmcv MultiScaleDeformableAttention core.  value (bs,S,128) contiguous; offsets (bs,nq,8*L*P*2) and logits
+    (bs,nq,8*L*P): views (possibly into one packed projection) with unit column stride; ref (1|bs,nq,L,2) float32;
+    level_hw [(H,W),...] -> (bs,nq,128)."""
+    _dev(value, offsets, logits, ref)
+    bs, S, E = value.shape
+    nq, L = offsets.shape[1], len(level_hw)
+    assert E == 128 and value.is_contiguous() and offsets.dtype == value.dtype == logits.dtype
+    assert offsets.shape[-1] == 8 * L * n_points * 2 and logits.shape[-1] == 8 * L * n_points
+    assert sum(h * w for h, w in level_hw) == S and ref.dtype == torch.float32 and ref.is_contiguous()
+    assert ref.shape[1:] == (nq, L, 2) and ref.shape[0] in (1, bs)
+    op, ors = _rows(offsets)
+    lp, lrs = _rows(logits)
+    out = torch.empty((bs, nq, E), dtype=value.dtype, device=value.device)
+    import ctypes
+    hw = (ctypes.c_int32 * (2 * L))(*[int(x) for pair in level_hw for x in pair])
+    _profiled('ms_deform_attn_fwd', bs * nq, lambda: _lib.call(
+        'di_ms_deform_attn_fwd', value.data_ptr(), op, ors, lp, lrs, ref.data_ptr(), int(ref.shape[0] == 1),
+        out.data_ptr(), bs, nq, L, n_points, ctypes.addressof(hw), _code(value), _stream()))
+    return out
+
+
+def grid_gather(feat, grid, add=None, grids_per_feat=1):
+    """Bilinear grid_sample (zeros, align_corners=False) of a channels-last map at explicit points.  feat (Bf,C,H,W)
+    channels-last, grid (Bg,N,2) float32 in [-1,1] (x,y), add (N,C) or None -> (Bg,N,C); grid g reads
+    feat[g // grids_per_feat]."""
+    _dev(feat, grid)
+    assert _is_cl(feat) and grid.dtype == torch.float32 and grid.is_contiguous() and grid.shape[-1] == 2
+    Bf, C, H, W = feat.shape
+    Bg, N = grid.shape[:2]
+    assert Bg == Bf * grids_per_feat
+    if add is not None:
+        assert add.shape == (N, C) and add.dtype == feat.dtype and add.is_contiguous()
+    out = torch.empty((Bg, N, C), dtype=feat.dtype, device=feat.device)
+    _lib.call('di_grid_gather_fwd', feat.data_ptr(), grid.data_ptr(), 0 if add is None else add.data_ptr(),
+              out.data_ptr(), Bg, N, grids_per_feat, H, W, C, _code(feat), _stream())
+    return out
+
+
+def polar_bev_sample(polar, bev, proj, aug_rev, cam_xy, params):
+    """fusion_transformerv4.py:581-640 for all cameras at once.  polar (B,V,Wp,R,C) contiguous (ray-major), bev (B,C,Hb,Wb)
+    channels-last, proj (B,V,4,4) / aug_rev (B,12) / cam_xy (B,V,2) / params (10,) float32 -> (B,C,Hb,Wb)."""
+    _dev(polar, bev, proj, aug_rev, cam_xy, params)
+    B, V, Wp, R, C = polar.shape
+    assert polar.is_contiguous() and _is_cl(bev) and bev.dtype == polar.dtype and bev.shape[:2] == (B, C)
+    for t, shp in ((proj, (B, V, 4, 4)), (aug_rev, (B, 12)), (cam_xy, (B, V, 2)), (params, (10,))):
+        assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shp, (t.shape, shp)
+    Hb, Wb = bev.shape[-2:]
+    out = empty_cl(B, C, Hb, Wb, bev)
+    _profiled('polar_bev_sample_fwd', B * Hb * Wb, lambda: _lib.call(
+        'di_polar_bev_sample_fwd', polar.data_ptr(), bev.data_ptr(), proj.data_ptr(), aug_rev.data_ptr(),
+        cam_xy.data_ptr(), params.data_ptr(), out.data_ptr(), B, V, R, Wp, Hb, Wb, C, _code(bev), _stream()))
+    return out
+
+
+def mha_small(q, k, v, num_heads):
+    """softmax(q k^T / sqrt(16)) v per head for many short sequences.  q (N,T,E), k/v (N,S,E) views with unit column
+    stride (k and v share a row stride, e.g. halves of one packed projection) -> (N,T,E) contiguous."""
+    _dev(q, k, v)
+    N, T, E = q.shape
+    S = k.shape[1]
+    assert E == num_heads * 16 and k.shape == v.shape == (N, S, E) and q.dtype == k.dtype == v.dtype
+    qp, qrs = _rows(q)
+    kp, krs = _rows(k)
+    vp, vrs = _rows(v)
+    assert krs == vrs
+    out = torch.empty((N, T, E), dtype=q.dtype, device=q.device)
+    _profiled('mha_small_fwd', N, lambda: _lib.call(
+        'di_mha_small_fwd', qp, qrs, kp, vp, krs, out.data_ptr(), E, N, T, S, num_heads, 16, 0.25, _code(q), _stream()))
+    return out

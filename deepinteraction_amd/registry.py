@@ -41,6 +41,8 @@ def _try(path, name):
 
 NECKS = _try('mmdet3d.models.builder', 'NECKS') or Registry('neck')
 HEADS = _try('mmdet3d.models.builder', 'HEADS') or Registry('head')
+TRANSFORMER_LAYER = _try('mmcv.cnn.bricks.registry', 'TRANSFORMER_LAYER') or Registry('transformer layer')
+ATTENTION = _try('mmcv.cnn.bricks.registry', 'ATTENTION') or Registry('attention')
 BBOX_CODERS = _try('mmdet.core.bbox.builder', 'BBOX_CODERS') or Registry('bbox_coder')
 
 

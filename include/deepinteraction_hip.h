@@ -202,6 +202,35 @@ int di_mha_decode_scratch_floats(int B, int Q, int S, int num_heads);
 int di_mha_decode_fwd(const void *q, const void *kv, void *out, float *scratch, int B, int Q, int S,
                       int num_heads, int head_dim, float scale, int dtype, void *stream);
 
+/* ---------------------------------------------------------------- DeepInteraction++ operators (row a20)
+ * di_ms_deform_attn_fwd: the core of mmcv-full 1.3.18 `MultiScaleDeformableAttention` (CUDA op `ms_deform_attn`,
+ *   reached from necks/fusion_transformerv4.py:170-178 and :238), 8 heads x 16 channels, 4 points, 1 or 2 levels,
+ *   with `softmax` over the L*P logits and `loc = ref + off / (W_l, H_l)` fused in.
+ *   value (bs, sum H_l W_l, 128); offsets: bs*nq rows of (8, L, 4, 2), `off_row_stride` elements apart; logits:
+ *   rows of (8, L*4), `logit_row_stride` apart (both may point into one packed GEMM output); ref (1 or bs, nq, L, 2)
+ *   float32 in [0,1] (x, y), `ref_shared` = 1 when its batch dim is 1; out (bs, nq, 128).  `level_hw` is a HOST
+ *   array of 2*n_levels ints [H_0, W_0, H_1, W_1].
+ * di_grid_gather_fwd: out[g, n, :] = bilinear(feat[g / grids_per_feat], grid[g, n]) (+ add[n, :]); zeros padding,
+ *   align_corners=False; feat (Bf,H,W,C) channels-last, grid (n_grids, n_points, 2) float32 in [-1,1]; `add` may
+ *   be NULL.  The polar ray queries, fusion_transformerv4.py:574-575.
+ * di_polar_bev_sample_fwd: fusion_transformerv4.py:581-640 over all cameras: polar (B,V,Wp,R,C) per-camera polar
+ *   maps stored ray-major (image column, radius, channel), bev (B,Hb,Wb,C) residual, proj (B,V,4,4) lidar2img, aug_rev (B,12) [A row-major | t], cam_xy (B,V,2)
+ *   camera centres, params = [pc_range(6), input_H, input_W, radius_min, n_radius] (device, float32);
+ *   out (B,Hb,Wb,C) = mean over seeing cameras of the sampled polar map + bev.
+ * di_mha_small_fwd: softmax(q k^T * scale) v per head for n_seq short sequences; q (n_seq,Tq,*), k/v (n_seq,S,*)
+ *   with the given row strides (elements) so packed projections can be passed in place; head_dim 16. */
+int di_ms_deform_attn_fwd(const void *value, const void *offsets, int off_row_stride, const void *logits,
+                          int logit_row_stride, const float *ref, int ref_shared, void *out, int bs, int nq,
+                          int n_levels, int n_points, const int32_t *level_hw, int dtype, void *stream);
+int di_grid_gather_fwd(const void *feat, const float *grid, const void *add, void *out, int n_grids, int n_points,
+                       int grids_per_feat, int H, int W, int C, int dtype, void *stream);
+int di_polar_bev_sample_fwd(const void *polar, const void *bev, const float *proj, const float *aug_rev,
+                            const float *cam_xy, const float *params, void *out, int B, int V, int R, int Wp, int Hb,
+                            int Wb, int C, int dtype, void *stream);
+int di_mha_small_fwd(const void *q, int q_row_stride, const void *k, const void *v, int kv_row_stride, void *out,
+                     int out_row_stride, int n_seq, int Tq, int S, int num_heads, int head_dim, float scale, int dtype,
+                     void *stream);
+
 /* ---------------------------------------------------------------- pillar / voxel producer
  * Hard voxelisation (spconv PointToVoxel as wrapped by models/updated_modules/sparse_voxelize.py:9-70), three
  * kernels around two key sorts the caller runs (any stable 64-bit sort):
