@@ -181,31 +181,43 @@ class MMRI_I2P_Polar(nn.Module):
         self.im_scale = 4.
         self.transformer_layers = _RayTransformer(embed_dims, 8, embed_dims * 4, num_decoder_layers)
         self._const = {}
+        self._params = None
 
     # -- host-side, feature independent (:538-572)
     def ray_grid(self, img_meta, H, W):
         """BEV sampling grid of the ray queries of one sample: (V, W*R, 2) float32 in [-1,1], tokens ordered (w, r);
-        and the camera centres (V,2)."""
-        R = self.radius
-        l2i = torch.as_tensor(np.asarray(img_meta['lidar2img']), dtype=torch.float32)
-        c2l = torch.as_tensor(np.asarray(img_meta['cam2lidar']), dtype=torch.float32)
+        and the camera centres (V,2).  numpy float32 on the host (a few thousand points)."""
+        R, f32 = self.radius, np.float32
+        l2i = np.asarray(img_meta['lidar2img'], dtype=f32)
+        c2l = np.asarray(img_meta['cam2lidar'], dtype=f32)
         V = l2i.shape[0]
-        xr = torch.arange(0., float(W), 1.).unsqueeze(0).repeat(V, 1)
-        cam = torch.stack([xr + 0.5, torch.zeros_like(xr) + H // 2, torch.ones_like(xr), torch.ones_like(xr)], 1)
-        cam[:, :2] *= self.im_scale
-        on_ray = torch.bmm(torch.linalg.inv(l2i), cam)[:, :2]                    # (V,2,W)
-        cam_xy = c2l[:, :2, -1:]
-        d = on_ray - cam_xy
-        d = d / d.norm(dim=1, p=2, keepdim=True)
+        xr = np.arange(W, dtype=f32)
+        cam = np.stack([(xr + f32(0.5)) * f32(self.im_scale), np.full(W, (H // 2) * self.im_scale, f32),
+                        np.ones(W, f32), np.ones(W, f32)], 0)                    # (4,W): depth-1 points of row H//2
+        on_ray = np.matmul(np.linalg.inv(l2i), cam[None])[:, :2]                 # (V,2,W)
+        cam_xy = c2l[:, :2, 3]                                                   # (V,2)
+        d = on_ray - cam_xy[:, :, None]
+        d = d / np.sqrt((d * d).sum(1, keepdims=True))
         rr = self.radius_range
-        depths = torch.arange(rr[0], rr[1], rr[2]) + rr[2] / 2
-        centers = (depths[None, None, :, None] * d[:, :, None]).permute(0, 3, 2, 1)     # (V,W,R,2)
-        A = torch.from_numpy(aug_affine(img_meta, False)).float()
-        p = centers.reshape(-1, 2)
-        p = torch.cat([p, torch.zeros_like(p[:, :1])], -1) @ A[:9].view(3, 3) + A[9:]
+        depths = (np.arange(rr[0], rr[1], rr[2]) + rr[2] / 2).astype(f32)
+        centers = depths[None, None, :, None] * d[:, :, None, :]                 # (V,2,R,W): NOT offset by the camera
+        centers = centers.transpose(0, 3, 2, 1).reshape(-1, 2)                   # rows ordered (v, w, r)
+        A = aug_affine(img_meta, False).astype(f32)
+        p = centers @ A[:9].reshape(3, 3)[:2] + A[9:]                            # z = 0 before the augmentation
         r = self.pc_range
-        g = torch.stack([(p[:, 0] - r[0]) / (r[3] - r[0]), (p[:, 1] - r[1]) / (r[4] - r[1])], -1) * 2 - 1
-        return g.view(V, W * R, 2), cam_xy[:, :, 0]
+        g = np.stack([(p[:, 0] - f32(r[0])) / f32(r[3] - r[0]), (p[:, 1] - f32(r[1])) / f32(r[4] - r[1])], -1)
+        g = g * f32(2) - f32(1)
+        return torch.from_numpy(g.reshape(V, W * R, 2).astype(f32)), torch.from_numpy(np.ascontiguousarray(cam_xy))
+
+    def sample_rays(self, img_metas, pts_metas, b, H, W, device):
+        """Per-sample ray geometry on the device, cached with the rest of the sample's geometry for the forward."""
+        geom = eu.sample_geometry(img_metas, pts_metas, b, (H, W), device)
+        key = (H, W, self.radius, tuple(self.radius_range))
+        if getattr(geom, 'polar_key', None) != key:
+            grid, cam_xy = self.ray_grid(img_metas[b], H, W)
+            geom.polar = (grid.to(device, non_blocking=True), cam_xy.to(device, non_blocking=True))
+            geom.polar_key = key
+        return geom
 
     def constants(self, H, W, dtype, device):
         key = (H, W, dtype, device)
@@ -221,19 +233,23 @@ class MMRI_I2P_Polar(nn.Module):
         _, _, H, W = img_feat.shape
         R, dev, dt = self.radius, lidar_feat.device, lidar_feat.dtype
         V = img_feat.shape[0] // B
-        geo = [self.ray_grid(m, H, W) for m in img_metas]
-        grid = torch.stack([g[0] for g in geo]).view(B * V, W * R, 2).to(dev)
-        cam_xy = torch.stack([g[1] for g in geo]).contiguous().to(dev)
+        geoms = [self.sample_rays(img_metas, pts_metas, b, H, W, dev) for b in range(B)]
+        grid = (geoms[0].polar[0] if B == 1 else torch.cat([g.polar[0] for g in geoms])).view(B * V, W * R, 2)
+        cam_xy = (geoms[0].polar[1][None] if B == 1 else torch.stack([g.polar[1] for g in geoms])).contiguous()
         ray_pos, img_pos = self.constants(H, W, dt, dev)
         rays = ops.grid_gather(lidar_feat, grid, add=ray_pos, grids_per_feat=V)             # (B*V, W*R, C)
         rays = rays.view(B * V * W, R, C)
         cols = (_tokens(img_feat) + img_pos).view(B * V, H, W, C).transpose(1, 2).reshape(B * V * W, H, C)
         polar = self.transformer_layers(cols, rays).view(B, V, W, R, C)                     # ray-major polar maps
-        proj = torch.stack([eu.sample_geometry(img_metas, pts_metas, b, (H, W), dev).lidar2img for b in range(B)])
-        aug = torch.stack([eu.sample_geometry(img_metas, pts_metas, b, (H, W), dev).aug_rev for b in range(B)])
+        proj = geoms[0].lidar2img[None] if B == 1 else torch.stack([g.lidar2img for g in geoms])
+        aug = geoms[0].aug_rev[None] if B == 1 else torch.stack([g.aug_rev for g in geoms])
         ishape = img_metas[0]['input_shape']                                                 # sample 0 for all (:606)
-        params = torch.tensor(list(self.pc_range) + [float(ishape[0]), float(ishape[1]), float(self.radius_range[0]),
-                                                     float(R)], dtype=torch.float32, device=dev)
+        pkey = (dev, float(ishape[0]), float(ishape[1]))
+        if self._params is None or self._params[0] != pkey:
+            self._params = (pkey, torch.tensor(list(self.pc_range) + [float(ishape[0]), float(ishape[1]),
+                                                                      float(self.radius_range[0]), float(R)],
+                                               dtype=torch.float32, device=dev))
+        params = self._params[1]
         return ops.polar_bev_sample(polar, lidar_feat, proj.contiguous(), aug.contiguous(), cam_xy, params)
 
 
