@@ -36,6 +36,10 @@ SIGNATURES = {
     'di_grid_gather_fwd': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p],
     'di_polar_bev_sample_fwd': [_c_p] * 7 + [_c_i] * 8 + [_c_p],
     'di_mha_small_fwd': [_c_p, _c_i, _c_p, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_i, _c_p],
+    'di_add_layernorm_fwd': [_c_p] * 5 + [ctypes.c_longlong, _c_i, _c_f, _c_i, _c_p],
+    'di_ms_deform_attn_bwd': [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_i, _c_p],
+    'di_grid_gather_bwd': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p],
+    'di_polar_bev_sample_bwd': [_c_p] * 6 + [_c_i] * 8 + [_c_p],
     'di_voxel_keys': [_c_p, _c_i, _c_i, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p],
     'di_voxel_heads': [_c_p, _c_i, _c_p, _c_p, _c_p],
     'di_voxel_scatter': [_c_p, _c_i, _c_i, _c_i] + [_c_p] * 5 + [_c_i] * 4 + [_c_p] * 4,

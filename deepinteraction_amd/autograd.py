@@ -60,3 +60,57 @@ class I2PAttention(torch.autograd.Function):
         g_img, g_q = ops.i2p_attention_bwd(img, qfold, grad_ctx, pillars, coors, num_points, proj, aug_rev,
                                            ctx.ori_hw, ctx.dropout_p, ctx.seed)
         return g_img.to(img.dtype), g_q.to(qfold.dtype), None, None, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------- DeepInteraction++ samplers
+class MSDeformAttn(torch.autograd.Function):
+    """mmcv MultiScaleDeformableAttention core on the packed [offsets | logits] projection (csrc/plusplus.hip /
+    plusplus_bwd.hip).  Gradients: value, packed projection.  Reference points are constants."""
+
+    @staticmethod
+    def forward(ctx, value, proj, ref, level_hw, n_points):
+        L = len(level_hw)
+        n_off = 8 * L * n_points * 2
+        ctx.save_for_backward(value, proj, ref)
+        ctx.level_hw, ctx.n_points, ctx.n_off = list(level_hw), n_points, n_off
+        return ops.ms_deform_attn(value, proj[..., :n_off], proj[..., n_off:], ref, level_hw, n_points)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        value, proj, ref = ctx.saved_tensors
+        n_off = ctx.n_off
+        gv, gp = ops.ms_deform_attn_bwd(value, proj[..., :n_off], proj[..., n_off:], ref, ctx.level_hw, grad_out,
+                                        ctx.n_points)
+        return gv.to(value.dtype), gp, None, None, None
+
+
+class GridGather(torch.autograd.Function):
+    """out[g, n] = bilinear(feat[g // per_feat], grid[g, n]) + add[n]; gradient w.r.t. feat only (the grid is
+    geometry, the additive term a constant encoding)."""
+
+    @staticmethod
+    def forward(ctx, feat, grid, add, grids_per_feat):
+        ctx.save_for_backward(grid)
+        ctx.shape, ctx.dtype, ctx.per = tuple(feat.shape), feat.dtype, grids_per_feat
+        return ops.grid_gather(feat, grid, add, grids_per_feat)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grid,) = ctx.saved_tensors
+        return ops.grid_gather_bwd(grid, grad_out, ctx.shape, ctx.per).to(ctx.dtype), None, None, None
+
+
+class PolarBEVSample(torch.autograd.Function):
+    """out = mean over seeing cameras of bilinear(polar[cam], loc(cell, cam)) + bev  (fusion_transformerv4.py:581-640)."""
+
+    @staticmethod
+    def forward(ctx, polar, bev, proj, aug_rev, cam_xy, params):
+        ctx.save_for_backward(proj, aug_rev, cam_xy, params)
+        ctx.shape, ctx.dtype = tuple(polar.shape), polar.dtype
+        return ops.polar_bev_sample(polar, bev, proj, aug_rev, cam_xy, params)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        proj, aug_rev, cam_xy, params = ctx.saved_tensors
+        gp = ops.polar_bev_sample_bwd(grad_out, proj, aug_rev, cam_xy, params, ctx.shape)
+        return gp.to(ctx.dtype), grad_out, None, None, None, None

@@ -51,8 +51,33 @@ __device__ __forceinline__ void bilinear8(const T *__restrict__ map, int H, int 
   corner8(map, H, W, sy, sx, y0 + 1, x0 + 1, wgt * ay * ax, acc);
 }
 
-template <typename T>
-__device__ __forceinline__ float ldf(const T *p) { return (float)*p; }
+// N consecutive elements (N in {4, 8, 16}, N*sizeof(T)-byte aligned up to 16 B) as floats, in the widest loads.
+template <int N>
+__device__ __forceinline__ void ldvec(const float *p, float (&f)[N]) {
+  const float4 *q = reinterpret_cast<const float4 *>(p);
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) {
+    const float4 v = q[i];
+    f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+  }
+}
+template <int N>
+__device__ __forceinline__ void ldvec(const __half *p, float (&f)[N]) {
+  if constexpr (N == 4) {
+    const uint2 r = *reinterpret_cast<const uint2 *>(p);
+    const __half2 *h = reinterpret_cast<const __half2 *>(&r);
+    const float2 a = __half22float2(h[0]), b = __half22float2(h[1]);
+    f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < N / 8; ++i) {
+      float t[8];
+      unpack8(ld8(p + 8 * i), t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[8 * i + j] = t[j];
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Deformable attention.  value (bs, S, 128) [S = sum H_l W_l, 8 heads x 16 ch]; off (bs*nq rows, row stride
@@ -71,14 +96,12 @@ __global__ __launch_bounds__(256) void ms_deform_attn_kernel(const T *__restrict
   if (row >= total) return;
   const int b = (int)(row / nq), q = (int)(row - (long long)b * nq);
   // softmax over the head's L*P logits
-  float w[LP];
-  const T *lg = logit + (size_t)row * logit_rs + head * LP;
+  float w[LP], ofs[LP * 2];
+  ldvec<LP>(logit + (size_t)row * logit_rs + head * LP, w);
+  ldvec<LP * 2>(off + (size_t)row * off_rs + head * LP * 2, ofs);
   float m = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < LP; ++i) {
-    w[i] = ldf(lg + i);
-    m = fmaxf(m, w[i]);
-  }
+  for (int i = 0; i < LP; ++i) m = fmaxf(m, w[i]);
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < LP; ++i) {
@@ -86,7 +109,6 @@ __global__ __launch_bounds__(256) void ms_deform_attn_kernel(const T *__restrict
     sum += w[i];
   }
   const float inv = 1.f / sum;
-  const T *of = off + (size_t)row * off_rs + head * LP * 2;
   const float *rf = ref + ((size_t)(ref_shared ? 0 : b) * nq + q) * L * 2;
   float acc[8];
 #pragma unroll
@@ -99,7 +121,7 @@ __global__ __launch_bounds__(256) void ms_deform_attn_kernel(const T *__restrict
     const float rx = rf[l * 2], ry = rf[l * 2 + 1];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const float ox = ldf(of + (l * P + p) * 2), oy = ldf(of + (l * P + p) * 2 + 1);
+      const float ox = ofs[(l * P + p) * 2], oy = ofs[(l * P + p) * 2 + 1];
       // loc = ref + off / (W, H);  pixel = loc * size - 0.5   (grid_sample, align_corners=False)
       const float px = (rx + ox / (float)W) * (float)W - 0.5f;
       const float py = (ry + oy / (float)H) * (float)H - 0.5f;
@@ -286,10 +308,77 @@ __global__ __launch_bounds__(256) void mha_small_kernel(const T *__restrict__ q,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// out = LayerNorm(x (+ res)) * gamma + beta over C <= 128 channels; one 16-lane group per token, statistics in
+// fp32 (mean, then centred variance), DPP row reductions.  Fuses the residual add that precedes every post-norm.
+template <typename T, bool HAS_RES>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const T *__restrict__ x, const T *__restrict__ res,
+                                                            const T *__restrict__ gamma, const T *__restrict__ beta,
+                                                            T *__restrict__ out, long long n_tokens, int C, float eps) {
+  const int l16 = threadIdx.x & 15, ch0 = l16 * kChPerLane;
+  const bool ok = ch0 < C;
+  float g[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) g[i] = b[i] = 0.f;
+  if (ok) {
+    unpack8(ld8(gamma + ch0), g);
+    unpack8(ld8(beta + ch0), b);
+  }
+  const float invC = 1.f / (float)C;
+  const long long stride = (long long)gridDim.x * 16;
+  for (long long t = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); t < n_tokens; t += stride) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    if (ok) {
+      unpack8(ld8(x + t * C + ch0), v);
+      if (HAS_RES) {
+        float r[8];
+        unpack8(ld8(res + t * C + ch0), r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += r[i];
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+    const float mean = row16_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float d = ok ? v[i] - mean : 0.f;
+      q = fmaf(d, d, q);
+    }
+    const float rstd = rsqrtf(row16_sum(q) * invC + eps);
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = fmaf((v[i] - mean) * rstd, g[i], b[i]);
+      st8(out + t * C + ch0, pack8f(v, T()));
+    }
+  }
+}
+
 }  // namespace pp
 }  // namespace di
 
 extern "C" {
+
+int di_add_layernorm_fwd(const void *x, const void *res, const void *gamma, const void *beta, void *out,
+                         long long n_tokens, int C, float eps, int dtype, void *stream) {
+  DI_REQUIRE(n_tokens >= 0 && C > 0 && C % 8 == 0 && C <= 128, "C=%d must be a multiple of 8, <= 128", C);
+  if (n_tokens == 0) return DI_OK;
+  const long long want = (n_tokens + 15) / 16;
+  const dim3 g((unsigned)(want < 256 * 32 ? want : 256 * 32)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+#define DI_LN(TT, RR)                                                                                             \
+  hipLaunchKernelGGL((di::pp::add_layernorm_kernel<TT, RR>), g, blk, 0, s, (const TT *)x, (const TT *)res,          \
+                     (const TT *)gamma, (const TT *)beta, (TT *)out, n_tokens, C, eps)
+  if (dtype == DI_F16) { if (res) DI_LN(__half, true); else DI_LN(__half, false); }
+  else if (dtype == DI_F32) { if (res) DI_LN(float, true); else DI_LN(float, false); }
+  else { di::set_error("unsupported dtype %d", dtype); return DI_ERR_ARG; }
+#undef DI_LN
+  return di::check_launch("add_layernorm_fwd");
+}
 
 int di_ms_deform_attn_fwd(const void *value, const void *offsets, int off_row_stride, const void *logits,
                           int logit_row_stride, const float *ref, int ref_shared, void *out, int bs, int nq,
@@ -297,6 +386,13 @@ int di_ms_deform_attn_fwd(const void *value, const void *offsets, int off_row_st
   DI_REQUIRE(bs > 0 && nq > 0, "bad deformable attention shape");
   DI_REQUIRE((n_levels == 1 || n_levels == 2) && n_points == 4, "levels %d / points %d unsupported (1|2 levels, 4 points)",
              n_levels, n_points);
+  {   // the offsets / logits of one head are fetched with 8- / 16-byte loads
+    const size_t esz = dtype == DI_F16 ? 2 : 4;
+    const size_t la = (size_t)n_levels * 4 * esz < 16 ? (size_t)n_levels * 4 * esz : 16;
+    DI_REQUIRE(((uintptr_t)offsets % 16) == 0 && (off_row_stride * esz) % 16 == 0 && ((uintptr_t)logits % la) == 0 &&
+                   (logit_row_stride * esz) % la == 0,
+               "offsets / logits rows must be 16-byte aligned (packed projection of 8*L*P*3 columns)");
+  }
   di::pp::Levels lv;
   lv.n = n_levels;
   int S = 0;

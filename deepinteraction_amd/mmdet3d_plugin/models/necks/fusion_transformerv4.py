@@ -17,10 +17,11 @@ import torch.nn.functional as F
 from torch import nn
 
 from .... import ops
+from ....autograd import GridGather, PolarBEVSample
 from ....geometry import PC_RANGE, aug_affine
 from ....registry import ATTENTION, NECKS, TRANSFORMER_LAYER
 from ..utils import encoder_utils as eu
-from ..utils.transformer_bricks import MultiScaleDeformableAttention, TransFFN
+from ..utils.transformer_bricks import MultiScaleDeformableAttention, TransFFN, post_norm
 
 if 'MultiScaleDeformableAttention' not in getattr(ATTENTION, 'module_dict', {}):
     ATTENTION.register_module(module=MultiScaleDeformableAttention)
@@ -49,14 +50,14 @@ class MMRI_P2I(nn.Module):
         self.Warp = eu.BEVWarp()
         self.Local = MultiScaleDeformableAttention(embed_dims, num_levels=1, batch_first=batch_first)
 
-    def forward(self, img_feats, lidar_feats, img_metas, pts_metas, reference_points=None, **kwargs):
+    def forward(self, img_feats, lidar_feats, img_metas, pts_metas, reference_points=None, then_norm=None, **kwargs):
         B = lidar_feats.size(0)
         _, C, H, W = img_feats.shape
         warped = self.Warp(ops.cl(lidar_feats), img_feats.reshape(B, -1, C, H, W), img_metas, pts_metas)
         q = _tokens(img_feats)
         v = _tokens(warped.reshape(-1, C, H, W))
         out = self.Local(query=q, value=v, reference_points=reference_points, spatial_shapes=[(H, W)],
-                         level_start_index=None)
+                         level_start_index=None, then_norm=then_norm)
         return _map(out, H, W)
 
 
@@ -100,25 +101,40 @@ class PackedMHA(nn.Module):
     """Parameters of the reference's `FlashMultiheadAttention` (:715-760): `in_proj_weight`, `in_proj_bias`,
     `out_proj.*`.  The attention itself is `ops.mha_small`."""
 
-    def __init__(self, embed_dim, num_heads):
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
         super().__init__()
-        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
         self.out_proj = nn.Linear(embed_dim, embed_dim)
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.)
 
+    def _attend(self, q, k, v):
+        if not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)):
+            return ops.mha_small(q, k, v, self.num_heads)
+        # training: scores materialised per (sequence, head) through library GEMMs and their autograd (what
+        # flash-attn's backward recomputes); attention dropout as in FlashAttention(attention_dropout=dropout)
+        N, T, E = q.shape
+        h, d = self.num_heads, E // self.num_heads
+        qh = q.reshape(N, T, h, d).transpose(1, 2) * (float(d) ** -0.5)
+        kh = k.reshape(N, -1, h, d).transpose(1, 2)
+        vh = v.reshape(N, -1, h, d).transpose(1, 2)
+        a = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)).float(), -1).to(vh.dtype)
+        if self.training and self.dropout > 0:
+            a = F.dropout(a, self.dropout)
+        return torch.matmul(a, vh).transpose(1, 2).reshape(N, T, E)
+
     def self_attention(self, x):
         E = self.embed_dim
         qkv = F.linear(x, self.in_proj_weight, self.in_proj_bias)               # (N,T,3E): q | k | v in place
-        return self.out_proj(ops.mha_small(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], self.num_heads))
+        return self.out_proj(self._attend(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]))
 
     def cross_attention(self, x, memory):
         E = self.embed_dim
         q = F.linear(x, self.in_proj_weight[:E], self.in_proj_bias[:E])
         kv = F.linear(memory, self.in_proj_weight[E:], self.in_proj_bias[E:])   # (N,S,2E): k | v
-        return self.out_proj(ops.mha_small(q, kv[..., :E], kv[..., E:], self.num_heads))
+        return self.out_proj(self._attend(q, kv[..., :E], kv[..., E:]))
 
 
 class _RayDecoderLayer(nn.Module):
@@ -127,14 +143,16 @@ class _RayDecoderLayer(nn.Module):
 
     def __init__(self, d, heads, ff, dropout=0.1):
         super().__init__()
-        self.self_attn, self.multihead_attn = PackedMHA(d, heads), PackedMHA(d, heads)
+        self.self_attn, self.multihead_attn = PackedMHA(d, heads, dropout), PackedMHA(d, heads, dropout)
         self.linear1, self.linear2 = nn.Linear(d, ff), nn.Linear(ff, d)
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
+        self.drop = nn.Dropout(dropout)                        # torch's dropout / dropout1..3 (p = 0.1), training only
 
     def forward(self, tgt, memory):
-        tgt = self.norm1(tgt + self.self_attn.self_attention(tgt))
-        tgt = self.norm2(tgt + self.multihead_attn.cross_attention(tgt, memory))
-        return self.norm3(tgt + self.linear2(torch.relu_(self.linear1(tgt))))
+        dr = self.drop
+        tgt = post_norm(self.norm1, tgt, dr(self.self_attn.self_attention(tgt)))
+        tgt = post_norm(self.norm2, tgt, dr(self.multihead_attn.cross_attention(tgt, memory)))
+        return post_norm(self.norm3, tgt, dr(self.linear2(dr(torch.relu(self.linear1(tgt))))))
 
 
 class _Stack(nn.Module):
@@ -157,10 +175,10 @@ class _RayTransformer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, src, tgt):
-        memory = self.encoder.norm(src)
+        memory = post_norm(self.encoder.norm, src)
         for layer in self.decoder.layers:
             tgt = layer(tgt, memory)
-        return self.decoder.norm(tgt)
+        return post_norm(self.decoder.norm, tgt)
 
 
 @ATTENTION.register_module()
@@ -237,7 +255,12 @@ class MMRI_I2P_Polar(nn.Module):
         grid = (geoms[0].polar[0] if B == 1 else torch.cat([g.polar[0] for g in geoms])).view(B * V, W * R, 2)
         cam_xy = (geoms[0].polar[1][None] if B == 1 else torch.stack([g.polar[1] for g in geoms])).contiguous()
         ray_pos, img_pos = self.constants(H, W, dt, dev)
-        rays = ops.grid_gather(lidar_feat, grid, add=ray_pos, grids_per_feat=V)             # (B*V, W*R, C)
+        live = torch.is_grad_enabled() and (lidar_feat.requires_grad or img_feat.requires_grad
+                                            or any(p.requires_grad for p in self.parameters()))
+        if live:
+            rays = GridGather.apply(lidar_feat, grid, ray_pos, V)
+        else:
+            rays = ops.grid_gather(lidar_feat, grid, add=ray_pos, grids_per_feat=V)         # (B*V, W*R, C)
         rays = rays.view(B * V * W, R, C)
         cols = (_tokens(img_feat) + img_pos).view(B * V, H, W, C).transpose(1, 2).reshape(B * V * W, H, C)
         polar = self.transformer_layers(cols, rays).view(B, V, W, R, C)                     # ray-major polar maps
@@ -250,6 +273,8 @@ class MMRI_I2P_Polar(nn.Module):
                                                                       float(self.radius_range[0]), float(R)],
                                                dtype=torch.float32, device=dev))
         params = self._params[1]
+        if live:
+            return PolarBEVSample.apply(polar.contiguous(), lidar_feat, proj.contiguous(), aug.contiguous(), cam_xy, params)
         return ops.polar_bev_sample(polar, lidar_feat, proj.contiguous(), aug.contiguous(), cam_xy, params)
 
 
@@ -290,7 +315,10 @@ class DeepInteractionLayer(nn.Module):
         query = _tokens(query)
         ni = ai = fi = 0
         self_feat = None
-        for op in self.operation_order[:-2]:
+        order = self.operation_order[:-2]
+        fused = False                              # the previous step already applied this 'norm'
+        for i, op in enumerate(order):
+            nxt = self.norms[ni] if i + 1 < len(order) and order[i + 1] == 'norm' else None
             if op == 'self_attn':
                 query = self.attentions[ai](query=query, value=ms_query, identity=None,
                                             reference_points=reference_points, spatial_shapes=spatial_shapes,
@@ -298,24 +326,37 @@ class DeepInteractionLayer(nn.Module):
                 ai += 1
                 self_feat = query
             elif op == 'norm':
-                query = self.norms[ni](query)
+                if not fused:
+                    query = post_norm(self.norms[ni], query)
+                fused = False
                 ni += 1
             elif op == 'cross_attn':
-                out = self.attentions[ai](_map(query, qh, qw), value, img_metas=img_metas, pts_metas=pts_metas,
-                                          reference_points=reference_points[:, :, 0:1, :],
-                                          spatial_shapes=spatial_shapes, level_start_index=level_start_index)
+                att = self.attentions[ai]
+                kw = {}
+                if nxt is not None and isinstance(att, MMRI_P2I):
+                    kw['then_norm'], fused = nxt, True
+                out = att(_map(query, qh, qw), value, img_metas=img_metas, pts_metas=pts_metas,
+                          reference_points=reference_points[:, :, 0:1, :], spatial_shapes=spatial_shapes,
+                          level_start_index=level_start_index, **kw)
                 query = _tokens(out)
                 ai += 1
             elif op == 'ffn':
-                query = self.ffns[fi](query, None)
+                if nxt is not None:
+                    query, fused = self.ffns[fi].then_norm(nxt, query), True
+                else:
+                    query = self.ffns[fi](query, None)
                 fi += 1
-        for op in self.operation_order[-2:]:
-            if op == 'norm':
-                self_feat = self.norms[ni](self_feat)
-                ni += 1
-            elif op == 'ffn':
-                self_feat = self.ffns[fi](self_feat)
-                fi += 1
+        tail = self.operation_order[-2:]
+        if tail == ('ffn', 'norm'):
+            self_feat = self.ffns[fi].then_norm(self.norms[ni], self_feat)
+        else:
+            for op in tail:
+                if op == 'norm':
+                    self_feat = post_norm(self.norms[ni], self_feat)
+                    ni += 1
+                elif op == 'ffn':
+                    self_feat = self.ffns[fi](self_feat)
+                    fi += 1
         return _map(self_feat + self.scale * query, qh, qw)
 
 

@@ -452,3 +452,67 @@ def mha_small(q, k, v, num_heads):
     _profiled('mha_small_fwd', N, lambda: _lib.call(
         'di_mha_small_fwd', qp, qrs, kp, vp, krs, out.data_ptr(), E, N, T, S, num_heads, 16, 0.25, _code(q), _stream()))
     return out
+
+
+def add_layernorm(x, res, weight, bias, eps=1e-5):
+    """LayerNorm(x + res) over the last dim (res may be None); x (..., C) contiguous, C <= 128."""
+    _dev(x, weight, bias)
+    C = x.shape[-1]
+    assert x.is_contiguous() and weight.dtype == x.dtype == bias.dtype and weight.shape == (C,)
+    if res is not None:
+        assert res.shape == x.shape and res.dtype == x.dtype and res.is_contiguous()
+    out = torch.empty_like(x)
+    n = x.numel() // C
+    _profiled('add_layernorm_fwd', n, lambda: _lib.call(
+        'di_add_layernorm_fwd', x.data_ptr(), 0 if res is None else res.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+        out.data_ptr(), n, C, float(eps), _code(x), _stream()))
+    return out
+
+
+def _level_array(level_hw):
+    import ctypes
+    L = len(level_hw)
+    return (ctypes.c_int32 * (2 * L))(*[int(x) for pair in level_hw for x in pair])
+
+
+def ms_deform_attn_bwd(value, offsets, logits, ref, level_hw, grad_out, n_points=4):
+    """-> (grad_value (bs,S,128) float32, grad_proj (bs,nq,8*L*P*3) in the input dtype: [d offsets | d logits])."""
+    import ctypes
+    _dev(value, offsets, logits, ref, grad_out)
+    bs, S, E = value.shape
+    nq, L = offsets.shape[1], len(level_hw)
+    op, ors = _rows(offsets)
+    lp, lrs = _rows(logits)
+    grad_out = grad_out.contiguous()
+    gv = torch.zeros((bs, S, E), dtype=torch.float32, device=value.device)
+    ncol = 8 * L * n_points * 3
+    gp = torch.empty((bs, nq, ncol), dtype=value.dtype, device=value.device)
+    hw = _level_array(level_hw)
+    _lib.call('di_ms_deform_attn_bwd', value.data_ptr(), op, ors, lp, lrs, ref.data_ptr(), int(ref.shape[0] == 1),
+              grad_out.data_ptr(), gv.data_ptr(), gp.data_ptr(), ncol, bs, nq, L, n_points, ctypes.addressof(hw),
+              _code(value), _stream())
+    return gv, gp
+
+
+def grid_gather_bwd(grid, grad_out, feat_shape, grids_per_feat=1):
+    """-> grad_feat (Bf,C,H,W) float32, channels-last."""
+    _dev(grid, grad_out)
+    Bf, C, H, W = feat_shape
+    Bg, N = grid.shape[:2]
+    grad_out = grad_out.contiguous()
+    gf = torch.zeros((Bf, C, H, W), dtype=torch.float32, device=grid.device).contiguous(memory_format=torch.channels_last)
+    _lib.call('di_grid_gather_bwd', grid.data_ptr(), grad_out.data_ptr(), gf.data_ptr(), Bg, N, grids_per_feat, H, W, C,
+              _code(grad_out), _stream())
+    return gf
+
+
+def polar_bev_sample_bwd(grad_out, proj, aug_rev, cam_xy, params, polar_shape):
+    """grad_out (B,C,Hb,Wb) channels-last -> grad_polar (B,V,Wp,R,C) float32."""
+    _dev(grad_out, proj)
+    B, V, Wp, R, C = polar_shape
+    grad_out = cl(grad_out)
+    Hb, Wb = grad_out.shape[-2:]
+    gp = torch.zeros(polar_shape, dtype=torch.float32, device=grad_out.device)
+    _lib.call('di_polar_bev_sample_bwd', grad_out.data_ptr(), proj.data_ptr(), aug_rev.data_ptr(), cam_xy.data_ptr(),
+              params.data_ptr(), gp.data_ptr(), B, V, R, Wp, Hb, Wb, C, _code(grad_out), _stream())
+    return gp

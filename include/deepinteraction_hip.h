@@ -214,11 +214,16 @@ int di_mha_decode_fwd(const void *q, const void *kv, void *out, float *scratch, 
  *   align_corners=False; feat (Bf,H,W,C) channels-last, grid (n_grids, n_points, 2) float32 in [-1,1]; `add` may
  *   be NULL.  The polar ray queries, fusion_transformerv4.py:574-575.
  * di_polar_bev_sample_fwd: fusion_transformerv4.py:581-640 over all cameras: polar (B,V,Wp,R,C) per-camera polar
- *   maps stored ray-major (image column, radius, channel), bev (B,Hb,Wb,C) residual, proj (B,V,4,4) lidar2img, aug_rev (B,12) [A row-major | t], cam_xy (B,V,2)
- *   camera centres, params = [pc_range(6), input_H, input_W, radius_min, n_radius] (device, float32);
+ *   maps stored ray-major (image column, radius, channel), bev (B,Hb,Wb,C) residual, proj (B,V,4,4) lidar2img,
+ *   aug_rev (B,12) [A row-major | t], cam_xy (B,V,2) camera centres, params = [pc_range(6), input_H, input_W, radius_min, n_radius] (device, float32);
  *   out (B,Hb,Wb,C) = mean over seeing cameras of the sampled polar map + bev.
  * di_mha_small_fwd: softmax(q k^T * scale) v per head for n_seq short sequences; q (n_seq,Tq,*), k/v (n_seq,S,*)
- *   with the given row strides (elements) so packed projections can be passed in place; head_dim 16. */
+ *   with the given row strides (elements) so packed projections can be passed in place; head_dim 16.
+ * di_add_layernorm_fwd: out = LayerNorm(x + res) * gamma + beta over the last dim C (res may be NULL): the
+ *   `norm(x + dropout(branch))` post-norm steps of the ++ transformer layers (fusion_transformerv4.py:179-181,196-198;
+ *   torch nn.TransformerDecoderLayer inside MMRI_I2P_Polar), statistics in float32. */
+int di_add_layernorm_fwd(const void *x, const void *res, const void *gamma, const void *beta, void *out,
+                         long long n_tokens, int C, float eps, int dtype, void *stream);
 int di_ms_deform_attn_fwd(const void *value, const void *offsets, int off_row_stride, const void *logits,
                           int logit_row_stride, const float *ref, int ref_shared, void *out, int bs, int nq,
                           int n_levels, int n_points, const int32_t *level_hw, int dtype, void *stream);
@@ -230,6 +235,24 @@ int di_polar_bev_sample_fwd(const void *polar, const void *bev, const float *pro
 int di_mha_small_fwd(const void *q, int q_row_stride, const void *k, const void *v, int kv_row_stride, void *out,
                      int out_row_stride, int n_seq, int Tq, int S, int num_heads, int head_dim, float scale, int dtype,
                      void *stream);
+
+/* Backward of the ++ samplers (training).  Gradient maps are float32, zero-filled by the caller, accumulated with
+ * atomics; sampling geometry carries no gradient (detached in the reference too).
+ * di_ms_deform_attn_bwd: grad_out (bs,nq,128) -> grad_value (bs,S,128) float32 and grad_proj: bs*nq rows of
+ *   [d offsets (8,L,4,2) | d logits (8,L*4)] (through the fused softmax), `grad_proj_row_stride` elements apart,
+ *   same dtype as the inputs.  mmcv's `ms_deform_attn_backward`.
+ * di_grid_gather_bwd: grad_feat (Bf,H,W,C) float32 += bilinear weights * grad_out (n_grids,n_points,C).
+ * di_polar_bev_sample_bwd: grad_polar (B,V,Wp,R,C) float32 += weights / n_seeing_cameras * grad_out (B,Hb,Wb,C);
+ *   the residual's gradient is grad_out itself. */
+int di_ms_deform_attn_bwd(const void *value, const void *offsets, int off_row_stride, const void *logits,
+                          int logit_row_stride, const float *ref, int ref_shared, const void *grad_out,
+                          float *grad_value, void *grad_proj, int grad_proj_row_stride, int bs, int nq, int n_levels,
+                          int n_points, const int32_t *level_hw, int dtype, void *stream);
+int di_grid_gather_bwd(const float *grid, const void *grad_out, float *grad_feat, int n_grids, int n_points,
+                       int grids_per_feat, int H, int W, int C, int dtype, void *stream);
+int di_polar_bev_sample_bwd(const void *grad_out, const float *proj, const float *aug_rev, const float *cam_xy,
+                            const float *params, float *grad_polar, int B, int V, int R, int Wp, int Hb, int Wb,
+                            int C, int dtype, void *stream);
 
 /* ---------------------------------------------------------------- pillar / voxel producer
  * Hard voxelisation (spconv PointToVoxel as wrapped by models/updated_modules/sparse_voxelize.py:9-70), three

@@ -79,6 +79,19 @@ def test_mha_small_kernel(dtype, tol, T, S):
     assert (out.float().cpu() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-6), (torch.float16, 2e-3)])
+@pytest.mark.parametrize('C,res', [(128, True), (128, False), (64, True)])
+def test_add_layernorm_kernel(dtype, tol, C, res):
+    from deepinteraction_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = (torch.randn(3, 1001, C, generator=g) * 3 + 1).to(dtype)
+    r = torch.randn(3, 1001, C, generator=g).to(dtype) if res else None
+    w, b = (1 + 0.2 * torch.randn(C, generator=g)).to(dtype), (0.1 * torch.randn(C, generator=g)).to(dtype)
+    out = ops.add_layernorm(x.to(DEV), None if r is None else r.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
+    want = F.layer_norm(x.float() + (r.float() if res else 0), (C,), w.float(), b.float(), 1e-5)
+    assert (out.float().cpu() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+
+
 def _pp_pair(cls_ref_builder, aug, dtype):
     from deepinteraction_amd.mmdet3d_plugin import FusionTransformerv4
     O, inp = mg.encoder_pp_case(opp.FusionTransformerv4, aug)
