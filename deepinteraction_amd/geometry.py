@@ -99,4 +99,3 @@ class SampleGeometry:
         assert host.numel() == self._buf.numel(), 'view count changed: rebuild the geometry'
         self._buf.copy_(host, non_blocking=True)
         self.sparse_depth = self.dense_depth = None
-        self.polar_key = None

@@ -33,9 +33,11 @@ class GraphedHotPath:
     def __init__(self, encoder, decoder, inputs, warmup=3):
         assert not encoder.training and not decoder.training, 'graph capture is for the inference form'
         self.enc, self.dec = encoder, decoder
-        dev = inputs['img_feats'].device
-        self.img_feats = inputs['img_feats'].clone(memory_format=torch.preserve_format)
-        self.pts_feats = inputs['pts_feats'].clone(memory_format=torch.preserve_format)
+        # one map per modality (v1 neck) or a list of levels (DeepInteraction++ neck)
+        self.img_feats = self._clone(inputs['img_feats'])
+        self.pts_feats = self._clone(inputs['pts_feats'])
+        first_img = self.img_feats[0] if isinstance(self.img_feats, list) else self.img_feats
+        dev = first_img.device
         pm = inputs['pts_metas']
         self.batch = len(inputs['img_metas'])
         self.img_metas = [dict(m) for m in inputs['img_metas']]
@@ -50,12 +52,26 @@ class GraphedHotPath:
             self.bounds = [0]
             for c in cnt:
                 self.bounds.append(self.bounds[-1] + c)
-        Hi, Wi = self.img_feats.shape[-2:]
+        Hi, Wi = first_img.shape[-2:]
         self.sample_geom = [SampleGeometry(m, (Hi, Wi), dev) for m in self.img_metas]
         self.query_geom = QueryGeometry(self.img_metas, dev)
         self.graph = None
         self.out = None
         self._capture(warmup)
+
+    @staticmethod
+    def _clone(x):
+        if isinstance(x, (list, tuple)):
+            return [t.clone(memory_format=torch.preserve_format) for t in x]
+        return x.clone(memory_format=torch.preserve_format)
+
+    @staticmethod
+    def _copy(dst, src):
+        if isinstance(dst, list):
+            for d, s_ in zip(dst, src):
+                d.copy_(s_, non_blocking=True)
+        else:
+            dst.copy_(src, non_blocking=True)
 
     def _pts_metas(self):
         return {'pillars': self.pillars, 'pillar_coors': self.pillar_coors,
@@ -100,8 +116,8 @@ class GraphedHotPath:
     def load(self, inputs):
         """Copy a new batch into the static buffers (same shapes; points / pillars up to the captured
         capacity) and refresh the geometry constants in place."""
-        self.img_feats.copy_(inputs['img_feats'], non_blocking=True)
-        self.pts_feats.copy_(inputs['pts_feats'], non_blocking=True)
+        self._copy(self.img_feats, inputs['img_feats'])
+        self._copy(self.pts_feats, inputs['pts_feats'])
         pm = inputs['pts_metas']
         if self.batch != len(inputs['img_metas']):
             raise ValueError('batch size differs from the captured one')
@@ -120,6 +136,9 @@ class GraphedHotPath:
                 self._fit(self.pillar_coors[lo:hi], pm['pillar_coors'][sel], 0)
                 self._fit(self.pillars_num_points[lo:hi], pm['pillars_num_points'][sel], 0)
         self.img_metas = [dict(m) for m in inputs['img_metas']]
-        for g, m in zip(self.sample_geom, self.img_metas):
+        for b, (g, m) in enumerate(zip(self.sample_geom, self.img_metas)):
             g.update(m)
+            for mod in self.enc.modules():       # per-sample constants some operators keep next to the geometry
+                if hasattr(mod, 'refresh_static_geometry'):
+                    mod.refresh_static_geometry(g, m)
         self.query_geom.update(self.img_metas)

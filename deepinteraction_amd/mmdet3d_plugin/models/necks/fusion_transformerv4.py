@@ -237,6 +237,15 @@ class MMRI_I2P_Polar(nn.Module):
             geom.polar_key = key
         return geom
 
+    def refresh_static_geometry(self, geom, img_meta):
+        """New sample behind a captured hipGraph: rewrite the ray geometry IN PLACE (the graph has the addresses)."""
+        if getattr(geom, 'polar_key', None) is None:
+            return
+        H, W = geom.polar_key[:2]
+        grid, cam_xy = self.ray_grid(img_meta, H, W)
+        geom.polar[0].copy_(grid, non_blocking=True)
+        geom.polar[1].copy_(cam_xy, non_blocking=True)
+
     def constants(self, H, W, dtype, device):
         key = (H, W, dtype, device)
         if key not in self._const:

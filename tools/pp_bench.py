@@ -47,6 +47,15 @@ torch.cuda.synchronize(); dtm = (time.perf_counter() - t0) / a.steps
 print(f'DeepInteraction++ forward {a.dtype} (eager): {dtm*1e3:.2f} ms  ({1/dtm:.1f} samples/s), '
       f'finite: {all(torch.isfinite(v).all().item() for v in out.values())}, '
       f'peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB, pillars {pm["pillars"].shape[0]}')
+from deepinteraction_amd.graphed import GraphedHotPath
+gr = GraphedHotPath(enc, dec, dict(img_feats=img, pts_feats=pts, img_metas=inp['img_metas'], pts_metas=pm))
+for _ in range(3):
+    gr()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(a.steps):
+    gr()
+torch.cuda.synchronize(); dtg = (time.perf_counter() - t0) / a.steps
+print(f'DeepInteraction++ forward {a.dtype} (hipGraph replay): {dtg*1e3:.2f} ms  ({1/dtg:.1f} samples/s)')
 ops.PROFILE = []
 fwd(); fwd()
 torch.cuda.synchronize()
