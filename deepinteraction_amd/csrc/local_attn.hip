@@ -367,6 +367,8 @@ int launch_local_attn_mfma(const void *q, const void *k, const void *v, void *ou
                            float scale, hipStream_t stream);   // local_attn_mfma.hip
 int launch_local_attn_mfma2(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                             float scale, int cfg, hipStream_t stream);   // local_attn_mfma2.hip
+int launch_local_attn_mfma4(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
+                            float scale, int cfg, hipStream_t stream);
 int launch_local_attn_mfma3(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                             float scale, int cfg, hipStream_t stream);   // local_attn_mfma3.hip
 
@@ -392,6 +394,13 @@ int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out,
   if (variant == DI_LA_MFMA && !mfma_ok) {
     di::set_error("MFMA local attention needs fp16, C=128, 9x9 (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
     return DI_ERR_ARG;
+  }
+  if (variant >= DI_LA_MFMA4 && variant < DI_LA_MFMA4 + 16) {
+    if (!mfma_ok) {
+      di::set_error("the vertical-streaming kernel needs fp16, C=128, 9x9");
+      return DI_ERR_ARG;
+    }
+    return di::launch_local_attn_mfma4(q, k, v, out, n, H, W, scale, variant - DI_LA_MFMA4, (hipStream_t)stream);
   }
   if (variant >= DI_LA_MFMA3 && variant < DI_LA_MFMA3 + 3) {
     if (!mfma_ok) {

@@ -1,0 +1,475 @@
+// Fused 9x9 local-window attention on the gfx950 matrix cores, fourth generation: VERTICAL STREAMING.
+//
+// The second generation (local_attn_mfma2.hip, 0.47 of the HBM roofline) re-stages the full 24 x 12-texel halo
+// of every 16 x 4 tile: 4.5x the K/V bytes cross the L2 -> LDS path (344 MB per image-side launch through the
+// texture path and as many LDS writes), and that staging - not HBM (1.07x algorithmic traffic), not the MFMA
+// work, not the LDS fragment reads - is what the kernel waits for.  Consecutive tiles of one column share 8 of
+// their 12 halo rows, so here a workgroup owns a 16-pixel-wide STRIP segment and walks it downwards 4 rows at a
+// time with the halo in a ring:
+//
+//   * LDS = K ring + V ring, 12 rows x 24 columns x 128 channels each (2 x 72 KB, one workgroup per CU); a step
+//     consumes all 12 rows and replaces only the 4 oldest: 1/3 of the second generation's staging per step,
+//     K/V amplification (24/16 columns) x (rows + 8)/rows ~ 1.8x instead of 4.5x;
+//   * the ring rotates by one 4-row group per step, the step body is instantiated for the 3 rotations so every
+//     LDS address is an immediate;
+//   * per step: S^T = K . Q^T over all 128 channels (40 MFMAs per wave), softmax, O^T = V^T . P^T (40 MFMAs),
+//     exactly the row-pair formulation, fragment layouts, masks and swizzle of the second generation.  The next
+//     step's 4 new K and V rows (12 x 16-B loads per lane) are issued at the top of the step and ride under both
+//     MFMA passes; K rows are committed to the ring after the S pass (their old rows are dead once every wave
+//     has left it), V rows after the O pass: two barriers per step, no separate staging phase;
+//   * strips are cut into segments so that (images x strips x segments) fills the CUs once; every XCD owns a
+//     contiguous range of neighbouring strips (shared halo columns stay in one L2).
+#include <type_traits>
+
+#include "di_common.h"
+
+namespace di {
+namespace m4 {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct G {
+  static constexpr int WX = 2, WY = 2, NW = 4, NT = 256;
+  static constexpr int TW = 16, TH = 4;              // queries per step
+  static constexpr int HC = 24, HR = 12;             // halo columns / rows
+  static constexpr int S = 256;                      // bytes of one texel slice (128 channels)
+  static constexpr int CPT = 16, NSEG = 8;           // 16-B chunks / 32-B segments per slice
+  static constexpr int ROWB = HC * S;                // 6144
+  static constexpr int GRPB = 4 * ROWB;              // one 4-row group of the ring
+  static constexpr int RINGB = HR * ROWB;            // 73728
+  static constexpr int LDS_BYTES = 2 * RINGB + 4 * 4096;   // K ring | V ring | output staging = exactly 160 KB
+  static constexpr int NLD = 4 * HC * CPT / NT;      // 16-B loads per lane per operand per group = 6
+  static constexpr int KK = 4, NN = 8;
+};
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// byte offset of 16-B chunk `c16` inside the 256-B slice of halo column `hc`.  A slice is a whole LDS bank row, so
+// 16 lanes that read the same chunk of 16 consecutive columns (the K fragments) must land on 16 different 16-B
+// positions: the 32-B segment is XOR-ed with the column's low 3 bits and the half inside the segment with bit 3.
+// The transposed V reads touch 8 consecutive columns per 32-lane phase (distinct segments) and see the half swap as
+// a per-lane constant; the staging writes of one texel are a permutation of its 16 chunks.
+__device__ __forceinline__ int swz(int hc, int c16) {
+  return ((((c16 >> 1) ^ (hc & 7))) << 5) | (((c16 & 1) ^ ((hc >> 3) & 1)) << 4);
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void pin_vmem() { __builtin_amdgcn_sched_barrier(0x0381); }
+
+template <bool TS>
+__global__ __launch_bounds__(G::NT, 1) void local_attn_m4_kernel(const __half *__restrict__ q,
+                                                                 const __half *__restrict__ k,
+                                                                 const __half *__restrict__ v,
+                                                                 __half *__restrict__ out, int n, int H, int W,
+                                                                 float scale, int strips_x, int steps_y, int nseg) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  constexpr int NLD = G::NLD, ROWB = G::ROWB, S = G::S;
+  unsigned char *kring = lds, *vring = lds + G::RINGB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wx = wave % G::WX;
+  const int wy = __builtin_amdgcn_readfirstlane(wave / G::WX);
+  const int i = lane & 15, g = lane >> 4;
+  const int j = i & 7, qrow = i >> 3;
+
+  // ---- staging constants: slot s moves chunk e = s*NT + tid of a 4-row group
+  // a slot spans at most two image rows: row (16 s) / 24 for its first lanes, the next one for the rest
+  int st_lds[NLD], st_col[NLD];                      // LDS offset inside the group; (halo column) * 256 + chunk * 16
+  unsigned st_hi = 0;                                // bit s: this lane's chunk of slot s lies in the slot's second row
+#pragma unroll
+  for (int s = 0; s < NLD; ++s) {
+    const int e = s * G::NT + tid;
+    const int tex = e / G::CPT, c16 = e % G::CPT;
+    const int hr = tex / G::HC, hc = tex - hr * G::HC;
+    st_lds[s] = hr * ROWB + hc * S + swz(hc, c16);
+    st_col[s] = hc * 256 + c16 * 16;
+    st_hi |= (unsigned)(hr != (16 * s) / G::HC) << s;
+  }
+  // ---- fragment constants (as in the second generation)
+  const int hcq = wx * 8 + i;
+  int koff[G::KK];
+#pragma unroll
+  for (int kl = 0; kl < G::KK; ++kl) koff[kl] = hcq * S + swz(hcq, kl * 4 + g);
+  const int kcv = wx * 8 + 4 * g + (i >> 2);
+  const int vsw = kcv & 7;
+  const int vbase = kcv * S + (i & 3) * 8;
+  int vso[G::NN];
+#pragma unroll
+  for (int nl = 0; nl < G::NN; ++nl) vso[nl] = kcv * S + ((nl ^ vsw) << 5) + (((i & 3) ^ (((kcv >> 3) & 1) << 1)) * 8);
+  const float cs = scale * 1.44269504088896f;
+  f4 nm_mid, nm_first, nm_last;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool in_band = 4 * g + r >= j && 4 * g + r <= j + 8;
+    nm_mid[r] = in_band ? 0.f : -INFINITY;
+    nm_first[r] = (in_band && qrow == 0) ? 0.f : -INFINITY;
+    nm_last[r] = (in_band && qrow == 1) ? 0.f : -INFINITY;
+  }
+  // ring slot (byte offset of the row) of halo row h = 2*wy + c in rotation PH
+  auto rowoff = [&](int c, int ph) {
+    int r = c + 4 * ph + 2 * wy;
+    r = r >= 12 ? r - 12 : r;
+    r = r >= 12 ? r - 12 : r;
+    return r * ROWB;
+  };
+
+  // measurement build only: lane 0 of every wave of workgroup 0 samples the shader clock at the phase boundaries
+  // measurement build: lane 0 of every wave of workgroup 0 writes its samples to the upper 2 KB of wave 3's output
+  // staging area (queries 8..15 of that wave come out wrong in this build: timing only); they are copied to the
+  // start of `out` when the workgroup ends
+  unsigned long long *ts_l = reinterpret_cast<unsigned long long *>(lds + G::LDS_BYTES - 2048) + wave * 64;
+  int tsi = 0;
+#define DI_TS()                                                                                                     \
+  do {                                                                                                              \
+    if (TS && blockIdx.x == 0 && lane == 0 && tsi < 64) ts_l[tsi++] = __builtin_readcyclecounter();   \
+  } while (0)
+  DI_TS();
+
+  // ---- work items: (image, segment, strip), strip fastest; every XCD owns a contiguous range
+  const int items = n * nseg * strips_x;
+  const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+  const int gxw = ((int)gridDim.x - xcd + 7) >> 3;
+  const int it_end = (int)(((long long)items * (xcd + 1)) >> 3);
+  int item = (int)(((long long)items * xcd) >> 3) + wl;
+
+  uint4 RK[NLD], RV[NLD];
+  unsigned okK = 0, okV = 0;
+  h8 qf[4];
+  // Finished outputs leave through a per-wave 4 KB LDS staging area: the MFMA result layout (lane = query i, 4
+  // channels per 16-channel block) would store 8-byte pieces scattered over 16 pixels (8 instructions x 16 partial
+  // lines per step - measured 1200 clocks of issue stalls); staged and read back, lane L of store m owns 16 B of
+  // pixel 4m + L/16: four adjacent pixels = 1 KB contiguous per instruction.  Rows XOR-swizzled by the query.
+  unsigned char *stg = lds + 2 * G::RINGB + wave * 4096;
+  const int stg_w = i * 256 + g * 8;                 // + ((nl ^ (i & 7)) << 5)
+  const int stg_qi = lane >> 4, stg_c = lane & 15;   // read-back: query 4m + stg_qi, chunk stg_c
+  int pend_y0 = 0, pend_x0 = 0, pend_img = 0;
+  bool pend_any = false;
+  auto stage = [&](int nl, h4 val) {
+    *reinterpret_cast<h4 *>(stg + stg_w + ((nl ^ (i & 7)) << 5)) = val;
+  };
+  auto st_pend = [&](int m) {                        // m = 0..3
+    if (!pend_any) return;
+    const int qi = 4 * m + stg_qi;
+    const uint4 val = *reinterpret_cast<const uint4 *>(stg + qi * 256 + ((((stg_c >> 1) ^ (qi & 7))) << 5) + (stg_c & 1) * 16);
+    const int gy = pend_y0 + 2 * wy + (m >> 1), gx = pend_x0 + 8 * wx + 4 * (m & 1) + stg_qi;
+    if (gy < H && gx < W)
+      *reinterpret_cast<uint4 *>(out + ((size_t)(pend_img * H + gy) * W + gx) * 128 + stg_c * 8) = val;
+  };
+
+  for (; item < it_end; item += gxw) {
+    const int strip = item % strips_x;
+    const int seg = (item / strips_x) % nseg;
+    const int img = item / (strips_x * nseg);
+    const int st0 = (int)(((long long)steps_y * seg) / nseg), st1 = (int)(((long long)steps_y * (seg + 1)) / nseg);
+    const int x0 = strip * G::TW;
+    const int nsteps = st1 - st0;
+    if (nsteps <= 0) continue;
+    const unsigned char *kimg = reinterpret_cast<const unsigned char *>(k) + (size_t)img * H * W * 256;
+    const unsigned char *vimg = reinterpret_cast<const unsigned char *>(v) + (size_t)img * H * W * 256;
+    // per-slot column validity and clamped column byte offset: constant over the item
+    unsigned colok = 0;
+    unsigned coloff[NLD];
+#pragma unroll
+    for (int s = 0; s < NLD; ++s) {
+      const int gx = x0 - 4 + (st_col[s] >> 8);
+      const int cx = min(max(gx, 0), W - 1);
+      colok |= (unsigned)(gx == cx) << s;
+      coloff[s] = (unsigned)cx * 256u + (unsigned)(st_col[s] & 255);
+    }
+    // the 4 rows of a group: clamped byte offsets and validity are wave-uniform (scalar registers).  Four named
+    // scalars, not an array: a lane-dependent choice between two array elements would be turned into an indexed
+    // access of a stack array (scratch traffic whose vmcnt waits serialise every load behind it)
+    unsigned rowb0 = 0, rowb1 = 0, rowb2 = 0, rowb3 = 0, rowok = 0;
+    auto prep_rows = [&](int y) {
+      auto one = [&](int r, unsigned &rb) {
+        const int gy = y + r, cy = min(max(gy, 0), H - 1);
+        rb = (unsigned)cy * (unsigned)W * 256u;
+        rowok = (rowok & ~(1u << r)) | ((unsigned)(gy == cy) << r);
+      };
+      one(0, rowb0); one(1, rowb1); one(2, rowb2); one(3, rowb3);
+    };
+    auto rowb_at = [&](auto rc) -> unsigned {
+      constexpr int r = decltype(rc)::value;
+      if constexpr (r == 0) return rowb0;
+      else if constexpr (r == 1) return rowb1;
+      else if constexpr (r == 2) return rowb2;
+      else return rowb3;
+    };
+    // load slot s of the prepared group: address = image base (scalar) + 32-bit lane offset
+    auto ld_group = [&](uint4 (&R)[NLD], unsigned &okbits, const unsigned char *src, auto sc) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int lo = (16 * s) / G::HC;
+      constexpr bool two = (16 * s + 15) / G::HC != lo;
+      unsigned rb = rowb_at(std::integral_constant<int, lo>{}), rk = (rowok >> lo) & 1u;
+      if constexpr (two) {
+        const unsigned hi = (st_hi >> s) & 1u;       // 0 / 1 per lane
+        const unsigned d = rowb_at(std::integral_constant<int, lo + 1>{}) - rb;
+        rb += hi * d;
+        rk = ((rowok >> lo) >> hi) & 1u;
+      }
+      const unsigned ok = rk & (colok >> s) & 1u;
+      okbits = (okbits & ~(1u << s)) | (ok << s);
+      R[s] = *reinterpret_cast<const uint4 *>(src + (rb + coloff[s]));
+    };
+    auto commit = [&](const uint4 (&R)[NLD], unsigned okbits, unsigned char *ring, int grp) {
+#pragma unroll
+      for (int s = 0; s < NLD; ++s) {
+        uint4 val = R[s];
+        if (!((okbits >> s) & 1u)) val = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4 *>(ring + grp * G::GRPB + st_lds[s]) = val;
+      }
+    };
+    const unsigned char *qbase = nullptr;
+    auto prep_q = [&](int y0) {
+      const int gy = min(y0 + 2 * wy + qrow, H - 1), gx = min(x0 + 8 * wx + j, W - 1);
+      qbase = reinterpret_cast<const unsigned char *>(q) + ((size_t)((img * H + gy) * W + gx) << 8) + g * 16;
+    };
+    auto ld_q = [&](int kk) { qf[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(qbase + kk * 64)); };
+
+    // ---- prologue: the 12 halo rows of the first step -> groups 0, 1, 2 (rotation 0)
+    int y0 = st0 * G::TH;
+    lds_barrier();                                   // the previous item's last O pass is over
+    prep_q(y0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ld_q(kk);
+    {
+      uint4 PK[3][NLD], PV[3][NLD];                  // all 36 + 36 loads in flight, then one commit sweep
+      unsigned pk_ok[3] = {0, 0, 0}, pv_ok[3] = {0, 0, 0};
+      static_for<0, 3>([&](auto gc) {
+        constexpr int grp = decltype(gc)::value;
+        prep_rows(y0 - 4 + 4 * grp);
+        static_for<0, NLD>([&](auto sc) { ld_group(PK[grp], pk_ok[grp], kimg, sc); });
+        static_for<0, NLD>([&](auto sc) { ld_group(PV[grp], pv_ok[grp], vimg, sc); });
+      });
+      static_for<0, 3>([&](auto gc) { commit(PK[decltype(gc)::value], pk_ok[decltype(gc)::value], kring, decltype(gc)::value); });
+      static_for<0, 3>([&](auto gc) { commit(PV[decltype(gc)::value], pv_ok[decltype(gc)::value], vring, decltype(gc)::value); });
+    }
+    prep_rows(y0 + 8);                               // K rows of step 1
+    static_for<0, NLD>([&](auto sc) { ld_group(RK, okK, kimg, sc); });
+    lds_barrier();
+    DI_TS();
+
+    // ---- one step in rotation PH; returns after committing the next step's rows
+    auto step = [&](auto phc, bool has_next) {
+      constexpr int PH = decltype(phc)::value;
+      f4 s[10];
+#pragma unroll
+      for (int rr = 0; rr < 10; ++rr) s[rr] = f4{0.f, 0.f, 0.f, 0.f};
+      // S^T = K . Q^T; background: the 12 loads of the next step's rows, then the previous step's stores
+      prep_rows(y0 + 8);                             // V rows of step t+1 (K rows are one phase ahead, see the O pass)
+      // explicit LDS-read pipeline: with one wave per SIMD nothing else hides the LDS latency, and four MFMAs that
+      // accumulate into the same registers run at the MFMA LATENCY, not its issue rate.  Rows are therefore
+      // processed in pairs: the K fragments of the next pair are requested before the MFMAs of the current one, and
+      // consecutive MFMAs alternate between the pair's two accumulators.
+      uint4 kf[10][G::KK];
+      auto rd_k = [&](auto rc) {
+        constexpr int rr = decltype(rc)::value;
+        // rows (2p, 2p+1) never straddle the ring's wrap (2p + 4PH + 2wy is even): one address per pair
+        const unsigned char *row = kring + rowoff(rr & ~1, PH) + (rr & 1) * ROWB;
+#pragma unroll
+        for (int kl = 0; kl < G::KK; ++kl) kf[rr][kl] = *reinterpret_cast<const uint4 *>(row + koff[kl]);
+      };
+      static_for<0, 2>(rd_k);
+      static_for<0, 5>([&](auto gc) {
+        constexpr int grp = decltype(gc)::value;     // row pair (2 grp, 2 grp + 1): two accumulators alternate
+        constexpr int r0 = 2 * grp;
+        // background of this pair: the next step's V rows, then the previous step's stores.  Loads are issued
+        // unconditionally (rows past the segment are clamped and never committed): a load under a branch would make
+        // the compiler fall back from counted vmcnt waits to vmcnt(0)
+        static_for<0, 3>([&](auto bc) {
+          constexpr int b = grp * 3 + decltype(bc)::value;
+          if constexpr (b < NLD) {
+            ld_group(RV, okV, vimg, std::integral_constant<int, b>{});
+          } else if constexpr (b < NLD + 4) {
+            st_pend(b - NLD);
+          }
+        });
+        if constexpr (grp < 4) static_for<r0 + 2, r0 + 4>(rd_k);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kl = 0; kl < G::KK; ++kl) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            s[r0 + r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, kf[r0 + r][kl]), qf[kl], s[r0 + r],
+                                                               0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (grp == 0 || grp == 2) DI_TS();
+      });
+      // qf is dead: the next step's Q fragments start now (a full softmax + O pass ahead of their first use)
+      prep_q(y0 + G::TH);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) ld_q(kk);
+      DI_TS();
+      // softmax over the 81 window slots of query i, log2 units
+      float m = -INFINITY;
+#pragma unroll
+      for (int rr = 0; rr < 10; ++rr) {
+        const f4 nm = rr == 0 ? nm_first : (rr == 9 ? nm_last : nm_mid);
+        s[rr] = s[rr] * cs + nm;
+        m = fmaxf(m, fmaxf(fmaxf(s[rr][0], s[rr][1]), fmaxf(s[rr][2], s[rr][3])));
+      }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      h8 pf[5];
+      f2 sum2 = {0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < 5; ++pr) {
+        h8 pk;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f4 d = s[2 * pr + t] - m;
+          f4 e;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(d[r]);
+          sum2 += f2{e[0], e[1]} + f2{e[2], e[3]};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[4 * t + r] = (_Float16)e[r];
+        }
+        pf[pr] = pk;
+      }
+      float sum = sum2[0] + sum2[1];
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      DI_TS();
+      // every wave has left the S pass: the 4 oldest K rows are dead, the next step's rows take their group
+      lds_barrier();
+      DI_TS();
+      if (has_next) commit(RK, okK, kring, PH);
+      DI_TS();
+      // O^T = V^T . P^T; background: the next step's Q fragments (qf is dead)
+      const float inv = 1.f / sum;
+      prep_rows(y0 + 12);                            // K rows of step t+2 ride under this O pass
+      f4 acc[G::NN];
+#pragma unroll
+      for (int nl = 0; nl < G::NN; ++nl) acc[nl] = f4{0.f, 0.f, 0.f, 0.f};
+      hv4 vf[5][G::NN][2];
+      auto rd_v = [&](auto pc) {
+        constexpr int pr = decltype(pc)::value;
+        const unsigned char *r0 = vring + rowoff(2 * pr, PH);
+#pragma unroll
+        for (int nl = 0; nl < G::NN; ++nl) {
+          const unsigned char *a = r0 + vso[nl];
+          vf[pr][nl][0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(a));
+          vf[pr][nl][1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(a + ROWB));
+        }
+      };
+      rd_v(std::integral_constant<int, 0>{});
+      static_for<0, 5>([&](auto pc) {
+        constexpr int pr = decltype(pc)::value;
+        if constexpr (pr < 4) rd_v(std::integral_constant<int, pr + 1>{});
+        if constexpr (pr < 3) {
+          ld_group(RK, okK, kimg, std::integral_constant<int, 2 * pr>{});
+          ld_group(RK, okK, kimg, std::integral_constant<int, 2 * pr + 1>{});
+        }
+#pragma unroll
+        for (int nl = 0; nl < G::NN; ++nl) {
+          const hv4 a0 = vf[pr][nl][0], a1 = vf[pr][nl][1];
+          h8 a;
+          a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3];
+          a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+          acc[nl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[pr], acc[nl], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      DI_TS();
+      // the previous step's stores were issued during the S pass; stage this step's results
+#pragma unroll
+      for (int nl = 0; nl < G::NN; ++nl) {
+        const f4 o = acc[nl] * inv;
+        h4 hv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = (_Float16)o[r];
+        stage(nl, hv);
+      }
+      pend_y0 = y0;
+      pend_x0 = x0;
+      pend_img = img;
+      pend_any = true;
+      lds_barrier();                                 // every wave has left the O pass: the oldest V rows are dead
+      DI_TS();
+      if (has_next) commit(RV, okV, vring, PH);
+      DI_TS();
+      y0 += G::TH;
+    };
+
+    int t = 0;
+    for (;;) {
+      step(std::integral_constant<int, 0>{}, t + 1 < nsteps);
+      if (++t == nsteps) break;
+      step(std::integral_constant<int, 1>{}, t + 1 < nsteps);
+      if (++t == nsteps) break;
+      step(std::integral_constant<int, 2>{}, t + 1 < nsteps);
+      if (++t == nsteps) break;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) st_pend(m);
+  if (TS && blockIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long *dump = reinterpret_cast<unsigned long long *>(out);
+      const unsigned long long *src = reinterpret_cast<const unsigned long long *>(lds + G::LDS_BYTES - 2048);
+      dump[0] = 4 * 64;
+      for (int e = 0; e < 4 * 64; ++e) dump[1 + e] = src[e];
+    }
+  }
+#undef DI_TS
+}
+
+}  // namespace m4
+
+// cfg: 0 = segments chosen so that the work items fill the CUs once; 1..14 = that many segments per strip;
+//      15 = measurement build (phase timestamps of workgroup 0 overwrite the start of `out`)
+int launch_local_attn_mfma4(const void *q, const void *k, const void *v, void *out, int n, int H, int W, float scale,
+                            int cfg, hipStream_t stream) {
+  using m4::G;
+  DI_REQUIRE((long long)n * H * W * 256 < (1ll << 31), "map of %d x %d x %d texels exceeds the 2 GiB offset range", n, H, W);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+      set_error("cannot query the CU count");
+      return DI_ERR_LAUNCH;
+    }
+    hipError_t e = hipFuncSetAttribute((const void *)m4::local_attn_m4_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)m4::local_attn_m4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              G::LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DI_ERR_LAUNCH;
+    }
+    n_cu = cus;
+  }
+  const int strips_x = (W + G::TW - 1) / G::TW, steps_y = (H + G::TH - 1) / G::TH;
+  const bool ts = cfg == 15;
+  int nseg = (cfg > 0 && !ts) ? cfg : n_cu / (n * strips_x);
+  nseg = nseg < 1 ? 1 : (nseg > steps_y ? steps_y : nseg);
+  const long long items = (long long)n * nseg * strips_x;
+  long long grid = n_cu;
+  if (grid > items) grid = (items + 7) / 8 * 8;
+  if (ts)
+    hipLaunchKernelGGL(m4::local_attn_m4_kernel<true>, dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, stream,
+                       (const __half *)q, (const __half *)k, (const __half *)v, (__half *)out, n, H, W, scale,
+                       strips_x, steps_y, nseg);
+  else
+    hipLaunchKernelGGL(m4::local_attn_m4_kernel<false>, dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, stream,
+                       (const __half *)q, (const __half *)k, (const __half *)v, (__half *)out, n, H, W, scale,
+                       strips_x, steps_y, nseg);
+  return check_launch("local_attn_m4");
+}
+
+}  // namespace di

@@ -62,7 +62,8 @@ int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, in
  * generic LDS-tiled VALU kernel.  The other codes select one implementation (tests, measurements). */
 enum { DI_LA_AUTO = 0, DI_LA_VALU = 1, DI_LA_MFMA = 2,
        DI_LA_MFMA2 = 3 /* + configuration: 3 = 16x8 tiles, 5 = 16x4 tiles (the AUTO choice), 7 = timestamps */,
-       DI_LA_MFMA3 = 8 /* producer/consumer wavefronts + direct-to-LDS loads (9, 10: measurement builds) */ };
+       DI_LA_MFMA3 = 8 /* producer/consumer wavefronts + direct-to-LDS loads (9, 10: measurement builds) */,
+       DI_LA_MFMA4 = 11 /* vertical streaming with the halo in an LDS ring; + k = k segments per strip (0 = fill the CUs once) */ };
 int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                          int C, int kH, int kW, float scale, int dtype, int variant, void *stream);
 

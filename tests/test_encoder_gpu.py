@@ -46,14 +46,15 @@ def test_local_attention_fused(dtype, tol, shape):
 
 
 @pytest.mark.parametrize('variant', [ops.LA_AUTO, ops.LA_VALU, ops.LA_MFMA, ops.LA_MFMA2, ops.LA_MFMA2 + 2,
-                                     ops.LA_MFMA3])
+                                     ops.LA_MFMA3, ops.LA_MFMA4, ops.LA_MFMA4 + 1, ops.LA_MFMA4 + 5])
 @pytest.mark.parametrize('shape', [(2, 13, 37), (1, 4, 16), (3, 9, 200), (1, 180, 180), (1, 1, 5), (6, 112, 200)])
 def test_local_attention_fp16_kernel_variants(variant, shape):
     """Both fp16 kernels of the fused op (LDS-tiled VALU; banded 16x16x32 MFMA) against the
     oracle: ragged tiles (W % 16, H % 4), image borders, several images, tiny maps, the full
     6x112x200 image-side shape.  Variants: the LDS-tiled VALU kernel, the three generations of
     matrix-core kernels (one-tile; persistent software-pipelined, 16x8 and 16x4 tiles;
-    producer/consumer with direct-to-LDS loads, 4 and 8 producer waves) and AUTO.  The MFMA
+    producer/consumer with direct-to-LDS loads; vertical streaming with the halo in an LDS ring: segments
+    filling the CUs, one segment per strip = every ring rotation incl. wrap-around, 5 segments) and AUTO.  The MFMA
     paths round the softmax weights to fp16 (rel 2^-11) before the PV product: 1e-3 budget."""
     _require_gpu()
     n, H, W = shape
