@@ -154,6 +154,7 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_m4_kernel(const __half *_
   int pend_y0 = 0, pend_x0 = 0, pend_img = 0;
   bool pend_any = false;
   auto stage = [&](int nl, h4 val) {
+    if (TS && wave == 3 && i >= 8) return;           // measurement build: that half holds the timestamps
     *reinterpret_cast<h4 *>(stg + stg_w + ((nl ^ (i & 7)) << 5)) = val;
   };
   auto st_pend = [&](int m) {                        // m = 0..3
@@ -282,16 +283,12 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_m4_kernel(const __half *_
       static_for<0, 5>([&](auto gc) {
         constexpr int grp = decltype(gc)::value;     // row pair (2 grp, 2 grp + 1): two accumulators alternate
         constexpr int r0 = 2 * grp;
-        // background of this pair: the next step's V rows, then the previous step's stores.  Loads are issued
+        // background of this pair: the next step's V rows (the previous step's stores ride in the softmax).  Loads are issued
         // unconditionally (rows past the segment are clamped and never committed): a load under a branch would make
         // the compiler fall back from counted vmcnt waits to vmcnt(0)
-        static_for<0, 3>([&](auto bc) {
-          constexpr int b = grp * 3 + decltype(bc)::value;
-          if constexpr (b < NLD) {
-            ld_group(RV, okV, vimg, std::integral_constant<int, b>{});
-          } else if constexpr (b < NLD + 4) {
-            st_pend(b - NLD);
-          }
+        static_for<0, 2>([&](auto bc) {
+          constexpr int b = grp * 2 + decltype(bc)::value;
+          if constexpr (b < NLD) ld_group(RV, okV, vimg, std::integral_constant<int, b>{});
         });
         if constexpr (grp < 4) static_for<r0 + 2, r0 + 4>(rd_k);
         __builtin_amdgcn_sched_barrier(0);
@@ -324,6 +321,7 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_m4_kernel(const __half *_
       f2 sum2 = {0.f, 0.f};
 #pragma unroll
       for (int pr = 0; pr < 5; ++pr) {
+        if (pr < 4) st_pend(pr);                     // the previous step's results: LDS read-back + one 1 KB store
         h8 pk;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
