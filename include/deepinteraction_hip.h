@@ -57,7 +57,8 @@ const char *di_last_error(void);
  * Supported windows: kH,kW odd in {3,5,7,9}. */
 int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                       int C, int kH, int kW, float scale, int dtype, void *stream);
-/* Same op with an explicit kernel choice.  DI_LA_AUTO picks, for fp16 / C=128 / 9x9, the persistent
+/* Same op with an explicit kernel choice (DI_LA_MFMA4: the vertical-streaming kernel, on par with the default on
+ * the image-side maps).  DI_LA_AUTO picks, for fp16 / C=128 / 9x9, the persistent
  * software-pipelined matrix-core kernel (row-pair 16x16x32 MFMA tiles, local_attn_mfma2.hip), else the
  * generic LDS-tiled VALU kernel.  The other codes select one implementation (tests, measurements). */
 enum { DI_LA_AUTO = 0, DI_LA_VALU = 1, DI_LA_MFMA = 2,
