@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void ms_deform_attn_bwd_kernel(
   const int l16 = threadIdx.x & 15;
   const int head = l16 >> 1, half = l16 & 1;
   const long long total = (long long)bs * nq;
-  const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  // every XCD (private L2) takes one contiguous range of queries: with the default round-robin of consecutive
+  // workgroups over the 8 XCDs each L2 ends up fetching the WHOLE value map (measured: 8x the map per launch)
+  const long long row = (long long)xcd_remap(blockIdx.x, gridDim.x) * 16 + (threadIdx.x >> 4);
   if (row >= total) return;                         // whole 16-lane groups leave together: DPP pairs stay intact
   const int b = (int)(row / nq), q = (int)(row - (long long)b * nq);
   float w[LP], ofs[LP * 2], dA[LP], dox[LP], doy[LP];

@@ -14,7 +14,13 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o stats -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_run.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pp_prof -o stats -- python $REPO/tools/pp_bench.py --steps 10 > $OUT/pp_bench.txt 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pp_pmc_fetch -o pmc -- python $REPO/tools/pp_bench.py --steps 2 > $OUT/pp_pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pp_pmc_write -o pmc -- python $REPO/tools/pp_bench.py --steps 2 > $OUT/pp_pmc_write.log 2>&1
 cd $REPO
-find $OUT -name '*.csv' | head -20
+grep -E "forward|fwd" $OUT/pp_bench.txt | head -12
+timeout 200 python tools/train_bench.py --dtype f32 --steps 5 > $OUT/train_bench.txt 2>&1; tail -1 $OUT/train_bench.txt
+timeout 200 python tools/pp_train_bench.py --dtype f32 --steps 3 > $OUT/pp_train_bench.txt 2>&1; tail -1 $OUT/pp_train_bench.txt
+find $OUT -name '*.csv' | head -30
 # keep the merge-back small: drop full kernel traces above 20 MB
 find $OUT -name '*.csv' -size +20M -delete
