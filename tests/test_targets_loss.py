@@ -226,3 +226,37 @@ def test_loss_has_gradients_and_empty_gt():
     empty = M.get_targets([dc.LiDARBoxes(torch.zeros(0, 9))], [torch.zeros(0, dtype=torch.long)],
                           [{k: v.detach() for k, v in pd.items()}])
     assert (empty[0] == 10).all() and empty[5] == 0 and empty[7].abs().sum() == 0
+
+
+def test_pp_head_loss_matches_reference(ref):
+    """DeepInteraction++ head: forward (with the three shims of oracle/refpin), targets and every loss term against
+    the reference's own `DeepInteractionPlusPlusDecoder` - the ++ loss weights EVERY MMPI layer by the cumulative
+    on-the-image mask (deepinteractionplusplus_decoder.py:513-514), the v1 loss only the image layers."""
+    from deepinteraction_amd.mmdet3d_plugin import DeepInteractionPlusPlusDecoder
+    shape = synth.SHAPE_TINY
+    cfg = decoder_cfg(bev=36, num_proposals=24)
+    torch.manual_seed(7)
+    R = ref.decoder_pp.DeepInteractionPlusPlusDecoder(**dict(cfg, train_cfg=ref.stubs.ConfigDict(TRAIN_CFG)))
+    M = DeepInteractionPlusPlusDecoder(**dict(cfg, train_cfg=TRAIN_CFG))
+    M.load_state_dict(R.state_dict())
+    R.eval()
+    g = torch.Generator().manual_seed(0)
+    Hi, Wi = shape['img_hw']
+    B = 2
+    p0, p1 = torch.randn(B, 128, 36, 36, generator=g), torch.randn(B, 128, 36, 36, generator=g)
+    img = torch.randn(6 * B, 128, Hi, Wi, generator=g)
+    metas = synth.make_inputs(B, shape, seed=0)['img_metas']
+    with torch.no_grad():
+        preds = R([p0, p1], img, metas)
+    assert len(R.on_the_image_mask) == 4 and not all(m.all() for m in R.on_the_image_mask)
+    M.query_labels, M.on_the_image_mask = R.query_labels, R.on_the_image_mask
+    gt_boxes, gt_labels = _gt_from_preds(M, preds, 5, 3)
+    gt_ref = [ref.stubs.LiDARInstance3DBoxes(b) for b in gt_boxes]
+    gt_our = [dc.LiDARBoxes(b) for b in gt_boxes]
+    clone = lambda: [[{k: v.clone() for k, v in preds[0][0].items()}]]
+    lr = R.loss(gt_ref, gt_labels, clone())
+    lm = M.loss(gt_our, gt_labels, clone())
+    assert set(lr) == set(lm)
+    for k in lr:
+        assert torch.allclose(lr[k].float(), lm[k].float(), rtol=1e-5, atol=1e-6), (k, lr[k], lm[k])
+    assert lr['layer_1_loss_bbox'] > 0
