@@ -300,3 +300,52 @@ def circle_nms(dets, thresh, post_max_size=83):
             if (x1[i] - x1[j]) ** 2 + (y1[i] - y1[j]) ** 2 <= thresh:
                 suppressed[j] = 1
     return keep[:post_max_size]
+
+
+def xywhr2xyxyr(boxes_xywhr):
+    """mmdet3d.core.xywhr2xyxyr: (n,5) [x, y, w, h, r] -> [x1, y1, x2, y2, r]."""
+    b = torch.zeros_like(boxes_xywhr)
+    half_w, half_h = boxes_xywhr[:, 2] / 2, boxes_xywhr[:, 3] / 2
+    b[:, 0], b[:, 1] = boxes_xywhr[:, 0] - half_w, boxes_xywhr[:, 1] - half_h
+    b[:, 2], b[:, 3] = boxes_xywhr[:, 0] + half_w, boxes_xywhr[:, 1] + half_h
+    b[:, 4] = boxes_xywhr[:, 4]
+    return b
+
+
+def boxes_iou_bev_xyxyr(a, b):
+    """Pairwise rotated BEV IoU of [x1, y1, x2, y2, r] boxes (mmdet3d iou3d `boxes_iou_bev`): (N,5),(M,5) -> (N,M)."""
+    N, M = a.shape[0], b.shape[0]
+    if N == 0 or M == 0:
+        return a.new_zeros(N, M)
+    to_c = lambda t: torch.stack([(t[:, 0] + t[:, 2]) / 2, (t[:, 1] + t[:, 3]) / 2, t[:, 2] - t[:, 0], t[:, 3] - t[:, 1],
+                                  t[:, 4]], 1)
+    ca, cb = to_c(a), to_c(b)
+    i, j = torch.meshgrid(torch.arange(N, device=a.device), torch.arange(M, device=a.device), indexing='ij')
+    inter = rotated_intersection_area(ca[i.reshape(-1)], cb[j.reshape(-1)]).view(N, M)
+    sa, sb = (ca[:, 2] * ca[:, 3])[:, None], (cb[:, 2] * cb[:, 3])[None]
+    return inter / (sa + sb - inter).clamp(min=1e-8)
+
+
+def nms_rotated_bev(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
+    """mmdet3d 0.17.1 `nms_gpu(boxes [x1,y1,x2,y2,r], scores, thresh, pre_maxsize, post_max_size)`: greedy suppression
+    in score order of boxes whose rotated BEV IoU with a kept box exceeds `thresh`; returns kept indices (int64)."""
+    order = scores.sort(0, descending=True)[1]
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    b = boxes[order].contiguous()
+    n = b.shape[0]
+    if n == 0:
+        return order
+    iou = boxes_iou_bev_xyxyr(b, b)
+    over = (iou > thresh).cpu()
+    suppressed = torch.zeros(n, dtype=torch.bool)
+    keep = []
+    for i in range(n):
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        suppressed |= over[i]
+    keep = order[torch.tensor(keep, dtype=torch.long, device=order.device)]
+    if post_max_size is not None:
+        keep = keep[:post_max_size]
+    return keep

@@ -17,6 +17,7 @@ from torch import nn
 
 from .... import ops
 from ....det3d_compat import (AssignResult, LiDARBoxes, build_loss, circle_nms, clip_sigmoid, draw_heatmap_gaussian,
+                              nms_rotated_bev, xywhr2xyxyr,
                               gaussian_radius, pseudo_sample)
 from ....registry import HEADS, build_bbox_coder
 from ...core.bbox.assigners import build_assigner
@@ -356,18 +357,20 @@ class DeepInteractionDecoder(nn.Module):
             for i in range(batch_size):
                 boxes3d, scores, labels = temp[i]['bboxes'], temp[i]['scores'], temp[i]['labels']
                 if self.test_cfg['nms_type'] is not None:
-                    if self.test_cfg['nms_type'] != 'circle':
-                        raise NotImplementedError('rotated NMS (mmdet3d nms_gpu) is outside this port')
                     keep_mask = torch.zeros_like(scores)
                     for task in tasks:
                         task_mask = torch.zeros_like(scores)
                         for cls_idx in task['indices']:
                             task_mask += labels == cls_idx
                         task_mask = task_mask.bool()
-                        if task['radius'] > 0:
+                        if task['radius'] > 0 and self.test_cfg['nms_type'] == 'circle':
                             dets = torch.cat([boxes3d[task_mask][:, :2], scores[:, None][task_mask]], dim=1)
                             keep = torch.tensor(circle_nms(dets.detach().cpu().numpy(), task['radius']),
                                                 dtype=torch.long, device=scores.device)
+                        elif task['radius'] > 0:        # rotated BEV NMS, the task's `radius` is the IoU threshold
+                            bev = boxes3d[task_mask][:, [0, 1, 3, 4, 6]]
+                            keep = nms_rotated_bev(xywhr2xyxyr(bev), scores[task_mask], task['radius'],
+                                                   self.test_cfg.get('pre_maxsize'), self.test_cfg.get('post_maxsize'))
                         else:
                             keep = torch.arange(int(task_mask.sum()), device=scores.device)
                         if keep.shape[0] != 0:

@@ -260,3 +260,40 @@ def test_pp_head_loss_matches_reference(ref):
     for k in lr:
         assert torch.allclose(lr[k].float(), lm[k].float(), rtol=1e-5, atol=1e-6), (k, lr[k], lm[k])
     assert lr['layer_1_loss_bbox'] > 0
+
+
+def test_rotated_nms_first_principles():
+    """mmdet3d `nms_gpu` restated (det3d_compat.nms_rotated_bev): IoU matrix against rasterisation, known answers,
+    greedy order, pre/post caps; and the head's get_bboxes with nms_type='rotate'."""
+    g = torch.Generator().manual_seed(1)
+    n = 12
+    c = torch.cat([torch.rand(n, 2, generator=g) * 4, torch.rand(n, 2, generator=g) * 2 + 0.8,
+                   (torch.rand(n, 1, generator=g) - 0.5) * 3], 1)
+    iou = dc.boxes_iou_bev_xyxyr(dc.xywhr2xyxyr(c), dc.xywhr2xyxyr(c))
+    assert torch.allclose(iou.diag(), torch.ones(n), atol=1e-6) and torch.allclose(iou, iou.t(), atol=1e-6)
+    for i, j in ((0, 1), (2, 7), (3, 4), (5, 11)):
+        inter = _raster_area(c[i].tolist(), c[j].tolist())
+        ref = inter / (c[i, 2] * c[i, 3] + c[j, 2] * c[j, 3] - inter).item()
+        assert abs(iou[i, j].item() - ref) <= 0.02, (i, j, iou[i, j].item(), ref)
+    sq = torch.tensor([[0., 0., 1., 1., 0.], [0., 0., 1., 1., math.pi / 4], [3., 0., 1., 1., 0.2], [0., 0., 1., 1., 0.]])
+    assert abs(dc.boxes_iou_bev_xyxyr(dc.xywhr2xyxyr(sq[:1]), dc.xywhr2xyxyr(sq[1:2])).item() - 2 ** -0.5) < 1e-5
+    sc = torch.tensor([0.5, 0.9, 0.3, 0.8])
+    assert dc.nms_rotated_bev(dc.xywhr2xyxyr(sq), sc, 0.6).tolist() == [1, 2]            # 3 and 0 overlap box 1 by 0.707
+    assert dc.nms_rotated_bev(dc.xywhr2xyxyr(sq), sc, 0.75).tolist() == [1, 3, 2]        # box 0 == box 3: suppressed
+    assert dc.nms_rotated_bev(dc.xywhr2xyxyr(sq), sc, 0.75, post_max_size=2).tolist() == [1, 3]
+    assert dc.nms_rotated_bev(dc.xywhr2xyxyr(sq), sc, 0.75, pre_maxsize=2).tolist() == [1, 3]
+    assert dc.nms_rotated_bev(sq[:0], sc[:0], 0.5).numel() == 0
+    # through the head: pedestrians (class 8) closer than the threshold collapse to the best one
+    cfg = decoder_cfg(bev=36, num_proposals=6)
+    cfg['test_cfg'].update(nms_type='rotate', pre_maxsize=1000, post_maxsize=83)
+    M = DeepInteractionDecoder(**cfg).eval()
+    Q = 6
+    pd = dict(center=torch.tensor([[[10., 10.05, 20., 10.1, 30., 5.], [10., 10., 20., 10.05, 30., 5.]]]),
+              height=torch.zeros(1, 1, Q), dim=torch.zeros(1, 3, Q), rot=torch.tensor([[[0.] * Q, [1.] * Q]]),
+              vel=torch.zeros(1, 2, Q), heatmap=torch.full((1, 10, Q), 3.0),
+              query_heatmap_score=torch.tensor([0.9, 0.8, 0.7, 0.6, 0.5, 0.4]).view(1, 1, Q).expand(1, 10, Q).clone())
+    M.query_labels = torch.tensor([[8, 8, 8, 8, 9, 0]])
+    boxes, scores, labels = M.get_bboxes([[pd]], [dict()])[0]
+    # queries 0, 1, 3 are pedestrians within a fraction of a box of each other (IoU > 0.175): only the best stays
+    assert sorted(labels.tolist()) == [0, 8, 8, 9] and len(boxes) == 4
+    assert abs(scores[labels == 8].max().item() - torch.sigmoid(torch.tensor(3.0)).item() * 0.9) < 1e-6
