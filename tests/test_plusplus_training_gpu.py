@@ -165,3 +165,51 @@ def test_pp_head_gradients_match_oracle():
     assert n > 100, n
     assert not bad, bad
     print('worst relative L2:', worst)
+
+
+def test_pp_full_training_step_with_loss():
+    """DeepInteraction++: forward (train mode, dropout on) -> head.loss -> backward -> one SGD step, all on the HIP
+    path: every trainable parameter gets a finite gradient (except the detached proposal heat-map head, as in the
+    v1 model) and the loss goes down."""
+    from deepinteraction_amd import det3d_compat as dc
+    from deepinteraction_amd.mmdet3d_plugin import DeepInteractionPlusPlusDecoder, FusionTransformerv4
+    from test_targets_loss import TRAIN_CFG
+    shape = synth.SHAPE_PP_TINY
+    torch.backends.cudnn.deterministic = True
+    cfg = configs.decoder_cfg(bev=shape['bev_hw'][0], num_proposals=24)
+    torch.manual_seed(2)
+    enc = FusionTransformerv4(**configs.encoder_pp_cfg(shape['c_img'], shape['c_pts'])).to(DEV).train()
+    dec = DeepInteractionPlusPlusDecoder(**dict(cfg, train_cfg=TRAIN_CFG)).to(DEV).train()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():               # off the zero init: offsets / logits projections take part
+        for m in enc.modules():
+            if hasattr(m, 'sampling_offsets'):
+                m.sampling_offsets.weight.add_((torch.randn(m.sampling_offsets.weight.shape, generator=g) * 0.05).to(DEV))
+                m.attention_weights.weight.add_((torch.randn(m.attention_weights.weight.shape, generator=g) * 0.05).to(DEV))
+    inp = synth.make_inputs_pp(1, shape, seed=4)
+    pm = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
+    pm['pts'] = [p.to(DEV) for p in inp['pts_metas']['pts']]
+    img, pts = [f.to(DEV) for f in inp['img_feats']], [f.to(DEV) for f in inp['pts_feats']]
+    gt = [dc.LiDARBoxes(torch.tensor([[5.0, 3, -1.5, 1.9, 4.6, 1.7, 0.4, 1, 0], [-12.0, 8, -1.2, 0.7, 0.7, 1.8, 0.0, 0, 0],
+                                      [20.0, -15, -1.0, 2.5, 8.0, 3.0, 1.3, 0, 2]]))]
+    labels = [torch.tensor([0, 8, 3])]
+    params = [p for m in (enc, dec) for p in m.parameters()]
+    opt = torch.optim.SGD(params, lr=2e-4)
+
+    def total_loss():
+        torch.manual_seed(99)
+        im, p = enc(img, pts, inp['img_metas'], dict(pm))
+        losses = dec.loss(gt, labels, dec(p, im, inp['img_metas']))
+        return sum(v for k, v in losses.items() if k != 'matched_ious')
+    l0 = total_loss()
+    opt.zero_grad()
+    l0.backward()
+    missing = [n for m in (enc, dec) for n, p in m.named_parameters() if p.grad is None]
+    assert all(n.startswith('heatmap_head.') for n in missing), missing[:5]
+    assert all(torch.isfinite(p.grad).all() for p in params if p.grad is not None)
+    touched = sum(1 for p in enc.parameters() if p.grad is not None and p.grad.abs().max() > 0)
+    assert touched >= 0.9 * len(list(enc.parameters())), touched
+    opt.step()
+    with torch.no_grad():
+        l1 = total_loss()
+    assert torch.isfinite(l0) and l1 < l0, (float(l0), float(l1))
