@@ -7,6 +7,8 @@ physically (n,H,W,C) - the layout the kernels are written for.
 
 No CPU implementation lives here; CPU tensors are rejected.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -397,8 +399,7 @@ def ms_deform_attn(value, offsets, logits, ref, level_hw, n_points=4):
     op, ors = _rows(offsets)
     lp, lrs = _rows(logits)
     out = torch.empty((bs, nq, E), dtype=value.dtype, device=value.device)
-    import ctypes
-    hw = (ctypes.c_int32 * (2 * L))(*[int(x) for pair in level_hw for x in pair])
+    hw = _level_array(level_hw)
     _profiled('ms_deform_attn_fwd', bs * nq, lambda: _lib.call(
         'di_ms_deform_attn_fwd', value.data_ptr(), op, ors, lp, lrs, ref.data_ptr(), int(ref.shape[0] == 1),
         out.data_ptr(), bs, nq, L, n_points, ctypes.addressof(hw), _code(value), _stream()))
@@ -471,14 +472,12 @@ def add_layernorm(x, res, weight, bias, eps=1e-5):
 
 
 def _level_array(level_hw):
-    import ctypes
     L = len(level_hw)
     return (ctypes.c_int32 * (2 * L))(*[int(x) for pair in level_hw for x in pair])
 
 
 def ms_deform_attn_bwd(value, offsets, logits, ref, level_hw, grad_out, n_points=4):
     """-> (grad_value (bs,S,128) float32, grad_proj (bs,nq,8*L*P*3) in the input dtype: [d offsets | d logits])."""
-    import ctypes
     _dev(value, offsets, logits, ref, grad_out)
     bs, S, E = value.shape
     nq, L = offsets.shape[1], len(level_hw)
