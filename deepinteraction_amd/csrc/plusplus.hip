@@ -311,6 +311,90 @@ __global__ __launch_bounds__(256) void mha_small_kernel(const T *__restrict__ q,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Matrix-core form of the short-sequence attention (fp16, S <= 16 * NT16 <= 128): workgroup = (sequence, 4 heads),
+// wave = head.  The head's K and V rows are staged in LDS ([head][key][K16 | V16], 64-B rows); per 16 queries:
+//   S^T = K . Q^T   one 16x16x16 MFMA per 16-key tile (A = K rows from LDS, B = Q^T straight from global),
+//   softmax per query = per lane column (two cross-row exchanges), scores never leave registers,
+//   O^T = V^T . P^T with the exp registers as the B operand and V^T from ds_read_b64_tr_b16.
+typedef _Float16 sh4 __attribute__((ext_vector_type(4)));
+typedef __fp16 shv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float sf4 __attribute__((ext_vector_type(4)));
+
+template <int NT16>
+__global__ __launch_bounds__(256) void mha_small_mfma_kernel(const __half *__restrict__ q, int q_rs,
+                                                             const __half *__restrict__ k,
+                                                             const __half *__restrict__ v, int kv_rs,
+                                                             __half *__restrict__ out, int out_rs, int Tq, int S,
+                                                             int heads, float scale_log2) {
+  constexpr int KC = NT16 * 16;
+  __shared__ __align__(16) unsigned char lds[4 * KC * 64];
+  const int n = blockIdx.x, head0 = blockIdx.y * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  // stage: 16-B piece p of a key: p >> 3 = K | V, (p >> 1) & 3 = local head, p & 1 = half of the head's 16 dims
+  for (int e = tid; e < KC * 16; e += 256) {
+    const int key = e >> 4, p = e & 15;
+    const int isv = p >> 3, hh = (p >> 1) & 3, half8 = p & 1;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (key < S && head0 + hh < heads)
+      val = *reinterpret_cast<const uint4 *>((isv ? v : k) + ((size_t)n * S + key) * kv_rs + (head0 + hh) * 16 + half8 * 8);
+    *reinterpret_cast<uint4 *>(lds + ((hh * KC + key) * 64 + isv * 32 + half8 * 16)) = val;
+  }
+  __syncthreads();
+  const int h = head0 + wave;
+  if (h >= heads) return;
+  const unsigned char *hb = lds + (size_t)wave * KC * 64;
+  const int nqg = (Tq + 15) / 16;
+  for (int qg = 0; qg < nqg; ++qg) {
+    const int qi = qg * 16 + i;
+    const int qc = qi < Tq ? qi : Tq - 1;
+    const sh4 qf = *reinterpret_cast<const sh4 *>(q + ((size_t)n * Tq + qc) * q_rs + h * 16 + 4 * g);
+    sf4 sc[NT16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) {
+      const sh4 kf = *reinterpret_cast<const sh4 *>(hb + (16 * t + i) * 64 + g * 8);
+      sf4 c = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf, sf4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x = (16 * t + 4 * g + r < S) ? c[r] * scale_log2 : -INFINITY;   // key 4g + r of the tile
+        c[r] = x;
+        m = fmaxf(m, x);
+      }
+      sc[t] = c;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+    sf4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) {
+      sh4 pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = exp2f(sc[t][r] - m);
+        l += e;
+        pf[r] = (_Float16)e;
+      }
+      const shv4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+          (shv4 __attribute__((address_space(3))) *)(hb + (16 * t + 4 * g + (i >> 2)) * 64 + 32 + (i & 3) * 8));
+      sh4 vf;
+      vf[0] = vt[0]; vf[1] = vt[1]; vf[2] = vt[2]; vf[3] = vt[3];
+      acc = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, acc, 0, 0, 0);
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (qi < Tq) {
+      const float inv = 1.f / l;
+      sh4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc[r] * inv);               // O^T[dim 4g + r][query i]
+      *reinterpret_cast<sh4 *>(out + ((size_t)n * Tq + qi) * out_rs + h * 16 + 4 * g) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // out = LayerNorm(x (+ res)) * gamma + beta over C <= 128 channels; one 16-lane group per token, statistics in
 // fp32 (mean, then centred variance), DPP row reductions.  Fuses the residual add that precedes every post-norm.
 template <typename T, bool HAS_RES>
@@ -475,6 +559,17 @@ int di_mha_small_fwd(const void *q, int q_row_stride, const void *k, const void 
   const dim3 g(n_seq, (num_heads + 3) / 4), blk(256);
   hipStream_t s = (hipStream_t)stream;
   const float sl2 = scale * 1.4426950408889634f;
+  if (dtype == DI_F16 && S <= 128) {                 // matrix-core kernel, K/V of 4 heads in static LDS
+    if (S <= 64)
+      hipLaunchKernelGGL((di::pp::mha_small_mfma_kernel<4>), g, blk, 0, s, (const __half *)q, q_row_stride,
+                         (const __half *)k, (const __half *)v, kv_row_stride, (__half *)out, out_row_stride, Tq, S,
+                         num_heads, sl2);
+    else
+      hipLaunchKernelGGL((di::pp::mha_small_mfma_kernel<8>), g, blk, 0, s, (const __half *)q, q_row_stride,
+                         (const __half *)k, (const __half *)v, kv_row_stride, (__half *)out, out_row_stride, Tq, S,
+                         num_heads, sl2);
+    return di::check_launch("mha_small_fwd");
+  }
   if (dtype == DI_F16)
     hipLaunchKernelGGL((di::pp::mha_small_kernel<__half>), g, blk, lds, s, (const __half *)q, q_row_stride,
                        (const __half *)k, (const __half *)v, kv_row_stride, (__half *)out, out_row_stride, Tq, S,

@@ -63,7 +63,7 @@ def test_grid_gather_kernel(dtype, tol):
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.float16, 3e-3)])
-@pytest.mark.parametrize('T,S', [(60, 60), (60, 112), (7, 5), (70, 130)])
+@pytest.mark.parametrize('T,S', [(60, 60), (60, 112), (7, 5), (70, 130), (33, 64), (16, 128), (65, 65)])
 def test_mha_small_kernel(dtype, tol, T, S):
     from deepinteraction_amd import ops
     g = torch.Generator().manual_seed(5)
