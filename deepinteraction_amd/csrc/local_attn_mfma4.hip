@@ -307,34 +307,40 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_m4_kernel(const __half *_
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) ld_q(kk);
       DI_TS();
-      // softmax over the 81 window slots of query i, log2 units
-      float m = -INFINITY;
+      // softmax over the 81 window slots of query i, log2 units.  One wave per SIMD: a dependent VALU chain runs at
+      // about half the issue rate, so the reductions are trees / four partial sums instead of one running value
+      float mx[10];
 #pragma unroll
       for (int rr = 0; rr < 10; ++rr) {
         const f4 nm = rr == 0 ? nm_first : (rr == 9 ? nm_last : nm_mid);
         s[rr] = s[rr] * cs + nm;
-        m = fmaxf(m, fmaxf(fmaxf(s[rr][0], s[rr][1]), fmaxf(s[rr][2], s[rr][3])));
+        mx[rr] = fmaxf(fmaxf(s[rr][0], s[rr][1]), fmaxf(s[rr][2], s[rr][3]));
       }
+      float m = fmaxf(fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3])), fmaxf(fmaxf(mx[4], mx[5]), fmaxf(mx[6], mx[7])));
+      m = fmaxf(m, fmaxf(mx[8], mx[9]));
       m = fmaxf(m, __shfl_xor(m, 16));
       m = fmaxf(m, __shfl_xor(m, 32));
       h8 pf[5];
-      f2 sum2 = {0.f, 0.f};
+      f2 part[5];
 #pragma unroll
       for (int pr = 0; pr < 5; ++pr) {
         if (pr < 4) st_pend(pr);                     // the previous step's results: LDS read-back + one 1 KB store
         h8 pk;
+        f2 acc2 = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const f4 d = s[2 * pr + t] - m;
           f4 e;
 #pragma unroll
           for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(d[r]);
-          sum2 += f2{e[0], e[1]} + f2{e[2], e[3]};
+          acc2 += f2{e[0], e[1]} + f2{e[2], e[3]};
 #pragma unroll
           for (int r = 0; r < 4; ++r) pk[4 * t + r] = (_Float16)e[r];
         }
         pf[pr] = pk;
+        part[pr] = acc2;
       }
+      const f2 sum2 = (part[0] + part[1]) + (part[2] + part[3]) + part[4];
       float sum = sum2[0] + sum2[1];
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
@@ -380,15 +386,19 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_m4_kernel(const __half *_
         __builtin_amdgcn_sched_barrier(0);
       });
       DI_TS();
-      // the previous step's stores were issued during the S pass; stage this step's results
+      // stage this step's results: three independent sweeps (scale, convert, write) instead of eight serial chains
+      f4 ov[G::NN];
 #pragma unroll
-      for (int nl = 0; nl < G::NN; ++nl) {
-        const f4 o = acc[nl] * inv;
-        h4 hv;
+      for (int nl = 0; nl < G::NN; ++nl) ov[nl] = acc[nl] * inv;
+      __builtin_amdgcn_sched_barrier(0);
+      h4 hv[G::NN];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hv[r] = (_Float16)o[r];
-        stage(nl, hv);
-      }
+      for (int nl = 0; nl < G::NN; ++nl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[nl][r] = (_Float16)ov[nl][r];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nl = 0; nl < G::NN; ++nl) stage(nl, hv[nl]);
       pend_y0 = y0;
       pend_x0 = x0;
       pend_img = img;
