@@ -113,6 +113,12 @@ class MultiheadAttention(nn.Module):
         return o.transpose(0, 1), None
 
 
+def _post_norm(norm, x, branch=None):
+    """norm(x + branch): one fused kernel at inference (see transformer_bricks.post_norm)."""
+    from .transformer_bricks import post_norm
+    return post_norm(norm, x, branch)
+
+
 def mha_tokens(q_in, k_in, v_in, w, b, out_proj, H, dropout_p=0.0, key_allowed=None):
     """Batch-first multi-head attention on small token sets with library GEMMs.
     q_in (B,L,E), k_in/v_in (B,S,E); key_allowed: optional bool (B,L,S) - query l attends only to the
@@ -183,9 +189,9 @@ class TransformerDecoderLayer(nn.Module):
         if not self.cross_only:
             sa = self.self_attn
             qq = x + qpe
-            x = self.norm1(x + self.dropout1(mha_tokens(qq, qq, qq, sa.in_proj_weight, sa.in_proj_bias,
-                                                        sa.out_proj, sa.num_heads,
-                                                        sa.dropout if self.training else 0.0)))
+            x = _post_norm(self.norm1, x, self.dropout1(mha_tokens(qq, qq, qq, sa.in_proj_weight, sa.in_proj_bias,
+                                                                   sa.out_proj, sa.num_heads,
+                                                                   sa.dropout if self.training else 0.0)))
         ca = self.multihead_attn
         E = ca.embed_dim
         q = F.linear(x + qpe, ca.in_proj_weight[:E], ca.in_proj_bias[:E])
@@ -204,8 +210,8 @@ class TransformerDecoderLayer(nn.Module):
             if self.training and ca.dropout > 0:
                 a = F.dropout(a, ca.dropout)
             o = torch.matmul(a, vh).transpose(1, 2).reshape(Bq, Lq, E)
-        x = self.norm2(x + self.dropout2(ca.out_proj(o)))
-        x = self.norm3(x + self.dropout3(self.linear2(self.dropout(self.activation(self.linear1(x))))))
+        x = _post_norm(self.norm2, x, self.dropout2(ca.out_proj(o)))
+        x = _post_norm(self.norm3, x, self.dropout3(self.linear2(self.dropout(self.activation(self.linear1(x))))))
         return x.transpose(1, 2)
 
 
@@ -303,10 +309,10 @@ class DynamicConv(nn.Module):
         params = self.dynamic_layer(pro)                                    # (n, 2*128*128)
         p1 = params[:, :self.num_params].view(-1, self.hidden_dim, self.dim_dynamic)
         p2 = params[:, self.num_params:].view(-1, self.dim_dynamic, self.hidden_dim)
-        f = self.activation(self.norm1(torch.bmm(roi, p1)))
-        f = self.activation(self.norm2(torch.bmm(f, p2)))
+        f = self.activation(_post_norm(self.norm1, torch.bmm(roi, p1)))
+        f = self.activation(_post_norm(self.norm2, torch.bmm(f, p2)))
         f = self.out_layer(f.flatten(1))                                    # 49-major flatten (:624)
-        return self.activation(self.norm3(f))
+        return self.activation(_post_norm(self.norm3, f))
 
 
 class QueryGeometry:
@@ -361,11 +367,11 @@ class _RCNNBase(nn.Module):
         sa = g('dyconv_pre_self_attn')
         p = sa.dropout if self.training else 0.0
         a = mha_tokens(x, x, x, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj, sa.num_heads, p, key_allowed)
-        x = g('norm1')(x + g('dropout1')(a))
+        x = _post_norm(g('norm1'), x, g('dropout1')(a))
         shp = x.shape
         dy = g('dyconv').forward_nk(x.reshape(-1, shp[-1]), roi)
-        x = g('norm2')(x + g('dropout2')(dy.view(shp)))
-        x = g('norm3')(x + g('dropout3')(g('linear2')(g('dropout')(g('activation')(g('linear1')(x))))))
+        x = _post_norm(g('norm2'), x, g('dropout2')(dy.view(shp)))
+        x = _post_norm(g('norm3'), x, g('dropout3')(g('linear2')(g('dropout')(g('activation')(g('linear1')(x))))))
         return x
 
 
@@ -490,14 +496,14 @@ class _V2Mix:
         sa = g('dyconv_pre_self_attn')
         p = sa.dropout if self.training else 0.0
         a = mha_tokens(q_tok, x, x, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj, sa.num_heads, p, key_allowed)
-        return g('norm1')(q_tok + g('dropout1')(a))
+        return _post_norm(g('norm1'), q_tok, g('dropout1')(a))
 
     def _main_branch(self, y, roi, sfx):
         g = lambda n: getattr(self, n + sfx)
         shp = y.shape
         dy = g('dyconv').forward_nk(y.reshape(-1, shp[-1]), roi)
-        z = g('norm2')(y + g('dropout2')(dy.view(shp)))
-        return g('norm3')(self.ffn(z))
+        z = _post_norm(g('norm2'), y, g('dropout2')(dy.view(shp)))
+        return self.ffn.then_norm(g('norm3'), z)
 
 
 class ImageRCNNBlockV2(_V2Mix, ImageRCNNBlock):
@@ -521,7 +527,7 @@ class ImageRCNNBlockV2(_V2Mix, ImageRCNNBlock):
         firstc = first.clamp(max=Q - 1)
         xf = x.gather(1, firstc.unsqueeze(-1).expand(B, V, C))
         yf = self._attend(xf, x, '', sel | (first >= Q).unsqueeze(-1))           # (B,V,C)
-        sf = self.self_norm(self.self_ffn(yf))
+        sf = self.self_ffn.then_norm(self.self_norm, yf)
         s = sf.gather(1, lastc.unsqueeze(-1).expand(B, Q, C))                    # self feature of view v*(q)
         return z * self.scale + s * self.self_scale
 
@@ -537,5 +543,5 @@ class PointRCNNBlockV2(_V2Mix, PointRCNNBlock):
     def _refine_all(self, x, roi):
         y = self._attend(x, x, '_pts', None)
         z = self._main_branch(y, roi, '_pts')
-        s0 = self.self_norm_pts(self.self_ffn(y[:, 0:1]))                        # query 0's self feature, for all
+        s0 = self.self_ffn.then_norm(self.self_norm_pts, y[:, 0:1].contiguous())   # query 0's self feature, for all
         return z * self.scale + s0 * self.self_scale
