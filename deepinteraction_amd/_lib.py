@@ -43,13 +43,14 @@ SIGNATURES = {
     'di_voxel_keys': [_c_p, _c_i, _c_i, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p],
     'di_voxel_heads': [_c_p, _c_i, _c_p, _c_p, _c_p],
     'di_voxel_scatter': [_c_p, _c_i, _c_i, _c_i] + [_c_p] * 5 + [_c_i] * 4 + [_c_p] * 4,
+    'di_topk_fwd': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p],
     'di_heatmap_nms': [_c_p] * 3 + [_c_i] * 5 + [ctypes.c_uint, _c_i, _c_p],
     'di_query_geometry': [_c_p] * 10 + [_c_i] * 3 + [_c_f] * 5 + [_c_p],
     'di_roi_align_fwd': [_c_p] * 3 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
     'di_mha_decode_fwd': [_c_p] * 4 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
 }
 # helpers that return a value instead of an error code
-VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4}
+VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 2}
 
 _lib = None
 
@@ -74,7 +75,7 @@ def lib():
         for name, argtypes in list(SIGNATURES.items()) + list(VALUE_FUNCS.items()):
             fn = getattr(L, name)
             fn.argtypes = argtypes
-            fn.restype = _c_i
+            fn.restype = ctypes.c_longlong if name == 'di_topk_workspace_bytes' else _c_i
         _lib = L
     return _lib
 

@@ -1,0 +1,158 @@
+// Top-Q proposals of the NMS-ed heat map (deepinteraction_decoder.py:242: `heatmap.view(B,-1).argsort(descending)
+// [..., :Q]`; torch's sort-based top-k of 324 000 scores is 18 launches / ~118 us per forward).
+//
+// Radix SELECT instead of a sort.  Every element gets the 52-bit key
+//        K = float_bits(score) << 20 | (0xFFFFF - index)          (scores >= 0: their bit patterns are ordered)
+// so all keys are distinct and "value descending, lower index first on ties" is plain descending K - a
+// deterministic rule where the reference's argsort leaves ties unspecified.  Five digit levels (11+11+10 value bits,
+// 10+10 index bits), each a multi-block histogram of the elements that still match the selected prefix and a
+// one-block pick of the digit that holds the k-th largest key; then one pass collects the exactly k keys >= K*
+// (order irrelevant) and one block bitonic-sorts them.  12 small launches, no host synchronisation, no atomics on
+// floating point, bit-reproducible.
+#include "di_common.h"
+
+namespace di {
+namespace tk {
+
+constexpr int kBins = 2048;
+struct State {
+  unsigned long long prefix;   // the digits selected so far, right aligned
+  int need;                    // how many keys of the selected bin are still to be taken
+  int count;                   // collect pass: append cursor
+};
+
+__device__ __forceinline__ unsigned long long make_key(float v, int idx) {
+  return ((unsigned long long)__float_as_uint(v) << 20) | (unsigned long long)(0xFFFFFu - (unsigned)idx);
+}
+
+// histogram of digit (K >> shift) & (2^bits - 1) over the elements whose higher bits equal state.prefix
+__global__ __launch_bounds__(256) void hist_kernel(const float *__restrict__ scores, const State *__restrict__ st,
+                                                   int *__restrict__ hist, int N, int shift, int bits, int first) {
+  __shared__ int lh[kBins];
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < kBins; i += 256) lh[i] = 0;
+  __syncthreads();
+  const unsigned long long prefix = first ? 0ull : st[b].prefix;
+  const unsigned mask = (1u << bits) - 1u;
+  const float *s = scores + (size_t)b * N;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    const unsigned long long K = make_key(s[i], i);
+    if ((K >> (shift + bits)) == prefix) atomicAdd(&lh[(unsigned)(K >> shift) & mask], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kBins; i += 256)
+    if (lh[i]) atomicAdd(&hist[b * kBins + i], lh[i]);
+}
+
+// one block per sample: the bin T with  #(bins > T) < need <= #(bins >= T); prefix <- prefix:T, need -= #(bins > T)
+__global__ __launch_bounds__(1024) void pick_kernel(State *__restrict__ st, int *__restrict__ hist, int bits, int k,
+                                                    int first) {
+  __shared__ int suf[kBins];
+  const int b = blockIdx.x, nb = 1 << bits, t = threadIdx.x;
+  int *h = hist + b * kBins;
+  // suffix sums over reversed bins (Hillis-Steele on <= 2048 entries, two per thread)
+  for (int i = t; i < kBins; i += 1024) suf[i] = i < nb ? h[nb - 1 - i] : 0;      // suf[r]: bin nb-1-r
+  __syncthreads();
+  for (int d = 1; d < nb; d <<= 1) {
+    int v0 = 0, v1 = 0;
+    const int i0 = t, i1 = t + 1024;
+    if (i0 >= d) v0 = suf[i0 - d];
+    if (i1 < kBins && i1 >= d) v1 = suf[i1 - d];
+    __syncthreads();
+    suf[i0] += v0;
+    if (i1 < kBins) suf[i1] += v1;
+    __syncthreads();
+  }
+  const int need = first ? k : st[b].need;
+  const unsigned long long prefix = first ? 0ull : st[b].prefix;
+  for (int r = t; r < nb; r += 1024) {
+    const int incl = suf[r], excl = r ? suf[r - 1] : 0;
+    if (excl < need && need <= incl) {
+      st[b].prefix = (prefix << bits) | (unsigned long long)(nb - 1 - r);
+      st[b].need = need - excl;
+      st[b].count = 0;
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < kBins; i += 1024) h[i] = 0;   // ready for the next level
+}
+
+__global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ scores, State *__restrict__ st,
+                                                      unsigned long long *__restrict__ cand, int N, int k) {
+  const int b = blockIdx.y;
+  const unsigned long long Kstar = st[b].prefix;   // all 52 bits selected
+  const float *s = scores + (size_t)b * N;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+    const unsigned long long K = make_key(s[i], i);
+    if (K >= Kstar) {
+      const int pos = atomicAdd(&st[b].count, 1);
+      if (pos < k) cand[(size_t)b * k + pos] = K;
+    }
+  }
+}
+
+// one block per sample: bitonic sort (descending) of the k <= 1024 collected keys, indices out
+__global__ __launch_bounds__(1024) void sort_kernel(const unsigned long long *__restrict__ cand,
+                                                    long long *__restrict__ out_idx, float *__restrict__ out_val,
+                                                    int k) {
+  __shared__ unsigned long long a[1024];
+  const int b = blockIdx.x, t = threadIdx.x;
+  a[t] = t < k ? cand[(size_t)b * k + t] : 0ull;
+  __syncthreads();
+  for (int len = 2; len <= 1024; len <<= 1) {
+    for (int j = len >> 1; j > 0; j >>= 1) {
+      const int p = t ^ j;
+      if (p > t) {
+        const bool desc = (t & len) == 0;
+        const unsigned long long x = a[t], y = a[p];
+        if ((x < y) == desc) {
+          a[t] = y;
+          a[p] = x;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (t < k) {
+    const unsigned long long K = a[t];
+    out_idx[(size_t)b * k + t] = (long long)(0xFFFFFu - (unsigned)(K & 0xFFFFFull));
+    if (out_val != nullptr) out_val[(size_t)b * k + t] = __uint_as_float((unsigned)(K >> 20));
+  }
+}
+
+}  // namespace tk
+}  // namespace di
+
+extern "C" {
+
+long long di_topk_workspace_bytes(int B, int k) {
+  return (long long)B * (di::tk::kBins * (long long)sizeof(int) + (long long)sizeof(di::tk::State) + (long long)k * 8) + 64;
+}
+
+int di_topk_fwd(const float *scores, long long *out_idx, float *out_val, void *workspace, int B, int N, int k,
+                void *stream) {
+  using namespace di::tk;
+  DI_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 1024 && k <= N, "bad top-k shape (k <= min(N, 1024))");
+  DI_REQUIRE(N <= (1 << 20), "N=%d exceeds the 2^20 indices of the composite key", N);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char *w = reinterpret_cast<unsigned char *>(workspace);
+  int *hist = reinterpret_cast<int *>(w);
+  State *st = reinterpret_cast<State *>(w + (size_t)B * kBins * sizeof(int));
+  unsigned long long *cand = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(st) +
+                                                                     (((size_t)B * sizeof(State) + 63) / 64) * 64);
+  if (hipMemsetAsync(hist, 0, (size_t)B * kBins * sizeof(int), s) != hipSuccess) {
+    di::set_error("hipMemsetAsync failed");
+    return DI_ERR_LAUNCH;
+  }
+  const int nblk = (N + 256 * 8 - 1) / (256 * 8);
+  const int shifts[5] = {41, 30, 20, 10, 0}, nbits[5] = {11, 11, 10, 10, 10};
+  for (int l = 0; l < 5; ++l) {
+    hipLaunchKernelGGL(hist_kernel, dim3(nblk, B), dim3(256), 0, s, scores, st, hist, N, shifts[l], nbits[l], l == 0);
+    hipLaunchKernelGGL(pick_kernel, dim3(B), dim3(1024), 0, s, st, hist, nbits[l], k, l == 0);
+  }
+  hipLaunchKernelGGL(collect_kernel, dim3(nblk, B), dim3(256), 0, s, scores, st, cand, N, k);
+  hipLaunchKernelGGL(sort_kernel, dim3(B), dim3(1024), 0, s, cand, out_idx, out_val, k);
+  return di::check_launch("topk_fwd");
+}
+
+}  // extern "C"

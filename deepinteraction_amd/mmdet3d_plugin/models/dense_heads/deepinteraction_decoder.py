@@ -152,7 +152,11 @@ class DeepInteractionDecoder(nn.Module):
                                   [c for c in k1 if c < self.num_classes]).view(B, self.num_classes, HW)
 
         # top proposals over all (class, cell) pairs: reference argsort(descending)[:Q] (:242)
-        top = heatmap.view(B, -1).topk(self.num_proposals, dim=-1, largest=True, sorted=True).indices
+        flat_scores = heatmap.view(B, -1)
+        if flat_scores.is_cuda and self.num_proposals <= 1024 and flat_scores.shape[1] <= (1 << 20):
+            top = ops.topk(flat_scores, self.num_proposals)           # radix select; ties: lower index first
+        else:
+            top = flat_scores.topk(self.num_proposals, dim=-1, largest=True, sorted=True).indices
         top_class = top // HW
         top_index = top % HW
         self.query_labels = top_class

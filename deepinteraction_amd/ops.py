@@ -279,6 +279,20 @@ def heatmap_nms(dense_a, dense_b, nms_kernel, k1_classes):
     return out
 
 
+def topk(scores, k, with_values=False):
+    """Indices (B,k) int64 of the k largest entries of each row of non-negative float32 `scores` (B,N), ordered by
+    value descending and lower index first on ties (radix select + k-element sort, csrc/topk.hip)."""
+    _dev(scores)
+    assert scores.dtype == torch.float32 and scores.dim() == 2 and scores.is_contiguous()
+    B, N = scores.shape
+    idx = torch.empty((B, k), dtype=torch.int64, device=scores.device)
+    val = torch.empty((B, k), dtype=torch.float32, device=scores.device) if with_values else None
+    ws = torch.empty((int(_lib.lib().di_topk_workspace_bytes(B, k)),), dtype=torch.uint8, device=scores.device)
+    _lib.call('di_topk_fwd', scores.data_ptr(), idx.data_ptr(), 0 if val is None else val.data_ptr(), ws.data_ptr(),
+              B, N, k, _stream())
+    return (idx, val) if with_values else idx
+
+
 def query_geometry(res, proj, aug_rev, per_sample, cell, pc_xy, bev_cell, dim_scale, want_img, want_bev):
     """res: dict of float32 (B,k,Q) tensors (center, height, dim, rot).  Returns
     (on_img (B,V,Q) int32, rect_img (B,V,Q,4), rect_bev (B,Q,4)); absent groups are None."""

@@ -201,3 +201,32 @@ def test_decoder_forward(dtype, tol, narrow):
             if k not in ('dense_heatmap', 'query_heatmap_score'):
                 first = d[..., :2 * Q]                                       # layers before any flip can matter
                 assert first.max().item() <= 0.3 * scale * 0.05 + 0.15, (k, first.max().item())
+
+
+@pytest.mark.parametrize('B,N,k', [(1, 324000, 200), (2, 324000, 400), (3, 5000, 1024), (1, 300, 300), (2, 70000, 1)])
+def test_topk_radix_select(B, N, k):
+    """di_topk_fwd: tie-free data -> exactly torch.topk's indices; heavy ties (quantised scores, many zeros) -> the
+    same multiset of values, descending, and within equal values ascending indices starting from the lowest ones."""
+    g = torch.Generator().manual_seed(N + k)
+    x = torch.rand(B, N, generator=g)
+    x[torch.rand(B, N, generator=g) < 0.6] = 0.0                              # the NMS zeroes most cells
+    xd = x.to(DEV)
+    idx, val = ops.topk(xd, k, with_values=True)
+    ref = torch.topk(x, k, dim=-1, largest=True, sorted=True)
+    assert torch.equal(val.cpu(), ref.values)
+    pos = ref.values > 0                                                     # positive scores are distinct here
+    assert torch.equal(idx.cpu()[pos], ref.indices[pos])
+    # quantised: 16 distinct values -> massive ties
+    q = (torch.rand(B, N, generator=g) * 16).floor() / 16
+    idx, val = ops.topk(q.to(DEV), k, with_values=True)
+    idx, val = idx.cpu(), val.cpu()
+    assert torch.equal(val, torch.topk(q, k, dim=-1).values)
+    assert torch.equal(q.gather(1, idx), val)
+    for b in range(B):
+        for v in val[b].unique():
+            sel = idx[b][val[b] == v]
+            assert torch.all(sel[1:] > sel[:-1])                             # ascending indices inside a tie group
+            allv = (q[b] == v).nonzero().flatten()
+            if (val[b] == v).sum() < allv.numel():                           # partially taken group: the lowest indices
+                assert torch.equal(sel, allv[:sel.numel()])
+    assert torch.equal(ops.topk(q.to(DEV), k), ops.topk(q.to(DEV), k))       # bit-reproducible
