@@ -50,6 +50,10 @@ __global__ __launch_bounds__(1024) void pick_kernel(State *__restrict__ st, int 
   __shared__ int suf[kBins];
   const int b = blockIdx.x, nb = 1 << bits, t = threadIdx.x;
   int *h = hist + b * kBins;
+  // The previous level's selection is read HERE, ahead of the scan: every barrier of the scan below separates these
+  // loads from the single thread that rewrites st[b] at the end (no wave can observe the new prefix / need).
+  const int need = first ? k : st[b].need;
+  const unsigned long long prefix = first ? 0ull : st[b].prefix;
   // suffix sums over reversed bins (Hillis-Steele on <= 2048 entries, two per thread)
   for (int i = t; i < kBins; i += 1024) suf[i] = i < nb ? h[nb - 1 - i] : 0;      // suf[r]: bin nb-1-r
   __syncthreads();
@@ -63,8 +67,6 @@ __global__ __launch_bounds__(1024) void pick_kernel(State *__restrict__ st, int 
     if (i1 < kBins) suf[i1] += v1;
     __syncthreads();
   }
-  const int need = first ? k : st[b].need;
-  const unsigned long long prefix = first ? 0ull : st[b].prefix;
   for (int r = t; r < nb; r += 1024) {
     const int incl = suf[r], excl = r ? suf[r - 1] : 0;
     if (excl < need && need <= incl) {

@@ -61,12 +61,15 @@ def lidar_corners(boxes):
 
 
 def _rect_corners_bev(b):
-    """(N,5) [x, y, dx, dy, yaw] -> (N,4,2) counter-clockwise."""
+    """(N,5) [x, y, dx, dy, yaw] -> (N,4,2), vertices in counter-clockwise order.  The yaw convention is the
+    one of mmdet3d 0.17.1's iou3d kernel (`rotate_around_center`: x' = x cos + y sin, y' = -x sin + y cos), of
+    `lidar_corners` above and of the `query_geometry` HIP kernel - a positive yaw turns the box CLOCKWISE in the
+    BEV plane.  (A rotation keeps the orientation of the vertex loop, so the clipper's "inside = left" holds.)"""
     hx, hy = b[:, 2] * 0.5, b[:, 3] * 0.5
     lx = torch.stack([-hx, hx, hx, -hx], 1)
     ly = torch.stack([-hy, -hy, hy, hy], 1)
     c, s = torch.cos(b[:, 4])[:, None], torch.sin(b[:, 4])[:, None]
-    return torch.stack([b[:, 0:1] + lx * c - ly * s, b[:, 1:2] + lx * s + ly * c], -1)
+    return torch.stack([b[:, 0:1] + lx * c + ly * s, b[:, 1:2] - lx * s + ly * c], -1)
 
 
 def rotated_intersection_area(a, b):

@@ -343,7 +343,8 @@ class MMRI_I2P(nn.Module):
             s, e = bounds[b], bounds[b + 1]
             geom = sample_geometry(img_metas, pts_metas, b, (Hi, Wi), lidar_feat.device)
             args = (img_feat[b], qfold[b:b + 1], pts_metas['pillars'][s:e], pts_metas['pillar_coors'][s:e],
-                    pts_metas['pillars_num_points'][s:e], geom.lidar2img, geom.aug_rev, geom.ori_hw, drop, seed + b)
+                    pts_metas['pillars_num_points'][s:e], geom.lidar2img, geom.aug_rev, geom.ori_hw, drop,
+                    (seed + b * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)   # per-sample stream: no mask reuse across b
             ctx, valid = I2PAttention.apply(*args) if live else ops.i2p_attention(*args)
             o = F.linear(ctx.permute(0, 2, 3, 1).reshape(-1, Ci), w_ov, b_ov)
             o = o * valid.reshape(-1, 1)                                         # empty pillars / cells stay 0

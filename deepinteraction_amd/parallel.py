@@ -80,37 +80,130 @@ def throughput(units_per_rank_per_step, steps, elapsed_max, world):
     return world * units_per_rank_per_step * steps / elapsed_max
 
 
-def allreduce_gradients(params, world, bucket_bytes=64 << 20):
-    """Average gradients across ranks in few large flat buckets (xGMI rings are per-link bound: fewer,
-    larger messages).  Parameters without a gradient (e.g. RoI-block branches skipped in this
-    iteration, SURVEY 2.2c `find_unused_parameters`) contribute zeros so every rank reduces the same
-    layout."""
-    if world == 1:
-        return
-    bucket, size = [], 0
+class GradientReducer:
+    """Gradient averaging across ranks for the sample-sharded training step (the reference wraps the
+    detector in `MMDistributedDataParallel(find_unused_parameters=True)`, tools/train.py + mmdet `train_detector`).
 
-    def flush():
-        nonlocal bucket, size
-        if not bucket:
+    * few large flat float32 buckets (xGMI rings are per-link bound: fewer, larger messages); parameters are
+      bucketed in REVERSE registration order - the order backward produces their gradients;
+    * OVERLAP with backward: a post-accumulate-grad hook copies each gradient into its bucket slice and, once a
+      bucket is complete, its all-reduce is launched asynchronously while backward continues.  Buckets are launched
+      strictly in index order so that every rank issues the same sequence of collectives even when a rank did not
+      touch some parameter (that bucket then waits for `finish()` on this rank only);
+    * `find_unused_parameters` semantics: a parameter no rank produced a gradient for keeps `grad = None` (AdamW
+      then leaves it alone - no weight decay on a frozen-by-construction branch such as the detached heat-map
+      head); a parameter unused on THIS rank but used elsewhere contributes zeros.  The used-bitmap is reduced
+      (MAX) after the last bucket.
+
+        red = GradientReducer(model.parameters(), world)
+        loss.backward(); red.finish(); optimizer.step()
+    """
+
+    def __init__(self, params, world, bucket_bytes=64 << 20, overlap=True):
+        self.world = world
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []                      # [(flat, [(param, offset, numel)])]
+        self._where = {}
+        self._handles = []
+        if world == 1:
             return
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
-        dist.all_reduce(flat)
-        flat /= world
-        o = 0
-        for p in bucket:
-            n = p.numel()
-            g = flat[o:o + n].view_as(p).to(p.dtype)
-            if p.grad is None:
+        cur, size = [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= bucket_bytes:
+                self._close(cur)
+                cur, size = [], 0
+        if cur:
+            self._close(cur)
+        self._hooks = []
+        if overlap:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._reset()
+
+    def _close(self, ps):
+        n = sum(p.numel() for p in ps)
+        flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+        items, o = [], 0
+        for p in ps:
+            items.append((p, o, p.numel()))
+            self._where[id(p)] = (len(self.buckets), o)
+            o += p.numel()
+        self.buckets.append((flat, items))
+
+    def _reset(self):
+        self._filled = [0] * len(self.buckets)
+        self._seen = set()
+        self._next = 0
+        self._handles = []
+
+    def _fill(self, p):
+        b, o = self._where[id(p)]
+        self.buckets[b][0][o:o + p.numel()].copy_(p.grad.reshape(-1))
+        self._seen.add(id(p))
+        self._filled[b] += 1
+
+    def _launch_ready(self, force=False):
+        while self._next < len(self.buckets):
+            flat, items = self.buckets[self._next]
+            if self._filled[self._next] < len(items):
+                if not force:
+                    return
+                for p, o, n in items:          # not produced on this rank: zeros
+                    if id(p) not in self._seen:
+                        flat[o:o + n].zero_()
+            self._handles.append(dist.all_reduce(flat, async_op=True))
+            self._next += 1
+
+    def _on_grad(self, p):
+        if id(p) in self._seen:                # a second backward before finish(): re-copy at finish
+            return
+        self._fill(p)
+        self._launch_ready()
+
+    def finish(self):
+        """Call after backward: completes the outstanding buckets, resolves unused parameters, leaves the averaged
+        gradients in `p.grad` (views of the bucket buffers for float32 parameters)."""
+        if self.world == 1:
+            return
+        for p in self.params:                  # no-hook mode, or gradients produced outside the hook path
+            if p.grad is not None and id(p) not in self._seen:
+                self._fill(p)
+        self._launch_ready(force=True)
+        used = torch.tensor([1.0 if id(p) in self._seen else 0.0 for p in self.params],
+                            dtype=torch.float32, device=self.params[0].device)
+        h = dist.all_reduce(used, op=dist.ReduceOp.MAX, async_op=True)
+        for w in self._handles:
+            w.wait()
+        h.wait()
+        used = used.tolist()
+        inv = 1.0 / self.world
+        for flat, _ in self.buckets:
+            flat.mul_(inv)
+        for p, u in zip(self.params, used):
+            if u == 0.0:
+                p.grad = None                  # unused on every rank: stays frozen, as under DDP
+                continue
+            b, o = self._where[id(p)]
+            g = self.buckets[b][0][o:o + p.numel()].view_as(p)
+            if p.dtype == torch.float32:
                 p.grad = g
+            elif p.grad is None:
+                p.grad = g.to(p.dtype)
             else:
                 p.grad.copy_(g)
-            o += n
-        bucket, size = [], 0
-    for p in params:
-        if not p.requires_grad:
-            continue
-        bucket.append(p)
-        size += p.numel() * 4
-        if size >= bucket_bytes:
-            flush()
-    flush()
+        self._reset()
+
+    def remove(self):
+        for h in getattr(self, '_hooks', []):
+            h.remove()
+        self._hooks = []
+
+
+def allreduce_gradients(params, world, bucket_bytes=64 << 20):
+    """One-shot form (after backward, no overlap): average the gradients of `params` across ranks with the
+    `GradientReducer` rules - parameters unused on every rank keep `grad = None`."""
+    if world == 1:
+        return
+    GradientReducer(params, world, bucket_bytes, overlap=False).finish()

@@ -54,6 +54,36 @@ def _worker(rank, world, port, out):
     assert torch.allclose(ps[1].grad, torch.arange(7.0) * 1.5)
     assert ps[2].grad is None
     assert torch.allclose(ps[3].grad, torch.full((4,), 0.5))
+    # (iv) the overlapped form: hooks launch the bucket all-reduces DURING backward; a branch no rank touches
+    # keeps grad None (DDP find_unused_parameters semantics - AdamW must not decay it), a branch only rank 0 uses
+    # is averaged with zeros
+    torch.manual_seed(1)
+    net = torch.nn.ModuleDict(dict(a=torch.nn.Linear(6, 8), b=torch.nn.Linear(8, 8), only0=torch.nn.Linear(8, 8),
+                                   never=torch.nn.Linear(8, 8), c=torch.nn.Linear(8, 1)))
+    red = parallel.GradientReducer(net.parameters(), world, bucket_bytes=256)
+    assert len(red.buckets) > 2
+    ref = {}
+    for it in range(2):                                                    # two steps: state resets between them
+        for p in net.parameters():
+            p.grad = None
+        x = torch.full((3, 6), float(rank + 1 + it))
+        h = net['b'](torch.relu(net['a'](x)))
+        if rank == 0:
+            h = h + net['only0'](h)
+        net['c'](h).sum().backward()
+        local = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+        red.finish()
+        allg = [None] * world
+        dist.all_gather_object(allg, local)
+        for n, p in net.named_parameters():
+            gs = [g[n] for g in allg]
+            if all(g is None for g in gs):
+                assert p.grad is None, n
+                assert n.startswith('never')
+            else:
+                want = sum(g if g is not None else torch.zeros_like(p) for g in gs) / world
+                assert torch.allclose(p.grad, want, atol=1e-6), n
+        assert net['only0'].weight.grad is not None and net['never'].weight.grad is None
     out.put((rank, el))
     dist.destroy_process_group()
 

@@ -40,8 +40,9 @@ def _raster_area(a, b, n=1200):
 
     def inside(r):
         c, s = math.cos(r[4]), math.sin(r[4])
-        u = (X - r[0]) * c + (Y - r[1]) * s
-        w = -(X - r[0]) * s + (Y - r[1]) * c
+        # mmdet3d 0.17.1 yaw convention (clockwise in BEV): world = [[c, s], [-s, c]] . local
+        u = (X - r[0]) * c - (Y - r[1]) * s
+        w = (X - r[0]) * s + (Y - r[1]) * c
         return (np.abs(u) <= r[2] / 2) & (np.abs(w) <= r[3] / 2)
     return (inside(a) & inside(b)).mean() * (hi - lo) * (hi2 - lo2)
 
@@ -64,6 +65,28 @@ def test_rotated_intersection():
     assert abs(dc.rotated_intersection_area(r(0, 0, 2, 2, 0), r(0, 0, 2, 2, math.pi / 4)).item()
                - (8 * math.sqrt(2) - 8)) < 1e-5                           # regular octagon
     assert abs(dc.rotated_intersection_area(r(0, 0, 10, 10, 0.2), r(0.5, 0.3, 1, 2, 1.1)).item() - 2) < 1e-6
+
+
+def test_bev_polygon_follows_lidar_corners_convention():
+    """The BEV rectangle the IoU / NMS code clips must be the footprint `lidar_corners` (and the query_geometry
+    kernel, and mmdet3d 0.17.1's iou3d `rotate_around_center`) gives a box: off-axis centres, non-zero yaw."""
+    g = torch.Generator().manual_seed(3)
+    b = torch.cat([(torch.rand(9, 3, generator=g) - 0.5) * 20, torch.rand(9, 3, generator=g) * 3 + 0.5,
+                   (torch.rand(9, 1, generator=g) - 0.5) * 6], 1)
+    foot = dc.lidar_corners(b)[:, [0, 3, 7, 4], :2]                   # bottom face
+    poly = dc._rect_corners_bev(b[:, [0, 1, 3, 4, 6]])
+    for i in range(9):                                                # same vertex SET (any starting vertex)
+        d = (foot[i][:, None, :] - poly[i][None, :, :]).norm(dim=-1)
+        assert d.min(1).values.max() < 1e-4 and d.min(0).values.max() < 1e-4, i
+    x, y = poly[..., 0], poly[..., 1]
+    assert ((x * y.roll(-1, 1) - x.roll(-1, 1) * y).sum(1) > 0).all()      # counter-clockwise loop
+    # the advisor's counter example: 4x1 boxes at (0,0) and (1,1), yaw pi/4 -> both lie along the ANTI-diagonal
+    # (clockwise yaw), side by side: no overlap.  With the opposite sign they would overlap (IoU 0.478).
+    a = torch.tensor([[0., 0, 0, 4, 1, 1, math.pi / 4]]); c = torch.tensor([[1., 1, 0, 4, 1, 1, math.pi / 4]])
+    assert dc.boxes_iou3d_lidar(a, c).item() < 1e-6
+    c2 = torch.tensor([[1., -1, 0, 4, 1, 1, math.pi / 4]])                # shifted ALONG the anti-diagonal
+    inter = 4 - math.sqrt(2)
+    assert abs(dc.boxes_iou3d_lidar(a, c2).item() - inter / (8 - inter)) < 1e-5
 
 
 def test_iou3d_identities():
