@@ -1,32 +1,37 @@
 #!/usr/bin/env python
-"""bench.py - forward throughput of the interaction hot path on MI355X.
+"""bench.py - throughput of the interaction hot path on MI355X.
 
-Metric (BASELINE.json): samples/sec forward, Fusion_0075 synthetic.  A "step" is one forward of
-the full MMRI encoder (2 layers) + MMPI decoder (1 decoder layer + 4 RoI layers, Q=200) over one
-batch of synthetic Fusion_0075_refactor-shaped inputs (BASELINE.json configs[1]: image features
-6x256x112x200, BEV 512x180x180, 262 144 points, fp16), inputs resident in HBM.
+Metric (BASELINE.json): samples/sec forward, Fusion_0075 synthetic.  A "step" is one pass of the hot path over one
+batch: the next device-resident synthetic sample of a small pool is made current (`GraphedHotPath.load`: features,
+points, pillars and geometry constants copied into the captured buffers) and the full MMRI encoder (2 layers) + MMPI
+decoder (1 decoder layer + 4 RoI layers, Q=200) forward runs on it.  Default workload = BASELINE.json configs[1]:
+Fusion_0075_refactor shapes (image features 6x256x112x200, BEV 512x180x180, 262 144 points), fp16.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py --gpus N --steps K --warmup W           N > 1 without a torchrun environment re-launches itself
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W              as `torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL)
 
-Forward inference shards by sample with no data-path collective: every rank runs
-its own replica on its own samples ("weak" scaling); the only collectives are the timing barrier
-and the max-over-ranks reduction.  Rank 0 prints ONE JSON line.
+Other workloads of BASELINE.json `configs` (parity-test configurations; not the headline line):
+    --model pp      configs[4]: DeepInteraction++ (Fusion_0075_plusplus neck + head) forward
+    --mode train    configs[2] (N = 1) / configs[3] (N > 1): forward + head loss + backward + gradient all-reduce + AdamW
 
-Also reported on the same line:
-  roofline      the dominant kernel (fused local-window attention on the 6x112x200 image maps):
-                algorithmic bytes 4*n*C*H*W*2 = 137.6 MB per launch / average launch duration
-                measured live with HIP events on the launch stream during the timed steps
-  cpu_baseline  the CPU oracle (PyTorch fp32 restatement of the reference path, kind "port")
-                timed on this box's host cores on one full-size sample (rank 0, N=1 only)
+The path shards by sample with no data-path collective in the forward: every rank runs its own replica
+on its own samples ("weak" scaling); the collectives are the timing barrier, the max-over-ranks reduction and - in
+training - the gradient all-reduce over RCCL.  Rank 0 prints ONE JSON line, with
+  roofline      the dominant kernel (fused local-window attention on the 6x112x200 image maps): algorithmic bytes
+                4*n*C*H*W*2 = 137.6 MB per launch / average launch duration measured live with HIP events on the
+                launch stream; `traffic`, `mfma_busy`, `lds_busy` from the committed rocprofv3 --pmc passes (profiles/)
+  cpu_baseline  the CPU oracle (PyTorch fp32 restatement of the reference path, kind "port") timed on this box's
+                host cores on one full-size sample (rank 0, N=1 only)
+  parity        the product's outputs on that same sample against the oracle's (same state_dict, no depth injection)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -35,129 +40,230 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def build_models(shape, num_proposals, dtype, device):
-    from deepinteraction_amd.mmdet3d_plugin import DeepInteractionDecoder, DeepInteractionEncoder
-    from deepinteraction_amd.configs import decoder_cfg
-    torch.manual_seed(1234)
-    enc = DeepInteractionEncoder(num_layers=2, in_channels_img=shape['c_img'], in_channels_pts=shape['c_pts'],
-                                 hidden_channel=128)
-    dec = DeepInteractionDecoder(**decoder_cfg(bev=shape['bev_hw'][0], num_proposals=num_proposals))
-    g = torch.Generator().manual_seed(5)
-    for m in list(enc.modules()) + list(dec.modules()):      # non-trivial BN statistics (random-init weights)
-        if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
-            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
-            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
-    return enc.to(device, dtype).eval(), dec.to(device, dtype).eval()
-
-
-def to_device(inp, device, dtype):
-    pm = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
-    pm['pts'] = [p.to(device) for p in inp['pts_metas']['pts']]
-    return dict(img_feats=inp['img_feats'].to(device, dtype).contiguous(memory_format=torch.channels_last),
-                pts_feats=inp['pts_feats'].to(device, dtype).contiguous(memory_format=torch.channels_last),
-                img_metas=inp['img_metas'], pts_metas=pm)
-
-
-def forward(enc, dec, d):
-    img, pts = enc(d['img_feats'], d['pts_feats'], d['img_metas'], d['pts_metas'])
-    return dec(pts, img, d['img_metas'])
-
-
-def cpu_baseline(shape, num_proposals, budget_s=25.0):
-    """The CPU oracle (kind "port": PyTorch fp32 restatement of the reference path, its per-sample
-    and per-view Python loops and scipy depth completion included) on this box's host cores.
-    BOUNDED: a 1/16-area probe of the workload is timed first; then the largest of
-    {1/16, 1/4, full} area samples whose predicted time fits `budget_s` is timed and scaled by its
-    area fraction to full-size-sample units.  Reported baseline only."""
-    from deepinteraction_amd import synth
-    from oracle import configs, decoder as odec, encoder as oenc
-    cores = min(os.cpu_count() or 1, 16)          # more threads only add overhead to these small ops
-    torch.set_num_threads(cores)
-
-    def run(div):
-        Hi, Wi = shape['img_hw'][0] // div, shape['img_hw'][1] // div
-        Hb = shape['bev_hw'][0] // div
-        sh = dict(shape, img_hw=(Hi, Wi), input_shape=(Hi * 4, Wi * 4), bev_hw=(Hb, Hb),
-                  n_points=shape['n_points'] // (div * div))
-        inp = synth.make_inputs(1, sh, seed=0)
-        torch.manual_seed(1234)
-        E = oenc.DeepInteractionEncoder(2, sh['c_img'], sh['c_pts'], 128).eval()
-        D = odec.DeepInteractionDecoder(**configs.decoder_cfg(bev=Hb, num_proposals=num_proposals)).eval()
-        with torch.no_grad():
-            t0 = time.time()
-            img, pts = E(inp['img_feats'], inp['pts_feats'], inp['img_metas'], inp['pts_metas'])
-            D(pts, img, inp['img_metas'])
-            return time.time() - t0, sh
-
-    t16, sh = run(4)
-    div, dt = 4, t16
-    for d, growth in ((2, 4.0), (1, 16.0)):       # predicted from the probe, ~linear in area
-        if t16 * growth * 1.3 <= budget_s:
-            div = d
-    if div != 4:
-        dt, sh = run(div)
-    frac = 1.0 / (div * div)
-    return dict(value=round(frac / dt, 5), unit='samples/s', cores=cores, kind='port',
-                sample=(f'oracle MMRI+MMPI forward, fp32, {cores} threads, on a 1/{div * div}-area sample '
-                        f'(image feats 6x{sh["c_img"]}x{sh["img_hw"][0]}x{sh["img_hw"][1]}, BEV {sh["bev_hw"][0]}^2, '
-                        f'{sh["n_points"]} points) in {dt:.1f} s; value = area fraction / time'))
-
-
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=1, help='samples per GPU per step')
     ap.add_argument('--proposals', type=int, default=200)
     ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
     ap.add_argument('--shape', default='R', choices=['R', 'A', 'TINY'])
+    ap.add_argument('--model', default='v1', choices=['v1', 'pp'], help='pp = DeepInteraction++ (configs[4])')
+    ap.add_argument('--mode', default='forward', choices=['forward', 'train'], help='train = configs[2]/[3]')
+    ap.add_argument('--pool', type=int, default=4, help='distinct device-resident samples cycled through the steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true',
                     help='launch every kernel from the host each step instead of replaying the captured hipGraph')
     ap.add_argument('--roofline-steps', type=int, default=5,
                     help='eager forwards run after the timed region to time the dominant kernel with HIP events')
-    args = ap.parse_args()
+    ap.add_argument('--settle-ms', type=float, default=300.0,
+                    help='untimed replays before the W warmup steps: the clocks of a just-leased, idle GPU ramp for a few '
+                         'hundred ms (the driver times 20 steps = 0.07 s); reported in config.settle_ms')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / timing protocol only (CPU, gloo): no GPU work; used by tests/test_parallel.py')
+    return ap.parse_args()
 
-    from deepinteraction_amd import ops, parallel, synth
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: one process per GPU through torch.distributed.run
+    on this node (the reference's tools/dist_train.sh:7-9 launch contract: one command per node)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ CPU side
+def cpu_baseline(shape, num_proposals, state, sample, product_out, budget_s=60.0):
+    """The CPU oracle (kind "port": PyTorch fp32 restatement of the reference path, its per-sample and per-view
+    Python loops and scipy depth completion included) on this box's host cores, BOUNDED: a 1/16-area probe of the
+    workload is timed first; when the predicted full-size time fits `budget_s` the oracle runs the full-size
+    `sample` with the product's own state_dict - that run is both the baseline and the reference of the `parity`
+    block - otherwise the largest area fraction that fits is timed and scaled, and parity is left to the tests."""
+    import torch
+    from deepinteraction_amd import synth
+    from oracle import parity
+    cores = min(os.cpu_count() or 1, 16)          # more threads only add overhead to these small ops
+    torch.set_num_threads(cores)
+
+    def probe(div):
+        Hi, Wi = shape['img_hw'][0] // div, shape['img_hw'][1] // div
+        Hb = shape['bev_hw'][0] // div
+        sh = dict(shape, img_hw=(Hi, Wi), input_shape=(Hi * 4, Wi * 4), bev_hw=(Hb, Hb),
+                  n_points=shape['n_points'] // (div * div))
+        inp = synth.make_inputs(1, sh, seed=0)
+        E, D = parity.build_oracle(sh, num_proposals)
+        t0 = time.time()
+        parity.oracle_decoder(D, parity.oracle_encoder(E, inp), inp['img_metas'])
+        return time.time() - t0, sh
+
+    t16, sh = probe(4)
+    par = None
+    if t16 * 16.0 * 1.3 <= budget_s:
+        E, D = parity.build_oracle(shape, num_proposals, state=state)
+        t0 = time.time()
+        ref_enc = parity.oracle_encoder(E, sample)
+        free = parity.oracle_decoder(D, ref_enc, sample['img_metas'])
+        dt, div, sh = time.time() - t0, 1, shape
+        if product_out is not None:
+            got_enc, out, labels, masks, top = product_out
+            forced = parity.oracle_decoder(D, ref_enc, sample['img_metas'], top_override=top.cpu())
+            par = parity.summarize(parity.compare_encoder(got_enc, ref_enc),
+                                   parity.compare_decoder(out, labels, masks, top, free, forced))
+            par['vs'] = ('CPU oracle full forward on the same sample and state_dict, no depth injection; continuous '
+                         'outputs as |got-ref|/max(1,max|ref|); decoder outputs against the oracle decoder run on '
+                         'the product\'s proposals')
+    else:
+        div = 2 if t16 * 4.0 * 1.3 <= budget_s else 4
+        dt, sh = probe(div) if div != 4 else (t16, sh)
+    frac = 1.0 / (div * div)
+    base = dict(value=round(frac / dt, 5), unit='samples/s', cores=cores, kind='port',
+                sample=(f'oracle MMRI+MMPI forward, fp32, {cores} threads, on a 1/{div * div}-area sample '
+                        f'(image feats 6x{sh["c_img"]}x{sh["img_hw"][0]}x{sh["img_hw"][1]}, BEV {sh["bev_hw"][0]}^2, '
+                        f'{sh["n_points"]} points) in {dt:.1f} s; value = area fraction / time'))
+    return base, par
+
+
+def pmc_file(name):
+    p = os.path.join(ROOT, 'profiles', name)
+    return json.load(open(p)) if os.path.exists(p) else {}
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def run_dry(args, parallel, rank, world):
+    """No GPU: exercises launcher, rank environment, barrier / max-over-ranks timing on gloo."""
+    parallel.init('gloo')
+    el = parallel.timed_region(lambda: time.sleep(0.002 * (rank + 1)), args.steps)
+    seen = parallel.sum_over_ranks(1)
+    if rank == 0:
+        print(json.dumps(dict(metric='dry-run (launcher + timing protocol only)', value=round(
+            parallel.throughput(args.batch, args.steps, el, world), 3), unit='samples/s', n_gpus=args.gpus,
+            steps=args.steps, warmup=args.warmup, ms_per_step=round(el / args.steps * 1e3, 3), higher_is_better=True,
+            scaling='weak', vs_baseline=None, dtype='none', data='none',
+            config=dict(workload='dry-run', ranks_seen=int(seen), backend='gloo'))))
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(self_launch(args))
+    import torch
+    from deepinteraction_amd import parallel
     rank, local, world = parallel.env_rank()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.dry_run:
+        run_dry(args, parallel, rank, world)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    from deepinteraction_amd import harness, ops, synth
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    parallel.init('nccl', device)                 # RCCL over xGMI; only the timing protocol uses it
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    parallel.init('nccl', device)                 # RCCL over xGMI
+    ranks_seen = int(parallel.sum_over_ranks(1, device))
+    if args.mode == 'train':
+        from deepinteraction_amd import train_step
+        out = train_step.bench(args, rank, world, device)
+    elif args.model == 'pp':
+        out = bench_forward_pp(args, rank, world, device)
+    else:
+        out = bench_forward(args, rank, world, device)
+    if rank == 0:
+        out['config']['ranks_seen'] = ranks_seen
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
-    shape = dict(R=synth.SHAPE_R, A=synth.SHAPE_A, TINY=synth.SHAPE_TINY)[args.shape]
+
+def settle(step, ms):
+    """Untimed: run `step` for about `ms` milliseconds so that the timed region starts on a GPU at its working clocks."""
+    import torch
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+
+
+def _line(args, metric, value, elapsed, dtype, workload, extra_cfg):
+    return dict(metric=metric, value=round(value, 3), unit='samples/s', n_gpus=args.gpus, steps=args.steps,
+                warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
+                scaling='weak', vs_baseline=None, dtype=dtype, data='synthetic',
+                config=dict(workload=workload, batch_per_gpu=args.batch, global_batch=args.batch * args.gpus,
+                            settle_ms=args.settle_ms,
+                            parallelism=f'{args.gpus} replicas, sharded by sample (one process per GPU)', **extra_cfg))
+
+
+def bench_forward(args, rank, world, device):
+    import torch
+    from deepinteraction_amd import harness, ops, parallel, synth
+    shape = harness.SHAPES[args.shape]
     dtype = dict(f16=torch.float16, f32=torch.float32)[args.dtype]
-    enc, dec = build_models(shape, args.proposals, dtype, device)
-    # weak scaling: rank r owns samples [r*batch, (r+1)*batch) of the global batch (deepinteraction_amd/parallel.py)
-    ids = parallel.sample_ids(0, args.batch, rank, world)
-    data = to_device(synth.make_inputs(args.batch, shape, seed=parallel.sample_seed(ids[0])), device, dtype)
-    n_pillars = int(data['pts_metas']['pillars'].shape[0])
+    enc, dec = harness.build_models(shape, args.proposals, dtype, device)
+    # weak scaling: rank r owns samples [r*batch, (r+1)*batch) of each global batch (deepinteraction_amd/parallel.py);
+    # a pool of `--pool` device-resident batches per rank is cycled through the steps
+    host_pool = []
+    for i in range(max(1, args.pool)):
+        ids = parallel.sample_ids(i, args.batch, rank, world)
+        inp = synth.make_inputs(args.batch, shape, seed=parallel.sample_seed(ids[0]))
+        inp['img_feats'], inp['pts_feats'] = inp['img_feats'].to(dtype).float(), inp['pts_feats'].to(dtype).float()
+        host_pool.append(inp)
+    dev_pool = [harness.to_device(inp, device, dtype) for inp in host_pool]
+    n_pillars = [int(d['pts_metas']['pillars'].shape[0]) for d in dev_pool]
 
-    # One step = one forward of encoder + decoder on the resident batch.  Default: the forward is captured
-    # once into a hipGraph (deepinteraction_amd/graphed.py) and every step replays it - all ~600 kernels
-    # run each step, only the host-side launch work is gone.  --eager launches them from Python instead.
     with torch.no_grad():
         if args.eager:
-            step = lambda: forward(enc, dec, data)
+            it = [0]
+
+            def step():
+                d = dev_pool[it[0] % len(dev_pool)]
+                it[0] += 1
+                harness.forward(enc, dec, d)
+            g = None
         else:
             from deepinteraction_amd.graphed import GraphedHotPath
-            step = GraphedHotPath(enc, dec, data)
+            cap = max(range(len(dev_pool)), key=lambda i: n_pillars[i])     # the largest sample sets the capacity
+            g = GraphedHotPath(enc, dec, dev_pool[cap])
+            records = [g.prepare(d) for d in dev_pool]
+            it = [0]
+
+            def step():
+                g.load(records[it[0] % len(records)])      # per-sample: copies into the captured buffers ...
+                it[0] += 1
+                g()                                         # ... and one replay of the captured forward
+        settle(step, args.settle_ms)
         for _ in range(args.warmup):
             step()
         # barrier + synchronize | K steps | barrier + synchronize, MAX over ranks
         elapsed = parallel.timed_region(step, args.steps, device)
-        # dominant-kernel timing: HIP events right around the launch, on the launch stream, in eager
-        # forwards of the same model and data (events cannot bracket one kernel inside a graph replay)
-        forward(enc, dec, data)
+
+        # parity sample: the product's outputs on pool[0], in the benched launch mode
+        product_out = None
+        if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+            if g is not None:
+                g.load(records[0])
+                res, (img, pts) = g()[0][0], g.enc_out
+            else:
+                (img, pts), res = harness.forward(enc, dec, dev_pool[0])
+                res = res[0][0]
+            torch.cuda.synchronize()
+            product_out = ((img.float().cpu(), [t.float().cpu() for t in pts]),
+                           {k: v.float().cpu() for k, v in res.items()}, dec.query_labels.cpu(),
+                           [m.cpu() for m in dec.on_the_image_mask], dec.top_proposals.cpu())
+        # dominant-kernel timing: HIP events right around the launch, on the launch stream, in eager forwards of
+        # the same model and data (events cannot bracket one kernel inside a graph replay)
+        harness.forward(enc, dec, dev_pool[0])
         torch.cuda.synchronize()
         ops.PROFILE = []
         for _ in range(args.roofline_steps):
-            forward(enc, dec, data)
+            harness.forward(enc, dec, dev_pool[0])
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
-    # roofline of the dominant kernel: fused local-window attention on the image maps
     Hi, Wi = shape['img_hw']
     n_img = 6 * args.batch
     es = 2 if dtype == torch.float16 else 4
@@ -165,34 +271,117 @@ def main():
     durs = [s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name == 'local_attn_fwd' and n == n_img]
     avg = sum(durs) / max(len(durs), 1)
     achieved = alg_bytes / avg / 1e9 if durs else None
-    roofline = dict(bound='hbm', kernel='di_local_attn_fwd, image side 6x112x200, 9x9, C=128 (local_attn_m2_kernel, 16x4 tiles)',
+    pmc = pmc_file('pmc_local_attn.json')
+    roofline = dict(bound='hbm', kernel=f'di_local_attn_fwd, image side {n_img}x{Hi}x{Wi}, 9x9, C=128 '
+                                        f'({ops.local_attention_kernel_name()})',
                     achieved=None if achieved is None else round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                    traffic=None, avg_launch_us=round(avg * 1e6, 2), launches=len(durs),
-                    algorithmic_bytes=alg_bytes,
+                    traffic=pmc.get('hbm_bytes_per_launch'), mfma_busy=pmc.get('mfma_busy'),
+                    lds_busy=pmc.get('lds_busy'), pmc_source=pmc.get('source'),
+                    avg_launch_us=round(avg * 1e6, 2), launches=len(durs), algorithmic_bytes=alg_bytes,
                     timed_in=f'{args.roofline_steps} eager forwards right after the timed region, HIP events on the launch stream')
-    pmc = os.path.join(ROOT, 'profiles', 'pmc_local_attn.json')
-    if os.path.exists(pmc):                            # HBM bytes per launch from a separate rocprofv3 --pmc pass
-        roofline['traffic'] = json.load(open(pmc)).get('hbm_bytes_per_launch')
+    out = _line(args, 'samples/sec forward (Fusion_0075 synthetic)',
+                parallel.throughput(args.batch, args.steps, elapsed, world), elapsed,
+                'f16' if dtype == torch.float16 else 'f32',
+                'Full MMRI encoder (2 layers) + MMPI decoder forward, '
+                f'Fusion_0075_refactor shapes (shape {args.shape}), random-init weights',
+                dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(dev_pool),
+                     launch='eager' if args.eager else 'per step: load() of the next pool sample into the captured '
+                                                       'buffers + hipGraph replay of the captured forward',
+                     graph_nodes=None if g is None else g.num_nodes()))
+    out['roofline'] = roofline
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        state = ({k: v.float().cpu() for k, v in enc.state_dict().items()},
+                 {k: v.float().cpu() for k, v in dec.state_dict().items()})
+        base, par = cpu_baseline(shape, args.proposals, state, host_pool[0], product_out)
+        out['cpu_baseline'] = base
+        out['parity'] = par
+    return out
 
-    if rank == 0:
-        out = dict(metric='samples/sec forward (Fusion_0075 synthetic)',
-                   value=round(parallel.throughput(args.batch, args.steps, elapsed, world), 3),
-                   unit='samples/s', n_gpus=args.gpus, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
-                   vs_baseline=None, dtype='f16' if dtype == torch.float16 else 'f32', data='synthetic',
-                   config=dict(workload='Full MMRI encoder (2 layers) + MMPI decoder forward, '
-                                        f'Fusion_0075_refactor shapes (shape {args.shape}), random-init weights',
-                               batch_per_gpu=args.batch, global_batch=args.batch * args.gpus,
-                               num_proposals=args.proposals, pillars=n_pillars,
-                               launch='eager' if args.eager else 'hipGraph replay of the captured forward',
-                               parallelism=f'{args.gpus} independent replicas, sharded by sample'),
-                   roofline=roofline)
-        if args.gpus == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(shape, args.proposals)
-        print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+
+def bench_forward_pp(args, rank, world, device):
+    """BASELINE.json configs[4]: DeepInteraction++ forward (Fusion_0075_plusplus.py:210-303 neck + head)."""
+    import torch
+    from deepinteraction_amd import configs, ops, parallel, synth
+    from deepinteraction_amd.graphed import GraphedHotPath
+    from deepinteraction_amd.mmdet3d_plugin import DeepInteractionPlusPlusDecoder, FusionTransformerv4
+    shape = synth.SHAPE_PP if args.shape != 'TINY' else synth.SHAPE_PP_TINY
+    bev = shape['bev_hw'][0]
+    dtype = dict(f16=torch.float16, f32=torch.float32)[args.dtype]
+    torch.manual_seed(0)
+    enc = FusionTransformerv4(**configs.encoder_pp_cfg(shape['c_img'], shape['c_pts'])).to(device, dtype).eval()
+    dec = DeepInteractionPlusPlusDecoder(**configs.decoder_cfg(bev=bev, num_proposals=args.proposals if bev >= 100 else 24)
+                                         ).to(device, dtype).eval()
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():                      # off the mmcv zero-init so that the sampling offsets are spread
+        for m in enc.modules():
+            if hasattr(m, 'sampling_offsets'):
+                for lin in (m.sampling_offsets, m.attention_weights):
+                    lin.weight.add_(torch.randn(lin.weight.shape, generator=gen).to(device, dtype) * 0.05)
+    cl = lambda t: t.to(device, dtype).contiguous(memory_format=torch.channels_last)
+
+    def dev(inp):
+        pm = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
+        pm['pts'] = [p.to(device) for p in inp['pts_metas']['pts']]
+        return dict(img_feats=[cl(f) for f in inp['img_feats']], pts_feats=[cl(f) for f in inp['pts_feats']],
+                    img_metas=inp['img_metas'], pts_metas=pm)
+    pool = [dev(synth.make_inputs_pp(args.batch, shape, seed=parallel.sample_seed(
+        parallel.sample_ids(i, args.batch, rank, world)[0]))) for i in range(max(1, args.pool))]
+    n_pillars = [int(d['pts_metas']['pillars'].shape[0]) for d in pool]
+
+    def eager(d):
+        im, p = enc(d['img_feats'], d['pts_feats'], d['img_metas'], dict(d['pts_metas']))
+        return dec(p, im, d['img_metas'])
+    with torch.no_grad():
+        it = [0]
+        if args.eager:
+            g = None
+
+            def step():
+                eager(pool[it[0] % len(pool)])
+                it[0] += 1
+        else:
+            g = GraphedHotPath(enc, dec, pool[max(range(len(pool)), key=lambda i: n_pillars[i])])
+            records = [g.prepare(d) for d in pool]
+
+            def step():
+                g.load(records[it[0] % len(records)])
+                it[0] += 1
+                g()
+        settle(step, args.settle_ms)
+        for _ in range(args.warmup):
+            step()
+        elapsed = parallel.timed_region(step, args.steps, device)
+        eager(pool[0])
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        for _ in range(args.roofline_steps):
+            eager(pool[0])
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+    Hi, Wi = shape['img_hw']
+    es = 2 if dtype == torch.float16 else 4
+    nq = 6 * args.batch * Hi * Wi
+    S = 6 * args.batch * (Hi * Wi + (Hi // 2) * (Wi // 2))
+    alg = (S * 128 + nq * (8 * 2 * 4 * 3 + 128)) * es        # value + packed offsets/logits + output (DESIGN 10)
+    durs = [s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name == 'ms_deform_attn_fwd' and n == nq]
+    # the image self-attention (2 levels) and the P2I cross attention (1 level) share nq: the 2-level one is slower
+    durs = sorted(durs)[len(durs) // 2:]
+    avg = sum(durs) / max(len(durs), 1)
+    out = _line(args, 'samples/sec forward (Fusion_0075_plusplus synthetic)',
+                parallel.throughput(args.batch, args.steps, elapsed, world), elapsed,
+                'f16' if dtype == torch.float16 else 'f32',
+                'DeepInteraction++ forward: FusionTransformerv4 neck (2 layers) + DeepInteractionPlusPlusDecoder, '
+                'Fusion_0075_plusplus shapes (2 image levels 112x200 / 56x100, BEV 180x180), random-init weights',
+                dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(pool),
+                     launch='eager' if args.eager else 'per step: load() + hipGraph replay',
+                     graph_nodes=None if g is None else g.num_nodes()))
+    out['roofline'] = dict(bound='hbm', kernel='pp::ms_deform_attn_kernel, image self-attention (2 levels)',
+                           achieved=round(alg / avg / 1e9, 1) if durs else None, peak=HBM_PEAK_GBS, unit='GB/s',
+                           frac=round(alg / avg / 1e9 / HBM_PEAK_GBS, 4) if durs else None,
+                           traffic=pmc_file('pmc_ms_deform_attn.json').get('hbm_bytes_per_launch'),
+                           avg_launch_us=round(avg * 1e6, 2), launches=len(durs), algorithmic_bytes=alg)
+    return out
 
 
 if __name__ == '__main__':

@@ -50,7 +50,9 @@ SIGNATURES = {
     'di_mha_decode_fwd': [_c_p] * 4 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
 }
 # helpers that return a value instead of an error code
-VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 2}
+VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 2,
+               'di_graph_node_count': [_c_p]}
+_LONGLONG = {'di_topk_workspace_bytes', 'di_graph_node_count'}
 
 _lib = None
 
@@ -75,7 +77,7 @@ def lib():
         for name, argtypes in list(SIGNATURES.items()) + list(VALUE_FUNCS.items()):
             fn = getattr(L, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_longlong if name == 'di_topk_workspace_bytes' else _c_i
+            fn.restype = ctypes.c_longlong if name in _LONGLONG else _c_i
         _lib = L
     return _lib
 

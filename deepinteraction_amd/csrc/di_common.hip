@@ -26,4 +26,14 @@ int check_launch(const char *what) {
 extern "C" {
 int di_abi_version(void) { return 1; }
 const char *di_last_error(void) { return di::g_err; }
+
+// number of nodes of a captured hipGraph_t (measurement plumbing for bench.py: "graph_nodes"); < 0 on error
+long long di_graph_node_count(void *graph) {
+  size_t n = 0;
+  if (graph == nullptr || hipGraphGetNodes((hipGraph_t)graph, nullptr, &n) != hipSuccess) {
+    di::set_error("hipGraphGetNodes failed");
+    return DI_ERR_LAUNCH;
+  }
+  return (long long)n;
+}
 }

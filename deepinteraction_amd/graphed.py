@@ -84,6 +84,7 @@ class GraphedHotPath:
         self.dec.static_geometry = self.query_geom
         try:
             img, pts = self.enc(self.img_feats, self.pts_feats, self.img_metas, self._pts_metas())
+            self.enc_out = (img, pts)           # static buffers too: valid after every replay
             return self.dec(pts, img, self.img_metas)
         finally:
             self.dec.static_geometry = None
@@ -96,49 +97,97 @@ class GraphedHotPath:
                 self._forward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.out = self._forward()
+        self._nodes = None
+        try:
+            from . import _lib
+            n = int(_lib.lib().di_graph_node_count(int(self.graph.raw_cuda_graph())))
+            self._nodes = n if n >= 0 else None
+        except Exception:      # measurement only: a torch build without raw graph access just reports None
+            self._nodes = None
+        self.graph.instantiate()
+
+    def num_nodes(self):
+        """Nodes (kernel launches, copies, memsets) of the captured forward, or None when torch does not expose it."""
+        return self._nodes
 
     def __call__(self):
         self.graph.replay()
         return self.out
 
-    @staticmethod
-    def _fit(dst, src, fill):
-        n = src.shape[0]
-        if n > dst.shape[0]:
-            raise ValueError(f'sample of {n} rows exceeds the captured capacity {dst.shape[0]}')
-        dst[:n].copy_(src, non_blocking=True)
-        if n < dst.shape[0]:
-            dst[n:].fill_(fill)
+    # ------------------------------------------------------------------ per-sample inputs
+    class Record:
+        """One batch, device resident and already in the captured layout (points / pillars padded to the captured
+        capacity, geometry constants packed): `load(record)` is a handful of device-to-device copies and no host
+        work, so it can sit inside a timed per-sample loop."""
+        __slots__ = ('img_feats', 'pts_feats', 'pts', 'pillars', 'pillar_coors', 'pillars_num_points', 'img_metas',
+                     'sample_geom', 'query_geom', 'extra')
 
-    def load(self, inputs):
-        """Copy a new batch into the static buffers (same shapes; points / pillars up to the captured
-        capacity) and refresh the geometry constants in place."""
-        self._copy(self.img_feats, inputs['img_feats'])
-        self._copy(self.pts_feats, inputs['pts_feats'])
-        pm = inputs['pts_metas']
+    @staticmethod
+    def _padded(src, like, fill):
+        n = src.shape[0]
+        if n > like.shape[0]:
+            raise ValueError(f'sample of {n} rows exceeds the captured capacity {like.shape[0]}')
+        out = torch.full_like(like, fill)
+        out[:n].copy_(src.to(like.dtype))
+        return out
+
+    def prepare(self, inputs):
+        """Pack a batch (dict as produced by `harness.to_device`) into a `Record` (may synchronise; do it ahead of
+        the per-sample loop).  Same shapes as the captured batch; points / pillars up to the captured capacity."""
         if self.batch != len(inputs['img_metas']):
             raise ValueError('batch size differs from the captured one')
-        for dst, src in zip(self.pts, pm['pts']):
-            self._fit(dst, src.to(dst.dtype), float('nan'))
+        r = GraphedHotPath.Record()
+        r.img_feats, r.pts_feats = inputs['img_feats'], inputs['pts_feats']
+        pm = inputs['pts_metas']
+        r.pts = [self._padded(src, dst, float('nan')) for dst, src in zip(self.pts, pm['pts'])]
         if self.batch == 1:
-            self._fit(self.pillars, pm['pillars'], 0.0)
-            self._fit(self.pillar_coors, pm['pillar_coors'], 0)
-            self._fit(self.pillars_num_points, pm['pillars_num_points'], 0)
-        else:
+            r.pillars = self._padded(pm['pillars'], self.pillars, 0.0)
+            r.pillar_coors = self._padded(pm['pillar_coors'], self.pillar_coors, 0)
+            r.pillars_num_points = self._padded(pm['pillars_num_points'], self.pillars_num_points, 0)
+        else:      # every sample's pillars go to that sample's fixed slice of the captured buffers
+            r.pillars = torch.zeros_like(self.pillars)
+            r.pillar_coors = torch.zeros_like(self.pillar_coors)
+            r.pillars_num_points = torch.zeros_like(self.pillars_num_points)
             b = pm['pillar_coors'][:, 0].long()
             for s in range(self.batch):
                 lo, hi = self.bounds[s], self.bounds[s + 1]
                 sel = (b == s).nonzero().flatten()
-                self._fit(self.pillars[lo:hi], pm['pillars'][sel], 0.0)
-                self._fit(self.pillar_coors[lo:hi], pm['pillar_coors'][sel], 0)
-                self._fit(self.pillars_num_points[lo:hi], pm['pillars_num_points'][sel], 0)
-        self.img_metas = [dict(m) for m in inputs['img_metas']]
-        for b, (g, m) in enumerate(zip(self.sample_geom, self.img_metas)):
-            g.update(m)
-            for mod in self.enc.modules():       # per-sample constants some operators keep next to the geometry
-                if hasattr(mod, 'refresh_static_geometry'):
-                    mod.refresh_static_geometry(g, m)
-        self.query_geom.update(self.img_metas)
+                if sel.numel() > hi - lo:
+                    raise ValueError(f'sample {s}: {sel.numel()} pillars exceed the captured capacity {hi - lo}')
+                n = sel.numel()
+                r.pillars[lo:lo + n] = pm['pillars'][sel]
+                r.pillar_coors[lo:lo + n] = pm['pillar_coors'][sel]
+                r.pillar_coors[lo:hi, 0] = s
+                r.pillars_num_points[lo:lo + n] = pm['pillars_num_points'][sel]
+        r.img_metas = [dict(m) for m in inputs['img_metas']]
+        dev = self.pillars.device
+        r.sample_geom = [SampleGeometry._pack(m, g.img_hw).to(dev) for g, m in zip(self.sample_geom, r.img_metas)]
+        r.query_geom = QueryGeometry._pack(r.img_metas)[0].to(dev)
+        r.extra = []                      # per-sample constants some operators keep next to the geometry (++ rays)
+        for mod in self.enc.modules():
+            if hasattr(mod, 'static_geometry_record'):
+                r.extra.append((mod, [mod.static_geometry_record(g, m) for g, m in zip(self.sample_geom, r.img_metas)]))
+        return r
+
+    def load(self, inputs):
+        """Make a new batch the current one: copy it into the static buffers and refresh the geometry constants in
+        place.  `inputs`: a `Record` from `prepare()` (device-to-device copies only) or a raw input dict."""
+        r = inputs if isinstance(inputs, GraphedHotPath.Record) else self.prepare(inputs)
+        self._copy(self.img_feats, r.img_feats)
+        self._copy(self.pts_feats, r.pts_feats)
+        for dst, src in zip(self.pts, r.pts):
+            dst.copy_(src, non_blocking=True)
+        self.pillars.copy_(r.pillars, non_blocking=True)
+        self.pillar_coors.copy_(r.pillar_coors, non_blocking=True)
+        self.pillars_num_points.copy_(r.pillars_num_points, non_blocking=True)
+        self.img_metas = r.img_metas
+        for g, buf in zip(self.sample_geom, r.sample_geom):
+            g._buf.copy_(buf, non_blocking=True)
+            g.sparse_depth = g.dense_depth = None
+        self.query_geom._buf.copy_(r.query_geom, non_blocking=True)
+        for mod, recs in r.extra:
+            for g, rec in zip(self.sample_geom, recs):
+                mod.load_static_geometry(g, rec)

@@ -237,14 +237,20 @@ class MMRI_I2P_Polar(nn.Module):
             geom.polar_key = key
         return geom
 
-    def refresh_static_geometry(self, geom, img_meta):
-        """New sample behind a captured hipGraph: rewrite the ray geometry IN PLACE (the graph has the addresses)."""
+    def static_geometry_record(self, geom, img_meta):
+        """Device copies of the ray geometry of a sample that will later run behind a captured hipGraph
+        (`GraphedHotPath.prepare`), or None when this operator has not built rays for `geom` yet."""
         if getattr(geom, 'polar_key', None) is None:
-            return
+            return None
         H, W = geom.polar_key[:2]
         grid, cam_xy = self.ray_grid(img_meta, H, W)
-        geom.polar[0].copy_(grid, non_blocking=True)
-        geom.polar[1].copy_(cam_xy, non_blocking=True)
+        return grid.to(geom.polar[0].device), cam_xy.to(geom.polar[1].device)
+
+    def load_static_geometry(self, geom, rec):
+        """New sample behind a captured hipGraph: rewrite the ray geometry IN PLACE (the graph has the addresses)."""
+        if rec is not None:
+            geom.polar[0].copy_(rec[0], non_blocking=True)
+            geom.polar[1].copy_(rec[1], non_blocking=True)
 
     def constants(self, H, W, dtype, device):
         key = (H, W, dtype, device)

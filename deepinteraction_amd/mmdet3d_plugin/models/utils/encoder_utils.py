@@ -224,14 +224,12 @@ class BEVWarp(nn.Module):
         super().__init__()
 
     @staticmethod
-    def dense_depth(geom, pts, I_H, I_W, pts_metas, b):
+    def dense_depth(geom, pts, I_H, I_W):
+        """Sparse depth scatter + ip_basic completion on the device (reference :155-182), cached per sample."""
         if getattr(geom, 'dense_depth', None) is None:
-            if isinstance(pts_metas, dict) and 'dense_depth' in pts_metas:      # injected (tests)
-                geom.dense_depth = pts_metas['dense_depth'][b].to(pts.device, torch.float32).contiguous()
-            else:
-                p = pts if pts.dtype == torch.float32 else pts.float()
-                geom.sparse_depth = ops.depth_scatter(p, geom.lidar2img, geom.aug_rev, I_H, I_W, geom.ori_hw)
-                geom.dense_depth = ops.depth_complete(geom.sparse_depth)
+            p = pts if pts.dtype == torch.float32 else pts.float()
+            geom.sparse_depth = ops.depth_scatter(p, geom.lidar2img, geom.aug_rev, I_H, I_W, geom.ori_hw)
+            geom.dense_depth = ops.depth_complete(geom.sparse_depth)
         return geom.dense_depth
 
     def forward(self, lidar_feats, img_feats, img_metas, pts_metas, **kwargs):
@@ -239,7 +237,7 @@ class BEVWarp(nn.Module):
         out = []
         for b in range(B):
             geom = sample_geometry(img_metas, pts_metas, b, (I_H, I_W), lidar_feats.device)
-            depth = self.dense_depth(geom, pts_metas['pts'][b], I_H, I_W, pts_metas, b)
+            depth = self.dense_depth(geom, pts_metas['pts'][b], I_H, I_W)
             if torch.is_grad_enabled() and lidar_feats.requires_grad:       # training: d(warped)/d(bev)
                 out.append(BEVWarpGather.apply(lidar_feats[b:b + 1], depth, geom.img2lidar, geom.aug_fwd,
                                                geom.xs, geom.ys, geom.pc_range))

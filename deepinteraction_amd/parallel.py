@@ -74,6 +74,15 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def sum_over_ranks(value, device=None):
+    """Sum of a per-rank number over the process group (bench.py: `ranks_seen` = how many ranks answered)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def throughput(units_per_rank_per_step, steps, elapsed_max, world):
     """Whole-job units/s: every rank processed units_per_rank_per_step * steps units within the slowest
     rank's time."""

@@ -1,0 +1,89 @@
+"""The data-parallel training step of the interaction hot path on synthetic nuScenes-shaped batches (BASELINE.json
+configs[2] at 1 GPU, configs[3] at N GPUs), as `bench.py --mode train` runs it.
+
+One process per GPU; every rank draws its own samples (`parallel.sample_ids`), runs encoder + decoder forward in
+train() mode, the head loss against synthetic ground truth (Hungarian assignment on the host, as the reference),
+backward through the HIP kernels, the bucketed gradient all-reduce over RCCL/xGMI LAUNCHED FROM BACKWARD HOOKS
+(`parallel.GradientReducer`: overlapped with the rest of backward; parameters no rank touched keep `grad = None`, the
+`find_unused_parameters=True` of the reference config) and AdamW with the reference's lr / weight decay / grad clip
+(projects/configs/nuscenes/Fusion_0075_refactor.py:252-253).
+"""
+import torch
+
+from . import det3d_compat as dc, harness, parallel, synth
+
+TRAIN_CFG = dict(
+    dataset='nuScenes',
+    assigner=dict(type='HungarianAssigner3D', iou_calculator=dict(type='BboxOverlaps3D', coordinate='lidar'),
+                  cls_cost=dict(type='FocalLossCost', gamma=2, alpha=0.25, weight=0.15),
+                  reg_cost=dict(type='BBoxBEVL1Cost', weight=0.25), iou_cost=dict(type='IoU3DCost', weight=0.25)),
+    pos_weight=-1, gaussian_overlap=0.1, min_radius=2, grid_size=[1440, 1440, 40], voxel_size=[0.075, 0.075, 0.2],
+    out_size_factor=8, code_weights=[1.0] * 8 + [0.2, 0.2], point_cloud_range=[-54.0, -54.0, -5.0, 54.0, 54.0, 3.0])
+
+
+def synth_gt(seed, n=30):
+    """Synthetic ground truth of one sample: `n` boxes (x, y, z, dx, dy, dz, yaw, vx, vy) and labels."""
+    g = torch.Generator().manual_seed(seed)
+    xy = (torch.rand(n, 2, generator=g) - 0.5) * 100
+    z = torch.rand(n, 1, generator=g) * 2 - 2.5
+    dims = torch.stack([torch.rand(n, generator=g) * 2 + 0.5, torch.rand(n, generator=g) * 5 + 0.5,
+                        torch.rand(n, generator=g) * 2 + 0.8], 1)
+    yaw = (torch.rand(n, 1, generator=g) - 0.5) * 6.28
+    vel = torch.randn(n, 2, generator=g)
+    return dc.LiDARBoxes(torch.cat([xy, z, dims, yaw, vel], 1)), torch.randint(0, 10, (n,), generator=g)
+
+
+class Trainer:
+    def __init__(self, shape, num_proposals, device, world, batch=1, pool=2, rank=0, seed=0):
+        bev = shape['bev_hw'][0]
+        tc = dict(TRAIN_CFG, grid_size=[bev * 8, bev * 8, 40], voxel_size=[108.0 / (bev * 8)] * 2 + [0.2])
+        self.enc, self.dec = harness.build_models(shape, num_proposals, torch.float32, device, seed=seed, train_cfg=tc)
+        self.enc.train(), self.dec.train()                            # identical initial weights on every rank
+        self.params = [p for m in (self.enc, self.dec) for p in m.parameters()]
+        self.opt = torch.optim.AdamW(self.params, lr=1e-4, weight_decay=0.01)
+        self.world = world
+        self.reducer = parallel.GradientReducer(self.params, world)
+        # a small pool of device-resident batches per rank, built before the timed region (the data loader is out
+        # of scope; generating 262 144 points + pillars on the host takes longer than the step)
+        self.pool = []
+        for i in range(pool):
+            ids = parallel.sample_ids(i, batch, rank, world)
+            inp = synth.make_inputs(batch, shape, seed=parallel.sample_seed(ids[0]))
+            d = harness.to_device(inp, device, torch.float32)
+            self.pool.append((d, [synth_gt(parallel.sample_seed(s)) for s in ids]))
+        self.i = 0
+
+    def step(self):
+        d, gts = self.pool[self.i % len(self.pool)]
+        self.i += 1
+        img, pts = self.enc(d['img_feats'], d['pts_feats'], d['img_metas'], dict(d['pts_metas']))
+        losses = self.dec.loss([g[0] for g in gts], [g[1] for g in gts], self.dec(pts, img, d['img_metas']))
+        loss = sum(v for k, v in losses.items() if k != 'matched_ious')
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()                                               # bucket all-reduces start inside
+        self.reducer.finish()
+        torch.nn.utils.clip_grad_norm_([p for p in self.params if p.grad is not None], max_norm=0.1, norm_type=2)
+        self.opt.step()
+        return loss
+
+
+def bench(args, rank, world, device):
+    """`bench.py --mode train`: returns rank 0's JSON line (a dict)."""
+    shape = harness.SHAPES[args.shape]
+    tr = Trainer(shape, args.proposals, device, world, batch=args.batch, pool=max(2, min(args.pool, 2)), rank=rank)
+    losses = []
+    for _ in range(args.warmup):
+        tr.step()
+    elapsed = parallel.timed_region(lambda: losses.append(tr.step()), args.steps, device)
+    losses = [float(l) for l in losses]
+    return dict(metric='samples/sec training step (forward + loss + backward + gradient all-reduce + AdamW)',
+                value=round(parallel.throughput(args.batch, args.steps, elapsed, world), 3), unit='samples/s',
+                n_gpus=args.gpus, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 2),
+                higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                config=dict(workload=f'Fusion_0075_refactor training step (shape {args.shape}): MMRI encoder + MMPI '
+                                     'decoder forward, head loss (Hungarian assignment on the host), backward, '
+                                     'bucketed gradient all-reduce launched from backward hooks, AdamW + grad clip',
+                            batch_per_gpu=args.batch, global_batch=args.batch * args.gpus,
+                            num_proposals=args.proposals, pool=len(tr.pool),
+                            parallelism=f'dp{args.gpus} by sample, RCCL all-reduce of gradients only'),
+                first_loss=round(losses[0], 4), last_loss=round(losses[-1], 4))

@@ -47,6 +47,9 @@ enum {
 
 int di_abi_version(void);
 const char *di_last_error(void);
+/* Measurement plumbing: number of nodes of a captured hipGraph_t (HOST handle), < 0 on error.  bench.py reports
+ * it as `graph_nodes` of the captured forward. */
+long long di_graph_node_count(void *graph_host);
 
 /* ---------------------------------------------------------------- local-window attention
  * Fused forward of LocalContextAttentionBlock.forward (encoder_utils.py:132-134):

@@ -368,6 +368,7 @@ class DeepInteractionDecoder(nn.Module):
         top = heat.view(B, -1).argsort(dim=-1, descending=True)[..., :self.num_proposals]     # :242
         if top_override is not None:
             top = top_override
+        self.top_proposals = top                 # flattened (class, cell) picks, for the parity reports
         top_class = top // heat.shape[-1]
         top_index = top % heat.shape[-1]
         query_feat = flat.gather(-1, top_index[:, None, :].expand(-1, C, -1))

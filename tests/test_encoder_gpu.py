@@ -205,7 +205,7 @@ def test_depth_completion_matches_oracle():
 
 @pytest.mark.parametrize('aug', [None, 'aug'])
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-4), (torch.float16, 1e-3)])
-def test_bevwarp_module(dtype, tol, aug):
+def test_bevwarp_module(dtype, tol, aug, inject_depth):
     """Product BEVWarp vs oracle BEVWarp with an injected dense depth (kernel parity must not
     hinge on the completion)."""
     _require_gpu()
@@ -222,7 +222,8 @@ def test_bevwarp_module(dtype, tol, aug):
     pm = dict(inp['pts_metas'], dense_depth=dense)
     bd, bo = _q(bev, dtype)
     ref = oenc.BEVWarp()(bo, img5, inp['img_metas'], pm)
-    pm_dev = dict(pm, pts=[p.to(DEV) for p in pm['pts']])
+    pm_dev = dict(inp['pts_metas'], pts=[p.to(DEV) for p in pm['pts']])
+    inject_depth(pm_dev['pts'], dense)
     got = BEVWarp()(bd, img5.to(DEV, dtype), inp['img_metas'], pm_dev).float().cpu()
     # a pixel whose un-projected point sits on the pc_range boundary or a texel edge may flip
     diff = (got - ref).abs().amax(2)                   # (1,6,H,W)
@@ -270,7 +271,7 @@ def test_i2p_module(dtype, tol, aug):
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 5e-4), (torch.float16, 2e-2)])
-def test_encoder_forward(dtype, tol):
+def test_encoder_forward(dtype, tol, inject_depth):
     """Whole DeepInteractionEncoder (2 layers): product on the GPU vs oracle on the CPU, shared
     state_dict, injected dense depth.  fp32: GEMM/conv summation-order noise through ~12 stacked
     projections per layer.  fp16: every intermediate map is stored in fp16 (2^-11 relative per
@@ -294,8 +295,9 @@ def test_encoder_forward(dtype, tol):
         pm = dict(inp['pts_metas'], dense_depth=dense)
         (imd, imo), (ptd, pto) = _q(inp['img_feats'], dtype), _q(inp['pts_feats'], dtype)
         ri, (rp0, rp1) = O(imo, pto, inp['img_metas'], pm)
-        pmd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in pm.items()}
+        pmd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
         pmd['pts'] = [p.to(DEV) for p in pm['pts']]
+        inject_depth(pmd['pts'], dense)
         gi, (gp0, gp1) = M.to(DEV, dtype)(imd, ptd, inp['img_metas'], pmd)
     assert '_di_geometry' not in pmd
     for name, got, ref in [('img', gi, ri), ('pts_conv', gp0, rp0), ('pts', gp1, rp1)]:

@@ -108,3 +108,20 @@ def test_single_process_defaults():
     assert parallel.sample_ids(2, 3, 0, 1) == [6, 7, 8]
     assert parallel.max_over_ranks(1.25) == 1.25
     assert parallel.throughput(2, 10, 4.0, 1) == 5.0
+
+
+def test_bench_self_launches_n_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment re-launches itself as one process per rank
+    (reference launch contract: one command per node, tools/dist_train.sh:7-9).  --dry-run keeps it on CPU / gloo."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '4'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout                                     # rank 0 prints ONE json line
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['ranks_seen'] == 2 and rec['steps'] == 4
+    # the slowest rank (rank 1 sleeps 4 ms per step) sets the time
+    assert rec['ms_per_step'] >= 3.9

@@ -114,9 +114,11 @@ def _inject_depth(inp):
     return inp
 
 
-def _to_dev(inp, dtype):
-    pm = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
+def _to_dev(inp, dtype, inject_depth=None):
+    pm = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items() if k != 'dense_depth'}
     pm['pts'] = [p.to(DEV) for p in inp['pts_metas']['pts']]
+    if 'dense_depth' in inp['pts_metas']:
+        inject_depth(pm['pts'], inp['pts_metas']['dense_depth'])       # test-only fixture (tests/conftest.py)
     return ([f.to(DEV, dtype) for f in inp['img_feats']], [f.to(DEV, dtype) for f in inp['pts_feats']],
             inp['img_metas'], pm)
 
@@ -144,13 +146,13 @@ def test_polar_attention_matches_oracle(aug):
 
 @pytest.mark.parametrize('aug', [False, True])
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 5e-4), (torch.float16, 3e-2)])
-def test_pp_neck_matches_oracle(dtype, tol, aug):
+def test_pp_neck_matches_oracle(dtype, tol, aug, inject_depth):
     torch.backends.cudnn.deterministic = True
     O, M, inp = _pp_pair(None, aug, dtype)
     q = lambda ts: [t.to(dtype).float() for t in ts]
     with torch.no_grad():
         ri, (rp0, rp1) = O(q(inp['img_feats']), q(inp['pts_feats']), inp['img_metas'], inp['pts_metas'])
-        gi, (gp0, gp1) = M(*_to_dev(inp, dtype))
+        gi, (gp0, gp1) = M(*_to_dev(inp, dtype, inject_depth))
     for name, got, ref in (('img', gi, ri), ('pts_conv', gp0, rp0), ('pts', gp1, rp1)):
         got = got.float().cpu()
         assert got.shape == ref.shape
@@ -161,13 +163,13 @@ def test_pp_neck_matches_oracle(dtype, tol, aug):
 
 
 @pytest.mark.parametrize('aug', [False, True])
-def test_pp_neck_matches_reference_golden(aug):
+def test_pp_neck_matches_reference_golden(aug, inject_depth):
     """The product neck (fp32) against vectors produced by the reference's own FusionTransformerv4."""
     torch.backends.cudnn.deterministic = True
     g = np.load(os.path.join(GOLD, 'modules_pp.npz'))
     _, M, inp = _pp_pair(None, aug, torch.float32)
     with torch.no_grad():
-        img, (p0, p1) = M(*_to_dev(inp, torch.float32))
+        img, (p0, p1) = M(*_to_dev(inp, torch.float32, inject_depth))
     for name, t in (('img', img), ('pts_conv', p0), ('pts', p1)):
         s = mg.summarize(t.float().cpu().contiguous())
         pre = f'enc{int(aug)}_{name}_'

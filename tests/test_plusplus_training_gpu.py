@@ -73,7 +73,7 @@ def test_polar_attention_backward_matches_oracle():
         assert _rel_l2(p.grad.cpu(), po[n].grad) <= 2e-3, (n, _rel_l2(p.grad.cpu(), po[n].grad))
 
 
-def test_pp_neck_gradients_match_oracle():
+def test_pp_neck_gradients_match_oracle(inject_depth):
     from deepinteraction_amd.mmdet3d_plugin import FusionTransformerv4
     from test_plusplus_gpu import _inject_depth
     torch.backends.cudnn.deterministic = True
@@ -90,6 +90,8 @@ def test_pp_neck_gradients_match_oracle():
         pts = [f.clone().to(dev).requires_grad_(True) for f in inp['pts_feats']]
         pm = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
         pm['pts'] = [p.to(dev) for p in inp['pts_metas']['pts']]
+        if dev != 'cpu':                               # the product has no injection hook: test-only fixture
+            inject_depth(pm['pts'], pm.pop('dense_depth'))
         oi, (p0, p1) = mod(imgs, pts, inp['img_metas'], pm)
         gg = torch.Generator().manual_seed(5)
         loss = sum((o.float() * torch.randn(o.shape, generator=gg).to(dev)).sum() for o in (oi, p0, p1))

@@ -165,7 +165,7 @@ def test_i2p_attention_dropout_is_consistent():
     assert abs(fd - an) <= 2e-2 * max(abs(an), 1.0), (fd, an)
 
 
-def test_training_step_gradients_match_oracle():
+def test_training_step_gradients_match_oracle(inject_depth):
     from deepinteraction_amd.mmdet3d_plugin import DeepInteractionDecoder, DeepInteractionEncoder
     shape = synth.SHAPE_TINY
     torch.backends.cudnn.deterministic = True     # MIOpen's atomic solvers add run-to-run noise on the tiny maps
@@ -202,8 +202,9 @@ def test_training_step_gradients_match_oracle():
         return loss
 
     ME, MD = ME.to(DEV), MD.to(DEV)
-    pmd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in pm.items()}
+    pmd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in pm.items() if k != 'dense_depth'}
     pmd['pts'] = [p.to(DEV) for p in pm['pts']]
+    inject_depth(pmd['pts'], pm['dense_depth'])        # test-only fixture: the product has no injection hook
 
     def check(name, got, ref, tol):
         scale = ref.abs().max().item()
