@@ -46,13 +46,22 @@ SIGNATURES = {
     'di_topk_fwd': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_p],
     'di_heatmap_nms': [_c_p] * 3 + [_c_i] * 5 + [ctypes.c_uint, _c_i, _c_p],
     'di_query_geometry': [_c_p] * 10 + [_c_i] * 3 + [_c_f] * 5 + [_c_p],
+    'di_query_geometry_ld': [_c_p] * 10 + [_c_i] * 4 + [_c_f] * 5 + [_c_p],
     'di_roi_align_fwd': [_c_p] * 3 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
     'di_mha_decode_fwd': [_c_p] * 4 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
+    'di_token_linear': [_c_p, _c_i, _c_p, _c_i, _c_i, _c_p, _c_i, _c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_p, _c_i, _c_p, _c_i,
+                        _c_p, _c_p, _c_f, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p],
+    'di_token_mha': [_c_p, _c_i, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_f, _c_p],
+    'di_dynconv_fwd': [_c_p] * 7 + [_c_i, _c_f, _c_p],
+    'di_roi_select': [_c_p] * 7 + [_c_i] * 3 + [_c_p],
+    'di_query_init': [_c_p] * 12 + [_c_i] * 5 + [_c_p],
+    'di_pred_heads': [_c_p] * 11 + [_c_i, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
 }
 # helpers that return a value instead of an error code
 VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 2,
+               'di_token_linear_workspace_bytes': [_c_i] * 3,
                'di_graph_node_count': [_c_p]}
-_LONGLONG = {'di_topk_workspace_bytes', 'di_graph_node_count'}
+_LONGLONG = {'di_topk_workspace_bytes', 'di_graph_node_count', 'di_token_linear_workspace_bytes'}
 
 _lib = None
 

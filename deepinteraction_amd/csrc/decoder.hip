@@ -52,6 +52,7 @@ struct QGeomParams {
   float x0, y0;       // pc_range[0], pc_range[1]
   float bev_cell;     // voxel_size[0] * out_size_factor of the bbox coder (:810)
   float dim_scale;    // 1 (image block) or 2 (point block, :807)
+  int ld;             // row stride of the (B,k,ld) prediction tensors (>= Q: a column window of a wider tensor)
 };
 
 // res tensors are (B,k,Q) float32.  per_sample: [w, h, flip, orig_w, crop_x, crop_y] x B.
@@ -63,13 +64,13 @@ __global__ __launch_bounds__(256) void query_geometry_kernel(
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * Q) return;
   const int b = i / Q, q = i - b * Q;
-  const float cx = center[(b * 2 + 0) * Q + q] * P.cell + P.x0;   // :666, coder :61-62
-  const float cy = center[(b * 2 + 1) * Q + q] * P.cell + P.y0;
-  const float hz = height[b * Q + q];
-  const float dx = __expf(dim[(b * 3 + 0) * Q + q]) , dy = __expf(dim[(b * 3 + 1) * Q + q]);
-  const float dz = __expf(dim[(b * 3 + 2) * Q + q]);
+  const float cx = center[(b * 2 + 0) * P.ld + q] * P.cell + P.x0;   // :666, coder :61-62
+  const float cy = center[(b * 2 + 1) * P.ld + q] * P.cell + P.y0;
+  const float hz = height[b * P.ld + q];
+  const float dx = __expf(dim[(b * 3 + 0) * P.ld + q]) , dy = __expf(dim[(b * 3 + 1) * P.ld + q]);
+  const float dz = __expf(dim[(b * 3 + 2) * P.ld + q]);
   const float zb = hz - dz * 0.5f;                                  // gravity -> bottom centre (:68)
-  const float yaw = atan2f(rot[(b * 2 + 0) * Q + q], rot[(b * 2 + 1) * Q + q]);
+  const float yaw = atan2f(rot[(b * 2 + 0) * P.ld + q], rot[(b * 2 + 1) * P.ld + q]);
   const float sn = sinf(yaw), cs = cosf(yaw);
   float px[9], py[9], pz[9];
   px[0] = cx; py[0] = cy; pz[0] = hz;                               // query centre (gravity height, :667)
@@ -452,13 +453,26 @@ int di_heatmap_nms(const void *a, const void *b, float *out, int B, int num_clas
   return di::check_launch("heatmap_nms");
 }
 
+int di_query_geometry_ld(const float *center, const float *height, const float *dim, const float *rot,
+                         const float *proj, const float *aug_rev, const float *per_sample, int32_t *on_img,
+                         float *rect_img, float *rect_bev, int B, int Q, int ld, int n_views, float cell, float pc_x0,
+                         float pc_y0, float bev_cell, float dim_scale, void *stream);
+
 int di_query_geometry(const float *center, const float *height, const float *dim, const float *rot,
                       const float *proj, const float *aug_rev, const float *per_sample, int32_t *on_img,
                       float *rect_img, float *rect_bev, int B, int Q, int n_views, float cell, float pc_x0,
                       float pc_y0, float bev_cell, float dim_scale, void *stream) {
-  DI_REQUIRE(B > 0 && Q > 0, "bad query shape B=%d Q=%d", B, Q);
+  return di_query_geometry_ld(center, height, dim, rot, proj, aug_rev, per_sample, on_img, rect_img, rect_bev, B, Q, Q,
+                              n_views, cell, pc_x0, pc_y0, bev_cell, dim_scale, stream);
+}
+
+int di_query_geometry_ld(const float *center, const float *height, const float *dim, const float *rot,
+                         const float *proj, const float *aug_rev, const float *per_sample, int32_t *on_img,
+                         float *rect_img, float *rect_bev, int B, int Q, int ld, int n_views, float cell, float pc_x0,
+                         float pc_y0, float bev_cell, float dim_scale, void *stream) {
+  DI_REQUIRE(B > 0 && Q > 0 && ld >= Q, "bad query shape B=%d Q=%d ld=%d", B, Q, ld);
   DI_REQUIRE((rect_img == nullptr) == (on_img == nullptr), "rect_img and on_img go together");
-  di::QGeomParams P{cell, pc_x0, pc_y0, bev_cell, dim_scale};
+  di::QGeomParams P{cell, pc_x0, pc_y0, bev_cell, dim_scale, ld};
   hipLaunchKernelGGL(di::query_geometry_kernel, dim3((B * Q + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, center, height, dim, rot, proj, aug_rev, per_sample, on_img,
                      rect_img, rect_bev, B, Q, n_views, P);

@@ -97,17 +97,26 @@ class GraphedHotPath:
                 self._forward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.out = self._forward()
+        # node count of the captured forward (measurement only): a throw-away capture that keeps the hipGraph_t, then
+        # the real one (a graph object created with keep_graph=True re-instantiates on replay with this torch build)
         self._nodes = None
         try:
+            import os
+            if os.environ.get('DI_GRAPH_NODES', '1') == '0':
+                raise RuntimeError('node count disabled')
             from . import _lib
-            n = int(_lib.lib().di_graph_node_count(int(self.graph.raw_cuda_graph())))
+            probe = torch.cuda.CUDAGraph(keep_graph=True)
+            with torch.no_grad(), torch.cuda.graph(probe):
+                self._forward()
+            n = int(_lib.lib().di_graph_node_count(int(probe.raw_cuda_graph())))
             self._nodes = n if n >= 0 else None
-        except Exception:      # measurement only: a torch build without raw graph access just reports None
+            probe.reset()
+            del probe
+        except Exception:      # a torch build without raw graph access just reports None
             self._nodes = None
-        self.graph.instantiate()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = self._forward()
 
     def num_nodes(self):
         """Nodes (kernel launches, copies, memsets) of the captured forward, or None when torch does not expose it."""

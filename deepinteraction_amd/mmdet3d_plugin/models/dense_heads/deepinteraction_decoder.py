@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .... import ops
+from .... import decoder_fused, ops
 from ....det3d_compat import (AssignResult, LiDARBoxes, build_loss, circle_nms, clip_sigmoid, draw_heatmap_gaussian,
                               nms_rotated_bev, xywhr2xyxyr,
                               gaussian_radius, pseudo_sample)
@@ -93,6 +93,8 @@ class DeepInteractionDecoder(nn.Module):
         self.on_the_image_mask = []
         self.ret_idx = ret_idx
         self.static_geometry = None       # optional persistent QueryGeometry (deepinteraction_amd.graphed)
+        self.fused = True                 # fp16 inference: the token-kernel path (deepinteraction_amd/decoder_fused.py)
+        self._fused_path = None
         self.init_weights()
         self._init_assigner_sampler()
 
@@ -136,6 +138,11 @@ class DeepInteractionDecoder(nn.Module):
         return head(ops.cl(feat)).contiguous()                                  # (B,num_classes,H,W) NCHW
 
     def forward(self, pts_inputs, img_inputs, img_metas):
+        if self.fused and type(self)._mmpi is DeepInteractionDecoder._mmpi \
+                and decoder_fused.usable(self, pts_inputs[0], img_inputs):
+            if self._fused_path is None:
+                self._fused_path = decoder_fused.FusedDecoder()
+            return self._fused_path.forward(self, pts_inputs, img_inputs, img_metas)
         lidar_feat, new_lidar_feat = ops.cl(pts_inputs[0]), ops.cl(pts_inputs[1])
         B, C, H, W = lidar_feat.shape
         HW = H * W

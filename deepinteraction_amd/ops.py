@@ -298,10 +298,16 @@ def topk(scores, k, with_values=False):
     return (idx, val) if with_values else idx
 
 
-def query_geometry(res, proj, aug_rev, per_sample, cell, pc_xy, bev_cell, dim_scale, want_img, want_bev):
-    """res: dict of float32 (B,k,Q) tensors (center, height, dim, rot).  Returns
-    (on_img (B,V,Q) int32, rect_img (B,V,Q,4), rect_bev (B,Q,4)); absent groups are None."""
-    c, h, d, r = (res[k].contiguous() for k in ('center', 'height', 'dim', 'rot'))
+def query_geometry(res, proj, aug_rev, per_sample, cell, pc_xy, bev_cell, dim_scale, want_img, want_bev, ld=None):
+    """res: dict of float32 (B,k,Q) tensors (center, height, dim, rot) - or, with `ld`, column windows of (B,k,ld)
+    tensors (views sliced on the last axis).  Returns (on_img (B,V,Q) int32, rect_img (B,V,Q,4), rect_bev (B,Q,4));
+    absent groups are None."""
+    if ld is None:
+        c, h, d, r = (res[k].contiguous() for k in ('center', 'height', 'dim', 'rot'))
+    else:
+        c, h, d, r = (res[k] for k in ('center', 'height', 'dim', 'rot'))
+        for t in (c, h, d, r):
+            assert t.stride(2) == 1 and t.stride(1) == ld and t.stride(0) == ld * t.shape[1]
     _dev(c, h, d, r)
     assert c.dtype == torch.float32 and h.dtype == torch.float32
     B, _, Q = c.shape
@@ -311,9 +317,9 @@ def query_geometry(res, proj, aug_rev, per_sample, cell, pc_xy, bev_cell, dim_sc
     ri = torch.empty((B, V, Q, 4), dtype=torch.float32, device=dev) if want_img else None
     rb = torch.empty((B, Q, 4), dtype=torch.float32, device=dev) if want_bev else None
     p = lambda t: 0 if t is None else t.data_ptr()
-    _lib.call('di_query_geometry', c.data_ptr(), h.data_ptr(), d.data_ptr(), r.data_ptr(), p(proj), p(aug_rev),
-              p(per_sample), p(on), p(ri), p(rb), B, Q, V, float(cell), float(pc_xy[0]), float(pc_xy[1]),
-              float(bev_cell), float(dim_scale), _stream())
+    _lib.call('di_query_geometry_ld', c.data_ptr(), h.data_ptr(), d.data_ptr(), r.data_ptr(), p(proj), p(aug_rev),
+              p(per_sample), p(on), p(ri), p(rb), B, Q, Q if ld is None else ld, V, float(cell), float(pc_xy[0]),
+              float(pc_xy[1]), float(bev_cell), float(dim_scale), _stream())
     return on, ri, rb
 
 
@@ -535,3 +541,118 @@ def polar_bev_sample_bwd(grad_out, proj, aug_rev, cam_xy, params, polar_shape):
     _lib.call('di_polar_bev_sample_bwd', grad_out.data_ptr(), proj.data_ptr(), aug_rev.data_ptr(), cam_xy.data_ptr(),
               params.data_ptr(), gp.data_ptr(), B, V, R, Wp, Hb, Wb, C, _code(grad_out), _stream())
     return gp
+
+
+# ------------------------------------------------------------------ token-level kernels of the MMPI decoder (fp16)
+def _h16(t):
+    assert t.dtype == torch.float16 and t.stride(-1) == 1, 'token kernels take row-major fp16'
+    return t
+
+
+def token_linear(x, w, bias=None, x2=None, pos=None, act1=0, res1=None, ln1=None, act2=False, res2=None, ln2=None,
+                 keep=None, eps=1e-5, out=None):
+    """Y = epilogue(([x ; x2] + pos) @ w.T): bias, act1 (0 none / 1 ReLU / 2 GELU), LN1(. + res1), ReLU (act2),
+    LN2(. + res2), rows with keep == 0 zeroed.  x (M,K1) [x2 (M,K-K1)], w (N,K) fp16; bias float32 (N); ln* = (weight,
+    bias) fp16 (128); keep uint8 (M).  Returns (M,N) fp16."""
+    _dev(x, w)
+    _h16(x), _h16(w)
+    M, K1 = x.shape
+    N, K = w.shape
+    assert w.is_contiguous() and (x2 is None) == (K1 == K)
+    if x2 is not None:
+        _h16(x2)
+        assert x2.shape == (M, K - K1)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    y = torch.empty((M, N), dtype=torch.float16, device=x.device) if out is None else out
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    ld = lambda t: 0 if t is None else t.stride(0)
+    nws = int(_lib.lib().di_token_linear_workspace_bytes(M, N, K))
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
+    l1w, l1b = ln1 if ln1 is not None else (None, None)
+    l2w, l2b = ln2 if ln2 is not None else (None, None)
+    _lib.call('di_token_linear', x.data_ptr(), x.stride(0), ptr(x2), ld(x2), K1, ptr(pos), ld(pos), w.data_ptr(),
+              ptr(bias), int(act1), ptr(res1), ld(res1), ptr(l1w), ptr(l1b), int(bool(act2)), ptr(res2), ld(res2),
+              ptr(l2w), ptr(l2b), float(eps), ptr(keep), y.data_ptr(), y.stride(0), M, N, K, ptr(ws), _stream())
+    return y
+
+
+def token_mha(qkv, B, Q, heads, scale, member=None, view=None):
+    """qkv (B*Q, 3E) = [q | k | v] fp16 -> (B*Q, E): per-head soft-max attention among the Q tokens of each sample;
+    optional visibility (member uint8 (B*Q), view int8 (B*Q)), see include/deepinteraction_hip.h."""
+    _dev(qkv)
+    _h16(qkv)
+    E = heads * 16
+    assert qkv.shape == (B * Q, 3 * E)
+    out = torch.empty((B * Q, E), dtype=torch.float16, device=qkv.device)
+    _lib.call('di_token_mha', qkv.data_ptr(), qkv.stride(0), 0 if member is None else member.data_ptr(),
+              0 if view is None else view.data_ptr(), out.data_ptr(), out.stride(0), B, Q, heads, float(scale), _stream())
+    return out
+
+
+def dynconv(roi, params, n1, n2, eps=1e-5):
+    """roi (R,49,128), params (R,32768) in the fused layout, n1/n2 = (weight, bias) fp16 of DynamicConv.norm1/2
+    -> relu(LN2(relu(LN1(roi @ p1)) @ p2)) (R,49,128)."""
+    _dev(roi, params)
+    R = roi.shape[0]
+    assert roi.shape == (R, 49, 128) and roi.is_contiguous() and params.shape == (R, 32768) and params.is_contiguous()
+    out = torch.empty_like(roi)
+    _lib.call('di_dynconv_fwd', roi.data_ptr(), params.data_ptr(), n1[0].data_ptr(), n1[1].data_ptr(), n2[0].data_ptr(),
+              n2[1].data_ptr(), out.data_ptr(), R, float(eps), _stream())
+    return out
+
+
+def roi_select(rect, on=None):
+    """Image block: on (B,V,Q) int32, rect (B,V,Q,4) -> rois (B*Q,5), view int8 (B*Q), member uint8, keep uint8,
+    on_img float32 (B,Q).  Point block (on None): rect (B,Q,4) -> rois (B*Q,5)."""
+    _dev(rect)
+    dev = rect.device
+    if on is None:
+        B, Q = rect.shape[:2]
+        rois = torch.empty((B * Q, 5), dtype=torch.float32, device=dev)
+        _lib.call('di_roi_select', 0, rect.data_ptr(), rois.data_ptr(), 0, 0, 0, 0, B, 0, Q, _stream())
+        return rois
+    B, V, Q = on.shape
+    assert on.dtype == torch.int32 and on.is_contiguous() and rect.is_contiguous()
+    rois = torch.empty((B * Q, 5), dtype=torch.float32, device=dev)
+    view = torch.empty((B * Q,), dtype=torch.int8, device=dev)
+    member = torch.empty((B * Q,), dtype=torch.uint8, device=dev)
+    keep = torch.empty((B * Q,), dtype=torch.uint8, device=dev)
+    on_img = torch.empty((B, Q), dtype=torch.float32, device=dev)
+    _lib.call('di_roi_select', on.data_ptr(), rect.data_ptr(), rois.data_ptr(), view.data_ptr(), member.data_ptr(),
+              keep.data_ptr(), on_img.data_ptr(), B, V, Q, _stream())
+    return rois, view, member, keep, on_img
+
+
+def query_init(bev, top, ce_w, ce_b, pe):
+    """bev (B,128,H,W) channels-last fp16, top (B,Q) int64 flattened (class, cell) picks, ce_w (128,ncls) / ce_b (128)
+    fp16, pe = float32 (w1 (128,2), b1, w2 (128,128), b2) -> feat (B*Q,128), pos_embed (B*Q,128) fp16, pos (B,Q,2)
+    float32, labels (B,Q) int64."""
+    _dev(bev, top)
+    B, C, H, W = bev.shape
+    Q = top.shape[1]
+    assert C == 128 and _is_cl(bev) and bev.dtype == torch.float16 and top.dtype == torch.int64 and top.is_contiguous()
+    dev = bev.device
+    feat = torch.empty((B * Q, 128), dtype=torch.float16, device=dev)
+    pemb = torch.empty((B * Q, 128), dtype=torch.float16, device=dev)
+    pos = torch.empty((B, Q, 2), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, Q), dtype=torch.int64, device=dev)
+    _lib.call('di_query_init', bev.data_ptr(), top.data_ptr(), ce_w.data_ptr(), ce_b.data_ptr(), pe[0].data_ptr(),
+              pe[1].data_ptr(), pe[2].data_ptr(), pe[3].data_ptr(), feat.data_ptr(), pemb.data_ptr(), pos.data_ptr(),
+              labels.data_ptr(), B, Q, H, W, ce_w.shape[1], _stream())
+    return feat, pemb, pos, labels
+
+
+def pred_heads(x1, x2, folded, qpos, outs, B, Q, ldo, col0, center_head, keep=None, first=None, pos_out=None):
+    """All prediction heads of one stage: x1 (B*Q,128) [x2 (B*Q,128)] fp16; folded = (w1 fp16 (nheads*64, K), b1, w2
+    (sum cls, 64), b2 float32, cls list); outs / first = lists of float32 (B, cls_h, ldo | Q) tensors."""
+    w1, b1, w2, b2, cls = folded
+    n = len(cls)
+    arr_out = (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs])
+    arr_first = (ctypes.c_void_p * n)(*[t.data_ptr() for t in first]) if first is not None else None
+    arr_cls = (ctypes.c_int * n)(*cls)
+    _lib.call('di_pred_heads', x1.data_ptr(), 0 if x2 is None else x2.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+              w2.data_ptr(), b2.data_ptr(), qpos.data_ptr(), 0 if keep is None else keep.data_ptr(),
+              ctypes.addressof(arr_out), 0 if arr_first is None else ctypes.addressof(arr_first),
+              ctypes.addressof(arr_cls), n, center_head, 0 if pos_out is None else pos_out.data_ptr(), B, Q, ldo, col0,
+              _stream())

@@ -193,6 +193,12 @@ int di_query_geometry(const float *center, const float *height, const float *dim
                       const float *proj, const float *aug_rev, const float *per_sample, int32_t *on_img,
                       float *rect_img, float *rect_bev, int B, int Q, int n_views, float cell, float pc_x0,
                       float pc_y0, float bev_cell, float dim_scale, void *stream);
+/* The same on column windows of wider tensors: the inputs are (B,k,ld) with this stage's Q queries at the given
+ * pointers (the decoder writes every stage into the concatenated (B,k,L*Q) outputs, deepinteraction_decoder.py:304). */
+int di_query_geometry_ld(const float *center, const float *height, const float *dim, const float *rot,
+                         const float *proj, const float *aug_rev, const float *per_sample, int32_t *on_img,
+                         float *rect_img, float *rect_bev, int B, int Q, int ld, int n_views, float cell, float pc_x0,
+                         float pc_y0, float bev_cell, float dim_scale, void *stream);
 
 /* (3) detectron2 ROIAlign(output 7x7, sampling_ratio 2, aligned=True) (decoder_utils.py:641-646,
  *     739-741, 769-774, 822-823).  feat (N,H,W,C) channels-last; rois (R,5) float32 =
@@ -266,6 +272,49 @@ int di_grid_gather_bwd(const float *grid, const void *grad_out, float *grad_feat
 int di_polar_bev_sample_bwd(const void *grad_out, const float *proj, const float *aug_rev, const float *cam_xy,
                             const float *params, float *grad_polar, int B, int V, int R, int Wp, int Hb, int Wb,
                             int C, int dtype, void *stream);
+
+/* ---------------------------------------------------------------- token-level kernels of the MMPI decoder
+ * fp16 inference form of the reference's decoder layer / RoI blocks / prediction heads on the B*Q query tokens
+ * (models/utils/decoder_utils.py:35-113, 498-581, 584-629, 632-841; dense_heads/deepinteraction_decoder.py:242-297).
+ * Token matrices are row-major fp16 with an explicit row stride (`ld*`, in elements); weights are fp16 (N, K)
+ * row-major as `nn.Linear.weight`; biases float32; LayerNorm weights fp16 (as the half() module holds them).
+ *
+ * di_token_linear: Y = epilogue((X | [X ; X2]) + P) . W^T):
+ *     v = acc + bias; v = act1(v) (0 none, 1 ReLU, 2 GELU-erf); v = LN1(v + res1); v = relu(v) if act2;
+ *     v = LN2(v + res2); rows with keep[m] == 0 are written as zeros.    Every stage optional (null pointers).
+ *   N, K multiples of 128; a LayerNorm needs N == 128; [X ; X2] = channel concat split at k1 (multiple of 32).
+ *   Shapes with K >= 2048 (DynamicConv out_layer) run split-K and need `workspace` of
+ *   di_token_linear_workspace_bytes(M, N, K) bytes; K == 128, N >= 2048 with no epilogue runs weight-stationary.
+ * di_token_mha: softmax(q k^T scale) v per head (16 dims) among the Q <= 512 tokens of each sample, from the packed
+ *   projection qkv (B*Q, >= 3E) = [q | k | v]; optional visibility mask: key k is visible to query q when bit
+ *   view[q] of member[k] is set or view[q] < 0 (the per-view self attention of ImageRCNNBlock, :745).
+ * di_dynconv_fwd: F2 = relu(LN2(relu(LN1(roi . p1)) . p2)) per RoI (:617-622); roi (R,49,128); params (R, 32768) =
+ *   [p1^T (d,c) | p2^T (e, d permuted as k = 32kk+8g+4t+r <-> d = 32kk+16t+4g+r)]; out (R,49,128).
+ * di_roi_select: image block (on != null): last valid view per query, membership bits, RoIs, keep mask, float view
+ *   id (:681-759 bookkeeping); point block (on == null): rois = (b, BEV rect).
+ * di_query_init: query features = BEV token + class encoding, positions, learned positional embedding (float32
+ *   MLP, BatchNorm folded) and labels of the top-Q proposals (deepinteraction_decoder.py:242-253).
+ * di_pred_heads: all prediction heads of one stage (folded first layers stacked (nheads*64, K) fp16, second layers
+ *   stacked (sum cls, 64) float32), `center += query_pos`, the on-the-image merge with the first stage (`keep`),
+ *   written at column offset col0 of (B, cls_h, ldo) float32 outputs; pos_out = the new centres (B,Q,2). */
+int di_token_linear(const void *x, int ldx, const void *x2, int ldx2, int k1, const void *p, int ldp, const void *w,
+                    const float *bias, int act1, const void *res1, int ldr1, const void *ln1_w, const void *ln1_b,
+                    int act2, const void *res2, int ldr2, const void *ln2_w, const void *ln2_b, float eps,
+                    const void *keep, void *y, int ldy, int M, int N, int K, void *workspace, void *stream);
+long long di_token_linear_workspace_bytes(int M, int N, int K);
+int di_token_mha(const void *qkv, int ld, const void *member, const void *view, void *out, int ldo, int B, int Q,
+                 int heads, float scale, void *stream);
+int di_dynconv_fwd(const void *roi, const void *params, const void *n1w, const void *n1b, const void *n2w,
+                   const void *n2b, void *out, int R, float eps, void *stream);
+int di_roi_select(const int *on, const float *rect, float *rois, void *view, void *member, void *keep, float *on_img,
+                  int B, int V, int Q, void *stream);
+int di_query_init(const void *bev, const long long *top, const void *ce_w, const void *ce_b, const float *w1,
+                  const float *b1, const float *w2, const float *b2, void *feat, void *pe, float *pos,
+                  long long *labels, int B, int Q, int Hb, int Wb, int ncls, void *stream);
+int di_pred_heads(const void *x1, const void *x2, const void *w1, const float *b1, const float *w2, const float *b2,
+                  const float *qpos, const void *keep, float *const *out_host, const float *const *first_host,
+                  const int *cls_host, int nheads, int center_head, float *pos_out, int B, int Q, int ldo, int col0,
+                  void *stream);
 
 /* ---------------------------------------------------------------- pillar / voxel producer
  * Hard voxelisation (spconv PointToVoxel as wrapped by models/updated_modules/sparse_voxelize.py:9-70), three
