@@ -1,0 +1,174 @@
+// 3x3 convolutions of the hot path (stride 1, pad 1) on channels-last fp16 maps, as an implicit GEMM on the gfx950
+// matrix cores: the two shared convolutions of the MMRI encoder (reference necks/deepinteraction_encoder.py:45-62,
+// 256 -> 128 on the 6x112x200 image maps, 512 -> 128 on the 180x180 BEV map: 79 + 38 GFLOP per sample) and the heat-map
+// heads of the decoder (dense_heads/deepinteraction_decoder.py:96-119: 128 -> 128 + BN + ReLU, 128 -> classes).
+// Owning them removes the dependence of the step on MIOpen's solver selection / find-db state.
+//
+//   y[p][n] = act( sum_{tap, c} w[n][tap][c] * x[p + off(tap)][c] + b[n] )          (BatchNorm folded by the caller)
+//
+// A workgroup (4 waves) owns a tile of TH x 16 output pixels and all output channels.  The input halo tile
+// ((TH+2) x 18 pixels) of one 32-channel chunk is staged in LDS once and read nine times - once per tap, as the shifted
+// B operand of the 16x16x32 MFMA (lane = pixel, 8 consecutive channels = one ds_read_b128; 16-B slots swizzled so that
+// every read is conflict free).  The next chunk is fetched into registers while the current one is multiplied, then
+// written to the other LDS buffer: one barrier per chunk.  Weights (A operand, pre-packed (Cout, 9, Cin)) come straight
+// from L2, one tap ahead of the MFMAs that use them.  fp32 accumulate, bias / ReLU on the accumulators.
+#include "di_common.h"
+
+namespace di {
+namespace cv {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int TW = 16, CK = 32;
+
+// LDS image of a halo chunk: pixel P (row-major in the (TH+2) x 18 halo) at P * 64 bytes, its four 16-B channel slots
+// rotated: slot g of pixel P lives at ((g + 2 * (P >> 2)) & 3).
+__device__ __forceinline__ int lds_off(int P, int g) { return P * 64 + (((g + 2 * (P >> 2)) & 3) << 4); }
+
+// TH: tile rows; WN: waves along the output channels (WM = 4 / WN along the rows); NTW: 16-channel fragments per wave.
+template <int TH, int WN, int NTW>
+__global__ __launch_bounds__(256, 2) void conv3x3_kernel(const __half *__restrict__ x, const __half *__restrict__ w,
+                                                         const float *__restrict__ bias, __half *__restrict__ y,
+                                                         int H, int W, int Cin, int Cout, int relu, int nchw,
+                                                         int tiles_x, int tiles_y) {
+  constexpr int WM = 4 / WN, RW = TH / WM;                 // rows of the tile per wave
+  constexpr int HP = (TH + 2) * (TW + 2);                  // halo pixels
+  constexpr int NLD = (HP * 4 + 255) / 256;                // 16-B pieces per thread and chunk
+  __shared__ __align__(16) unsigned char lds[2][HP * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, img = t / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const __half *xi = x + (size_t)img * H * W * Cin;
+
+  // ---- staging: piece e = (halo pixel P, slot s); out-of-image pixels are zeros
+  uint4 stage[NLD];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int e = tid + j * 256;
+      const int P = e >> 2, s = e & 3;
+      const int hy = P / (TW + 2), hx = P - hy * (TW + 2);
+      const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e < HP * 4 && yy >= 0 && yy < H && xx >= 0 && xx < W)
+        v = *reinterpret_cast<const uint4 *>(xi + ((size_t)yy * W + xx) * Cin + c0 + s * 8);
+      stage[j] = v;
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int e = tid + j * 256;
+      if (e < HP * 4) *reinterpret_cast<uint4 *>(&lds[buf][lds_off(e >> 2, e & 3)]) = stage[j];
+    }
+  };
+
+  f4 acc[RW][NTW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[r][n] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nrow = wn * NTW * 16 + i;                      // this lane's weight row of fragment 0
+  const __half *wl = w + (size_t)nrow * 9 * Cin + g * 8;
+  auto load_a = [&](h8 (&a)[NTW], int tap, int c0) {
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+      a[n] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(wl + (size_t)n * 16 * 9 * Cin + tap * Cin + c0));
+  };
+
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  const int nchunk = Cin / CK;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1, c0 = ch * CK;
+    if (ch + 1 < nchunk) fetch(c0 + CK);                   // global loads in flight during the MFMAs below
+    h8 a[2][NTW];
+    load_a(a[0], 0, c0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) load_a(a[(tap + 1) & 1], tap + 1, c0);
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int P = (wm * RW + r + ky) * (TW + 2) + i + kx;
+        const h8 b = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(&lds[buf][lds_off(P, g)]));
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tap & 1][n], b, acc[r][n], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < nchunk) commit(buf ^ 1);                  // the other buffer: its last readers passed the barrier below
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds channels n0 + 4g + r of pixel (row, x0 + i)
+  const int xx = x0 + i;
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int yy = y0 + wm * RW + r;
+    if (yy >= H || xx >= W) continue;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      const int n0 = (wn * NTW + n) * 16 + 4 * g;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = acc[r][n][q] + (n0 + q < Cout ? bias[n0 + q] : 0.f);
+        if (relu) v[q] = fmaxf(v[q], 0.f);
+      }
+      if (!nchw) {
+        if (n0 + 3 < Cout) {
+          h4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = (_Float16)v[q];
+          *reinterpret_cast<h4 *>(y + (((size_t)img * H + yy) * W + xx) * Cout + n0) = o;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (n0 + q < Cout) y[(((size_t)img * H + yy) * W + xx) * Cout + n0 + q] = __float2half(v[q]);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (n0 + q < Cout) y[(((size_t)img * Cout + n0 + q) * H + yy) * W + xx] = __float2half(v[q]);
+      }
+    }
+  }
+}
+
+}  // namespace cv
+}  // namespace di
+
+extern "C" int di_conv3x3_fwd(const void *x, const void *w_packed, const float *bias, void *y, int n, int H, int W,
+                              int Cin, int Cout, int relu, int out_nchw, void *stream) {
+  using namespace di::cv;
+  DI_REQUIRE(n > 0 && H > 0 && W > 0 && x && w_packed && bias && y, "bad conv shape");
+  DI_REQUIRE(Cin % CK == 0, "Cin=%d must be a multiple of %d", Cin, CK);
+  DI_REQUIRE(Cout == 128 || Cout <= 16, "Cout=%d: 128 or <= 16 (weights padded to 16 rows)", Cout);
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles_x = (W + TW - 1) / TW;
+#define DI_CV(TH, WN, NTW)                                                                                          \
+  do {                                                                                                              \
+    const int tiles_y = (H + TH - 1) / TH;                                                                          \
+    hipLaunchKernelGGL((conv3x3_kernel<TH, WN, NTW>), dim3(tiles_x * tiles_y * n), dim3(256), 0, s,                 \
+                       (const __half *)x, (const __half *)w_packed, bias, (__half *)y, H, W, Cin, Cout, relu,      \
+                       out_nchw, tiles_x, tiles_y);                                                                 \
+  } while (0)
+  if (Cout == 128) {
+    // enough tiles to spread over the 256 CUs: 8-row tiles for the image maps, 4-row tiles for one BEV map
+    if ((long long)n * ((H + 7) / 8) * tiles_x >= 768) DI_CV(8, 2, 4);
+    else DI_CV(4, 2, 4);
+  } else {
+    DI_CV(4, 1, 1);
+  }
+#undef DI_CV
+  return di::check_launch("conv3x3_fwd");
+}

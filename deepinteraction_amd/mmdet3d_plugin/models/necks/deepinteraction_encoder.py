@@ -11,6 +11,7 @@ from torch import nn
 
 from .... import ops
 from ....registry import NECKS
+from ....utils import param_key
 from ..utils.encoder_utils import (GEOM_KEY, ConvBNReLU, LocalContextAttentionBlock, MMRI_I2P, MMRI_P2I,
                                    mix2)
 
@@ -72,9 +73,24 @@ class DeepInteractionEncoder(nn.Module):
             if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
                 m.momentum = self.bn_momentum
 
+    def _shared_conv(self, conv, x):
+        """The shared 3x3 convolution: the HIP implicit-GEMM kernel for fp16 inference (csrc/conv3x3.hip), the library
+        convolution otherwise (float32 parity path, training)."""
+        x = ops.cl(x)
+        if (x.is_cuda and x.dtype == torch.float16 and not torch.is_grad_enabled() and conv.in_channels % 32 == 0
+                and conv.out_channels == 128 and conv.weight.dtype == torch.float16):
+            cache = self.__dict__.setdefault('_conv_cache', {})
+            key = param_key(conv)
+            hit = cache.get(id(conv))
+            if hit is None or hit[0] != key:
+                hit = (key, ops.pack_conv3x3(conv.weight, conv.bias))
+                cache[id(conv)] = hit
+            return ops.conv3x3(x, *hit[1])
+        return conv(x)
+
     def forward(self, img_feats, pts_feats, img_metas, pts_metas):
-        new_img_feat = self.shared_conv_img(ops.cl(img_feats))
-        new_pts_feat = self.shared_conv_pts(ops.cl(pts_feats))
+        new_img_feat = self._shared_conv(self.shared_conv_img, img_feats)
+        new_pts_feat = self._shared_conv(self.shared_conv_pts, pts_feats)
         pts_feat_conv = new_pts_feat.clone()
         own_geom = GEOM_KEY not in pts_metas
         own_bounds = 'pillar_batch_bounds' not in pts_metas

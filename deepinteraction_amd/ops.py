@@ -543,6 +543,44 @@ def polar_bev_sample_bwd(grad_out, proj, aug_rev, cam_xy, params, polar_shape):
     return gp
 
 
+# ------------------------------------------------------------------ 3x3 convolutions (implicit GEMM on the matrix cores)
+def pack_conv3x3(weight, bias=None, bn=None):
+    """Constants of `conv3x3` from a torch Conv2d weight (Cout,Cin,3,3) [+ bias] [+ a following eval-mode BatchNorm2d,
+    folded in]: (w_packed fp16 (Cout_pad, 9, Cin), bias float32 (Cout))."""
+    with torch.no_grad():
+        w = weight.detach().float()
+        Cout = w.shape[0]
+        b = torch.zeros(Cout, device=w.device) if bias is None else bias.detach().float()
+        if bn is not None:
+            g = torch.rsqrt(bn.running_var.float() + bn.eps)
+            if bn.weight is not None:
+                g = g * bn.weight.float()
+            w = w * g[:, None, None, None]
+            b = (b - bn.running_mean.float()) * g + (0.0 if bn.bias is None else bn.bias.float())
+        wp = w.permute(0, 2, 3, 1).reshape(Cout, 9, -1)
+        if Cout < 16:
+            wp = torch.cat([wp, wp.new_zeros(16 - Cout, 9, wp.shape[-1])])
+        return wp.to(torch.float16).contiguous(), b.contiguous()
+
+
+def conv3x3(x, w_packed, bias, relu=False, out_nchw=False):
+    """x (n,Cin,H,W) channels-last fp16 -> (n,Cout,H,W), channels-last (or contiguous NCHW when out_nchw)."""
+    _dev(x, w_packed, bias)
+    x = cl(x)
+    n, Cin, H, W = x.shape
+    Cout = bias.numel()
+    assert x.dtype == torch.float16 and w_packed.dtype == torch.float16 and w_packed.shape[1:] == (9, Cin)
+    assert bias.dtype == torch.float32
+    if out_nchw:
+        y = torch.empty((n, Cout, H, W), dtype=x.dtype, device=x.device)
+    else:
+        y = empty_cl(n, Cout, H, W, x)
+    _profiled('conv3x3_fwd', n * Cin, lambda: _lib.call('di_conv3x3_fwd', x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(),
+                                                       y.data_ptr(), n, H, W, Cin, Cout, int(bool(relu)), int(bool(out_nchw)),
+                                                       _stream()))
+    return y
+
+
 # ------------------------------------------------------------------ token-level kernels of the MMPI decoder (fp16)
 def _h16(t):
     assert t.dtype == torch.float16 and t.stride(-1) == 1, 'token kernels take row-major fp16'

@@ -273,6 +273,16 @@ int di_polar_bev_sample_bwd(const void *grad_out, const float *proj, const float
                             const float *params, float *grad_polar, int B, int V, int R, int Wp, int Hb, int Wb,
                             int C, int dtype, void *stream);
 
+/* ---------------------------------------------------------------- 3x3 convolutions (stride 1, pad 1), implicit GEMM
+ * The shared convolutions of the MMRI encoder (necks/deepinteraction_encoder.py:45-62) and the heat-map heads of the
+ * decoder (dense_heads/deepinteraction_decoder.py:96-119) on fp16 channels-last maps:
+ *   y[p][n] = act(sum_{ky,kx,c} w[n][ky*3+kx][c] * x[p + (ky-1, kx-1)][c] + bias[n])
+ * x (n,H,W,Cin) fp16, Cin % 32 == 0; w_packed (Cout_pad, 9, Cin) fp16 = the torch weight (Cout,Cin,3,3) permuted to
+ * (Cout,3,3,Cin), rows zero-padded to 16 when Cout <= 16; bias float32 (Cout) (a following BatchNorm folded in by the
+ * caller); Cout == 128 or Cout <= 16; y (n,H,W,Cout) fp16, or (n,Cout,H,W) when out_nchw. */
+int di_conv3x3_fwd(const void *x, const void *w_packed, const float *bias, void *y, int n, int H, int W, int Cin,
+                   int Cout, int relu, int out_nchw, void *stream);
+
 /* ---------------------------------------------------------------- token-level kernels of the MMPI decoder
  * fp16 inference form of the reference's decoder layer / RoI blocks / prediction heads on the B*Q query tokens
  * (models/utils/decoder_utils.py:35-113, 498-581, 584-629, 632-841; dense_heads/deepinteraction_decoder.py:242-297).

@@ -46,6 +46,7 @@ def _report(name, stats):
 def ctx():
     assert torch.cuda.is_available(), 'gpu tests need a HIP device'
     torch.backends.cudnn.deterministic = True
+    threads = torch.get_num_threads()
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     inp = synth.make_inputs(2, SHAPE, seed=100)
     inp['img_feats'] = inp['img_feats'].half().float()          # fp16-representable data: identical for every side
@@ -61,7 +62,8 @@ def ctx():
     c = dict(inp=inp, models=models, state=state, D={200: D200, 400: D400}, ref_enc=ref_enc, free={})
     c['free'][200] = parity.oracle_decoder(D200, ref_enc, inp['img_metas'])
     _report('oracle_seconds', dict(encoder_B2=ref_enc['seconds'], decoder_B2_Q200=c['free'][200]['seconds']))
-    return c
+    yield c
+    torch.set_num_threads(threads)        # process-global: leave it as the other test modules found it
 
 
 def _sample(inp, b):
