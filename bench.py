@@ -255,6 +255,12 @@ def bench_forward(args, rank, world, device):
             product_out = ((img.float().cpu(), [t.float().cpu() for t in pts]),
                            {k: v.float().cpu() for k, v in res.items()}, dec.query_labels.cpu(),
                            [m.cpu() for m in dec.on_the_image_mask], dec.top_proposals.cpu())
+            if g is not None:      # the replayed graph against host launches of the same sample: must be identical
+                (_, _), eg = harness.forward(enc, dec, dev_pool[0])
+                torch.cuda.synchronize()
+                graph_vs_eager = dict(
+                    max_abs=max(float((eg[0][0][k].float().cpu() - product_out[1][k]).abs().max()) for k in product_out[1]),
+                    proposals_identical=bool(torch.equal(dec.top_proposals.cpu(), product_out[4])))
         # dominant-kernel timing: HIP events right around the launch, on the launch stream, in eager forwards of
         # the same model and data (events cannot bracket one kernel inside a graph replay)
         harness.forward(enc, dec, dev_pool[0])
@@ -295,6 +301,8 @@ def bench_forward(args, rank, world, device):
                  {k: v.float().cpu() for k, v in dec.state_dict().items()})
         base, par = cpu_baseline(shape, args.proposals, state, host_pool[0], product_out)
         out['cpu_baseline'] = base
+        if par is not None and g is not None:
+            par['graph_vs_eager'] = graph_vs_eager
         out['parity'] = par
     return out
 

@@ -144,11 +144,133 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const __half *__restric
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Second kernel, for Cout == 128: the weights go through LDS as well.  The K loop runs in STAGES = (32-channel chunk,
+// kernel row ky): a stage multiplies the three taps of one kernel row.  Its weight tile (3 taps x 128 rows x 32
+// channels = 24 KB, contiguous in the (chunk, ky, kx, n, c) packing) and - once per chunk - the next halo chunk are
+// fetched into registers at the START of the previous stage and written to the other LDS buffers at its end: the L2 /
+// HBM latency is covered by a whole stage of MFMAs (48 per wave) of both resident workgroups, and the A fragments
+// become conflict-free ds_read_b128 like the B fragments (same slot rotation by row).
+// ------------------------------------------------------------------------------------------------------------
+template <int TH>
+__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__restrict__ x, const __half *__restrict__ wst,
+                                                             const float *__restrict__ bias, __half *__restrict__ y,
+                                                             int H, int W, int Cin, int relu, int tiles_x, int tiles_y) {
+  constexpr int WN = 2, WM = 2, NTW = 4, RW = TH / WM;
+  constexpr int HP = (TH + 2) * (TW + 2);
+  constexpr int NLD = (HP * 4 + 255) / 256;                // halo pieces per thread and chunk
+  constexpr int ASZ = 3 * 128 * 64;                        // weight tile of a stage
+  constexpr int NLA = ASZ / 16 / 256;                      // = 6 pieces per thread and stage
+  __shared__ __align__(16) unsigned char lA[2][ASZ];
+  __shared__ __align__(16) unsigned char lB[2][HP * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, img = t / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const __half *xi = x + (size_t)img * H * W * Cin;
+
+  uint4 sB[NLD], sA[NLA];
+  auto fetch_b = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int e = tid + j * 256;
+      const int P = e >> 2, s = e & 3;
+      const int hy = P / (TW + 2), hx = P - hy * (TW + 2);
+      const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e < HP * 4 && yy >= 0 && yy < H && xx >= 0 && xx < W)
+        v = *reinterpret_cast<const uint4 *>(xi + ((size_t)yy * W + xx) * Cin + c0 + s * 8);
+      sB[j] = v;
+    }
+  };
+  auto commit_b = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int e = tid + j * 256;
+      if (e < HP * 4) *reinterpret_cast<uint4 *>(&lB[buf][lds_off(e >> 2, e & 3)]) = sB[j];
+    }
+  };
+  // stage st = chunk * 3 + ky: its weight tile is the contiguous 24 KB at wst + st * ASZ; piece e = (row = kx*128 + n, slot)
+  auto fetch_a = [&](int st) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(wst) + (size_t)st * ASZ);
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) sA[j] = src[tid + j * 256];
+  };
+  auto commit_a = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) {
+      const int e = tid + j * 256;
+      *reinterpret_cast<uint4 *>(&lA[buf][lds_off(e >> 2, e & 3)]) = sA[j];      // rows are 64 B, rotation by row >> 2
+    }
+  };
+
+  f4 acc[RW][NTW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[r][n] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nstage = (Cin / CK) * 3;
+  fetch_b(0);
+  fetch_a(0);
+  commit_b(0);
+  commit_a(0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int ch = st / 3, ky = st - ch * 3;
+    const int ab = st & 1, bb = ch & 1;
+    const bool more = st + 1 < nstage;
+    if (more) fetch_a(st + 1);
+    if (ky == 0 && (ch + 1) * CK < Cin) fetch_b((ch + 1) * CK);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      h8 a[NTW];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n)
+        a[n] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(&lA[ab][lds_off(kx * 128 + wn * 64 + n * 16 + i, g)]));
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int P = (wm * RW + r + ky) * (TW + 2) + i + kx;
+        const h8 b = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(&lB[bb][lds_off(P, g)]));
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b, acc[r][n], 0, 0, 0);
+      }
+    }
+    if (more) commit_a(ab ^ 1);
+    if (ky == 2 && (ch + 1) * CK < Cin) commit_b(bb ^ 1);
+    __syncthreads();
+  }
+
+  const int xx = x0 + i;
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int yy = y0 + wm * RW + r;
+    if (yy >= H || xx >= W) continue;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      const int n0 = (wn * NTW + n) * 16 + 4 * g;
+      h4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = acc[r][n][q] + bias[n0 + q];
+        if (relu) v = fmaxf(v, 0.f);
+        o[q] = (_Float16)v;
+      }
+      *reinterpret_cast<h4 *>(y + (((size_t)img * H + yy) * W + xx) * 128 + n0) = o;
+    }
+  }
+}
+
 }  // namespace cv
 }  // namespace di
 
-extern "C" int di_conv3x3_fwd(const void *x, const void *w_packed, const float *bias, void *y, int n, int H, int W,
-                              int Cin, int Cout, int relu, int out_nchw, void *stream) {
+extern "C" int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w_staged, const float *bias, void *y,
+                              int n, int H, int W, int Cin, int Cout, int relu, int out_nchw, void *stream) {
   using namespace di::cv;
   DI_REQUIRE(n > 0 && H > 0 && W > 0 && x && w_packed && bias && y, "bad conv shape");
   DI_REQUIRE(Cin % CK == 0, "Cin=%d must be a multiple of %d", Cin, CK);
@@ -162,8 +284,19 @@ extern "C" int di_conv3x3_fwd(const void *x, const void *w_packed, const float *
                        (const __half *)x, (const __half *)w_packed, bias, (__half *)y, H, W, Cin, Cout, relu,      \
                        out_nchw, tiles_x, tiles_y);                                                                 \
   } while (0)
-  if (Cout == 128) {
-    // enough tiles to spread over the 256 CUs: 8-row tiles for the image maps, 4-row tiles for one BEV map
+  if (Cout == 128 && w_staged != nullptr && !out_nchw) {
+    // weights through LDS; enough tiles to spread over the 256 CUs: 8-row tiles for the image maps, 4-row tiles
+    // for one BEV map
+    if ((long long)n * ((H + 7) / 8) * tiles_x >= 768) {
+      const int tiles_y = (H + 7) / 8;
+      hipLaunchKernelGGL((conv3x3_lds_kernel<8>), dim3(tiles_x * tiles_y * n), dim3(256), 0, s, (const __half *)x,
+                         (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x, tiles_y);
+    } else {
+      const int tiles_y = (H + 3) / 4;
+      hipLaunchKernelGGL((conv3x3_lds_kernel<4>), dim3(tiles_x * tiles_y * n), dim3(256), 0, s, (const __half *)x,
+                         (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x, tiles_y);
+    }
+  } else if (Cout == 128) {
     if ((long long)n * ((H + 7) / 8) * tiles_x >= 768) DI_CV(8, 2, 4);
     else DI_CV(4, 2, 4);
   } else {

@@ -546,7 +546,7 @@ def polar_bev_sample_bwd(grad_out, proj, aug_rev, cam_xy, params, polar_shape):
 # ------------------------------------------------------------------ 3x3 convolutions (implicit GEMM on the matrix cores)
 def pack_conv3x3(weight, bias=None, bn=None):
     """Constants of `conv3x3` from a torch Conv2d weight (Cout,Cin,3,3) [+ bias] [+ a following eval-mode BatchNorm2d,
-    folded in]: (w_packed fp16 (Cout_pad, 9, Cin), bias float32 (Cout))."""
+    folded in]: (w_packed fp16 (Cout_pad, 9, Cin), w_staged fp16 (Cin/32, 3, 3, 128, 32) or None, bias float32 (Cout))."""
     with torch.no_grad():
         w = weight.detach().float()
         Cout = w.shape[0]
@@ -560,10 +560,14 @@ def pack_conv3x3(weight, bias=None, bn=None):
         wp = w.permute(0, 2, 3, 1).reshape(Cout, 9, -1)
         if Cout < 16:
             wp = torch.cat([wp, wp.new_zeros(16 - Cout, 9, wp.shape[-1])])
-        return wp.to(torch.float16).contiguous(), b.contiguous()
+        ws = None
+        Cin = w.shape[1]
+        if Cout == 128 and Cin % 32 == 0:          # (chunk, ky, kx, n, c): one contiguous 24 KB tile per (chunk, ky)
+            ws = w.view(128, Cin // 32, 32, 3, 3).permute(1, 3, 4, 0, 2).to(torch.float16).contiguous()
+        return wp.to(torch.float16).contiguous(), ws, b.contiguous()
 
 
-def conv3x3(x, w_packed, bias, relu=False, out_nchw=False):
+def conv3x3(x, w_packed, w_staged, bias, relu=False, out_nchw=False, use_staged=True):
     """x (n,Cin,H,W) channels-last fp16 -> (n,Cout,H,W), channels-last (or contiguous NCHW when out_nchw)."""
     _dev(x, w_packed, bias)
     x = cl(x)
@@ -575,9 +579,10 @@ def conv3x3(x, w_packed, bias, relu=False, out_nchw=False):
         y = torch.empty((n, Cout, H, W), dtype=x.dtype, device=x.device)
     else:
         y = empty_cl(n, Cout, H, W, x)
-    _profiled('conv3x3_fwd', n * Cin, lambda: _lib.call('di_conv3x3_fwd', x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(),
-                                                       y.data_ptr(), n, H, W, Cin, Cout, int(bool(relu)), int(bool(out_nchw)),
-                                                       _stream()))
+    ws = 0 if (w_staged is None or not use_staged) else w_staged.data_ptr()
+    _profiled('conv3x3_fwd', n * Cin, lambda: _lib.call('di_conv3x3_fwd', x.data_ptr(), w_packed.data_ptr(), ws,
+                                                       bias.data_ptr(), y.data_ptr(), n, H, W, Cin, Cout, int(bool(relu)),
+                                                       int(bool(out_nchw)), _stream()))
     return y
 
 

@@ -97,6 +97,8 @@ def compare_decoder(prod_out, prod_labels, prod_masks, prod_top, free, forced=No
     res['labels_equal_on_same_proposals'] = bool(torch.equal(labels, ref['labels']))
     res['mask_agreement'] = [float((a.cpu() == b).float().mean()) for a, b in zip(prod_masks, ref['masks'])]
     res['keys'] = {k: rel_stats(prod_out[k], ref['out'][k]) for k in ref['out']}
+    res['first_proposals'] = dict(product=top[0, :6].tolist(), oracle=free['top'][0, :6].tolist(),
+                                  product_labels=labels[0, :6].tolist(), oracle_labels=free['labels'][0, :6].tolist())
     return res
 
 
@@ -109,4 +111,5 @@ def summarize(enc_stats, dec_stats):
     out['proposal_set_overlap'] = r3(dec_stats['proposal_set_overlap'])
     out['label_agreement'] = r3(dec_stats['label_agreement'])
     out['mask_agreement'] = [r3(m) for m in dec_stats['mask_agreement']]
+    out['first_proposals'] = dec_stats['first_proposals']
     return out

@@ -36,14 +36,15 @@ def test_conv3x3_matches_torch(shape):
         ref = _ref(x.to(dev), w.to(dev), b.to(dev)).cpu()
     else:
         ref = _ref(x, w, b)
-    wp, bp = ops.pack_conv3x3(w.to(dev), b.to(dev))
-    for nchw in ([False] if Cout == 128 else [False, True]):
-        got = ops.conv3x3(x.to(dev).contiguous(memory_format=torch.channels_last), wp, bp, out_nchw=nchw)
+    packed = ops.pack_conv3x3(w.to(dev), b.to(dev))
+    # both kernels for 128 output channels (weights through LDS / weights from L2), NHWC and NCHW for the class logits
+    for nchw, staged in ([(False, True), (False, False)] if Cout == 128 else [(False, False), (True, False)]):
+        got = ops.conv3x3(x.to(dev).contiguous(memory_format=torch.channels_last), *packed, out_nchw=nchw, use_staged=staged)
         assert got.shape == ref.shape
         if nchw:
             assert got.is_contiguous()
         err = (got.double().cpu() - ref).abs().max().item()
-        assert err <= 1e-3 * max(1.0, ref.abs().max().item()), (nchw, err, ref.abs().max().item())
+        assert err <= 1e-3 * max(1.0, ref.abs().max().item()), (nchw, staged, err, ref.abs().max().item())
 
 
 def test_conv3x3_folds_batchnorm_and_relu():
@@ -58,8 +59,8 @@ def test_conv3x3_folds_batchnorm_and_relu():
         bn.bias.normal_(0, 0.2, generator=g)
     conv, bn = conv.half(), bn.half()
     ref = _ref(x, conv.weight.detach(), None, bn, relu=True)
-    wp, bp = ops.pack_conv3x3(conv.weight.to(DEV), None, bn.to(DEV))
-    got = ops.conv3x3(x.to(DEV).contiguous(memory_format=torch.channels_last), wp, bp, relu=True)
+    packed = ops.pack_conv3x3(conv.weight.to(DEV), None, bn.to(DEV))
+    got = ops.conv3x3(x.to(DEV).contiguous(memory_format=torch.channels_last), *packed, relu=True)
     err = (got.double().cpu() - ref).abs().max().item()
     assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err          # the folded weights are re-rounded to fp16
     assert (got == 0).float().mean().item() > 0.2                        # the ReLU is active
