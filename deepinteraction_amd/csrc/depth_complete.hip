@@ -17,6 +17,21 @@ namespace di {
 
 __device__ __forceinline__ float inv_depth(float d) { return d > 0.1f ? 100.f - d : d; }  // :171-174
 
+// float <-> unsigned with the same ordering (per-view min / max by integer atomics)
+__device__ __forceinline__ unsigned f2ord(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+// first valid row of a column, accumulated with atomicMin by the kernel that PRODUCES the map; H = "no valid pixel",
+// which np.argmax reports as row 0 (:209-213, :228)
+__device__ __forceinline__ int first_row(const int32_t *__restrict__ first, int idx, int H) {
+  const int f = first[idx];
+  return f >= H ? 0 : f;
+}
+
 // ---- stage 1 (:166-196): three depth-binned cross dilations of the inverted map
 template <int R>
 __device__ __forceinline__ float cross_dilate_bin(const float *__restrict__ d, int H, int W, int y,
@@ -39,9 +54,15 @@ __device__ __forceinline__ float cross_dilate_bin(const float *__restrict__ d, i
 }
 
 __global__ __launch_bounds__(256) void dc_multiscale_kernel(const float *__restrict__ in,
-                                                            float *__restrict__ out, int V, int H,
-                                                            int W) {
+                                                            float *__restrict__ out, int32_t *__restrict__ first_a,
+                                                            int32_t *__restrict__ first_b, unsigned *__restrict__ mm,
+                                                            int V, int H, int W) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < V * W) first_a[i] = first_b[i] = H;          // accumulators of the later stages of this chain
+  if (i < V) {
+    mm[2 * i] = 0xFFFFFFFFu;
+    mm[2 * i + 1] = 0u;
+  }
   if (i >= V * H * W) return;
   const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
   const float *d = in + (size_t)v * H * W;
@@ -109,30 +130,15 @@ __device__ __forceinline__ float median25(const float *__restrict__ d, int H, in
 
 // :203-206  s4 = s3 > 0.1 ? median(s3) : s3
 __global__ __launch_bounds__(256) void dc_median_valid_kernel(const float *__restrict__ in,
-                                                              float *__restrict__ out, int V, int H,
-                                                              int W) {
+                                                              float *__restrict__ out, int32_t *__restrict__ first,
+                                                              int V, int H, int W) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= V * H * W) return;
   const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
   const float c = in[i];
-  out[i] = c > 0.1f ? median25(in + (size_t)v * H * W, H, W, y, x) : c;
-}
-
-// first row with a valid pixel per column (np.argmax(col > 0.1): 0 when none)  :209-213, :228
-__global__ __launch_bounds__(256) void dc_col_first_kernel(const float *__restrict__ in,
-                                                           int32_t *__restrict__ first, int V, int H,
-                                                           int W) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V * W) return;
-  const int v = i / W, x = i - v * W;
-  const float *d = in + (size_t)v * H * W;
-  int f = 0;
-  for (int y = 0; y < H; ++y)
-    if (d[y * W + x] > 0.1f) {
-      f = y;
-      break;
-    }
-  first[i] = f;
+  const float o = c > 0.1f ? median25(in + (size_t)v * H * W, H, W, y, x) : c;
+  out[i] = o;
+  if (o > 0.1f) atomicMin(&first[v * W + x], y);       // top of the valid region of s4, per column
 }
 
 // :216-222  empty = !(s4 > 0.1) & top_mask ; s5 = empty ? dilate9x9(s4) : s4
@@ -140,59 +146,53 @@ __global__ __launch_bounds__(256) void dc_col_first_kernel(const float *__restri
 template <int R, bool STRICT_LT>
 __global__ __launch_bounds__(256) void dc_fill_kernel(const float *__restrict__ in,
                                                       const int32_t *__restrict__ first,
-                                                      float *__restrict__ out, int V, int H, int W) {
+                                                      float *__restrict__ out, int32_t *__restrict__ first_out,
+                                                      int V, int H, int W) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= V * H * W) return;
   const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
   const float c = in[i];
-  const bool top = y >= first[v * W + x];
+  const bool top = y >= first_row(first, v * W + x, H);
   const bool empty = (STRICT_LT ? (c < 0.1f) : !(c > 0.1f)) && top;
-  out[i] = empty ? box_extreme<R, true>(in + (size_t)v * H * W, H, W, y, x) : c;
+  const float o = empty ? box_extreme<R, true>(in + (size_t)v * H * W, H, W, y, x) : c;
+  out[i] = o;
+  if (first_out != nullptr && o > 0.1f) atomicMin(&first_out[v * W + x], y);   // top of the valid region of s5
 }
 
 // :248-250  valid = (s7 > 0.1) & top_mask ; s7 = valid ? median(s7) : s7   (valid kept for :260)
 __global__ __launch_bounds__(256) void dc_median_top_kernel(const float *__restrict__ in,
                                                             const int32_t *__restrict__ first,
                                                             float *__restrict__ out,
-                                                            float *__restrict__ valid, int V, int H,
-                                                            int W) {
+                                                            float *__restrict__ valid, unsigned *__restrict__ mm,
+                                                            int V, int H, int W) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V * H * W) return;
-  const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
-  const float c = in[i];
-  const bool ok = c > 0.1f && y >= first[v * W + x];
-  valid[i] = ok ? 1.f : 0.f;
-  out[i] = ok ? median25(in + (size_t)v * H * W, H, W, y, x) : c;
-}
-
-// per-view min / max (cv::minMaxLoc inside bilateralFilter_32f)
-__global__ __launch_bounds__(1024) void dc_minmax_kernel(const float *__restrict__ in,
-                                                         float *__restrict__ mm, int H, int W) {
-  __shared__ float smin[16], smax[16];
-  const int v = blockIdx.x;
-  const float *d = in + (size_t)v * H * W;
-  float mn = INFINITY, mx = -INFINITY;
-  for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
-    mn = fminf(mn, d[i]);
-    mx = fmaxf(mx, d[i]);
+  const bool in_map = i < V * H * W;
+  const int ic = in_map ? i : V * H * W - 1;
+  const int v = ic / (H * W), r = ic - v * H * W, y = r / W, x = r - y * W;
+  const float c = in[ic];
+  const bool ok = c > 0.1f && y >= first_row(first, v * W + x, H);
+  const float o = ok ? median25(in + (size_t)v * H * W, H, W, y, x) : c;
+  if (in_map) {
+    valid[i] = ok ? 1.f : 0.f;
+    out[i] = o;
   }
+  // per-view min / max of the result (cv::minMaxLoc inside bilateralFilter_32f): one pair of atomics per wave when
+  // the wave lies inside one view, per lane otherwise
+  unsigned lo = f2ord(o), hi = lo;
+  const int v0 = __shfl(v, 0);
+  if (__all(v == v0)) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    mn = fminf(mn, __shfl_xor(mn, o));
-    mx = fmaxf(mx, __shfl_xor(mx, o));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    smin[threadIdx.x >> 6] = mn;
-    smax[threadIdx.x >> 6] = mx;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
-      mn = fminf(mn, smin[w]);
-      mx = fmaxf(mx, smax[w]);
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      lo = min(lo, (unsigned)__shfl_xor((int)lo, sft));
+      hi = max(hi, (unsigned)__shfl_xor((int)hi, sft));
     }
-    mm[2 * v] = mn;
-    mm[2 * v + 1] = mx;
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&mm[2 * v], lo);
+      atomicMax(&mm[2 * v + 1], hi);
+    }
+  } else {
+    atomicMin(&mm[2 * v], lo);
+    atomicMax(&mm[2 * v + 1], hi);
   }
 }
 
@@ -205,7 +205,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // :259-266  blurred = bilateralFilter(s7, 5, 0.5, 2.0); s7[valid] = blurred[valid]; invert back.
 __global__ __launch_bounds__(256) void dc_bilateral_invert_kernel(const float *__restrict__ in,
                                                                   const float *__restrict__ valid,
-                                                                  const float *__restrict__ mm,
+                                                                  const unsigned *__restrict__ mm,
                                                                   float *__restrict__ out, int V,
                                                                   int H, int W) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void dc_bilateral_invert_kernel(const float *_
   const float *d = in + (size_t)v * H * W;
   const float c = d[r];
   float res = c;
-  const float mn = mm[2 * v], mx = mm[2 * v + 1];
+  const float mn = ord2f(mm[2 * v]), mx = ord2f(mm[2 * v + 1]);
   if (valid[i] != 0.f && !(fabsf(mn - mx) < FLT_EPSILON)) {
     const double gcc = -0.5 / (0.5 * 0.5);   // sigma_color 0.5
     const double gsc = -0.5 / (2.0 * 2.0);   // sigma_space 2.0
@@ -251,24 +251,23 @@ extern "C" int di_depth_complete(const float *sparse, float *dense, float *scrat
   hipStream_t s = (hipStream_t)stream;
   const int V = n_views, H = Hi, W = Wi;
   const int n = V * H * W;
-  const dim3 g((n + 255) / 256), b(256), gc((V * W + 255) / 256);
+  const dim3 g((n + 255) / 256), b(256);
   float *A = scratch, *B = scratch + (size_t)n, *valid = scratch + 2 * (size_t)n;
-  float *mm = scratch + 3 * (size_t)n;
-  int32_t *first = iscratch;
-  hipLaunchKernelGGL(dc_multiscale_kernel, g, b, 0, s, sparse, A, V, H, W);              // s2
+  unsigned *mm = reinterpret_cast<unsigned *>(scratch + 3 * (size_t)n);
+  int32_t *first_a = iscratch, *first_b = iscratch + (size_t)V * W;
+  // 13 launches: the per-column "first valid row" and the per-view min / max are accumulated with integer atomics by
+  // the kernels that produce the maps they describe
+  hipLaunchKernelGGL(dc_multiscale_kernel, g, b, 0, s, sparse, A, first_a, first_b, mm, V, H, W);   // s2 (+ accumulator init)
   hipLaunchKernelGGL((dc_box_kernel<2, true>), g, b, 0, s, A, B, V, H, W);               // close: dilate
   hipLaunchKernelGGL((dc_box_kernel<2, false>), g, b, 0, s, B, A, V, H, W);              //        erode -> s3
-  hipLaunchKernelGGL(dc_median_valid_kernel, g, b, 0, s, A, B, V, H, W);                 // s4
-  hipLaunchKernelGGL(dc_col_first_kernel, gc, b, 0, s, B, first, V, H, W);
-  hipLaunchKernelGGL((dc_fill_kernel<4, false>), g, b, 0, s, B, first, A, V, H, W);      // s5
-  hipLaunchKernelGGL(dc_col_first_kernel, gc, b, 0, s, A, first, V, H, W);               // top mask of s5
+  hipLaunchKernelGGL(dc_median_valid_kernel, g, b, 0, s, A, B, first_a, V, H, W);        // s4 (+ its top rows)
+  hipLaunchKernelGGL((dc_fill_kernel<4, false>), g, b, 0, s, B, first_a, A, first_b, V, H, W);      // s5 (+ its top rows)
   float *src = A, *dst = B;
   for (int it = 0; it < 6; ++it) {                                                       // s7
-    hipLaunchKernelGGL((dc_fill_kernel<2, true>), g, b, 0, s, src, first, dst, V, H, W);
+    hipLaunchKernelGGL((dc_fill_kernel<2, true>), g, b, 0, s, src, first_b, dst, (int32_t *)nullptr, V, H, W);
     float *t = src; src = dst; dst = t;
   }
-  hipLaunchKernelGGL(dc_median_top_kernel, g, b, 0, s, src, first, dst, valid, V, H, W);
-  hipLaunchKernelGGL(dc_minmax_kernel, dim3(V), dim3(1024), 0, s, dst, mm, H, W);
+  hipLaunchKernelGGL(dc_median_top_kernel, g, b, 0, s, src, first_b, dst, valid, mm, V, H, W);
   hipLaunchKernelGGL(dc_bilateral_invert_kernel, g, b, 0, s, dst, valid, mm, dense, V, H, W);
   return check_launch("depth_complete");
 }

@@ -6,28 +6,35 @@
 // so all keys are distinct and "value descending, lower index first on ties" is plain descending K - a
 // deterministic rule where the reference's argsort leaves ties unspecified.  Five digit levels (11+11+10 value bits,
 // 10+10 index bits), each a multi-block histogram of the elements that still match the selected prefix and a
-// one-block pick of the digit that holds the k-th largest key; then one pass collects the exactly k keys >= K*
-// (order irrelevant) and one block bitonic-sorts them.  12 small launches, no host synchronisation, no atomics on
-// floating point, bit-reproducible.
+// one-block pick of the digit that holds the k-th largest key; then one block collects the exactly k keys >= K*
+// (order irrelevant) and bitonic-sorts them.  11 small launches, no host synchronisation, no global atomics,
+// bit-reproducible.
 #include "di_common.h"
 
 namespace di {
 namespace tk {
 
+// NO global atomics and no buffer that is zeroed by one kernel and accumulated into by the next: every block writes
+// its own partial histogram with plain stores and the pick kernel sums the partials.  (The first version accumulated
+// one global histogram with atomicAdd after a plain-store clear by the previous kernel; replayed from a hipGraph that
+// went wrong from the second replay on - atomics and plain stores to the same lines do not meet in the same cache
+// level across the XCDs - while eager launches, with their full cache maintenance at every boundary, were fine.)
 constexpr int kBins = 2048;
+constexpr int kHistBlocks = 32;      // partial histograms per sample
 struct State {
   unsigned long long prefix;   // the digits selected so far, right aligned
   int need;                    // how many keys of the selected bin are still to be taken
-  int count;                   // collect pass: append cursor
+  int pad;
 };
 
 __device__ __forceinline__ unsigned long long make_key(float v, int idx) {
   return ((unsigned long long)__float_as_uint(v) << 20) | (unsigned long long)(0xFFFFFu - (unsigned)idx);
 }
 
-// histogram of digit (K >> shift) & (2^bits - 1) over the elements whose higher bits equal state.prefix
+// partial histogram of digit (K >> shift) & (2^bits - 1) over this block's slice of the elements whose higher bits
+// equal state.prefix
 __global__ __launch_bounds__(256) void hist_kernel(const float *__restrict__ scores, const State *__restrict__ st,
-                                                   int *__restrict__ hist, int N, int shift, int bits, int first) {
+                                                   int *__restrict__ part, int N, int shift, int bits, int first) {
   __shared__ int lh[kBins];
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < kBins; i += 256) lh[i] = 0;
@@ -35,27 +42,34 @@ __global__ __launch_bounds__(256) void hist_kernel(const float *__restrict__ sco
   const unsigned long long prefix = first ? 0ull : st[b].prefix;
   const unsigned mask = (1u << bits) - 1u;
   const float *s = scores + (size_t)b * N;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+  const int per = (N + kHistBlocks - 1) / kHistBlocks;
+  const int lo = blockIdx.x * per, hi = min(lo + per, N);
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
     const unsigned long long K = make_key(s[i], i);
     if ((K >> (shift + bits)) == prefix) atomicAdd(&lh[(unsigned)(K >> shift) & mask], 1);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kBins; i += 256)
-    if (lh[i]) atomicAdd(&hist[b * kBins + i], lh[i]);
+  int *dst = part + ((size_t)b * kHistBlocks + blockIdx.x) * kBins;
+  for (int i = threadIdx.x; i < kBins; i += 256) dst[i] = lh[i];
 }
 
 // one block per sample: the bin T with  #(bins > T) < need <= #(bins >= T); prefix <- prefix:T, need -= #(bins > T)
-__global__ __launch_bounds__(1024) void pick_kernel(State *__restrict__ st, int *__restrict__ hist, int bits, int k,
+__global__ __launch_bounds__(1024) void pick_kernel(State *__restrict__ st, const int *__restrict__ part, int bits, int k,
                                                     int first) {
   __shared__ int suf[kBins];
   const int b = blockIdx.x, nb = 1 << bits, t = threadIdx.x;
-  int *h = hist + b * kBins;
-  // The previous level's selection is read HERE, ahead of the scan: every barrier of the scan below separates these
-  // loads from the single thread that rewrites st[b] at the end (no wave can observe the new prefix / need).
+  const int *h = part + (size_t)b * kHistBlocks * kBins;
+  // the previous level's selection is read ahead of the scan: its barriers separate these loads from the single
+  // thread that rewrites st[b] at the end
   const int need = first ? k : st[b].need;
   const unsigned long long prefix = first ? 0ull : st[b].prefix;
   // suffix sums over reversed bins (Hillis-Steele on <= 2048 entries, two per thread)
-  for (int i = t; i < kBins; i += 1024) suf[i] = i < nb ? h[nb - 1 - i] : 0;      // suf[r]: bin nb-1-r
+  for (int i = t; i < kBins; i += 1024) {
+    int c = 0;
+    if (i < nb)
+      for (int p = 0; p < kHistBlocks; ++p) c += h[p * kBins + nb - 1 - i];
+    suf[i] = c;                                                                  // suf[r]: bin nb-1-r
+  }
   __syncthreads();
   for (int d = 1; d < nb; d <<= 1) {
     int v0 = 0, v1 = 0;
@@ -72,34 +86,30 @@ __global__ __launch_bounds__(1024) void pick_kernel(State *__restrict__ st, int 
     if (excl < need && need <= incl) {
       st[b].prefix = (prefix << bits) | (unsigned long long)(nb - 1 - r);
       st[b].need = need - excl;
-      st[b].count = 0;
     }
   }
-  __syncthreads();
-  for (int i = t; i < kBins; i += 1024) h[i] = 0;   // ready for the next level
 }
 
-__global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ scores, State *__restrict__ st,
-                                                      unsigned long long *__restrict__ cand, int N, int k) {
-  const int b = blockIdx.y;
+// one block per sample: gather the exactly k keys >= K* (all keys are distinct) into LDS, bitonic-sort them
+// (descending), write the indices
+__global__ __launch_bounds__(1024) void collect_sort_kernel(const float *__restrict__ scores, const State *__restrict__ st,
+                                                            long long *__restrict__ out_idx, float *__restrict__ out_val,
+                                                            int N, int k) {
+  __shared__ unsigned long long a[1024];
+  __shared__ int cnt;
+  const int b = blockIdx.x, t = threadIdx.x;
   const unsigned long long Kstar = st[b].prefix;   // all 52 bits selected
+  a[t] = 0ull;
+  if (t == 0) cnt = 0;
+  __syncthreads();
   const float *s = scores + (size_t)b * N;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+  for (int i = t; i < N; i += 1024) {
     const unsigned long long K = make_key(s[i], i);
     if (K >= Kstar) {
-      const int pos = atomicAdd(&st[b].count, 1);
-      if (pos < k) cand[(size_t)b * k + pos] = K;
+      const int pos = atomicAdd(&cnt, 1);          // LDS atomic: order irrelevant, the sort follows
+      if (pos < 1024) a[pos] = K;
     }
   }
-}
-
-// one block per sample: bitonic sort (descending) of the k <= 1024 collected keys, indices out
-__global__ __launch_bounds__(1024) void sort_kernel(const unsigned long long *__restrict__ cand,
-                                                    long long *__restrict__ out_idx, float *__restrict__ out_val,
-                                                    int k) {
-  __shared__ unsigned long long a[1024];
-  const int b = blockIdx.x, t = threadIdx.x;
-  a[t] = t < k ? cand[(size_t)b * k + t] : 0ull;
   __syncthreads();
   for (int len = 2; len <= 1024; len <<= 1) {
     for (int j = len >> 1; j > 0; j >>= 1) {
@@ -128,7 +138,8 @@ __global__ __launch_bounds__(1024) void sort_kernel(const unsigned long long *__
 extern "C" {
 
 long long di_topk_workspace_bytes(int B, int k) {
-  return (long long)B * (di::tk::kBins * (long long)sizeof(int) + (long long)sizeof(di::tk::State) + (long long)k * 8) + 64;
+  (void)k;
+  return (long long)B * ((long long)di::tk::kHistBlocks * di::tk::kBins * (long long)sizeof(int) + 64) + 64;
 }
 
 int di_topk_fwd(const float *scores, long long *out_idx, float *out_val, void *workspace, int B, int N, int k,
@@ -138,22 +149,14 @@ int di_topk_fwd(const float *scores, long long *out_idx, float *out_val, void *w
   DI_REQUIRE(N <= (1 << 20), "N=%d exceeds the 2^20 indices of the composite key", N);
   hipStream_t s = (hipStream_t)stream;
   unsigned char *w = reinterpret_cast<unsigned char *>(workspace);
-  int *hist = reinterpret_cast<int *>(w);
-  State *st = reinterpret_cast<State *>(w + (size_t)B * kBins * sizeof(int));
-  unsigned long long *cand = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(st) +
-                                                                     (((size_t)B * sizeof(State) + 63) / 64) * 64);
-  if (hipMemsetAsync(hist, 0, (size_t)B * kBins * sizeof(int), s) != hipSuccess) {
-    di::set_error("hipMemsetAsync failed");
-    return DI_ERR_LAUNCH;
-  }
-  const int nblk = (N + 256 * 8 - 1) / (256 * 8);
+  int *part = reinterpret_cast<int *>(w);
+  State *st = reinterpret_cast<State *>(w + (size_t)B * kHistBlocks * kBins * sizeof(int));
   const int shifts[5] = {41, 30, 20, 10, 0}, nbits[5] = {11, 11, 10, 10, 10};
   for (int l = 0; l < 5; ++l) {
-    hipLaunchKernelGGL(hist_kernel, dim3(nblk, B), dim3(256), 0, s, scores, st, hist, N, shifts[l], nbits[l], l == 0);
-    hipLaunchKernelGGL(pick_kernel, dim3(B), dim3(1024), 0, s, st, hist, nbits[l], k, l == 0);
+    hipLaunchKernelGGL(hist_kernel, dim3(kHistBlocks, B), dim3(256), 0, s, scores, st, part, N, shifts[l], nbits[l], l == 0);
+    hipLaunchKernelGGL(pick_kernel, dim3(B), dim3(1024), 0, s, st, part, nbits[l], k, l == 0);
   }
-  hipLaunchKernelGGL(collect_kernel, dim3(nblk, B), dim3(256), 0, s, scores, st, cand, N, k);
-  hipLaunchKernelGGL(sort_kernel, dim3(B), dim3(1024), 0, s, cand, out_idx, out_val, k);
+  hipLaunchKernelGGL(collect_sort_kernel, dim3(B), dim3(1024), 0, s, scores, st, out_idx, out_val, N, k);
   return di::check_launch("topk_fwd");
 }
 

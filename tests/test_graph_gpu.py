@@ -100,3 +100,59 @@ def test_graph_replay_of_the_plusplus_forward():
     _same(g()[0][0], ref_b)
     g.load(a)
     _same(g()[0][0], ref_a)
+
+
+def test_topk_replays_from_a_graph():
+    """The radix-select top-k replayed from a hipGraph on changing inputs (its first version kept one global histogram
+    - atomicAdd after a memset node / plain-store clear - and went wrong from the SECOND replay on; eager was fine)."""
+    from deepinteraction_amd import ops
+    B, N, k = 2, 324000, 200
+    g0 = torch.Generator(device='cuda').manual_seed(0)
+    xs = []
+    for _ in range(3):
+        x = torch.rand(B, N, device='cuda', generator=g0)
+        x[torch.rand(B, N, device='cuda', generator=g0) < 0.8] = 0
+        xs.append(x)
+    ref = [ops.topk(x, k).clone() for x in xs]
+    static = xs[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.topk(static, k)
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        idx = ops.topk(static, k)
+    for it in range(7):
+        static.copy_(xs[it % 3])
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(idx, ref[it % 3]), it
+
+
+def test_many_replays_over_a_pool_match_eager_at_the_benched_shape():
+    """bench.py's per-step sequence - load(record of the next pool sample), replay - at shape R, fp16, Q = 200: every
+    replay bit-identical to the eager forward of that sample (proposals, labels, all outputs)."""
+    from deepinteraction_amd import harness, parallel
+    shape = synth.SHAPE_R
+    enc, dec = harness.build_models(shape, 200, torch.float16, 'cuda')
+    pool = [harness.to_device(synth.make_inputs(1, shape, seed=parallel.sample_seed(i)), 'cuda', torch.float16)
+            for i in range(3)]
+    with torch.no_grad():
+        eager = []
+        for d in pool:
+            _, out = harness.forward(enc, dec, d)
+            torch.cuda.synchronize()
+            eager.append(({k: v.clone() for k, v in out[0][0].items()}, dec.top_proposals.clone(), dec.query_labels.clone()))
+        cap = max(range(3), key=lambda i: int(pool[i]['pts_metas']['pillars'].shape[0]))
+        g = GraphedHotPath(enc, dec, pool[cap])
+        recs = [g.prepare(d) for d in pool]
+        for it in range(7):
+            i = it % 3
+            g.load(recs[i])
+            out = g()[0][0]
+            torch.cuda.synchronize()
+            ref, top, labels = eager[i]
+            assert torch.equal(dec.top_proposals, top) and torch.equal(dec.query_labels, labels), (it, i)
+            _same(out, ref)
+    assert g.num_nodes() is None or g.num_nodes() < 200
