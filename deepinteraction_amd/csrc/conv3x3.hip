@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const __half *__restric
 // Second kernel, for Cout == 128: the weights go through LDS as well.  The K loop runs in STAGES = (32-channel chunk,
 // kernel row ky): a stage multiplies the three taps of one kernel row.  Its weight tile (3 taps x 128 rows x 32
 // channels = 24 KB, contiguous in the (chunk, ky, kx, n, c) packing) and - once per chunk - the next halo chunk are
-// fetched into registers at the START of the previous stage and written to the other LDS buffers at its end: the L2 /
+// fetched into registers TWO stages (one chunk) ahead and written to the other LDS buffers one stage ahead: the L2 /
 // HBM latency is covered by a whole stage of MFMAs (48 per wave) of both resident workgroups, and the A fragments
 // become conflict-free ds_read_b128 like the B fragments (same slot rotation by row).
 // ------------------------------------------------------------------------------------------------------------
@@ -215,18 +215,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
 #pragma unroll
     for (int n = 0; n < NTW; ++n) acc[r][n] = f4{0.f, 0.f, 0.f, 0.f};
 
+  // Pipeline: the weight tile of stage st+2 and the halo chunk ch+1 are in flight (in registers) while stage st is
+  // multiplied; a tile is written to LDS at the START of the stage before its use - a full stage after its loads were
+  // issued - into the buffer whose last readers passed the previous barrier.
   const int nstage = (Cin / CK) * 3;
   fetch_b(0);
   fetch_a(0);
   commit_b(0);
   commit_a(0);
+  if (nstage > 1) fetch_a(1);
   __syncthreads();
   for (int st = 0; st < nstage; ++st) {
     const int ch = st / 3, ky = st - ch * 3;
     const int ab = st & 1, bb = ch & 1;
-    const bool more = st + 1 < nstage;
-    if (more) fetch_a(st + 1);
-    if (ky == 0 && (ch + 1) * CK < Cin) fetch_b((ch + 1) * CK);
+    const bool next_chunk = (ch + 1) * CK < Cin;
+    if (st + 1 < nstage) commit_a(ab ^ 1);                 // stage st+1, fetched one stage ago
+    if (st + 2 < nstage) fetch_a(st + 2);
+    if (ky == 0 && next_chunk) fetch_b((ch + 1) * CK);
+    if (ky == 1 && next_chunk) commit_b(bb ^ 1);
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       h8 a[NTW];
@@ -241,8 +247,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
         for (int n = 0; n < NTW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b, acc[r][n], 0, 0, 0);
       }
     }
-    if (more) commit_a(ab ^ 1);
-    if (ky == 2 && (ch + 1) * CK < Cin) commit_b(bb ^ 1);
     __syncthreads();
   }
 
@@ -285,9 +289,10 @@ extern "C" int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w
                        out_nchw, tiles_x, tiles_y);                                                                 \
   } while (0)
   if (Cout == 128 && w_staged != nullptr && !out_nchw) {
-    // weights through LDS; enough tiles to spread over the 256 CUs: 8-row tiles for the image maps, 4-row tiles
-    // for one BEV map
-    if ((long long)n * ((H + 7) / 8) * tiles_x >= 768) {
+    // weights through LDS.  8-row tiles whenever the map has at least 8 rows: the kernel is latency bound per
+    // stage, so fewer, larger tiles that fit the resident slots in one round beat more, smaller ones
+    // (180 x 180: 276 tiles of 8 x 16 in one round instead of 540 of 4 x 16 in two)
+    if (H >= 8) {
       const int tiles_y = (H + 7) / 8;
       hipLaunchKernelGGL((conv3x3_lds_kernel<8>), dim3(tiles_x * tiles_y * n), dim3(256), 0, s, (const __half *)x,
                          (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x, tiles_y);
