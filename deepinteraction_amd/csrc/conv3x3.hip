@@ -159,9 +159,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
                                                              int H, int W, int Cin, int relu, int tiles_x, int tiles_y) {
   constexpr int WN = 2, WM = 2, NTW = 4, RW = TH / WM;
   constexpr int HP = (TH + 2) * (TW + 2);
-  constexpr int NLD = (HP * 4 + 255) / 256;                // halo pieces per thread and chunk
-  constexpr int ASZ = 3 * 128 * 64;                        // weight tile of a stage
-  constexpr int NLA = ASZ / 16 / 256;                      // = 6 pieces per thread and stage
+  constexpr int NLD = (HP * 4 + 255) / 256;                // halo pieces per thread and chunk (2 or 3)
+  constexpr int ASZ = 3 * 128 * 64;                        // weight tile of a stage: 6 pieces per thread
+  static_assert(NLD <= 3, "halo of at most 3 pieces per thread");
   __shared__ __align__(16) unsigned char lA[2][ASZ];
   __shared__ __align__(16) unsigned char lB[2][HP * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,40 +174,56 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
   const int y0 = ty * TH, x0 = tx * TW;
   const __half *xi = x + (size_t)img * H * W * Cin;
 
-  uint4 sB[NLD], sA[NLA];
-  auto fetch_b = [&](int c0) {
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
+  // The prefetched tiles live in NAMED registers: arrays that stay live across the back edge of the stage loop are
+  // not promoted to registers by hipcc (they went to scratch, and every scratch store waited for its load - the
+  // whole prefetch was lost: 2.7k cycles per stage instead of ~1k).
+  uint4 a0, a1, a2, a3, a4, a5, b0, b1, b2;
+  b0 = b1 = b2 = make_uint4(0, 0, 0, 0);
+  // halo piece j of this thread: pixel offset in the image (in elements, -1: outside) and LDS offset
+  int bsrc0, bsrc1, bsrc2, bdst0, bdst1, bdst2;
+  {
+    auto piece = [&](int j, int &src, int &dst) {
       const int e = tid + j * 256;
-      const int P = e >> 2, s = e & 3;
+      const int P = e >> 2, s4 = e & 3;
       const int hy = P / (TW + 2), hx = P - hy * (TW + 2);
       const int yy = y0 + hy - 1, xx = x0 + hx - 1;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (e < HP * 4 && yy >= 0 && yy < H && xx >= 0 && xx < W)
-        v = *reinterpret_cast<const uint4 *>(xi + ((size_t)yy * W + xx) * Cin + c0 + s * 8);
-      sB[j] = v;
-    }
-  };
-  auto commit_b = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-      const int e = tid + j * 256;
-      if (e < HP * 4) *reinterpret_cast<uint4 *>(&lB[buf][lds_off(e >> 2, e & 3)]) = sB[j];
-    }
-  };
-  // stage st = chunk * 3 + ky: its weight tile is the contiguous 24 KB at wst + st * ASZ; piece e = (row = kx*128 + n, slot)
-  auto fetch_a = [&](int st) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(wst) + (size_t)st * ASZ);
-#pragma unroll
-    for (int j = 0; j < NLA; ++j) sA[j] = src[tid + j * 256];
-  };
-  auto commit_a = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < NLA; ++j) {
-      const int e = tid + j * 256;
-      *reinterpret_cast<uint4 *>(&lA[buf][lds_off(e >> 2, e & 3)]) = sA[j];      // rows are 64 B, rotation by row >> 2
-    }
-  };
+      const bool ok = e < HP * 4 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      src = ok ? (yy * W + xx) * Cin + s4 * 8 : -1;
+      dst = e < HP * 4 ? lds_off(P, s4) : -1;
+    };
+    piece(0, bsrc0, bdst0);
+    piece(1, bsrc1, bdst1);
+    piece(2, bsrc2, bdst2);
+  }
+  const int adst0 = lds_off((tid) >> 2, tid & 3), adst1 = lds_off((tid + 256) >> 2, tid & 3);
+  const int adst2 = lds_off((tid + 512) >> 2, tid & 3), adst3 = lds_off((tid + 768) >> 2, tid & 3);
+  const int adst4 = lds_off((tid + 1024) >> 2, tid & 3), adst5 = lds_off((tid + 1280) >> 2, tid & 3);
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+#define DI_FETCH_A(st)                                                                                                  \
+  do {                                                                                                                  \
+    const uint4 *src_ = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(wst) + (size_t)(st) * ASZ) + tid; \
+    a0 = src_[0]; a1 = src_[256]; a2 = src_[512]; a3 = src_[768]; a4 = src_[1024]; a5 = src_[1280];                     \
+  } while (0)
+#define DI_COMMIT_A(buf)                                                                                                \
+  do {                                                                                                                  \
+    unsigned char *d_ = lA[buf];                                                                                        \
+    *reinterpret_cast<uint4 *>(d_ + adst0) = a0; *reinterpret_cast<uint4 *>(d_ + adst1) = a1;                           \
+    *reinterpret_cast<uint4 *>(d_ + adst2) = a2; *reinterpret_cast<uint4 *>(d_ + adst3) = a3;                           \
+    *reinterpret_cast<uint4 *>(d_ + adst4) = a4; *reinterpret_cast<uint4 *>(d_ + adst5) = a5;                           \
+  } while (0)
+#define DI_FETCH_B(c0)                                                                                                  \
+  do {                                                                                                                  \
+    b0 = bsrc0 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc0 + (c0)) : zero4;                                      \
+    b1 = bsrc1 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc1 + (c0)) : zero4;                                      \
+    if (NLD > 2) b2 = bsrc2 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc2 + (c0)) : zero4;                         \
+  } while (0)
+#define DI_COMMIT_B(buf)                                                                                                \
+  do {                                                                                                                  \
+    unsigned char *d_ = lB[buf];                                                                                        \
+    if (bdst0 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst0) = b0;                                                        \
+    if (bdst1 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst1) = b1;                                                        \
+    if (NLD > 2 && bdst2 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst2) = b2;                                             \
+  } while (0)
 
   f4 acc[RW][NTW];
 #pragma unroll
@@ -217,22 +233,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
 
   // Pipeline: the weight tile of stage st+2 and the halo chunk ch+1 are in flight (in registers) while stage st is
   // multiplied; a tile is written to LDS at the START of the stage before its use - a full stage after its loads were
-  // issued - into the buffer whose last readers passed the previous barrier.
-  const int nstage = (Cin / CK) * 3;
-  fetch_b(0);
-  fetch_a(0);
-  commit_b(0);
-  commit_a(0);
-  if (nstage > 1) fetch_a(1);
+  // issued - into the buffer whose last readers passed the previous barrier.  The loads are unconditional (the tail
+  // re-reads the last tile) so that no control flow surrounds them.
+  const int nstage = (Cin / CK) * 3, nchunk = Cin / CK;
+  DI_FETCH_B(0);
+  DI_FETCH_A(0);
+  DI_COMMIT_B(0);
+  DI_COMMIT_A(0);
+  DI_FETCH_A(nstage > 1 ? 1 : 0);
   __syncthreads();
   for (int st = 0; st < nstage; ++st) {
     const int ch = st / 3, ky = st - ch * 3;
     const int ab = st & 1, bb = ch & 1;
-    const bool next_chunk = (ch + 1) * CK < Cin;
-    if (st + 1 < nstage) commit_a(ab ^ 1);                 // stage st+1, fetched one stage ago
-    if (st + 2 < nstage) fetch_a(st + 2);
-    if (ky == 0 && next_chunk) fetch_b((ch + 1) * CK);
-    if (ky == 1 && next_chunk) commit_b(bb ^ 1);
+    DI_COMMIT_A(ab ^ 1);                                   // stage st+1, fetched one stage ago
+    DI_FETCH_A(st + 2 < nstage ? st + 2 : nstage - 1);
+    if (ky == 0) DI_FETCH_B((ch + 1 < nchunk ? ch + 1 : ch) * CK);
+    if (ky == 1) DI_COMMIT_B(bb ^ 1);
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       h8 a[NTW];
@@ -249,6 +265,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
     }
     __syncthreads();
   }
+#undef DI_FETCH_A
+#undef DI_COMMIT_A
+#undef DI_FETCH_B
+#undef DI_COMMIT_B
 
   const int xx = x0 + i;
 #pragma unroll
