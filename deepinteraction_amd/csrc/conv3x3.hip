@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
     DI_COMMIT_A(ab ^ 1);                                   // stage st+1, fetched one stage ago
     DI_FETCH_A(st + 2 < nstage ? st + 2 : nstage - 1);
     if (ky == 0) DI_FETCH_B((ch + 1 < nchunk ? ch + 1 : ch) * CK);
-    if (ky == 1) DI_COMMIT_B(bb ^ 1);
+    if (ky == 2) DI_COMMIT_B(bb ^ 1);                      // two stages after its (HBM) loads were issued
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       h8 a[NTW];

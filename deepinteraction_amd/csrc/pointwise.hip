@@ -70,6 +70,27 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
 
+  constexpr int KK1 = K1 / 32;
+  const long long nchunk = (M + 16 * PG - 1) / (16 * PG);
+  const long long ch0 = (long long)blockIdx.x * NW + wave, chstep = (long long)gridDim.x * NW;
+  // B operands of link 1: pixel i of each group, channels 32kk + 8g .. +7 (x1 then x2).  The FIRST chunk's loads are
+  // issued before the weights are staged (a launch gives a wave one or two chunks: its HBM round trip then overlaps
+  // the 64 KB weight staging instead of following it).
+  h8 xb[PG][KK1];
+  auto load_x = [&](long long ch) {
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+      const long long p = ch * (16 * PG) + pg * 16 + i;
+      const long long pc = p < M ? p : M - 1;                   // ragged tail: clamped read, no store
+#pragma unroll
+      for (int kk = 0; kk < KK1; ++kk) {
+        const __half *src = kk < 4 ? x1 : x2;
+        xb[pg][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(src + pc * 128 + (kk & 3) * 32 + g * 8));
+      }
+    }
+  };
+  if (ch0 < nchunk) load_x(ch0);
+
   stage_w<K1, false>(w1, lw1, tid);
   if (K2 > 0) stage_w<(K2 > 0 ? K2 : 128), true>(w2, lw2, tid);
   if (tid < 128) {
@@ -78,23 +99,11 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
   }
   __syncthreads();
 
-  constexpr int KK1 = K1 / 32;
-  const long long nchunk = (M + 16 * PG - 1) / (16 * PG);
-  for (long long ch = (long long)blockIdx.x * NW + wave; ch < nchunk; ch += (long long)gridDim.x * NW) {
+  for (long long ch = ch0; ch < nchunk; ch += chstep) {
     const long long p0 = ch * (16 * PG);
-    // ---- B operands of link 1: pixel i of each group, channels 32kk + 8g .. +7 (x1 then x2)
-    h8 xb[PG][KK1];
     long long pix[PG];
 #pragma unroll
-    for (int pg = 0; pg < PG; ++pg) {
-      pix[pg] = p0 + pg * 16 + i;
-      const long long pc = pix[pg] < M ? pix[pg] : M - 1;       // ragged tail: clamped read, no store
-#pragma unroll
-      for (int kk = 0; kk < KK1; ++kk) {
-        const __half *src = kk < 4 ? x1 : x2;
-        xb[pg][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(src + pc * 128 + (kk & 3) * 32 + g * 8));
-      }
-    }
+    for (int pg = 0; pg < PG; ++pg) pix[pg] = p0 + pg * 16 + i;
     // ---- link 1: H^T[oc][px] = W1 . X^T
     f4 acc[PG][8];
 #pragma unroll
@@ -132,6 +141,7 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
             *reinterpret_cast<h4 *>(y + pix[pg] * 128 + 16 * nb + 4 * g) = o;
           }
         }
+      if (ch + chstep < nchunk) load_x(ch + chstep);
       continue;
     }
     // ---- link 2: B operand = the hidden activations in registers (k = 8g + 4t + r <-> channel 32kk + 16t + 4g + r),
@@ -185,6 +195,7 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (ch + chstep < nchunk) load_x(ch + chstep);
   }
 }
 

@@ -40,7 +40,31 @@ struct Epilogue {
   const unsigned char *keep;     // (M) or null: rows with keep[m] == 0 are written as zeros (decoder_utils.py:665)
 };
 
-__device__ __forceinline__ void layer_norm8(float (&v)[8], const __half *w, const __half *b, int c0, float eps) {
+// The epilogue's memory operands of one (row, 8-channel) slot, fetched at the START of the kernel so that their round
+// trip overlaps the K loop (these kernels are a chain of dependent round trips; every one removed is ~1 us).
+struct EpiOperands {
+  Pack8<__half> r1, r2, w1, b1, w2, b2;
+  float bias[8];
+};
+__device__ __forceinline__ EpiOperands epilogue_prefetch(const Epilogue &e, long long m, int c0, bool row_ok) {
+  EpiOperands o;
+  o.r1 = o.r2 = o.w1 = o.b1 = o.w2 = o.b2 = zero8<__half>();
+  if (e.res1 && e.ln1_w && row_ok) o.r1 = ld8(e.res1 + m * e.ldr1 + c0);
+  if (e.res2 && e.ln2_w && row_ok) o.r2 = ld8(e.res2 + m * e.ldr2 + c0);
+  if (e.ln1_w) {
+    o.w1 = ld8(e.ln1_w + c0);
+    o.b1 = ld8(e.ln1_b + c0);
+  }
+  if (e.ln2_w) {
+    o.w2 = ld8(e.ln2_w + c0);
+    o.b2 = ld8(e.ln2_b + c0);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o.bias[j] = e.bias ? e.bias[c0 + j] : 0.f;
+  return o;
+}
+
+__device__ __forceinline__ void layer_norm8(float (&v)[8], const Pack8<__half> &w, const Pack8<__half> &b, float eps) {
   float s = 0.f, ss = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) s += v[j];
@@ -54,19 +78,17 @@ __device__ __forceinline__ void layer_norm8(float (&v)[8], const __half *w, cons
   ss = row16_sum(ss);
   const float inv = rsqrtf(ss * (1.f / 128.f) + eps);
   float wf[8], bf[8];
-  unpack8(ld8(w + c0), wf);
-  unpack8(ld8(b + c0), bf);
+  unpack8(w, wf);
+  unpack8(b, bf);
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = (v[j] - mean) * inv * wf[j] + bf[j];
 }
 
 // 16 consecutive lanes own one token row of 128 outputs, 8 channels each (c0 = 8 * (lane & 15)): needs N == 128 when
 // a LayerNorm is present.
-__device__ __forceinline__ void epilogue8(float (&v)[8], const Epilogue &e, long long m, int c0, bool row_ok) {
-  if (e.bias) {
+__device__ __forceinline__ void epilogue8(float (&v)[8], const Epilogue &e, const EpiOperands &o, long long m, bool row_ok) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] += e.bias[c0 + j];
-  }
+  for (int j = 0; j < 8; ++j) v[j] += o.bias[j];
   if (e.act1 == 1) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -75,26 +97,22 @@ __device__ __forceinline__ void epilogue8(float (&v)[8], const Epilogue &e, long
     for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
   }
   if (e.ln1_w) {
-    if (e.res1 && row_ok) {
-      float r[8];
-      unpack8(ld8(e.res1 + m * e.ldr1 + c0), r);
+    float r[8];
+    unpack8(o.r1, r);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += r[j];
-    }
-    layer_norm8(v, e.ln1_w, e.ln1_b, c0, e.eps);
+    for (int j = 0; j < 8; ++j) v[j] += r[j];
+    layer_norm8(v, o.w1, o.b1, e.eps);
   }
   if (e.act2) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
   }
   if (e.ln2_w) {
-    if (e.res2 && row_ok) {
-      float r[8];
-      unpack8(ld8(e.res2 + m * e.ldr2 + c0), r);
+    float r[8];
+    unpack8(o.r2, r);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += r[j];
-    }
-    layer_norm8(v, e.ln2_w, e.ln2_b, c0, e.eps);
+    for (int j = 0; j < 8; ++j) v[j] += r[j];
+    layer_norm8(v, o.w2, o.b2, e.eps);
   }
   if (e.keep && row_ok && !e.keep[m]) {
 #pragma unroll
@@ -119,6 +137,11 @@ __global__ __launch_bounds__(256) void tl_rowblock_kernel(const __half *__restri
   const int n0 = blockIdx.y * 128;
   const long long mr = m0 + i < M ? m0 + i : M - 1;            // ragged tail: clamped read, masked store
   const int kq = K / 4;                                        // this wave's K range
+  const int em = tid >> 4, ec0 = (tid & 15) * 8;               // this thread's epilogue slot: row em, channels ec0..+7
+  const bool eok = m0 + em < M;
+  Epilogue e = ep;
+  if (e.bias) e.bias += n0;
+  const EpiOperands eo = epilogue_prefetch(e, m0 + em, ec0, eok);
   f4 acc[8];
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
@@ -136,15 +159,11 @@ __global__ __launch_bounds__(256) void tl_rowblock_kernel(const __half *__restri
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb) *reinterpret_cast<f4 *>(&part[wave][i][16 * nb + 4 * g]) = acc[nb];
   __syncthreads();
-  const int m = tid >> 4, c0 = (tid & 15) * 8;
   float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = part[0][m][c0 + j] + part[1][m][c0 + j] + part[2][m][c0 + j] + part[3][m][c0 + j];
-  const bool ok = m0 + m < M;
-  Epilogue e = ep;
-  if (e.bias) e.bias += n0;
-  epilogue8(v, e, m0 + m, c0, ok);
-  if (ok) st8(Y + (m0 + m) * ldy + n0 + c0, pack8f(v, __half()));
+  for (int j = 0; j < 8; ++j) v[j] = part[0][em][ec0 + j] + part[1][em][ec0 + j] + part[2][em][ec0 + j] + part[3][em][ec0 + j];
+  epilogue8(v, e, eo, m0 + em, eok);
+  if (eok) st8(Y + (m0 + em) * ldy + n0 + ec0, pack8f(v, __half()));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -226,6 +245,7 @@ __global__ __launch_bounds__(256) void tl_finish_kernel(const float *__restrict_
   const int c0 = (threadIdx.x & 15) * 8;
   const bool ok = m < M;
   const long long mr = ok ? m : M - 1;
+  const EpiOperands eo = epilogue_prefetch(ep, m, c0, ok);
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(256) void tl_finish_kernel(const float *__restrict_
     v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
     v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
   }
-  epilogue8(v, ep, m, c0, ok);
+  epilogue8(v, ep, eo, m, ok);
   if (ok) st8(Y + m * ldy + c0, pack8f(v, __half()));
 }
 
@@ -486,64 +506,52 @@ struct HeadOut {
   int nheads, center_head;
 };
 
-template <int HID>
+// grid (query blocks of 16, B, heads): a workgroup evaluates ONE head for 16 queries (wave w = 16 of its 64 hidden
+// channels), so a stage is ~80 small workgroups instead of 13 long ones.
 __global__ __launch_bounds__(256) void pred_head_kernel(const __half *__restrict__ x1, const __half *__restrict__ x2, int K,
                                                         const __half *__restrict__ w1, const float *__restrict__ b1,
                                                         const float *__restrict__ w2 /*(rows, 64)*/, const float *__restrict__ b2,
                                                         const float *__restrict__ qpos /*(B,Q,2)*/,
                                                         const unsigned char *__restrict__ keep /*(B,Q) or null*/,
                                                         HeadOut ho, float *__restrict__ pos_out /*(B,Q,2) or null*/,
-                                                        int Q, int ldo, int col0, int nrows) {
-  __shared__ float hid[16][HID + 4];
+                                                        int Q, int ldo, int col0) {
+  __shared__ float hid[16][68];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y, q0 = blockIdx.x * 16;
+  const int b = blockIdx.y, q0 = blockIdx.x * 16, h = blockIdx.z;
   const int qr = q0 + i < Q ? q0 + i : Q - 1;
   const size_t row = (size_t)b * Q + qr;
-  constexpr int NB = HID / 64;                      // 16-row fragments per wave (HID / 16 / 4 waves)
-  f4 acc[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+  const int n0 = h * 64 + wave * 16;                       // this wave's 16 hidden channels (rows of the stacked W1)
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < K; k0 += 32) {
     const int kk = k0 + g * 8;
     const h8 bx = kk < 128 ? ld_h8(x1 + row * 128 + kk) : ld_h8(x2 + row * 128 + kk - 128);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const h8 a = ld_h8(w1 + (size_t)(wave * (HID / 4) + 16 * nb + i) * K + kk);
-      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bx, acc[nb], 0, 0, 0);
-    }
+    const h8 a = ld_h8(w1 + (size_t)(n0 + i) * K + kk);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bx, acc, 0, 0, 0);
   }
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = wave * (HID / 4) + 16 * nb + 4 * g;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hid[i][n + r] = fmaxf(acc[nb][r] + b1[n + r], 0.f);
-  }
+  for (int r = 0; r < 4; ++r) hid[i][wave * 16 + 4 * g + r] = fmaxf(acc[r] + b1[n0 + 4 * g + r], 0.f);
   __syncthreads();
-  // second layers: thread -> (query, stacked output row)
-  for (int e = tid; e < 16 * nrows; e += 256) {
-    const int m = e / nrows, o = e - m * nrows;
+  // second layer of this head: thread -> (query, class row)
+  const int ncls = ho.cls[h], r0 = ho.row0[h];
+  for (int e = tid; e < 16 * ncls; e += 256) {
+    const int m = e / ncls, cidx = e - m * ncls;
     const int q = q0 + m;
     if (q >= Q) continue;
-    int h = 0;
-#pragma unroll
-    for (int t = 1; t < kMaxHeads; ++t)
-      if (t < ho.nheads && o >= ho.row0[t]) h = t;
-    const int cidx = o - ho.row0[h];
-    const float *hv = &hid[m][h * 64];
+    const int o = r0 + cidx;
     const float4 *wr = reinterpret_cast<const float4 *>(w2 + (size_t)o * 64);
     float a = b2[o];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const float4 w = wr[j];
-      a = fmaf(w.x, hv[4 * j], a);
-      a = fmaf(w.y, hv[4 * j + 1], a);
-      a = fmaf(w.z, hv[4 * j + 2], a);
-      a = fmaf(w.w, hv[4 * j + 3], a);
+      a = fmaf(w.x, hid[m][4 * j], a);
+      a = fmaf(w.y, hid[m][4 * j + 1], a);
+      a = fmaf(w.z, hid[m][4 * j + 2], a);
+      a = fmaf(w.w, hid[m][4 * j + 3], a);
     }
     if (h == ho.center_head) a += qpos[((size_t)b * Q + q) * 2 + cidx];
-    if (keep != nullptr && !keep[(size_t)b * Q + q]) a = ho.first[h][((size_t)b * ho.cls[h] + cidx) * Q + q];
-    ho.out[h][((size_t)b * ho.cls[h] + cidx) * ldo + col0 + q] = a;
+    if (keep != nullptr && !keep[(size_t)b * Q + q]) a = ho.first[h][((size_t)b * ncls + cidx) * Q + q];
+    ho.out[h][((size_t)b * ncls + cidx) * ldo + col0 + q] = a;
     if (h == ho.center_head && pos_out != nullptr) pos_out[((size_t)b * Q + q) * 2 + cidx] = a;
   }
 }
@@ -713,8 +721,7 @@ int di_pred_heads(const void *x1, const void *x2, const void *w1, const float *b
                   const float *qpos, const void *keep, float *const *out, const float *const *first, const int *cls,
                   int nheads, int center_head, float *pos_out, int B, int Q, int ldo, int col0, void *stream) {
   using namespace di::tok;
-  DI_REQUIRE(nheads > 0 && nheads <= kMaxHeads && (nheads == 6 || nheads == 4 || nheads == 2 || nheads == 8),
-             "unsupported number of heads %d", nheads);
+  DI_REQUIRE(nheads > 0 && nheads <= kMaxHeads, "unsupported number of heads %d", nheads);
   HeadOut ho;
   int rows = 0;
   for (int h = 0; h < kMaxHeads; ++h) {
@@ -728,16 +735,9 @@ int di_pred_heads(const void *x1, const void *x2, const void *w1, const float *b
   ho.center_head = center_head;
   DI_REQUIRE(keep == nullptr || first != nullptr, "the on-the-image merge needs the first stage's outputs");
   const int K = x2 ? 256 : 128;
-  const dim3 grid((Q + 15) / 16, B), blk(256);
-  hipStream_t s = (hipStream_t)stream;
-#define DI_PH(HID)                                                                                                   \
-  hipLaunchKernelGGL((pred_head_kernel<HID>), grid, blk, 0, s, (const __half *)x1, (const __half *)x2, K,           \
-                     (const __half *)w1, b1, w2, b2, qpos, (const unsigned char *)keep, ho, pos_out, Q, ldo, col0, rows)
-  if (nheads == 6) DI_PH(384);
-  else if (nheads == 4) DI_PH(256);
-  else if (nheads == 8) DI_PH(512);
-  else DI_PH(128);
-#undef DI_PH
+  const dim3 grid((Q + 15) / 16, B, nheads), blk(256);
+  hipLaunchKernelGGL(pred_head_kernel, grid, blk, 0, (hipStream_t)stream, (const __half *)x1, (const __half *)x2, K,
+                     (const __half *)w1, b1, w2, b2, qpos, (const unsigned char *)keep, ho, pos_out, Q, ldo, col0);
   return di::check_launch("pred_heads");
 }
 
