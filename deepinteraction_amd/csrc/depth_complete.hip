@@ -17,14 +17,6 @@ namespace di {
 
 __device__ __forceinline__ float inv_depth(float d) { return d > 0.1f ? 100.f - d : d; }  // :171-174
 
-// float <-> unsigned with the same ordering (per-view min / max by integer atomics)
-__device__ __forceinline__ unsigned f2ord(float f) {
-  const unsigned b = __float_as_uint(f);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned u) {
-  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
-}
 // first valid row of a column, accumulated with atomicMin by the kernel that PRODUCES the map; H = "no valid pixel",
 // which np.argmax reports as row 0 (:209-213, :228)
 __device__ __forceinline__ int first_row(const int32_t *__restrict__ first, int idx, int H) {
@@ -55,14 +47,9 @@ __device__ __forceinline__ float cross_dilate_bin(const float *__restrict__ d, i
 
 __global__ __launch_bounds__(256) void dc_multiscale_kernel(const float *__restrict__ in,
                                                             float *__restrict__ out, int32_t *__restrict__ first_a,
-                                                            int32_t *__restrict__ first_b, unsigned *__restrict__ mm,
-                                                            int V, int H, int W) {
+                                                            int32_t *__restrict__ first_b, int V, int H, int W) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < V * W) first_a[i] = first_b[i] = H;          // accumulators of the later stages of this chain
-  if (i < V) {
-    mm[2 * i] = 0xFFFFFFFFu;
-    mm[2 * i + 1] = 0u;
-  }
   if (i >= V * H * W) return;
   const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
   const float *d = in + (size_t)v * H * W;
@@ -160,39 +147,41 @@ __global__ __launch_bounds__(256) void dc_fill_kernel(const float *__restrict__ 
 }
 
 // :248-250  valid = (s7 > 0.1) & top_mask ; s7 = valid ? median(s7) : s7   (valid kept for :260)
+// grid (blocks per view, views).  Also the block's min / max of the result (cv::minMaxLoc inside bilateralFilter_32f
+// needs the per-view extremes): plain stores of per-block partials - contended global atomics cost ~70 ns each here.
 __global__ __launch_bounds__(256) void dc_median_top_kernel(const float *__restrict__ in,
                                                             const int32_t *__restrict__ first,
                                                             float *__restrict__ out,
-                                                            float *__restrict__ valid, unsigned *__restrict__ mm,
+                                                            float *__restrict__ valid, float *__restrict__ mm_part,
                                                             int V, int H, int W) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in_map = i < V * H * W;
-  const int ic = in_map ? i : V * H * W - 1;
-  const int v = ic / (H * W), r = ic - v * H * W, y = r / W, x = r - y * W;
-  const float c = in[ic];
+  __shared__ float smin[4], smax[4];
+  const int v = blockIdx.y, r0 = blockIdx.x * 256 + threadIdx.x;
+  const bool in_map = r0 < H * W;
+  const int r = in_map ? r0 : H * W - 1;
+  const int y = r / W, x = r - y * W;
+  const size_t i = (size_t)v * H * W + r;
+  const float c = in[i];
   const bool ok = c > 0.1f && y >= first_row(first, v * W + x, H);
   const float o = ok ? median25(in + (size_t)v * H * W, H, W, y, x) : c;
   if (in_map) {
     valid[i] = ok ? 1.f : 0.f;
     out[i] = o;
   }
-  // per-view min / max of the result (cv::minMaxLoc inside bilateralFilter_32f): one pair of atomics per wave when
-  // the wave lies inside one view, per lane otherwise
-  unsigned lo = f2ord(o), hi = lo;
-  const int v0 = __shfl(v, 0);
-  if (__all(v == v0)) {
+  float mn = o, mx = o;
 #pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) {
-      lo = min(lo, (unsigned)__shfl_xor((int)lo, sft));
-      hi = max(hi, (unsigned)__shfl_xor((int)hi, sft));
-    }
-    if ((threadIdx.x & 63) == 0) {
-      atomicMin(&mm[2 * v], lo);
-      atomicMax(&mm[2 * v + 1], hi);
-    }
-  } else {
-    atomicMin(&mm[2 * v], lo);
-    atomicMax(&mm[2 * v + 1], hi);
+  for (int sft = 32; sft > 0; sft >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, sft));
+    mx = fmaxf(mx, __shfl_xor(mx, sft));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smin[threadIdx.x >> 6] = mn;
+    smax[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float *p = mm_part + ((size_t)v * gridDim.x + blockIdx.x) * 2;
+    p[0] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+    p[1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
   }
 }
 
@@ -205,16 +194,36 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 // :259-266  blurred = bilateralFilter(s7, 5, 0.5, 2.0); s7[valid] = blurred[valid]; invert back.
 __global__ __launch_bounds__(256) void dc_bilateral_invert_kernel(const float *__restrict__ in,
                                                                   const float *__restrict__ valid,
-                                                                  const unsigned *__restrict__ mm,
+                                                                  const float *__restrict__ mm_part,
                                                                   float *__restrict__ out, int V,
                                                                   int H, int W) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V * H * W) return;
-  const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
+  // grid (blocks per view, views); first the view's extremes from the per-block partials of the previous kernel
+  __shared__ float s_mm[2];
+  const int v = blockIdx.y;
+  if (threadIdx.x < 64) {
+    float mn_ = INFINITY, mx_ = -INFINITY;
+    for (int p = threadIdx.x; p < (int)gridDim.x; p += 64) {
+      mn_ = fminf(mn_, mm_part[((size_t)v * gridDim.x + p) * 2]);
+      mx_ = fmaxf(mx_, mm_part[((size_t)v * gridDim.x + p) * 2 + 1]);
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      mn_ = fminf(mn_, __shfl_xor(mn_, sft));
+      mx_ = fmaxf(mx_, __shfl_xor(mx_, sft));
+    }
+    if (threadIdx.x == 0) {
+      s_mm[0] = mn_;
+      s_mm[1] = mx_;
+    }
+  }
+  __syncthreads();
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= H * W) return;
+  const int i = v * H * W + r, y = r / W, x = r - y * W;
   const float *d = in + (size_t)v * H * W;
   const float c = d[r];
   float res = c;
-  const float mn = ord2f(mm[2 * v]), mx = ord2f(mm[2 * v + 1]);
+  const float mn = s_mm[0], mx = s_mm[1];
   if (valid[i] != 0.f && !(fabsf(mn - mx) < FLT_EPSILON)) {
     const double gcc = -0.5 / (0.5 * 0.5);   // sigma_color 0.5
     const double gsc = -0.5 / (2.0 * 2.0);   // sigma_space 2.0
@@ -253,11 +262,11 @@ extern "C" int di_depth_complete(const float *sparse, float *dense, float *scrat
   const int n = V * H * W;
   const dim3 g((n + 255) / 256), b(256);
   float *A = scratch, *B = scratch + (size_t)n, *valid = scratch + 2 * (size_t)n;
-  unsigned *mm = reinterpret_cast<unsigned *>(scratch + 3 * (size_t)n);
+  float *mm_part = scratch + 3 * (size_t)n;                  // per-block min / max partials: 2 * V * blocks-per-view
   int32_t *first_a = iscratch, *first_b = iscratch + (size_t)V * W;
-  // 13 launches: the per-column "first valid row" and the per-view min / max are accumulated with integer atomics by
-  // the kernels that produce the maps they describe
-  hipLaunchKernelGGL(dc_multiscale_kernel, g, b, 0, s, sparse, A, first_a, first_b, mm, V, H, W);   // s2 (+ accumulator init)
+  // 13 launches: the per-column "first valid row" is accumulated with integer atomics, the per-view min / max as
+  // per-block partials, by the kernels that produce the maps they describe
+  hipLaunchKernelGGL(dc_multiscale_kernel, g, b, 0, s, sparse, A, first_a, first_b, V, H, W);   // s2 (+ accumulator init)
   hipLaunchKernelGGL((dc_box_kernel<2, true>), g, b, 0, s, A, B, V, H, W);               // close: dilate
   hipLaunchKernelGGL((dc_box_kernel<2, false>), g, b, 0, s, B, A, V, H, W);              //        erode -> s3
   hipLaunchKernelGGL(dc_median_valid_kernel, g, b, 0, s, A, B, first_a, V, H, W);        // s4 (+ its top rows)
@@ -267,7 +276,8 @@ extern "C" int di_depth_complete(const float *sparse, float *dense, float *scrat
     hipLaunchKernelGGL((dc_fill_kernel<2, true>), g, b, 0, s, src, first_b, dst, (int32_t *)nullptr, V, H, W);
     float *t = src; src = dst; dst = t;
   }
-  hipLaunchKernelGGL(dc_median_top_kernel, g, b, 0, s, src, first_b, dst, valid, mm, V, H, W);
-  hipLaunchKernelGGL(dc_bilateral_invert_kernel, g, b, 0, s, dst, valid, mm, dense, V, H, W);
+  const dim3 gv((H * W + 255) / 256, V);
+  hipLaunchKernelGGL(dc_median_top_kernel, gv, b, 0, s, src, first_b, dst, valid, mm_part, V, H, W);
+  hipLaunchKernelGGL(dc_bilateral_invert_kernel, gv, b, 0, s, dst, valid, mm_part, dense, V, H, W);
   return check_launch("depth_complete");
 }

@@ -6,8 +6,8 @@
 // so all keys are distinct and "value descending, lower index first on ties" is plain descending K - a
 // deterministic rule where the reference's argsort leaves ties unspecified.  Five digit levels (11+11+10 value bits,
 // 10+10 index bits), each a multi-block histogram of the elements that still match the selected prefix and a
-// one-block pick of the digit that holds the k-th largest key; then one block collects the exactly k keys >= K*
-// (order irrelevant) and bitonic-sorts them.  11 small launches, no host synchronisation, no global atomics,
+// one-block pick of the digit that holds the k-th largest key; then the blocks collect the exactly k keys >= K*
+// into per-block segments and one block bitonic-sorts them.  12 small launches, no host synchronisation, no global atomics,
 // bit-reproducible.
 #include "di_common.h"
 
@@ -90,25 +90,50 @@ __global__ __launch_bounds__(1024) void pick_kernel(State *__restrict__ st, cons
   }
 }
 
-// one block per sample: gather the exactly k keys >= K* (all keys are distinct) into LDS, bitonic-sort them
-// (descending), write the indices
-__global__ __launch_bounds__(1024) void collect_sort_kernel(const float *__restrict__ scores, const State *__restrict__ st,
-                                                            long long *__restrict__ out_idx, float *__restrict__ out_val,
-                                                            int N, int k) {
-  __shared__ unsigned long long a[1024];
+// every block gathers the keys >= K* of its slice (all keys are distinct; exactly k exist in total) into its own
+// segment of `cand` (LDS counter, plain stores) and records how many it found
+__global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ scores, const State *__restrict__ st,
+                                                      unsigned long long *__restrict__ cand, int *__restrict__ cand_n,
+                                                      int N, int k) {
   __shared__ int cnt;
-  const int b = blockIdx.x, t = threadIdx.x;
+  const int b = blockIdx.y;
   const unsigned long long Kstar = st[b].prefix;   // all 52 bits selected
-  a[t] = 0ull;
-  if (t == 0) cnt = 0;
+  if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
   const float *s = scores + (size_t)b * N;
-  for (int i = t; i < N; i += 1024) {
+  const int per = (N + kHistBlocks - 1) / kHistBlocks;
+  const int lo = blockIdx.x * per, hi = min(lo + per, N);
+  unsigned long long *dst = cand + ((size_t)b * kHistBlocks + blockIdx.x) * k;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
     const unsigned long long K = make_key(s[i], i);
     if (K >= Kstar) {
       const int pos = atomicAdd(&cnt, 1);          // LDS atomic: order irrelevant, the sort follows
-      if (pos < 1024) a[pos] = K;
+      if (pos < k) dst[pos] = K;
     }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) cand_n[b * kHistBlocks + blockIdx.x] = min(cnt, k);
+}
+
+// one block per sample: concatenate the segments (k keys in total), bitonic-sort them (descending), write the indices
+__global__ __launch_bounds__(1024) void sort_kernel(const unsigned long long *__restrict__ cand, const int *__restrict__ cand_n,
+                                                    long long *__restrict__ out_idx, float *__restrict__ out_val, int k) {
+  __shared__ unsigned long long a[1024];
+  __shared__ int off[kHistBlocks + 1];
+  const int b = blockIdx.x, t = threadIdx.x;
+  a[t] = 0ull;
+  if (t == 0) {
+    int o = 0;
+    for (int p = 0; p < kHistBlocks; ++p) {
+      off[p] = o;
+      o += cand_n[b * kHistBlocks + p];
+    }
+    off[kHistBlocks] = o;
+  }
+  __syncthreads();
+  for (int e = t; e < kHistBlocks * k; e += 1024) {
+    const int p = e / k, j = e - p * k;
+    if (j < off[p + 1] - off[p] && off[p] + j < 1024) a[off[p] + j] = cand[((size_t)b * kHistBlocks + p) * k + j];
   }
   __syncthreads();
   for (int len = 2; len <= 1024; len <<= 1) {
@@ -138,8 +163,7 @@ __global__ __launch_bounds__(1024) void collect_sort_kernel(const float *__restr
 extern "C" {
 
 long long di_topk_workspace_bytes(int B, int k) {
-  (void)k;
-  return (long long)B * ((long long)di::tk::kHistBlocks * di::tk::kBins * (long long)sizeof(int) + 64) + 64;
+  return (long long)B * ((long long)di::tk::kHistBlocks * (di::tk::kBins * (long long)sizeof(int) + (long long)k * 8 + 4) + 64) + 64;
 }
 
 int di_topk_fwd(const float *scores, long long *out_idx, float *out_val, void *workspace, int B, int N, int k,
@@ -151,12 +175,15 @@ int di_topk_fwd(const float *scores, long long *out_idx, float *out_val, void *w
   unsigned char *w = reinterpret_cast<unsigned char *>(workspace);
   int *part = reinterpret_cast<int *>(w);
   State *st = reinterpret_cast<State *>(w + (size_t)B * kHistBlocks * kBins * sizeof(int));
+  unsigned long long *cand = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(st) + (size_t)B * 64);
+  int *cand_n = reinterpret_cast<int *>(cand + (size_t)B * kHistBlocks * k);
   const int shifts[5] = {41, 30, 20, 10, 0}, nbits[5] = {11, 11, 10, 10, 10};
   for (int l = 0; l < 5; ++l) {
     hipLaunchKernelGGL(hist_kernel, dim3(kHistBlocks, B), dim3(256), 0, s, scores, st, part, N, shifts[l], nbits[l], l == 0);
     hipLaunchKernelGGL(pick_kernel, dim3(B), dim3(1024), 0, s, st, part, nbits[l], k, l == 0);
   }
-  hipLaunchKernelGGL(collect_sort_kernel, dim3(B), dim3(1024), 0, s, scores, st, out_idx, out_val, N, k);
+  hipLaunchKernelGGL(collect_kernel, dim3(kHistBlocks, B), dim3(256), 0, s, scores, st, cand, cand_n, N, k);
+  hipLaunchKernelGGL(sort_kernel, dim3(B), dim3(1024), 0, s, cand, cand_n, out_idx, out_val, k);
   return di::check_launch("topk_fwd");
 }
 

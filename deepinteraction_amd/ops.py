@@ -234,7 +234,7 @@ def depth_complete(sparse):
     assert sparse.dtype == torch.float32 and sparse.is_contiguous() and sparse.dim() == 3
     V, H, W = sparse.shape
     dense = torch.empty_like(sparse)
-    scratch = torch.empty(3 * V * H * W + 2 * V, dtype=torch.float32, device=sparse.device)
+    scratch = torch.empty(3 * V * H * W + 2 * V * ((H * W + 255) // 256), dtype=torch.float32, device=sparse.device)
     iscratch = torch.empty(2 * V * W, dtype=torch.int32, device=sparse.device)
     _lib.call('di_depth_complete', sparse.data_ptr(), dense.data_ptr(), scratch.data_ptr(),
               iscratch.data_ptr(), V, H, W, _stream())

@@ -146,7 +146,7 @@ int di_depth_scatter(const float *pts, int n_pts, int pt_stride, const float *pr
                      const float *aug_rev, unsigned long long *packed, float *depth, int n_views,
                      int Hi, int Wi, float ori_H, float ori_W, void *stream);
 /* (2) ip_basic fill_in_multiscale(extrapolate=False, blur='bilateral') per view
- *     (depth_map_utils.py:134-287) on the GPU.  scratch: 3*n_views*Hi*Wi + 2*n_views floats;
+ *     (depth_map_utils.py:134-287) on the GPU.  scratch: 3*n_views*Hi*Wi + 2*n_views*ceil(Hi*Wi/256) floats;
  *     iscratch: 2*n_views*Wi int32 (first valid row per column of two intermediate maps). */
 int di_depth_complete(const float *sparse, float *dense, float *scratch, int32_t *iscratch,
                       int n_views, int Hi, int Wi, void *stream);
