@@ -230,8 +230,204 @@ static int launch(const void *x1, const void *x2, const void *x3, const void *w1
   return check_launch("pointwise_chain");
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// SEVERAL chains over ONE input map in one launch: the query / key / value projections of a
+// LocalContextAttentionBlock (and the query projection of the P2I block, which reads the same image map) - reference
+// encoder_utils.py:92-117, 127-131 - read their input once.  The input pixels of a wave (up to NG groups of 16) stay in
+// registers as MFMA B operands while the workgroup walks the chains: stage the chain's weights in LDS, multiply,
+// store that chain's output map.  Per chain the arithmetic is exactly pointwise_chain_kernel<128, 0 | 128>'s.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kMaxChains = 4;
+struct Chain {
+  const __half *w1, *w2;     // (128,128) fp16; w2 null: one link
+  const float *b1, *b2;
+  __half *y;
+  int relu1, relu2;
+};
+struct MultiArgs {
+  Chain c[kMaxChains];
+  int n;
+};
+
+template <int NG>
+__global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__restrict__ x, MultiArgs A, long long M) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  unsigned char *lw1 = lds;
+  unsigned char *lw2 = lds + 128 * 128 * 2;
+  float *lb = reinterpret_cast<float *>(lds + 2 * 128 * 128 * 2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const long long ngroups = (M + 15) / 16;
+  const long long wg = (long long)blockIdx.x * NW + wave, stride = (long long)gridDim.x * NW;
+
+  // this wave's pixels: group j = wg + j * stride; B operands (pixel i, channels 32kk + 8g .. +7) loaded ONCE
+  h8 xb[NG][4];
+  long long pix[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const long long grp = wg + j * stride;
+    pix[j] = grp < ngroups ? grp * 16 + i : M;                 // M: "no pixel" (never stored)
+    const long long pc = pix[j] < M ? pix[j] : M - 1;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      xb[j][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(x + pc * 128 + kk * 32 + g * 8));
+  }
+
+  for (int c = 0; c < A.n; ++c) {
+    const Chain ch = A.c[c];
+    const bool two = ch.w2 != nullptr;
+    if (c > 0) __syncthreads();                               // everybody is done with the previous chain's weights
+    stage_w<128, false>(ch.w1, lw1, tid);
+    if (two) stage_w<128, true>(ch.w2, lw2, tid);
+    if (tid < 128) {
+      lb[tid] = ch.b1[tid];
+      lb[128 + tid] = two ? ch.b2[tid] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j0 = 0; j0 < NG; j0 += 2) {
+      if (wg + j0 * stride >= ngroups) break;                 // wave-uniform: no barrier inside
+      // ---- link 1 on the pair of groups (j0, j0 + 1)
+      f4 acc[2][8];
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) acc[pg][nb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(16 * nb + i, 4 * kk + g)));
+#pragma unroll
+          for (int pg = 0; pg < 2; ++pg) acc[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[j0 + pg][kk], acc[pg][nb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        const f4 bias = *reinterpret_cast<const f4 *>(lb + 16 * nb + 4 * g);
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) {
+          f4 t = acc[pg][nb] + bias;
+          if (ch.relu1) t = __builtin_elementwise_max(t, f4{0.f, 0.f, 0.f, 0.f});
+          acc[pg][nb] = t;
+        }
+      }
+      if (!two) {
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg)
+          if (pix[j0 + pg] < M) {
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) {
+              h4 o;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[r] = (_Float16)acc[pg][nb][r];
+              *reinterpret_cast<h4 *>(ch.y + pix[j0 + pg] * 128 + 16 * nb + 4 * g) = o;
+            }
+          }
+        continue;
+      }
+      // ---- link 2: the hidden activations in registers are the B operand (k = 8g + 4t + r <-> channel 32kk + 16t + 4g + r)
+      h8 hb[2][4];
+#pragma unroll
+      for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          h8 t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            t[r] = (_Float16)acc[pg][2 * kk][r];
+            t[4 + r] = (_Float16)acc[pg][2 * kk + 1][r];
+          }
+          hb[pg][kk] = t;
+        }
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        f4 o2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(16 * nb + i, 4 * kk + g)));
+#pragma unroll
+          for (int pg = 0; pg < 2; ++pg) o2[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, hb[pg][kk], o2[pg], 0, 0, 0);
+        }
+        const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) {
+          f4 t = o2[pg] + bias;
+          if (ch.relu2) t = __builtin_elementwise_max(t, f4{0.f, 0.f, 0.f, 0.f});
+          if (pix[j0 + pg] < M) {
+            h4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (_Float16)t[r];
+            *reinterpret_cast<h4 *>(ch.y + pix[j0 + pg] * 128 + 16 * nb + 4 * g) = o;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
+template <int NG>
+static int launch_multi(const void *x, const MultiArgs &A, long long M, long long grid, hipStream_t stream) {
+  constexpr int LDS = 2 * 128 * 128 * 2 + 1024;
+  static bool attr = false;   // idempotent
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void *)pointwise_multi_kernel<NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return DI_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL((pointwise_multi_kernel<NG>), dim3((unsigned)grid), dim3(NT), LDS, stream, (const __half *)x, A, M);
+  return check_launch("pointwise_multi");
+}
+
 }  // namespace pw
 }  // namespace di
+
+extern "C" int di_pointwise_multi_fwd(const void *x, int n_chains, const void *const *w1, const float *const *b1,
+                                      const void *const *w2, const float *const *b2, void *const *y, const int *relu1,
+                                      const int *relu2, long long n_pixels, void *stream) {
+  using namespace di::pw;
+  DI_REQUIRE(n_pixels > 0 && x, "empty map");
+  DI_REQUIRE(n_chains >= 1 && n_chains <= kMaxChains, "1..%d chains, got %d", kMaxChains, n_chains);
+  MultiArgs A;
+  A.n = n_chains;
+  for (int c = 0; c < kMaxChains; ++c) {
+    Chain &ch = A.c[c];
+    if (c < n_chains) {
+      DI_REQUIRE(w1[c] && b1[c] && y[c], "chain %d: w1, b1, y are required", c);
+      DI_REQUIRE((w2[c] == nullptr) == (b2[c] == nullptr), "chain %d: second link needs w2 and b2", c);
+      ch = Chain{(const __half *)w1[c], (const __half *)w2[c], b1[c], b2[c], (__half *)y[c], relu1[c], relu2[c]};
+    } else {
+      ch = Chain{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    }
+  }
+  static int n_cu = 0;   // idempotent initialisation; a race only repeats the query
+  if (n_cu == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+      di::set_error("cannot query the CU count");
+      return DI_ERR_LAUNCH;
+    }
+    n_cu = cus;
+  }
+  // every wave keeps its pixel groups in registers: NG in {2, 4, 6} groups per wave, one workgroup per CU when the map
+  // allows it (more workgroups than CUs only beyond 6 groups per wave)
+  const long long ngroups = (n_pixels + 15) / 16;
+  long long grid = n_cu;
+  if (ngroups < (long long)grid * NW * 2) grid = (ngroups + NW * 2 - 1) / (NW * 2);
+  int ng = (int)((ngroups + grid * NW - 1) / (grid * NW));
+  if (ng > 6) {
+    grid = (ngroups + NW * 6 - 1) / (NW * 6);
+    ng = 6;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (ng <= 2) return launch_multi<2>(x, A, n_pixels, grid, s);
+  if (ng <= 4) return launch_multi<4>(x, A, n_pixels, grid, s);
+  return launch_multi<6>(x, A, n_pixels, grid, s);
+}
 
 extern "C" int di_pointwise_chain_fwd(const void *x1, const void *x2, const void *x3, const void *w1,
                                       const float *b1, const void *w2, const float *b2, void *y,

@@ -6,6 +6,8 @@ channels-last + HIP execution (see models/utils/encoder_utils.py).  Per forward 
 feature-independent geometry (projection constants, sparse depth, depth completion) is built
 once per sample and shared by all layers through a private key in `pts_metas`.
 """
+import math
+
 import torch
 from torch import nn
 
@@ -13,7 +15,7 @@ from .... import ops
 from ....registry import NECKS
 from ....utils import param_key
 from ..utils.encoder_utils import (GEOM_KEY, ConvBNReLU, LocalContextAttentionBlock, MMRI_I2P, MMRI_P2I,
-                                   mix2)
+                                   fusable_projections, mix2, project_many)
 
 
 class DeepInteractionEncoderLayer(nn.Module):
@@ -41,9 +43,16 @@ class DeepInteractionEncoderLayer(nn.Module):
         P2P_feat = self.P_IML(lidar_feat, lidar_feat)
         # P_integration(cat(P_out_proj(cat(I2P, P2P)), lidar)) (:26-27): one fused kernel at inference
         new_lidar_feat = mix2(self.P_out_proj, I2P_feat, P2P_feat, self.P_integration, lidar_feat)
-        # image side (reads the same layer inputs; independent of the BEV side)
-        P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas)
-        I2I_feat = self.I_IML(img_feat, img_feat)
+        # image side (reads the same layer inputs; independent of the BEV side).  fp16 inference: the four projections
+        # of the image map (query / key / value of I_IML and the query of P2I) are ONE launch that reads it once.
+        I, PL = self.I_IML, self.P2I_block.Local
+        if fusable_projections(img_feat, I.query_project, I.key_project, I.value_project, PL.query_project):
+            q_i, k_i, v_i, q_p = project_many([I.query_project, I.key_project, I.value_project, PL.query_project], img_feat)
+            P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas, query=q_p)
+            I2I_feat = ops.local_attention(q_i, k_i, v_i, I.kernel_size, I.kernel_size, 1.0 / math.sqrt(k_i.size(1)))
+        else:
+            P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas)
+            I2I_feat = self.I_IML(img_feat, img_feat)
         new_img_feat = mix2(self.I_out_proj, P2I_feat.view(BN, -1, I_H, I_W), I2I_feat, self.I_integration, img_feat)
         return new_img_feat, new_lidar_feat
 

@@ -118,6 +118,37 @@ def project(seq, x):
     return seq(x)
 
 
+def _chain_consts(seq, dtype):
+    """(w1, b1, relu1, w2 | None, b2 | None, relu2) of a one- or two-link projection (folded BatchNorm)."""
+    mods = list(seq) if isinstance(seq, nn.Sequential) else [seq]
+    w1, _, b1 = mods[0].folded(dtype)
+    if len(mods) == 1:
+        return (w1, b1, mods[0].use_activation, None, None, False)
+    w2, _, b2 = mods[1].folded(dtype)
+    return (w1, b1, mods[0].use_activation, w2, b2, mods[1].use_activation)
+
+
+def fusable_projections(x, *seqs):
+    """All of `seqs` are one- or two-link 128-channel fp16 inference chains (the form ops.pointwise_multi takes)."""
+    for seq in seqs:
+        mods = list(seq) if isinstance(seq, nn.Sequential) else [seq]
+        if not (len(mods) in (1, 2) and _fusable(x, *mods) and all(m.conv.in_channels == 128 for m in mods)):
+            return False
+    return len(seqs) <= 4
+
+
+def project_many(seqs, x):
+    """Several projections of the SAME map (e.g. query / key / value of a self-attention block): one launch that reads
+    x once (ops.pointwise_multi) for 128-channel fp16 inference chains, else one after the other."""
+    ok = 1 <= len(seqs) <= 4
+    for seq in seqs:
+        mods = list(seq) if isinstance(seq, nn.Sequential) else [seq]
+        ok = ok and len(mods) in (1, 2) and _fusable(x, *mods) and all(m.conv.in_channels == 128 for m in mods)
+    if ok and len(seqs) > 1:
+        return ops.pointwise_multi(x, [_chain_consts(seq, x.dtype) for seq in seqs])
+    return [project(seq, x) for seq in seqs]
+
+
 def mix2(proj1, a, b, proj2, c):
     """proj2(cat(proj1(cat(a, b)), c)) - the out_proj / integration pair of an encoder layer
     (deepinteraction_encoder.py:26-27, 31-32) - as ONE fused kernel when possible."""
@@ -190,10 +221,15 @@ class LocalContextAttentionBlock(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
-    def forward(self, target_feats, source_feats, **kwargs):
-        query = project(self.query_project, target_feats)
-        key = project(self.key_project, source_feats)
-        value = project(self.value_project, source_feats)
+    def forward(self, target_feats, source_feats, query=None, **kwargs):
+        """`query`: the already projected query map, when the caller computed it together with other projections of
+        `target_feats` (DeepInteractionEncoderLayer shares one read of the image map between both image-side blocks)."""
+        if query is None and target_feats is source_feats:
+            query, key, value = project_many([self.query_project, self.key_project, self.value_project], source_feats)
+        else:
+            if query is None:
+                query = project(self.query_project, target_feats)
+            key, value = project_many([self.key_project, self.value_project], source_feats)
         ks = self.kernel_size
         scale = 1.0 / math.sqrt(key.size(1))
         if not (torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)):
@@ -255,10 +291,10 @@ class MMRI_P2I(nn.Module):
         self.Warp = BEVWarp()
         self.Local = LocalContextAttentionBlock(in_channels, out_channels, kernel_size, last_affine=True)
 
-    def forward(self, lidar_feats, img_feats, img_metas, pts_metas, **kwargs):
+    def forward(self, lidar_feats, img_feats, img_metas, pts_metas, query=None, **kwargs):
         warped = self.Warp(lidar_feats, img_feats, img_metas, pts_metas)        # B, N, C, H, W
         B, N, C, H, W = warped.shape
-        out = self.Local(img_feats.reshape(B * N, C, H, W), warped.reshape(B * N, C, H, W))
+        out = self.Local(img_feats.reshape(B * N, C, H, W), warped.reshape(B * N, C, H, W), query=query)
         return out.view(B, N, C, H, W)
 
 

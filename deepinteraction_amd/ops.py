@@ -171,6 +171,32 @@ def pointwise_chain(x1, w1, b1, relu1, x2=None, w2=None, b2=None, relu2=False, x
     return y
 
 
+def pointwise_multi(x, chains):
+    """Several chains over one fp16 channels-last map (C = 128) in ONE launch, x read once.  chains: list of
+    (w1, b1, relu1, w2 | None, b2 | None, relu2) with w* fp16 (128,128), b* float32 (128).  Returns one map per chain."""
+    _dev(x)
+    x = cl(x)
+    n, C, H, W = x.shape
+    assert C == 128 and x.dtype == torch.float16 and 1 <= len(chains) <= 4
+    nc = len(chains)
+    ys = [empty_cl(n, 128, H, W, x) for _ in chains]
+    P, F, I = ctypes.c_void_p * nc, ctypes.c_void_p * nc, ctypes.c_int * nc
+    for (w1, b1, r1, w2, b2, r2) in chains:
+        assert w1.shape == (128, 128) and w1.dtype == torch.float16 and w1.is_contiguous() and b1.dtype == torch.float32
+        assert (w2 is None) == (b2 is None)
+        if w2 is not None:
+            assert w2.shape == (128, 128) and w2.dtype == torch.float16 and w2.is_contiguous() and b2.dtype == torch.float32
+    ptr = lambda t: None if t is None else t.data_ptr()
+    a_w1, a_b1 = P(*[c[0].data_ptr() for c in chains]), F(*[c[1].data_ptr() for c in chains])
+    a_w2, a_b2 = P(*[ptr(c[3]) for c in chains]), F(*[ptr(c[4]) for c in chains])
+    a_y = P(*[y.data_ptr() for y in ys])
+    a_r1, a_r2 = I(*[int(bool(c[2])) for c in chains]), I(*[int(bool(c[5])) for c in chains])
+    _profiled('pointwise_multi', n, lambda: _lib.call(
+        'di_pointwise_multi_fwd', x.data_ptr(), nc, ctypes.addressof(a_w1), ctypes.addressof(a_b1), ctypes.addressof(a_w2),
+        ctypes.addressof(a_b2), ctypes.addressof(a_y), ctypes.addressof(a_r1), ctypes.addressof(a_r2), n * H * W, _stream()))
+    return ys
+
+
 # ------------------------------------------------------------------ image -> BEV
 def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p=0.0, seed=0):
     """One sample.  img (V,C,Hi,Wi), qfold (1,C,Hb,Wb) channels-last; pillars (P,T,D) f32,

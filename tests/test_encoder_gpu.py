@@ -366,3 +366,24 @@ def test_pointwise_chain(k1, k2, relu, npix):
     ref = h.float().view(n, H, W, 128).permute(0, 3, 1, 2)
     err = (out - ref).abs().max().item()
     assert err <= 1e-3 * max(ref.abs().max().item(), 1.0), err
+
+
+@pytest.mark.parametrize('npix', [(1, 7, 5), (2, 33, 61), (1, 180, 180), (6, 112, 200), (12, 112, 200)])
+def test_pointwise_multi_equals_single_chains(npix):
+    """Several projections of one map in one launch (ops.pointwise_multi: the map is read once, the chains' weights are
+    staged one after the other) - bit-identical to launching ops.pointwise_chain per chain (same MFMA order)."""
+    _require_gpu()
+    n, H, W = npix
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(n, 128, H, W, generator=g).half().to(DEV).contiguous(memory_format=torch.channels_last)
+    mk = lambda: ((torch.randn(128, 128, generator=g) / math.sqrt(128)).half().to(DEV), (torch.randn(128, generator=g) * 0.1).to(DEV))
+    chains = []
+    for two, r1, r2 in ((True, True, True), (True, True, False), (False, False, False), (True, False, True)):
+        w1, b1 = mk()
+        w2, b2 = mk() if two else (None, None)
+        chains.append((w1, b1, r1, w2, b2, r2))
+    for k in (2, 3, 4):
+        got = ops.pointwise_multi(x, chains[:k])
+        for (w1, b1, r1, w2, b2, r2), y in zip(chains[:k], got):
+            ref = ops.pointwise_chain(x, w1, b1, r1, w2=w2, b2=b2, relu2=r2)
+            assert torch.equal(y, ref)
