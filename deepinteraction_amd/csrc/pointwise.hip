@@ -238,27 +238,47 @@ static int launch(const void *x1, const void *x2, const void *x3, const void *w1
 // store that chain's output map.  Per chain the arithmetic is exactly pointwise_chain_kernel<128, 0 | 128>'s.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kMaxChains = 4;
+constexpr int kChainImage = 2 * 128 * 128 * 2 + 1024;   // LDS image of a chain: W1 | W2 (swizzled, W2 k-permuted) | b1 | b2
 struct Chain {
-  const __half *w1, *w2;     // (128,128) fp16; w2 null: one link
-  const float *b1, *b2;
+  const unsigned char *img;  // kChainImage bytes, prepared once on the host (ops.chain_image)
   __half *y;
-  int relu1, relu2;
+  int relu1, relu2, two;
 };
 struct MultiArgs {
   Chain c[kMaxChains];
   int n;
 };
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
 
+// The chain images are moved by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land as one contiguous KiB, no
+// VGPRs, asynchronous) into one of TWO LDS buffers: the next chain's weights arrive while the current chain is
+// multiplied.
 template <int NG>
 __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__restrict__ x, MultiArgs A, long long M) {
   extern __shared__ __align__(16) unsigned char lds[];
-  unsigned char *lw1 = lds;
-  unsigned char *lw2 = lds + 128 * 128 * 2;
-  float *lb = reinterpret_cast<float *>(lds + 2 * 128 * 128 * 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const long long ngroups = (M + 15) / 16;
   const long long wg = (long long)blockIdx.x * NW + wave, stride = (long long)gridDim.x * NW;
+
+  auto dma_chain = [&](const Chain &ch, unsigned char *buf) {
+    const unsigned char *src = ch.img + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int chunk = wave * 4 + j;                         // W1: KiB chunks 0..31
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + chunk * 1024), (lptr_t)(buf + chunk * 1024), 16, 0, 0);
+    }
+    if (ch.two) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int chunk = 32 + wave * 4 + j;                  // W2: chunks 32..63
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + chunk * 1024), (lptr_t)(buf + chunk * 1024), 16, 0, 0);
+      }
+    }
+    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(src + 64 * 1024), (lptr_t)(buf + 64 * 1024), 16, 0, 0);   // biases
+  };
+  dma_chain(A.c[0], lds);
 
   // this wave's pixels: group j = wg + j * stride; B operands (pixel i, channels 32kk + 8g .. +7) loaded ONCE
   h8 xb[NG][4];
@@ -275,15 +295,14 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
 
   for (int c = 0; c < A.n; ++c) {
     const Chain ch = A.c[c];
-    const bool two = ch.w2 != nullptr;
-    if (c > 0) __syncthreads();                               // everybody is done with the previous chain's weights
-    stage_w<128, false>(ch.w1, lw1, tid);
-    if (two) stage_w<128, true>(ch.w2, lw2, tid);
-    if (tid < 128) {
-      lb[tid] = ch.b1[tid];
-      lb[128 + tid] = two ? ch.b2[tid] : 0.f;
-    }
+    const bool two = ch.two != 0;
+    unsigned char *buf = lds + (c & 1) * kChainImage;
+    const unsigned char *lw1 = buf, *lw2 = buf + 128 * 128 * 2;
+    const float *lb = reinterpret_cast<const float *>(buf + 2 * 128 * 128 * 2);
+    // chain c's image has landed (issued a whole chain ago), and everybody is done with the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (c + 1 < A.n) dma_chain(A.c[c + 1], lds + ((c + 1) & 1) * kChainImage);
 #pragma unroll
     for (int j0 = 0; j0 < NG; j0 += 2) {
       if (wg + j0 * stride >= ngroups) break;                 // wave-uniform: no barrier inside
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
 
 template <int NG>
 static int launch_multi(const void *x, const MultiArgs &A, long long M, long long grid, hipStream_t stream) {
-  constexpr int LDS = 2 * 128 * 128 * 2 + 1024;
+  constexpr int LDS = 2 * kChainImage;
   static bool attr = false;   // idempotent
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void *)pointwise_multi_kernel<NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -385,22 +404,20 @@ static int launch_multi(const void *x, const MultiArgs &A, long long M, long lon
 }  // namespace pw
 }  // namespace di
 
-extern "C" int di_pointwise_multi_fwd(const void *x, int n_chains, const void *const *w1, const float *const *b1,
-                                      const void *const *w2, const float *const *b2, void *const *y, const int *relu1,
-                                      const int *relu2, long long n_pixels, void *stream) {
+extern "C" int di_pointwise_multi_fwd(const void *x, int n_chains, const void *const *image, void *const *y,
+                                      const int *relu1, const int *relu2, const int *two_links, long long n_pixels,
+                                      void *stream) {
   using namespace di::pw;
   DI_REQUIRE(n_pixels > 0 && x, "empty map");
   DI_REQUIRE(n_chains >= 1 && n_chains <= kMaxChains, "1..%d chains, got %d", kMaxChains, n_chains);
   MultiArgs A;
   A.n = n_chains;
   for (int c = 0; c < kMaxChains; ++c) {
-    Chain &ch = A.c[c];
     if (c < n_chains) {
-      DI_REQUIRE(w1[c] && b1[c] && y[c], "chain %d: w1, b1, y are required", c);
-      DI_REQUIRE((w2[c] == nullptr) == (b2[c] == nullptr), "chain %d: second link needs w2 and b2", c);
-      ch = Chain{(const __half *)w1[c], (const __half *)w2[c], b1[c], b2[c], (__half *)y[c], relu1[c], relu2[c]};
+      DI_REQUIRE(image[c] && y[c], "chain %d: image and y are required", c);
+      A.c[c] = Chain{(const unsigned char *)image[c], (__half *)y[c], relu1[c], relu2[c], two_links[c]};
     } else {
-      ch = Chain{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+      A.c[c] = Chain{nullptr, nullptr, 0, 0, 0};
     }
   }
   static int n_cu = 0;   // idempotent initialisation; a race only repeats the query

@@ -118,14 +118,23 @@ def project(seq, x):
     return seq(x)
 
 
+_CHAIN_IMAGES = {}
+
+
 def _chain_consts(seq, dtype):
-    """(w1, b1, relu1, w2 | None, b2 | None, relu2) of a one- or two-link projection (folded BatchNorm)."""
+    """(LDS image, relu1, relu2, two links) of a one- or two-link projection (folded BatchNorm) for
+    ops.pointwise_multi; the image is rebuilt when a parameter of the projection changes."""
     mods = list(seq) if isinstance(seq, nn.Sequential) else [seq]
-    w1, _, b1 = mods[0].folded(dtype)
-    if len(mods) == 1:
-        return (w1, b1, mods[0].use_activation, None, None, False)
-    w2, _, b2 = mods[1].folded(dtype)
-    return (w1, b1, mods[0].use_activation, w2, b2, mods[1].use_activation)
+    key = tuple(param_key(m) for m in mods)
+    hit = _CHAIN_IMAGES.get(id(seq))
+    if hit is None or hit[0] != key:
+        w1, _, b1 = mods[0].folded(dtype)
+        w2, b2 = (None, None)
+        if len(mods) == 2:
+            w2, _, b2 = mods[1].folded(dtype)
+        hit = (key, ops.chain_image(w1, b1, w2, b2))
+        _CHAIN_IMAGES[id(seq)] = hit
+    return (hit[1], mods[0].use_activation, mods[-1].use_activation if len(mods) == 2 else False, len(mods) == 2)
 
 
 def fusable_projections(x, *seqs):

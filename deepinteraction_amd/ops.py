@@ -171,29 +171,48 @@ def pointwise_chain(x1, w1, b1, relu1, x2=None, w2=None, b2=None, relu2=False, x
     return y
 
 
+def chain_image(w1, b1, w2=None, b2=None):
+    """The 66 560-byte LDS image of a chain that `pointwise_multi` moves by LDS-DMA: W1 | W2 as 128 rows x 256 B with the
+    16-B chunks XOR-swizzled by the row (conflict-free ds_read_b128 fragments), W2's columns re-ordered for the
+    register-resident hidden operand (k = 8g + 4t + r <-> channel 32kk + 16t + 4g + r), then b1 | b2 (float32)."""
+    dev = w1.device
+
+    def img(w, perm):
+        w = w.detach().to(torch.float16).contiguous()
+        if perm:
+            w = w.view(128, 4, 2, 4, 4).permute(0, 1, 3, 2, 4).contiguous()          # [r][kk][g][t][4]
+        W = w.view(128, 16, 8)
+        r = torch.arange(128, device=dev).view(128, 1)
+        c = torch.arange(16, device=dev).view(1, 16)
+        out = torch.empty_like(W)
+        out[r.expand(128, 16), c ^ (r & 15)] = W
+        return out.view(-1).view(torch.uint8)
+    zero_w = torch.zeros(128 * 128 * 2, dtype=torch.uint8, device=dev)
+    zero_b = torch.zeros(128, dtype=torch.float32, device=dev)
+    parts = [img(w1, False), img(w2, True) if w2 is not None else zero_w,
+             b1.detach().float().contiguous().view(torch.uint8),
+             (b2.detach().float().contiguous() if b2 is not None else zero_b).view(torch.uint8)]
+    return torch.cat(parts).contiguous()
+
+
 def pointwise_multi(x, chains):
     """Several chains over one fp16 channels-last map (C = 128) in ONE launch, x read once.  chains: list of
-    (w1, b1, relu1, w2 | None, b2 | None, relu2) with w* fp16 (128,128), b* float32 (128).  Returns one map per chain."""
+    (image, relu1, relu2, two_links) with image = chain_image(...).  Returns one map per chain."""
     _dev(x)
     x = cl(x)
     n, C, H, W = x.shape
     assert C == 128 and x.dtype == torch.float16 and 1 <= len(chains) <= 4
     nc = len(chains)
     ys = [empty_cl(n, 128, H, W, x) for _ in chains]
-    P, F, I = ctypes.c_void_p * nc, ctypes.c_void_p * nc, ctypes.c_int * nc
-    for (w1, b1, r1, w2, b2, r2) in chains:
-        assert w1.shape == (128, 128) and w1.dtype == torch.float16 and w1.is_contiguous() and b1.dtype == torch.float32
-        assert (w2 is None) == (b2 is None)
-        if w2 is not None:
-            assert w2.shape == (128, 128) and w2.dtype == torch.float16 and w2.is_contiguous() and b2.dtype == torch.float32
-    ptr = lambda t: None if t is None else t.data_ptr()
-    a_w1, a_b1 = P(*[c[0].data_ptr() for c in chains]), F(*[c[1].data_ptr() for c in chains])
-    a_w2, a_b2 = P(*[ptr(c[3]) for c in chains]), F(*[ptr(c[4]) for c in chains])
-    a_y = P(*[y.data_ptr() for y in ys])
-    a_r1, a_r2 = I(*[int(bool(c[2])) for c in chains]), I(*[int(bool(c[5])) for c in chains])
+    P, I = ctypes.c_void_p * nc, ctypes.c_int * nc
+    for (im, r1, r2, two) in chains:
+        assert im.dtype == torch.uint8 and im.numel() == 2 * 128 * 128 * 2 + 1024 and im.is_cuda
+    a_im, a_y = P(*[c[0].data_ptr() for c in chains]), P(*[y.data_ptr() for y in ys])
+    a_r1, a_r2 = I(*[int(bool(c[1])) for c in chains]), I(*[int(bool(c[2])) for c in chains])
+    a_two = I(*[int(bool(c[3])) for c in chains])
     _profiled('pointwise_multi', n, lambda: _lib.call(
-        'di_pointwise_multi_fwd', x.data_ptr(), nc, ctypes.addressof(a_w1), ctypes.addressof(a_b1), ctypes.addressof(a_w2),
-        ctypes.addressof(a_b2), ctypes.addressof(a_y), ctypes.addressof(a_r1), ctypes.addressof(a_r2), n * H * W, _stream()))
+        'di_pointwise_multi_fwd', x.data_ptr(), nc, ctypes.addressof(a_im), ctypes.addressof(a_y), ctypes.addressof(a_r1),
+        ctypes.addressof(a_r2), ctypes.addressof(a_two), n * H * W, _stream()))
     return ys
 
 

@@ -275,12 +275,14 @@ int di_polar_bev_sample_bwd(const void *grad_out, const float *proj, const float
 
 /* Several 128-channel chains over ONE input map in one launch (the query / key / value projections of a
  * LocalContextAttentionBlock and of the P2I block read the same map, encoder_utils.py:92-117,127-131): chain c is
- * y[c] = act2(W2[c] . act1(W1[c] . x + b1[c]) + b2[c]) (second link optional: w2[c] == b2[c] == NULL).  x (n_pixels,128)
- * fp16 is read once; `w1`, `b1`, `w2`, `b2`, `y`, `relu1`, `relu2` are HOST arrays of n_chains <= 4 device pointers /
- * flags.  Same arithmetic as di_pointwise_chain_fwd per chain. */
-int di_pointwise_multi_fwd(const void *x, int n_chains, const void *const *w1_host, const float *const *b1_host,
-                           const void *const *w2_host, const float *const *b2_host, void *const *y_host,
-                           const int *relu1_host, const int *relu2_host, long long n_pixels, void *stream);
+ * y[c] = act2(W2[c] . act1(W1[c] . x + b1[c]) + b2[c]) (second link optional).  x (n_pixels,128) fp16 is read once.
+ * `image`, `y`, `relu1`, `relu2`, `two_links` are HOST arrays of n_chains <= 4 entries; image[c] is the DEVICE pointer
+ * of the chain's 66 560-byte LDS image, prepared once by the caller: W1 then W2 (zeros when absent), each 128 rows x
+ * 256 B with 16-B chunk c of row r at position c ^ (r & 15), W2's columns k-permuted (chunk 4kk+g = columns
+ * 32kk+4g..+3 | 32kk+16+4g..+3), then b1, b2 as 128 float32 each.  Same arithmetic as di_pointwise_chain_fwd. */
+int di_pointwise_multi_fwd(const void *x, int n_chains, const void *const *image_host, void *const *y_host,
+                           const int *relu1_host, const int *relu2_host, const int *two_links_host, long long n_pixels,
+                           void *stream);
 
 /* ---------------------------------------------------------------- 3x3 convolutions (stride 1, pad 1), implicit GEMM
  * The shared convolutions of the MMRI encoder (necks/deepinteraction_encoder.py:45-62) and the heat-map heads of the

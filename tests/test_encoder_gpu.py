@@ -382,8 +382,9 @@ def test_pointwise_multi_equals_single_chains(npix):
         w1, b1 = mk()
         w2, b2 = mk() if two else (None, None)
         chains.append((w1, b1, r1, w2, b2, r2))
-    for k in (2, 3, 4):
-        got = ops.pointwise_multi(x, chains[:k])
+    packed = [(ops.chain_image(w1, b1, w2, b2), r1, r2, w2 is not None) for (w1, b1, r1, w2, b2, r2) in chains]
+    for k in (1, 2, 3, 4):
+        got = ops.pointwise_multi(x, packed[:k])
         for (w1, b1, r1, w2, b2, r2), y in zip(chains[:k], got):
             ref = ops.pointwise_chain(x, w1, b1, r1, w2=w2, b2=b2, relu2=r2)
             assert torch.equal(y, ref)
