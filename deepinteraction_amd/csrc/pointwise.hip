@@ -259,8 +259,9 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const long long ngroups = (M + 15) / 16;
-  const long long wg = (long long)blockIdx.x * NW + wave, stride = (long long)gridDim.x * NW;
+  const int Mi = (int)M;                                       // < 2^24 pixels (checked by the host): 32-bit offsets
+  const int ngroups = (Mi + 15) / 16;
+  const int wg = blockIdx.x * NW + wave, stride = gridDim.x * NW;
 
   auto dma_chain = [&](const Chain &ch, unsigned char *buf) {
     const unsigned char *src = ch.img + lane * 16;
@@ -282,15 +283,15 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
 
   // this wave's pixels: group j = wg + j * stride; B operands (pixel i, channels 32kk + 8g .. +7) loaded ONCE
   h8 xb[NG][4];
-  long long pix[NG];
+  int pix[NG];
 #pragma unroll
   for (int j = 0; j < NG; ++j) {
-    const long long grp = wg + j * stride;
-    pix[j] = grp < ngroups ? grp * 16 + i : M;                 // M: "no pixel" (never stored)
-    const long long pc = pix[j] < M ? pix[j] : M - 1;
+    const int grp = wg + j * stride;
+    pix[j] = grp < ngroups ? grp * 16 + i : Mi;                // M: "no pixel" (never stored)
+    const int pc = pix[j] < Mi ? pix[j] : Mi - 1;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
-      xb[j][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(x + pc * 128 + kk * 32 + g * 8));
+      xb[j][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(x + (size_t)pc * 128 + kk * 32 + g * 8));
   }
 
   for (int c = 0; c < A.n; ++c) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
     __syncthreads();
     if (c + 1 < A.n) dma_chain(A.c[c + 1], lds + ((c + 1) & 1) * kChainImage);
 #pragma unroll
-    for (int j0 = 0; j0 < NG; j0 += 2) {
+    for (int j0 = 0; j0 < NG; j0 += 2) {                      // (odd NG: the last pair's second slot repeats the last group, unstored)
       if (wg + j0 * stride >= ngroups) break;                 // wave-uniform: no barrier inside
       // ---- link 1 on the pair of groups (j0, j0 + 1)
       f4 acc[2][8];
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
         for (int kk = 0; kk < 4; ++kk) {
           const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(16 * nb + i, 4 * kk + g)));
 #pragma unroll
-          for (int pg = 0; pg < 2; ++pg) acc[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[j0 + pg][kk], acc[pg][nb], 0, 0, 0);
+          for (int pg = 0; pg < 2; ++pg) acc[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[j0 + pg < NG ? j0 + pg : NG - 1][kk], acc[pg][nb], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -331,15 +332,20 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
         }
       }
       if (!two) {
+        // output rows of the LAST link are permuted in the image: fragment pair (2p, 2p+1) of lane group g holds
+        // channels 32p + 8g + 0..7 -> one 16-B store per pair (8-B stores are store-issue bound: ~7 B/clk/CU)
 #pragma unroll
         for (int pg = 0; pg < 2; ++pg)
-          if (pix[j0 + pg] < M) {
+          if (j0 + pg < NG && pix[j0 + pg < NG ? j0 + pg : NG - 1] < Mi) {
 #pragma unroll
-            for (int nb = 0; nb < 8; ++nb) {
-              h4 o;
+            for (int p2 = 0; p2 < 4; ++p2) {
+              h8 o;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = (_Float16)acc[pg][nb][r];
-              *reinterpret_cast<h4 *>(ch.y + pix[j0 + pg] * 128 + 16 * nb + 4 * g) = o;
+              for (int r = 0; r < 4; ++r) {
+                o[r] = (_Float16)acc[pg][2 * p2][r];
+                o[4 + r] = (_Float16)acc[pg][2 * p2 + 1][r];
+              }
+              *reinterpret_cast<h8 *>(ch.y + (size_t)pix[j0 + pg < NG ? j0 + pg : NG - 1] * 128 + 32 * p2 + 8 * g) = o;
             }
           }
         continue;
@@ -359,26 +365,36 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
           hb[pg][kk] = t;
         }
 #pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        f4 o2[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+      for (int p2 = 0; p2 < 4; ++p2) {
+        f4 o2[2][2];                                           // [fragment of the pair][pixel group]
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(16 * nb + i, 4 * kk + g)));
+        for (int e = 0; e < 2; ++e) {
+          const int nb = 2 * p2 + e;
+          o2[e][0] = o2[e][1] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int pg = 0; pg < 2; ++pg) o2[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, hb[pg][kk], o2[pg], 0, 0, 0);
-        }
-        const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
+          for (int kk = 0; kk < 4; ++kk) {
+            const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(16 * nb + i, 4 * kk + g)));
 #pragma unroll
-        for (int pg = 0; pg < 2; ++pg) {
-          f4 t = o2[pg] + bias;
-          if (ch.relu2) t = __builtin_elementwise_max(t, f4{0.f, 0.f, 0.f, 0.f});
-          if (pix[j0 + pg] < M) {
-            h4 o;
+            for (int pg = 0; pg < 2; ++pg) o2[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, hb[pg][kk], o2[e][pg], 0, 0, 0);
+          }
+          const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (_Float16)t[r];
-            *reinterpret_cast<h4 *>(ch.y + pix[j0 + pg] * 128 + 16 * nb + 4 * g) = o;
+          for (int pg = 0; pg < 2; ++pg) {
+            o2[e][pg] += bias;
+            if (ch.relu2) o2[e][pg] = __builtin_elementwise_max(o2[e][pg], f4{0.f, 0.f, 0.f, 0.f});
           }
         }
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg)
+          if (j0 + pg < NG && pix[j0 + pg < NG ? j0 + pg : NG - 1] < Mi) {
+            h8 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              o[r] = (_Float16)o2[0][pg][r];
+              o[4 + r] = (_Float16)o2[1][pg][r];
+            }
+            *reinterpret_cast<h8 *>(ch.y + (size_t)pix[j0 + pg < NG ? j0 + pg : NG - 1] * 128 + 32 * p2 + 8 * g) = o;   // channels 32p + 8g + 0..7
+          }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -408,7 +424,7 @@ extern "C" int di_pointwise_multi_fwd(const void *x, int n_chains, const void *c
                                       const int *relu1, const int *relu2, const int *two_links, long long n_pixels,
                                       void *stream) {
   using namespace di::pw;
-  DI_REQUIRE(n_pixels > 0 && x, "empty map");
+  DI_REQUIRE(n_pixels > 0 && n_pixels < (1ll << 24) && x, "bad map size (1 .. 2^24 - 1 pixels)");
   DI_REQUIRE(n_chains >= 1 && n_chains <= kMaxChains, "1..%d chains, got %d", kMaxChains, n_chains);
   MultiArgs A;
   A.n = n_chains;
@@ -430,20 +446,20 @@ extern "C" int di_pointwise_multi_fwd(const void *x, int n_chains, const void *c
     }
     n_cu = cus;
   }
-  // every wave keeps its pixel groups in registers: NG in {2, 4, 6} groups per wave, one workgroup per CU when the map
-  // allows it (more workgroups than CUs only beyond 6 groups per wave)
+  // every wave keeps its pixel groups in registers: NG in {2, 4, 5} groups per wave, one workgroup per CU when the map
+  // allows it (more workgroups than CUs only beyond 5 groups per wave)
   const long long ngroups = (n_pixels + 15) / 16;
   long long grid = n_cu;
   if (ngroups < (long long)grid * NW * 2) grid = (ngroups + NW * 2 - 1) / (NW * 2);
   int ng = (int)((ngroups + grid * NW - 1) / (grid * NW));
-  if (ng > 6) {
-    grid = (ngroups + NW * 6 - 1) / (NW * 6);
-    ng = 6;
+  if (ng > 5) {
+    grid = (ngroups + NW * 5 - 1) / (NW * 5);
+    ng = 5;
   }
   hipStream_t s = (hipStream_t)stream;
   if (ng <= 2) return launch_multi<2>(x, A, n_pixels, grid, s);
   if (ng <= 4) return launch_multi<4>(x, A, n_pixels, grid, s);
-  return launch_multi<6>(x, A, n_pixels, grid, s);
+  return launch_multi<5>(x, A, n_pixels, grid, s);
 }
 
 extern "C" int di_pointwise_chain_fwd(const void *x1, const void *x2, const void *x3, const void *w1,

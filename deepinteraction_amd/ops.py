@@ -174,8 +174,18 @@ def pointwise_chain(x1, w1, b1, relu1, x2=None, w2=None, b2=None, relu2=False, x
 def chain_image(w1, b1, w2=None, b2=None):
     """The 66 560-byte LDS image of a chain that `pointwise_multi` moves by LDS-DMA: W1 | W2 as 128 rows x 256 B with the
     16-B chunks XOR-swizzled by the row (conflict-free ds_read_b128 fragments), W2's columns re-ordered for the
-    register-resident hidden operand (k = 8g + 4t + r <-> channel 32kk + 16t + 4g + r), then b1 | b2 (float32)."""
+    register-resident hidden operand (k = 8g + 4t + r <-> channel 32kk + 16t + 4g + r), the rows of the last link
+    re-ordered for 16-B output stores, then b1 | b2 (float32)."""
     dev = w1.device
+    # output rows of the LAST link: image row 16nb + 4g + r holds channel 32(nb/2) + 8g + 4(nb%2) + r, so that a lane's
+    # fragment pair is 8 consecutive channels (one 16-B store)
+    rr = torch.arange(128, device=dev)
+    nb, gq, rq = rr // 16, (rr % 16) // 4, rr % 4
+    last = 32 * (nb // 2) + 8 * gq + 4 * (nb % 2) + rq
+    if w2 is None:
+        w1, b1 = w1[last], b1[last]
+    else:
+        w2, b2 = w2[last], b2[last]
 
     def img(w, perm):
         w = w.detach().to(torch.float16).contiguous()

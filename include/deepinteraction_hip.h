@@ -279,7 +279,9 @@ int di_polar_bev_sample_bwd(const void *grad_out, const float *proj, const float
  * `image`, `y`, `relu1`, `relu2`, `two_links` are HOST arrays of n_chains <= 4 entries; image[c] is the DEVICE pointer
  * of the chain's 66 560-byte LDS image, prepared once by the caller: W1 then W2 (zeros when absent), each 128 rows x
  * 256 B with 16-B chunk c of row r at position c ^ (r & 15), W2's columns k-permuted (chunk 4kk+g = columns
- * 32kk+4g..+3 | 32kk+16+4g..+3), then b1, b2 as 128 float32 each.  Same arithmetic as di_pointwise_chain_fwd. */
+ * 32kk+4g..+3 | 32kk+16+4g..+3), the rows (and bias entries) of the chain's LAST link permuted so that image row
+ * 16nb+4g+r is output channel 32(nb/2)+8g+4(nb%2)+r, then b1, b2 as 128 float32 each.  Same arithmetic as
+ * di_pointwise_chain_fwd. */
 int di_pointwise_multi_fwd(const void *x, int n_chains, const void *const *image_host, void *const *y_host,
                            const int *relu1_host, const int *relu2_host, const int *two_links_host, long long n_pixels,
                            void *stream);
