@@ -270,22 +270,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
 #undef DI_FETCH_B
 #undef DI_COMMIT_B
 
+  // epilogue.  The staged weight rows are permuted on the host (row 16nb + 4g + r = output channel 32(nb/2) + 8g +
+  // 4(nb%2) + r): a lane's fragment pair is 8 consecutive channels of pixel (row, x0 + i) = one 16-B store.
   const int xx = x0 + i;
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const int yy = y0 + wm * RW + r;
     if (yy >= H || xx >= W) continue;
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-      const int n0 = (wn * NTW + n) * 16 + 4 * g;
-      h4 o;
+    for (int p2 = 0; p2 < NTW / 2; ++p2) {
+      const int c0 = 32 * ((wn * NTW) / 2 + p2) + 8 * g;
+      h8 o;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float v = acc[r][n][q] + bias[n0 + q];
-        if (relu) v = fmaxf(v, 0.f);
-        o[q] = (_Float16)v;
+        float v0 = acc[r][2 * p2][q] + bias[c0 + q], v1 = acc[r][2 * p2 + 1][q] + bias[c0 + 4 + q];
+        if (relu) {
+          v0 = fmaxf(v0, 0.f);
+          v1 = fmaxf(v1, 0.f);
+        }
+        o[q] = (_Float16)v0;
+        o[4 + q] = (_Float16)v1;
       }
-      *reinterpret_cast<h4 *>(y + (((size_t)img * H + yy) * W + xx) * 128 + n0) = o;
+      *reinterpret_cast<h8 *>(y + (((size_t)img * H + yy) * W + xx) * 128 + c0) = o;
     }
   }
 }

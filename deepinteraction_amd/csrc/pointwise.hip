@@ -39,11 +39,19 @@ __device__ __forceinline__ int w_off(int r, int c) {
 
 // stage W (128 x K, row-major fp16 in global) into LDS; PERM: the first 128 columns are re-ordered for
 // the register-resident hidden operand: LDS column 32kk + 8g + 4t + r <- global column 32kk + 16t + 4g + r
-template <int K, bool PERM>
+// channel held by LDS row 16nb + 4g + r of the LAST link of a chain: 32(nb/2) + 8g + 4(nb%2) + r - a lane's fragment
+// pair (2p, 2p+1) is then 8 consecutive output channels = one 16-B store (8-B stores are store-issue bound)
+__device__ __forceinline__ int out_row(int rl) {
+  const int nb = rl >> 4, gq = (rl >> 2) & 3, rq = rl & 3;
+  return 32 * (nb >> 1) + 8 * gq + 4 * (nb & 1) + rq;
+}
+
+template <int K, bool PERM, bool ROWPERM = false>
 __device__ __forceinline__ void stage_w(const __half *__restrict__ w, unsigned char *lds, int tid) {
   constexpr int CH = K / 8;            // 16-B chunks per row
   for (int e = tid; e < 128 * CH; e += NT) {
-    const int r = e / CH, c = e - r * CH;
+    const int rl = e / CH, c = e - rl * CH;
+    const int r = ROWPERM ? out_row(rl) : rl;                // source row
     uint4 val;
     if (PERM && c < 16) {
       // destination chunk c = 4kk + g holds columns 32kk + 8g + (4t + r'), i.e. two 8-B pieces of the source
@@ -54,7 +62,7 @@ __device__ __forceinline__ void stage_w(const __half *__restrict__ w, unsigned c
     } else {
       val = *reinterpret_cast<const uint4 *>(w + (size_t)r * K + c * 8);
     }
-    *reinterpret_cast<uint4 *>(lds + w_off<K>(r, c)) = val;
+    *reinterpret_cast<uint4 *>(lds + w_off<K>(rl, c)) = val;
   }
 }
 
@@ -91,11 +99,11 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
   };
   if (ch0 < nchunk) load_x(ch0);
 
-  stage_w<K1, false>(w1, lw1, tid);
-  if (K2 > 0) stage_w<(K2 > 0 ? K2 : 128), true>(w2, lw2, tid);
+  stage_w<K1, false, K2 == 0>(w1, lw1, tid);                  // the rows of the LAST link are permuted (16-B stores)
+  if (K2 > 0) stage_w<(K2 > 0 ? K2 : 128), true, true>(w2, lw2, tid);
   if (tid < 128) {
-    lb[tid] = b1[tid];
-    lb[128 + tid] = K2 > 0 ? b2[tid] : 0.f;
+    lb[tid] = b1[K2 == 0 ? out_row(tid) : tid];
+    lb[128 + tid] = K2 > 0 ? b2[out_row(tid)] : 0.f;
   }
   __syncthreads();
 
@@ -134,11 +142,14 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
       for (int pg = 0; pg < PG; ++pg)
         if (pix[pg] < M) {
 #pragma unroll
-          for (int nb = 0; nb < 8; ++nb) {
-            h4 o;
+          for (int p2 = 0; p2 < 4; ++p2) {
+            h8 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (_Float16)acc[pg][nb][r];
-            *reinterpret_cast<h4 *>(y + pix[pg] * 128 + 16 * nb + 4 * g) = o;
+            for (int r = 0; r < 4; ++r) {
+              o[r] = (_Float16)acc[pg][2 * p2][r];
+              o[4 + r] = (_Float16)acc[pg][2 * p2 + 1][r];
+            }
+            *reinterpret_cast<h8 *>(y + pix[pg] * 128 + 32 * p2 + 8 * g) = o;
           }
         }
       if (ch + chstep < nchunk) load_x(ch + chstep);
@@ -170,29 +181,38 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
       }
     }
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      f4 o2[PG];
+    for (int p2 = 0; p2 < 4; ++p2) {
+      f4 o2[2][PG];                                            // [fragment of the pair][pixel group]
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) o2[pg] = f4{0.f, 0.f, 0.f, 0.f};
+      for (int e = 0; e < 2; ++e) {
+        const int nb = 2 * p2 + e;
 #pragma unroll
-      for (int kk = 0; kk < KK2; ++kk) {
-        const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<(K2 > 0 ? K2 : 128)>(16 * nb + i, 4 * kk + g)));
+        for (int pg = 0; pg < PG; ++pg) o2[e][pg] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int pg = 0; pg < PG; ++pg)
-          o2[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, kk < 4 ? hb[pg][kk] : xb[pg][kk & 3], o2[pg], 0, 0, 0);
-      }
-      const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
+        for (int kk = 0; kk < KK2; ++kk) {
+          const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<(K2 > 0 ? K2 : 128)>(16 * nb + i, 4 * kk + g)));
 #pragma unroll
-      for (int pg = 0; pg < PG; ++pg) {
-        f4 t = o2[pg] + bias;
-        if (relu2) t = __builtin_elementwise_max(t, f4{0.f, 0.f, 0.f, 0.f});
-        if (pix[pg] < M) {
-          h4 o;
+          for (int pg = 0; pg < PG; ++pg)
+            o2[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, kk < 4 ? hb[pg][kk] : xb[pg][kk & 3], o2[e][pg], 0, 0, 0);
+        }
+        const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (_Float16)t[r];
-          *reinterpret_cast<h4 *>(y + pix[pg] * 128 + 16 * nb + 4 * g) = o;
+        for (int pg = 0; pg < PG; ++pg) {
+          o2[e][pg] += bias;
+          if (relu2) o2[e][pg] = __builtin_elementwise_max(o2[e][pg], f4{0.f, 0.f, 0.f, 0.f});
         }
       }
+#pragma unroll
+      for (int pg = 0; pg < PG; ++pg)
+        if (pix[pg] < M) {
+          h8 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o[r] = (_Float16)o2[0][pg][r];
+            o[4 + r] = (_Float16)o2[1][pg][r];
+          }
+          *reinterpret_cast<h8 *>(y + pix[pg] * 128 + 32 * p2 + 8 * g) = o;     // channels 32p + 8g + 0..7
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (ch + chstep < nchunk) load_x(ch + chstep);

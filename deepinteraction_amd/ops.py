@@ -618,7 +618,11 @@ def pack_conv3x3(weight, bias=None, bn=None):
         ws = None
         Cin = w.shape[1]
         if Cout == 128 and Cin % 32 == 0:          # (chunk, ky, kx, n, c): one contiguous 24 KB tile per (chunk, ky)
-            ws = w.view(128, Cin // 32, 32, 3, 3).permute(1, 3, 4, 0, 2).to(torch.float16).contiguous()
+            # rows permuted for 16-B output stores: staged row 16nb + 4g + r = channel 32(nb/2) + 8g + 4(nb%2) + r
+            rr = torch.arange(128, device=w.device)
+            nb, gq, rq = rr // 16, (rr % 16) // 4, rr % 4
+            wr = w[32 * (nb // 2) + 8 * gq + 4 * (nb % 2) + rq]
+            ws = wr.view(128, Cin // 32, 32, 3, 3).permute(1, 3, 4, 0, 2).to(torch.float16).contiguous()
         return wp.to(torch.float16).contiguous(), ws, b.contiguous()
 
 

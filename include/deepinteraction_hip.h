@@ -293,7 +293,8 @@ int di_pointwise_multi_fwd(const void *x, int n_chains, const void *const *image
  * x (n,H,W,Cin) fp16, Cin % 32 == 0; w_packed (Cout_pad, 9, Cin) fp16 = the torch weight (Cout,Cin,3,3) permuted to
  * (Cout,3,3,Cin), rows zero-padded to 16 when Cout <= 16; bias float32 (Cout) (a following BatchNorm folded in by the
  * caller); Cout == 128 or Cout <= 16; y (n,H,W,Cout) fp16, or (n,Cout,H,W) when out_nchw.
- * w_staged (optional, Cout == 128): the same weights as (Cin/32, 3 ky, 3 kx, 128, 32) fp16 - with it the kernel
+ * w_staged (optional, Cout == 128): the same weights as (Cin/32, 3 ky, 3 kx, 128, 32) fp16 with the 128 rows
+ * permuted (row 16nb+4g+r = output channel 32(nb/2)+8g+4(nb%2)+r, for 16-B stores) - with it the kernel
  * that stages the weights through LDS runs (the fast one); NULL selects the weights-from-L2 kernel. */
 int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w_staged, const float *bias, void *y, int n, int H,
                    int W, int Cin, int Cout, int relu, int out_nchw, void *stream);
