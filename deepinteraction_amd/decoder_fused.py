@@ -15,7 +15,8 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .utils import param_key
+from . import utils
+from .utils import fork_join, param_key
 
 
 def usable(dec, lidar_feat, img_feat):
@@ -122,7 +123,15 @@ class FusedDecoder:
         h = ops.token_linear(z, l1.weight.detach(), b1, act1=2)
         return ops.token_linear(h, l2.weight.detach(), b2, res1=z, ln1=_ln(g('norm3')), keep=keep, eps=g('norm3').eps)
 
-    def _decoder_layer(self, layer, x, qpe, lidar_flat_tokens, bev_pos, B, Q):
+    def _cross_kv(self, layer, lidar_flat_tokens, bev_pos):
+        """K and V of the cross attention (decoder_utils.py:98-105): they depend on the BEV map only, not on the queries."""
+        ca = layer.multihead_attn
+        cw = self._c('dl_ca', ca, lambda: _mha_consts(ca))[0]
+        E = ca.embed_dim
+        kpe = layer.key_pos_embed(bev_pos, lidar_flat_tokens.dtype)
+        return F.linear(lidar_flat_tokens + kpe, cw[E:], ca.in_proj_bias[E:])       # (B,HW,2C) = [K | V]
+
+    def _decoder_layer(self, layer, x, qpe, kv, B, Q):
         """decoder_utils.py:83-113 (post-norm; positional embeddings added to q, k and v)."""
         sa, ca = layer.self_attn, layer.multihead_attn
         wq, bq, wo, bo = self._c('dl_sa', sa, lambda: _mha_consts(sa))
@@ -132,8 +141,6 @@ class FusedDecoder:
         cw, cb, cwo, cbo = self._c('dl_ca', ca, lambda: _mha_consts(ca))
         E = ca.embed_dim
         q = ops.token_linear(x, cw[:E], cb[:E], pos=qpe)
-        kpe = layer.key_pos_embed(bev_pos, x.dtype)
-        kv = F.linear(lidar_flat_tokens + kpe, cw[E:], ca.in_proj_bias[E:])         # (B,HW,2C) = [K | V]
         o = ops.mha_decode(q.view(B, Q, E), kv, ca.num_heads, float(ca.head_dim) ** -0.5).view(B * Q, E)
         x = ops.token_linear(o, cwo, cbo, res1=x, ln1=_ln(layer.norm2), eps=layer.norm2.eps)
         b1, b2 = self._c('dl_ffn', [layer.linear1.bias, layer.linear2.bias],
@@ -152,8 +159,17 @@ class FusedDecoder:
         BN, I_C, I_H, I_W = img_feat.shape
         V = dec.num_views
 
-        dense_heatmap = dec._heatmap(dec.heatmap_head, lidar_feat)
-        dense_heatmap_img = dec._heatmap(dec.heatmap_head_img, new_lidar_feat)
+        tokens = lidar_feat.permute(0, 2, 3, 1).reshape(B, HW, C)                    # view of the channels-last map
+
+        def first_map():        # everything that needs the shared-conv BEV map only
+            return dec._heatmap(dec.heatmap_head, lidar_feat), self._cross_kv(dec.decoder[0], tokens, dec._bev_pos(dev))
+
+        if utils.OVERLAP & 8:
+            dense_heatmap_img, (dense_heatmap, kv) = fork_join(
+                dev, lambda: dec._heatmap(dec.heatmap_head_img, new_lidar_feat), first_map)
+        else:
+            dense_heatmap, kv = first_map()
+            dense_heatmap_img = dec._heatmap(dec.heatmap_head_img, new_lidar_feat)
         k1 = {'nuScenes': (8, 9), 'Waymo': (1, 2)}.get(dec.test_cfg['dataset'], ())
         heatmap = ops.heatmap_nms(dense_heatmap, dense_heatmap_img, dec.nms_kernel_size,
                                   [c for c in k1 if c < ncls]).view(B, ncls, HW)
@@ -164,8 +180,7 @@ class FusedDecoder:
         x, qpe, pos, labels = ops.query_init(lidar_feat, top, ce_w, ce_b, pe_consts)
         dec.query_labels, dec.top_proposals = labels, top
 
-        tokens = lidar_feat.permute(0, 2, 3, 1).reshape(B, HW, C)                    # view of the channels-last map
-        x = self._decoder_layer(dec.decoder[0], x, qpe, tokens, dec._bev_pos(dev), B, Q)
+        x = self._decoder_layer(dec.decoder[0], x, qpe, kv, B, Q)
 
         heads0 = self._c('ph0', dec.prediction_heads[0], lambda: _heads_consts(dec.prediction_heads[0], x.dtype))
         names, cls = list(dec.prediction_heads[0].heads), heads0[4]

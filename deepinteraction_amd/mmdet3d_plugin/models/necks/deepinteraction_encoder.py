@@ -13,9 +13,10 @@ from torch import nn
 
 from .... import ops
 from ....registry import NECKS
-from ....utils import param_key
-from ..utils.encoder_utils import (GEOM_KEY, ConvBNReLU, LocalContextAttentionBlock, MMRI_I2P, MMRI_P2I,
-                                   fusable_projections, mix2, project_many)
+from .... import utils
+from ....utils import fork_join, param_key
+from ..utils.encoder_utils import (GEOM_KEY, BEVWarp, ConvBNReLU, LocalContextAttentionBlock, MMRI_I2P, MMRI_P2I,
+                                   fusable_projections, mix2, project_many, sample_geometry)
 
 
 class DeepInteractionEncoderLayer(nn.Module):
@@ -34,17 +35,21 @@ class DeepInteractionEncoderLayer(nn.Module):
         self.I_integration = ConvBNReLU(2 * hidden_channel, hidden_channel, kernel_size=1,
                                         norm_layer=nn.BatchNorm2d, activation_layer=None)
 
-    def forward(self, img_feat, lidar_feat, img_metas, pts_metas):
-        batch_size = lidar_feat.shape[0]
-        BN, I_C, I_H, I_W = img_feat.shape
-        img5 = img_feat.view(batch_size, -1, I_C, I_H, I_W)
-        # BEV side
+    # The BEV side and the image side of a layer read the same inputs and are independent (reference :21-33).  The BEV
+    # side is a chain of SMALL launches (127-276 workgroups on a 180 x 180 map: half of the 256 CUs idle), so at
+    # inference it runs on a second HIP stream, forked from and joined with the caller's stream - under hipGraph capture
+    # the two sides become parallel branches of the graph.
+
+    def _bev_side(self, lidar_feat, img5, img_metas, pts_metas):
         I2P_feat = self.I2P_block(lidar_feat, img5, img_metas, pts_metas)
         P2P_feat = self.P_IML(lidar_feat, lidar_feat)
         # P_integration(cat(P_out_proj(cat(I2P, P2P)), lidar)) (:26-27): one fused kernel at inference
-        new_lidar_feat = mix2(self.P_out_proj, I2P_feat, P2P_feat, self.P_integration, lidar_feat)
-        # image side (reads the same layer inputs; independent of the BEV side).  fp16 inference: the four projections
-        # of the image map (query / key / value of I_IML and the query of P2I) are ONE launch that reads it once.
+        return mix2(self.P_out_proj, I2P_feat, P2P_feat, self.P_integration, lidar_feat)
+
+    def _image_side(self, img_feat, img5, lidar_feat, img_metas, pts_metas):
+        BN, I_C, I_H, I_W = img_feat.shape
+        # fp16 inference: the four projections of the image map (query / key / value of I_IML and the query of P2I)
+        # are ONE launch that reads it once.
         I, PL = self.I_IML, self.P2I_block.Local
         if fusable_projections(img_feat, I.query_project, I.key_project, I.value_project, PL.query_project):
             q_i, k_i, v_i, q_p = project_many([I.query_project, I.key_project, I.value_project, PL.query_project], img_feat)
@@ -53,7 +58,22 @@ class DeepInteractionEncoderLayer(nn.Module):
         else:
             P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas)
             I2I_feat = self.I_IML(img_feat, img_feat)
-        new_img_feat = mix2(self.I_out_proj, P2I_feat.view(BN, -1, I_H, I_W), I2I_feat, self.I_integration, img_feat)
+        return mix2(self.I_out_proj, P2I_feat.view(BN, -1, I_H, I_W), I2I_feat, self.I_integration, img_feat)
+
+    def forward(self, img_feat, lidar_feat, img_metas, pts_metas):
+        batch_size = lidar_feat.shape[0]
+        BN, I_C, I_H, I_W = img_feat.shape
+        img5 = img_feat.view(batch_size, -1, I_C, I_H, I_W)
+        if utils.OVERLAP & 1 and lidar_feat.is_cuda and not torch.is_grad_enabled():
+            # fork: everything already queued on the caller's stream (the layer inputs, the per-sample geometry)
+            # precedes the BEV side; join: the caller's stream continues after both sides.  Tensors crossing the fork
+            # or the join stay referenced until after the join, so neither stream's allocator pool can recycle them
+            # under a kernel of the other stream.
+            return tuple(fork_join(lidar_feat.device,
+                                   lambda: self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas),
+                                   lambda: self._bev_side(lidar_feat, img5, img_metas, pts_metas)))
+        new_lidar_feat = self._bev_side(lidar_feat, img5, img_metas, pts_metas)
+        new_img_feat = self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas)
         return new_img_feat, new_lidar_feat
 
 
@@ -98,13 +118,37 @@ class DeepInteractionEncoder(nn.Module):
         return conv(x)
 
     def forward(self, img_feats, pts_feats, img_metas, pts_metas):
-        new_img_feat = self._shared_conv(self.shared_conv_img, img_feats)
-        new_pts_feat = self._shared_conv(self.shared_conv_pts, pts_feats)
-        pts_feat_conv = new_pts_feat.clone()
         own_geom = GEOM_KEY not in pts_metas
         own_bounds = 'pillar_batch_bounds' not in pts_metas
+        dev = img_feats.device
+        I_H, I_W = img_feats.shape[-2:]
         if own_geom:
             pts_metas[GEOM_KEY] = [None] * len(img_metas)
+        geoms = [sample_geometry(img_metas, pts_metas, b, (I_H, I_W), dev) for b in range(len(img_metas))]
+
+        def depth_maps():
+            # sparse depth + completion depend on the points and the metas only: ~15 tiny launches per sample
+            for b, g in enumerate(geoms):
+                BEVWarp.dense_depth(g, pts_metas['pts'][b], I_H, I_W)
+
+        def pts_conv():
+            y = self._shared_conv(self.shared_conv_pts, pts_feats)
+            return y, y.clone()
+
+        if img_feats.is_cuda and not torch.is_grad_enabled() and utils.OVERLAP & 6:
+            # the image conv fills the chip for 4.1 waves of tiles, the BEV conv for 1.1 and the depth chain never does:
+            # concurrent branches (fork/join, parallel paths under capture)
+            if utils.OVERLAP & 2:
+                outs = fork_join(dev, lambda: self._shared_conv(self.shared_conv_img, img_feats), pts_conv,
+                                 depth_maps if utils.OVERLAP & 4 else None)
+                new_img_feat, (new_pts_feat, pts_feat_conv) = outs[0], outs[1]
+            else:
+                def convs():
+                    return self._shared_conv(self.shared_conv_img, img_feats), pts_conv()
+                (new_img_feat, (new_pts_feat, pts_feat_conv)), _ = fork_join(dev, convs, depth_maps)
+        else:
+            new_img_feat = self._shared_conv(self.shared_conv_img, img_feats)
+            new_pts_feat, pts_feat_conv = pts_conv()
         try:
             for i in range(self.num_layers):
                 new_img_feat, new_pts_feat = self.fusion_blocks[i](new_img_feat, new_pts_feat, img_metas,
