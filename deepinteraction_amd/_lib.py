@@ -24,8 +24,9 @@ SIGNATURES = {
     'di_locatt_weighting_bwd_ori': [_c_p] * 3 + [_c_i] * 7 + [_c_p],
     'di_locatt_weighting_bwd_weight': [_c_p] * 3 + [_c_i] * 7 + [_c_p],
     'di_pointwise_chain_fwd': [_c_p] * 8 + [ctypes.c_longlong] + [_c_i] * 4 + [_c_p],
-    'di_i2p_attn_fwd': [_c_p] * 9 + [_c_i] * 9 + [_c_f, _c_f, _c_i, _c_p],
-    'di_i2p_attn_fwd_ex': [_c_p] * 9 + [_c_i] * 9 + [_c_f, _c_f, _c_f, ctypes.c_ulonglong, _c_i, _c_p],
+    'di_pointwise_chain_masked_fwd': [_c_p] * 8 + [ctypes.c_longlong] + [_c_i] * 4 + [_c_p, _c_p, _c_p],
+    'di_i2p_build_keys': [_c_p] * 6 + [_c_i] * 8 + [_c_f, _c_f, _c_p],
+    'di_i2p_attn_fwd': [_c_p] * 6 + [_c_i] * 7 + [_c_f, ctypes.c_ulonglong, _c_i, _c_p],
     'di_i2p_attn_bwd': [_c_p] * 10 + [_c_i] * 9 + [_c_f, _c_f, _c_f, ctypes.c_ulonglong, _c_i, _c_p],
     'di_bevwarp_gather_bwd': [_c_p] * 8 + [_c_i] * 7 + [_c_p],
     'di_roi_align_bwd': [_c_p] * 3 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
@@ -60,10 +61,10 @@ SIGNATURES = {
     'di_pred_heads': [_c_p] * 11 + [_c_i, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
 }
 # helpers that return a value instead of an error code
-VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 2,
+VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_i2p_key_table_bytes': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 2,
                'di_token_linear_workspace_bytes': [_c_i] * 3,
                'di_graph_node_count': [_c_p]}
-_LONGLONG = {'di_topk_workspace_bytes', 'di_graph_node_count', 'di_token_linear_workspace_bytes'}
+_LONGLONG = {'di_topk_workspace_bytes', 'di_i2p_key_table_bytes', 'di_graph_node_count', 'di_token_linear_workspace_bytes'}
 
 _lib = None
 

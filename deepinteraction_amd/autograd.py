@@ -46,11 +46,11 @@ class I2PAttention(torch.autograd.Function):
     (encoder_utils.py:257-320 with the single-head attention folded, see MMRI_I2P)."""
 
     @staticmethod
-    def forward(ctx, img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p, seed):
+    def forward(ctx, img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p, seed, keys=None):
         ctx.save_for_backward(img, qfold, pillars, coors, num_points, proj, aug_rev)
         ctx.ori_hw, ctx.dropout_p, ctx.seed = ori_hw, float(dropout_p), int(seed)
         out, valid = ops.i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p,
-                                       seed)
+                                       seed, keys)
         ctx.mark_non_differentiable(valid)
         return out, valid
 
@@ -59,7 +59,7 @@ class I2PAttention(torch.autograd.Function):
         img, qfold, pillars, coors, num_points, proj, aug_rev = ctx.saved_tensors
         g_img, g_q = ops.i2p_attention_bwd(img, qfold, grad_ctx, pillars, coors, num_points, proj, aug_rev,
                                            ctx.ori_hw, ctx.dropout_p, ctx.seed)
-        return g_img.to(img.dtype), g_q.to(qfold.dtype), None, None, None, None, None, None, None, None
+        return g_img.to(img.dtype), g_q.to(qfold.dtype), None, None, None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------- DeepInteraction++ samplers

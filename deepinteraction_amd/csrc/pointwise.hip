@@ -70,11 +70,12 @@ template <int K1, int K2>
 __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
     const __half *__restrict__ x1, const __half *__restrict__ x2, const __half *__restrict__ x3,
     const __half *__restrict__ w1, const float *__restrict__ b1, const __half *__restrict__ w2,
-    const float *__restrict__ b2, __half *__restrict__ y, long long M, int relu1, int relu2) {
+    const float *__restrict__ b2, __half *__restrict__ y, long long M, int relu1, int relu2,
+    const __half *__restrict__ mask, const float *__restrict__ bm) {
   extern __shared__ __align__(16) unsigned char lds[];
   unsigned char *lw1 = lds;
   unsigned char *lw2 = lds + 128 * K1 * 2;
-  float *lb = reinterpret_cast<float *>(lds + 128 * K1 * 2 + 128 * K2 * 2);   // b1[128], b2[128]
+  float *lb = reinterpret_cast<float *>(lds + 128 * K1 * 2 + 128 * K2 * 2);   // b1[128], b2[128], bm[128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
 
@@ -85,11 +86,13 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
   // issued before the weights are staged (a launch gives a wave one or two chunks: its HBM round trip then overlaps
   // the 64 KB weight staging instead of following it).
   h8 xb[PG][KK1];
+  _Float16 xm[PG];                                              // per-pixel mask of the masked link-1 bias (optional)
   auto load_x = [&](long long ch) {
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) {
       const long long p = ch * (16 * PG) + pg * 16 + i;
       const long long pc = p < M ? p : M - 1;                   // ragged tail: clamped read, no store
+      xm[pg] = mask != nullptr ? reinterpret_cast<const _Float16 *>(mask)[pc] : (_Float16)0;
 #pragma unroll
       for (int kk = 0; kk < KK1; ++kk) {
         const __half *src = kk < 4 ? x1 : x2;
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
   if (tid < 128) {
     lb[tid] = b1[K2 == 0 ? out_row(tid) : tid];
     lb[128 + tid] = K2 > 0 ? b2[out_row(tid)] : 0.f;
+    lb[256 + tid] = bm != nullptr ? bm[K2 == 0 ? out_row(tid) : tid] : 0.f;
   }
   __syncthreads();
 
@@ -130,9 +134,11 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) {
       const f4 bias = *reinterpret_cast<const f4 *>(lb + 16 * nb + 4 * g);
+      const f4 mb = *reinterpret_cast<const f4 *>(lb + 256 + 16 * nb + 4 * g);
 #pragma unroll
       for (int pg = 0; pg < PG; ++pg) {
         f4 t = acc[pg][nb] + bias;
+        if (mask != nullptr) t += mb * (float)xm[pg];           // bias that applies to the masked pixels only
         if (relu1) t = __builtin_elementwise_max(t, f4{0.f, 0.f, 0.f, 0.f});
         acc[pg][nb] = t;
       }
@@ -222,8 +228,8 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
 template <int K1, int K2>
 static int launch(const void *x1, const void *x2, const void *x3, const void *w1, const float *b1,
                   const void *w2, const float *b2, void *y, long long M, int relu1, int relu2,
-                  hipStream_t stream) {
-  constexpr int LDS = 128 * K1 * 2 + 128 * K2 * 2 + 1024;
+                  const void *mask, const float *bm, hipStream_t stream) {
+  constexpr int LDS = 128 * K1 * 2 + 128 * K2 * 2 + 1536;
   static int n_cu = 0;   // idempotent initialisation; a race only repeats the queries
   if (n_cu == 0) {
     int dev = 0, cus = 0;
@@ -246,7 +252,7 @@ static int launch(const void *x1, const void *x2, const void *x3, const void *w1
   if (grid * NW > nchunk) grid = (nchunk + NW - 1) / NW;
   hipLaunchKernelGGL((pointwise_chain_kernel<K1, K2>), dim3((unsigned)grid), dim3(NT), LDS, stream,
                      (const __half *)x1, (const __half *)x2, (const __half *)x3, (const __half *)w1, b1,
-                     (const __half *)w2, b2, (__half *)y, M, relu1, relu2);
+                     (const __half *)w2, b2, (__half *)y, M, relu1, relu2, (const __half *)mask, bm);
   return check_launch("pointwise_chain");
 }
 
@@ -482,17 +488,19 @@ extern "C" int di_pointwise_multi_fwd(const void *x, int n_chains, const void *c
   return launch_multi<5>(x, A, n_pixels, grid, s);
 }
 
-extern "C" int di_pointwise_chain_fwd(const void *x1, const void *x2, const void *x3, const void *w1,
-                                      const float *b1, const void *w2, const float *b2, void *y,
-                                      long long n_pixels, int k1, int k2, int relu1, int relu2, void *stream) {
+extern "C" int di_pointwise_chain_masked_fwd(const void *x1, const void *x2, const void *x3, const void *w1,
+                                             const float *b1, const void *w2, const float *b2, void *y,
+                                             long long n_pixels, int k1, int k2, int relu1, int relu2,
+                                             const void *mask, const float *bm, void *stream) {
   DI_REQUIRE(n_pixels > 0, "empty map");
+  DI_REQUIRE((mask == nullptr) == (bm == nullptr), "mask and its bias come together");
   DI_REQUIRE(x1 && w1 && b1 && y, "x1, w1, b1, y are required");
   DI_REQUIRE((k1 == 128 && !x2) || (k1 == 256 && x2), "k1 = 128 (x1) or 256 (x1 ; x2), got %d", k1);
   DI_REQUIRE(k2 == 0 || (w2 && b2), "second link needs w2 and b2");
   DI_REQUIRE((k2 == 0 && !x3) || (k2 == 128 && !x3) || (k2 == 256 && x3), "k2 = 0, 128 (h) or 256 (h ; x3), got %d", k2);
   hipStream_t s = (hipStream_t)stream;
 #define DI_PW(A, B) \
-  if (k1 == A && k2 == B) return di::pw::launch<A, B>(x1, x2, x3, w1, b1, w2, b2, y, n_pixels, relu1, relu2, s)
+  if (k1 == A && k2 == B) return di::pw::launch<A, B>(x1, x2, x3, w1, b1, w2, b2, y, n_pixels, relu1, relu2, mask, bm, s)
   DI_PW(128, 0);
   DI_PW(128, 128);
   DI_PW(256, 0);
@@ -502,4 +510,11 @@ extern "C" int di_pointwise_chain_fwd(const void *x1, const void *x2, const void
 #undef DI_PW
   di::set_error("unsupported chain k1=%d k2=%d", k1, k2);
   return DI_ERR_ARG;
+}
+
+extern "C" int di_pointwise_chain_fwd(const void *x1, const void *x2, const void *x3, const void *w1,
+                                      const float *b1, const void *w2, const float *b2, void *y,
+                                      long long n_pixels, int k1, int k2, int relu1, int relu2, void *stream) {
+  return di_pointwise_chain_masked_fwd(x1, x2, x3, w1, b1, w2, b2, y, n_pixels, k1, k2, relu1, relu2, nullptr, nullptr,
+                                       stream);
 }

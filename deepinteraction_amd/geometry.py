@@ -75,6 +75,12 @@ class SampleGeometry:
         self.pc_range = take(6)
         self.xs = take(Wi)
         self.ys = take(Hi)
+        self.forget()
+
+    def forget(self):
+        """Drop what was derived from the previous sample's POINTS (the depth maps of BEVWarp, the key table of the
+        pillar attention): they are rebuilt by the next forward."""
+        self.sparse_depth = self.dense_depth = self.pillar_keys = None
 
     @staticmethod
     def _pack(img_meta, img_hw):
@@ -98,4 +104,4 @@ class SampleGeometry:
         host = self._pack(img_meta, self.img_hw)
         assert host.numel() == self._buf.numel(), 'view count changed: rebuild the geometry'
         self._buf.copy_(host, non_blocking=True)
-        self.sparse_depth = self.dense_depth = None
+        self.forget()

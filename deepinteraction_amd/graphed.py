@@ -80,7 +80,7 @@ class GraphedHotPath:
 
     def _forward(self):
         for g in self.sample_geom:          # depth scatter + completion belong to every forward
-            g.sparse_depth = g.dense_depth = None
+            g.forget()
         self.dec.static_geometry = self.query_geom
         try:
             img, pts = self.enc(self.img_feats, self.pts_feats, self.img_metas, self._pts_metas())
@@ -195,7 +195,7 @@ class GraphedHotPath:
         self.img_metas = r.img_metas
         for g, buf in zip(self.sample_geom, r.sample_geom):
             g._buf.copy_(buf, non_blocking=True)
-            g.sparse_depth = g.dense_depth = None
+            g.forget()
         self.query_geom._buf.copy_(r.query_geom, non_blocking=True)
         for mod, recs in r.extra:
             for g, rec in zip(self.sample_geom, recs):

@@ -9,6 +9,7 @@ once per sample and shared by all layers through a private key in `pts_metas`.
 import math
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .... import ops
@@ -16,7 +17,13 @@ from ....registry import NECKS
 from .... import utils
 from ....utils import fork_join, param_key
 from ..utils.encoder_utils import (GEOM_KEY, BEVWarp, ConvBNReLU, LocalContextAttentionBlock, MMRI_I2P, MMRI_P2I,
-                                   fusable_projections, mix2, project_many, sample_geometry)
+                                   fusable_projections, mix2, mix2_folded, pillar_batch_bounds,
+                                   project_many, _fusable as _fusable_mods,
+                                   sample_geometry)
+
+
+def _fusable_mix(x, proj1, proj2):
+    return (_fusable_mods(x, proj1, proj2) and proj1.conv.in_channels == 256 and proj2.conv.in_channels == 256)
 
 
 class DeepInteractionEncoderLayer(nn.Module):
@@ -41,6 +48,21 @@ class DeepInteractionEncoderLayer(nn.Module):
     # the two sides become parallel branches of the graph.
 
     def _bev_side(self, lidar_feat, img5, img_metas, pts_metas):
+        P, I2P = self.P_IML, self.I2P_block
+        if (not torch.is_grad_enabled() and not I2P.training and I2P.pts_channels == 128 and I2P.img_channels == 128
+                and fusable_projections(lidar_feat, P.query_project, P.key_project, P.value_project)):
+            # fp16 inference: the three projections of P_IML and the folded query of the pillar attention are ONE launch
+            # over the BEV map; the attention's output projection is folded into P_out_proj (no GEMM, no mask pass)
+            q, k, v, qfold = project_many([P.query_project, P.key_project, P.value_project,
+                                           I2P.query_chain(lidar_feat.dtype)], lidar_feat)
+            ctx, valid = I2P.attend(qfold, img5, img_metas, pts_metas)
+            P2P_feat = ops.local_attention(q, k, v, P.kernel_size, P.kernel_size, 1.0 / math.sqrt(k.size(1)))
+            if _fusable_mix(ctx, self.P_out_proj, self.P_integration):
+                return mix2_folded(self.P_out_proj, ctx, I2P.folded(torch.float32)[2:], valid, P2P_feat, self.P_integration,
+                                   lidar_feat, self.__dict__.setdefault('_mix_cache', {}))
+            _, _, w_ov, b_ov = I2P.folded(ctx.dtype)
+            o = F.linear(ctx.permute(0, 2, 3, 1), w_ov, b_ov).permute(0, 3, 1, 2) * valid
+            return mix2(self.P_out_proj, o, P2P_feat, self.P_integration, lidar_feat)
         I2P_feat = self.I2P_block(lidar_feat, img5, img_metas, pts_metas)
         P2P_feat = self.P_IML(lidar_feat, lidar_feat)
         # P_integration(cat(P_out_proj(cat(I2P, P2P)), lidar)) (:26-27): one fused kernel at inference
@@ -127,9 +149,12 @@ class DeepInteractionEncoder(nn.Module):
         geoms = [sample_geometry(img_metas, pts_metas, b, (I_H, I_W), dev) for b in range(len(img_metas))]
 
         def depth_maps():
-            # sparse depth + completion depend on the points and the metas only: ~15 tiny launches per sample
+            # what depends on the points and the metas only: sparse depth + completion (~15 tiny launches per sample)
+            # and the key table of the pillar attention
+            bounds = pillar_batch_bounds(pts_metas, len(img_metas))
             for b, g in enumerate(geoms):
                 BEVWarp.dense_depth(g, pts_metas['pts'][b], I_H, I_W)
+                MMRI_I2P.pillar_keys(g, pts_metas, bounds[b], bounds[b + 1], (I_H, I_W), tuple(pts_feats.shape[-2:]))
 
         def pts_conv():
             y = self._shared_conv(self.shared_conv_pts, pts_feats)

@@ -140,6 +140,8 @@ def _chain_consts(seq, dtype):
 def fusable_projections(x, *seqs):
     """All of `seqs` are one- or two-link 128-channel fp16 inference chains (the form ops.pointwise_multi takes)."""
     for seq in seqs:
+        if isinstance(seq, tuple):          # an already packed chain (image, relu1, relu2, two links)
+            continue
         mods = list(seq) if isinstance(seq, nn.Sequential) else [seq]
         if not (len(mods) in (1, 2) and _fusable(x, *mods) and all(m.conv.in_channels == 128 for m in mods)):
             return False
@@ -151,10 +153,13 @@ def project_many(seqs, x):
     x once (ops.pointwise_multi) for 128-channel fp16 inference chains, else one after the other."""
     ok = 1 <= len(seqs) <= 4
     for seq in seqs:
+        if isinstance(seq, tuple):
+            continue
         mods = list(seq) if isinstance(seq, nn.Sequential) else [seq]
         ok = ok and len(mods) in (1, 2) and _fusable(x, *mods) and all(m.conv.in_channels == 128 for m in mods)
     if ok and len(seqs) > 1:
-        return ops.pointwise_multi(x, [_chain_consts(seq, x.dtype) for seq in seqs])
+        return ops.pointwise_multi(x, [seq if isinstance(seq, tuple) else _chain_consts(seq, x.dtype) for seq in seqs])
+    assert not any(isinstance(seq, tuple) for seq in seqs), 'packed chains need the fused path'
     return [project(seq, x) for seq in seqs]
 
 
@@ -170,6 +175,22 @@ def mix2(proj1, a, b, proj2, c):
     if not proj1.training and not torch.is_grad_enabled() and a.is_cuda:
         return pointwise(proj2, pointwise(proj1, a, b), c)
     return proj2(torch.cat((proj1(torch.cat((a, b), dim=1)), c), dim=1))
+
+
+def mix2_folded(proj1, a, fold, mask, b, proj2, c, cache):
+    """mix2 where the first input is `mask * (a @ w_f^T + b_f)` with fold = (w_f, b_f) - the output projection of the
+    pillar attention on its valid cells (encoder_utils.py:314-319) - WITHOUT materialising it: w_f goes into the first
+    half of proj1's weight and b_f becomes a bias on the marked pixels (ops.pointwise_chain mask / bm)."""
+    key = (param_key(proj1), tuple(t.data_ptr() for t in fold), tuple(t._version for t in fold))
+    if cache.get('key') != key:
+        w1, _, b1 = proj1.folded(torch.float32)
+        w_f, b_f = fold[0].float(), fold[1].float()
+        wa = w1[:, :128] @ w_f
+        cache.update(key=key, w=torch.cat([wa, w1[:, 128:]], 1).to(a.dtype).contiguous(), b=b1.float().contiguous(),
+                     bm=(w1[:, :128] @ b_f).contiguous())
+    w2, _, b2 = proj2.folded(a.dtype)
+    return ops.pointwise_chain(a, cache['w'], cache['b'], proj1.use_activation, x2=b, w2=w2, b2=b2,
+                               relu2=proj2.use_activation, x3=c, mask=mask, bm=cache['bm'])
 
 
 class similarFunction(torch.autograd.Function):
@@ -334,9 +355,12 @@ class MMRI_I2P(nn.Module):
             wq, wk, wv = la.in_proj_weight.chunk(3, 0)
         else:
             wq, wk, wv = la.q_proj_weight, la.k_proj_weight, la.v_proj_weight
-        key = (dtype, param_key(la))
-        if self._fold_cache is not None and self._fold_cache[0] == key:
-            return self._fold_cache[1]
+        key = param_key(la)
+        if self._fold_cache is None or self._fold_cache[0] != key:
+            self._fold_cache = (key, {})                       # per dtype
+        hit = self._fold_cache[1].get(dtype)
+        if hit is not None:
+            return hit
         with torch.no_grad():
             E = self.pts_channels
             bq, _, bv = la.in_proj_bias.float().chunk(3, 0)
@@ -347,7 +371,7 @@ class MMRI_I2P(nn.Module):
             w_ov = la.out_proj.weight.float() @ wv          # (pts_channels, img_channels)
             b_ov = la.out_proj.weight.float() @ bv + la.out_proj.bias.float()
             out = tuple(t.to(dtype).contiguous() for t in (w_qk, b_qk, w_ov, b_ov))
-        self._fold_cache = (key, out)
+        self._fold_cache[1][dtype] = out
         return out
 
     def folded_live(self, dtype):
@@ -366,6 +390,44 @@ class MMRI_I2P(nn.Module):
         w_ov = la.out_proj.weight @ wv
         b_ov = la.out_proj.weight @ bv + la.out_proj.bias
         return tuple(t.to(dtype) for t in (w_qk, b_qk, w_ov, b_ov))
+
+    @staticmethod
+    def pillar_keys(geom, pts_metas, s, e, img_hw, bev_hw):
+        """The sample's key table (projection of every (point, camera) slot, masks, compaction): geometry only, so it
+        is built once per forward and shared by all layers (cached in the per-sample geometry object)."""
+        if getattr(geom, 'pillar_keys', None) is None:
+            geom.pillar_keys = ops.i2p_key_table(pts_metas['pillars'][s:e], pts_metas['pillar_coors'][s:e],
+                                                 pts_metas['pillars_num_points'][s:e], geom.lidar2img, geom.aug_rev,
+                                                 geom.ori_hw, img_hw, bev_hw)
+        return geom.pillar_keys
+
+    def query_chain(self, dtype):
+        """The folded query projection `qfold = x Wqk^T + bqk` as a packed chain for ops.pointwise_multi (one launch with
+        the other projections of the BEV map)."""
+        w_qk, b_qk, _, _ = self.folded(torch.float32)
+        hit = self.__dict__.get('_qchain')
+        if hit is None or hit[0] is not w_qk:
+            hit = (w_qk, (ops.chain_image(w_qk, b_qk), False, False, False))
+            self.__dict__['_qchain'] = hit
+        return hit[1]
+
+    def attend(self, qfold, img_feat, img_metas, pts_metas):
+        """Inference: the attention pass alone on an already projected query map.  Returns ctx (B,Ci,Hb,Wb) - BEFORE the
+        folded output projection - and valid (B,1,Hb,Wb); the caller applies `valid * (ctx Wov^T + bov)`."""
+        B, Ci, Hb, Wb = qfold.shape
+        _, V, _, Hi, Wi = img_feat.shape
+        bounds = pillar_batch_bounds(pts_metas, B)
+        ctxs, valids = [], []
+        for b in range(B):
+            s, e = bounds[b], bounds[b + 1]
+            geom = sample_geometry(img_metas, pts_metas, b, (Hi, Wi), qfold.device)
+            ctx, valid = ops.i2p_attention(img_feat[b], qfold[b:b + 1], pts_metas['pillars'][s:e],
+                                           pts_metas['pillar_coors'][s:e], pts_metas['pillars_num_points'][s:e],
+                                           geom.lidar2img, geom.aug_rev, geom.ori_hw,
+                                           keys=self.pillar_keys(geom, pts_metas, s, e, (Hi, Wi), (Hb, Wb)))
+            ctxs.append(ctx)
+            valids.append(valid)
+        return (ctxs[0], valids[0]) if B == 1 else (torch.cat(ctxs, 0), torch.cat(valids, 0))
 
     def forward(self, lidar_feat, img_feat, img_metas, pts_metas, **kwargs):
         B = len(img_metas)
@@ -387,7 +449,8 @@ class MMRI_I2P(nn.Module):
             geom = sample_geometry(img_metas, pts_metas, b, (Hi, Wi), lidar_feat.device)
             args = (img_feat[b], qfold[b:b + 1], pts_metas['pillars'][s:e], pts_metas['pillar_coors'][s:e],
                     pts_metas['pillars_num_points'][s:e], geom.lidar2img, geom.aug_rev, geom.ori_hw, drop,
-                    (seed + b * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)   # per-sample stream: no mask reuse across b
+                    (seed + b * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF,   # per-sample stream: no mask reuse across b
+                    self.pillar_keys(geom, pts_metas, s, e, (Hi, Wi), (Hb, Wb)))
             ctx, valid = I2PAttention.apply(*args) if live else ops.i2p_attention(*args)
             o = F.linear(ctx.permute(0, 2, 3, 1).reshape(-1, Ci), w_ov, b_ov)
             o = o * valid.reshape(-1, 1)                                         # empty pillars / cells stay 0

@@ -9,6 +9,9 @@ No CPU implementation lives here; CPU tensors are rejected.
 """
 import ctypes
 
+import collections
+import math
+
 import torch
 
 from . import _lib
@@ -144,9 +147,10 @@ def weighting_backward_weight(x_ori, grad_out, kH, kW):
 
 
 # ------------------------------------------------------------------ fused 1x1-convolution chains
-def pointwise_chain(x1, w1, b1, relu1, x2=None, w2=None, b2=None, relu2=False, x3=None):
-    """y = act2(W2 . [act1(W1 . [x1 ; x2] + b1) ; x3] + b2) over the pixels of fp16 channels-last maps
-    (C = 128); the second link is optional.  w* fp16 (128, 128 or 256), b* float32 (128)."""
+def pointwise_chain(x1, w1, b1, relu1, x2=None, w2=None, b2=None, relu2=False, x3=None, mask=None, bm=None):
+    """y = act2(W2 . [act1(W1 . [x1 ; x2] + b1 + mask * bm) ; x3] + b2) over the pixels of fp16 channels-last maps
+    (C = 128); the second link and the masked bias (mask (n,1,H,W) fp16, bm (128) float32) are optional.
+    w* fp16 (128, 128 or 256), b* float32 (128)."""
     _dev(x1, w1, b1)
     x1 = cl(x1)
     n, C, H, W = x1.shape
@@ -165,9 +169,13 @@ def pointwise_chain(x1, w1, b1, relu1, x2=None, w2=None, b2=None, relu2=False, x
     if w2 is not None:
         assert w2.shape == (128, k2) and w2.dtype == torch.float16 and w2.is_contiguous()
         assert b2.dtype == torch.float32 and b2.numel() == 128
+    if mask is not None:
+        assert mask.dtype == torch.float16 and mask.numel() == n * H * W and mask.is_contiguous()
+        assert bm.dtype == torch.float32 and bm.numel() == 128
     y = empty_cl(n, 128, H, W, x1)
-    _lib.call('di_pointwise_chain_fwd', x1.data_ptr(), ptr(x2), ptr(x3), w1.data_ptr(), b1.data_ptr(), ptr(w2),
-              ptr(b2), y.data_ptr(), n * H * W, k1, k2, int(bool(relu1)), int(bool(relu2)), _stream())
+    _lib.call('di_pointwise_chain_masked_fwd', x1.data_ptr(), ptr(x2), ptr(x3), w1.data_ptr(), b1.data_ptr(), ptr(w2),
+              ptr(b2), y.data_ptr(), n * H * W, k1, k2, int(bool(relu1)), int(bool(relu2)), ptr(mask), ptr(bm),
+              _stream())
     return y
 
 
@@ -227,25 +235,65 @@ def pointwise_multi(x, chains):
 
 
 # ------------------------------------------------------------------ image -> BEV
-def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p=0.0, seed=0):
-    """One sample.  img (V,C,Hi,Wi), qfold (1,C,Hb,Wb) channels-last; pillars (P,T,D) f32,
-    coors (P,4) i32, num_points (P,) i32, proj (V,4,4) f32, aug_rev (12,) f32.
-    Returns ctx (1,C,Hb,Wb) and valid (1,1,Hb,Wb) (same dtype as img)."""
-    _dev(img, qfold, pillars, coors, num_points, proj, aug_rev)
-    img, qfold = cl(img), cl(qfold)
-    V, C, Hi, Wi = img.shape
-    _, _, Hb, Wb = qfold.shape
+I2PKeys = collections.namedtuple('I2PKeys', 'table T V bev_hw')
+
+
+def i2p_key_table(pillars, coors, num_points, proj, aug_rev, ori_hw, img_hw, bev_hw):
+    """Geometry pass of the pillar attention for ONE sample: the per-cell key table (valid-key count, pillar id and the
+    compacted sampling coordinates of every (point, camera) slot that lands in an image).  Depends on the points and the
+    metas only - build it once per sample and hand it to every `i2p_attention` call (all encoder layers)."""
+    _dev(pillars, coors, num_points, proj, aug_rev)
     P, T, D = pillars.shape
+    V = proj.shape[0]
     assert pillars.dtype == torch.float32 and pillars.is_contiguous()
     assert coors.dtype == torch.int32 and coors.is_contiguous() and coors.shape[1] == 4
     assert num_points.dtype == torch.int32 and num_points.is_contiguous()
     assert proj.dtype == torch.float32 and proj.is_contiguous() and aug_rev.dtype == torch.float32
-    ctx = zeros_cl(1, C, Hb, Wb, img)
-    valid = torch.zeros((1, 1, Hb, Wb), dtype=img.dtype, device=img.device)
-    _lib.call('di_i2p_attn_fwd_ex', img.data_ptr(), qfold.data_ptr(), pillars.data_ptr(), coors.data_ptr(),
-              num_points.data_ptr(), proj.data_ptr(), aug_rev.data_ptr(), ctx.data_ptr(), valid.data_ptr(),
-              P, T, D, V, Hi, Wi, Hb, Wb, C, float(ori_hw[0]), float(ori_hw[1]), float(dropout_p), int(seed),
-              _code(img), _stream())
+    (Hi, Wi), (Hb, Wb) = img_hw, bev_hw
+    table = torch.empty(int(_lib.lib().di_i2p_key_table_bytes(Hb, Wb, T, V)), dtype=torch.uint8, device=pillars.device)
+    _lib.call('di_i2p_build_keys', pillars.data_ptr(), coors.data_ptr(), num_points.data_ptr(), proj.data_ptr(),
+              aug_rev.data_ptr(), table.data_ptr(), P, T, D, V, Hi, Wi, Hb, Wb, float(ori_hw[0]), float(ori_hw[1]),
+              _stream())
+    return I2PKeys(table, T, V, (Hb, Wb))
+
+
+_CELL_ORDER = {}
+
+
+def bev_sector_order(Hb, Wb, device):
+    """The BEV cells sorted by azimuth around the map centre (the ego vehicle), then by radius: the walk order of the
+    pillar attention (one eighth of it per XCD).  A constant of the map shape, cached on the device."""
+    key = (Hb, Wb, str(device))
+    hit = _CELL_ORDER.get(key)
+    if hit is None:
+        y, x = torch.meshgrid(torch.arange(Hb, dtype=torch.float64) - (Hb - 1) / 2,
+                              torch.arange(Wb, dtype=torch.float64) - (Wb - 1) / 2, indexing='ij')
+        ang = torch.atan2(y, x).reshape(-1)
+        wedge = torch.floor((ang + math.pi) / (2 * math.pi) * 512).clamp_(max=511)          # 512 wedges of 0.7 degrees
+        rad = torch.hypot(y, x).reshape(-1)
+        hit = torch.argsort(wedge * 1e6 + rad, stable=True).to(torch.int32).to(device)
+        _CELL_ORDER[key] = hit
+    return hit
+
+
+def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p=0.0, seed=0, keys=None,
+                  sector_order=True):
+    """One sample.  img (V,C,Hi,Wi), qfold (1,C,Hb,Wb) channels-last; pillars (P,T,D) f32,
+    coors (P,4) i32, num_points (P,) i32, proj (V,4,4) f32, aug_rev (12,) f32; `keys`: the sample's `i2p_key_table`
+    (built here when not given).  Returns ctx (1,C,Hb,Wb) and valid (1,1,Hb,Wb) (same dtype as img), every cell written."""
+    _dev(img, qfold)
+    img, qfold = cl(img), cl(qfold)
+    V, C, Hi, Wi = img.shape
+    _, _, Hb, Wb = qfold.shape
+    if keys is None:
+        keys = i2p_key_table(pillars, coors, num_points, proj, aug_rev, ori_hw, (Hi, Wi), (Hb, Wb))
+    T = keys.T
+    assert keys.V == V and keys.bev_hw == (Hb, Wb), 'key table of another geometry'
+    ctx = torch.empty((1, C, Hb, Wb), dtype=img.dtype, device=img.device).contiguous(memory_format=torch.channels_last)
+    valid = torch.empty((1, 1, Hb, Wb), dtype=img.dtype, device=img.device)
+    order = bev_sector_order(Hb, Wb, img.device).data_ptr() if sector_order else None
+    _lib.call('di_i2p_attn_fwd', img.data_ptr(), qfold.data_ptr(), keys.table.data_ptr(), order, ctx.data_ptr(),
+              valid.data_ptr(), T, V, Hi, Wi, Hb, Wb, C, float(dropout_p), int(seed), _code(img), _stream())
     return ctx, valid
 
 

@@ -100,6 +100,13 @@ int di_locatt_weighting_bwd_weight(const void *x_ori, const void *grad_out, floa
 int di_pointwise_chain_fwd(const void *x1, const void *x2, const void *x3, const void *w1, const float *b1,
                            const void *w2, const float *b2, void *y, long long n_pixels, int k1, int k2,
                            int relu1, int relu2, void *stream);
+/* The same with a bias on link 1 that applies to marked pixels only:  h = act1(W1 . [x1 ; x2] + b1 + mask[pixel] * bm)
+ * (mask (n_pixels) fp16, bm (128) float32; both NULL = di_pointwise_chain_fwd).  Used to fold the output projection of
+ * the pillar attention into the encoder layer's out_proj: I2P_feat = valid * (W_ov ctx + b_ov) (encoder_utils.py:
+ * 314-319) enters P_out_proj as W1a (W_ov ctx) + valid * (W1a b_ov). */
+int di_pointwise_chain_masked_fwd(const void *x1, const void *x2, const void *x3, const void *w1, const float *b1,
+                                  const void *w2, const float *b2, void *y, long long n_pixels, int k1, int k2,
+                                  int relu1, int relu2, const void *mask, const float *bm, void *stream);
 
 /* ---------------------------------------------------------------- image -> BEV pillar attention
  * MMRI_I2P.forward for ONE sample (encoder_utils.py:270-319), with the single-head
@@ -108,25 +115,30 @@ int di_pointwise_chain_fwd(const void *x1, const void *x2, const void *x3, const
  * and receives ctx[y,x,:] = sum_j softmax_j(<qfold, s_j>) s_j over the valid keys
  * s_j = bilinear(img[cam_j], uv_j) of the pillar at cell (y,x) (slot = point*6+cam,
  * :298,:309-310; points >= num_points masked, :303-307) and valid[y,x] = 1 where the
- * pillar has at least one valid key (:314).  ctx/valid must be zero-filled by the caller;
- * cells without a pillar are not touched (:259).
- *   pillars (P,T,D) float32 xyz in the first 3 of D; coors (P,4) int32 [b,z,y,x];
- *   proj (n_views,4,4) float32 row-major lidar2img; aug_rev 12 floats = A(3x3),t(3)
- *   of the REVERSE augmentation flow as `p' = p @ A + t` (apply_3d_transformation,
- *   reverse=True, :280); ori_H/ori_W = img_metas['input_shape'] (:288-290). */
-int di_i2p_attn_fwd(const void *img, const void *qfold, const float *pillars, const int32_t *coors,
-                    const int32_t *num_points, const float *proj, const float *aug_rev, void *ctx,
-                    void *valid, int P, int T, int D, int n_views, int Hi, int Wi, int Hb, int Wb,
-                    int C, float ori_H, float ori_W, int dtype, void *stream);
-
-/* Training form: attention dropout on the probabilities (nn.MultiheadAttention(dropout=0.1), encoder_utils.py:
- * 223-224): key (pillar, slot) is dropped with probability dropout_p, decided by a counter-based hash of
- * (seed, pillar, slot) that the backward regenerates; dropped keys stay in the softmax denominator. */
-int di_i2p_attn_fwd_ex(const void *img, const void *qfold, const float *pillars, const int32_t *coors,
-                       const int32_t *num_points, const float *proj, const float *aug_rev, void *ctx,
-                       void *valid, int P, int T, int D, int n_views, int Hi, int Wi, int Hb, int Wb,
-                       int C, float ori_H, float ori_W, float dropout_p, unsigned long long seed, int dtype,
-                       void *stream);
+ * pillar has at least one valid key (:314); cells without a pillar or without a valid key are 0 (:259, :314-315).
+ *
+ * Two calls.  di_i2p_build_keys is the geometry pass (projection of the T*n_views (point, camera) slots of every pillar,
+ * mask, compaction) - it depends on the points and the metas only, so ONE call per sample serves every encoder layer.
+ * It fills `key_table` (di_i2p_key_table_bytes bytes, device memory owned by the caller): per BEV cell the number of
+ * valid keys, the pillar id and the compacted sampling coordinates.
+ *   pillars (P,T,D) float32 xyz in the first 3 of D; coors (P,4) int32 [b,z,y,x] (unique cells; rows with
+ *   num_points <= 0 are padding and ignored); proj (n_views,4,4) float32 row-major lidar2img; aug_rev 12 floats =
+ *   A(3x3),t(3) of the REVERSE augmentation flow as `p' = p @ A + t` (apply_3d_transformation, reverse=True, :280);
+ *   ori_H/ori_W = img_metas['input_shape'] (:288-290). */
+long long di_i2p_key_table_bytes(int Hb, int Wb, int T, int n_views);
+int di_i2p_build_keys(const float *pillars, const int32_t *coors, const int32_t *num_points, const float *proj,
+                      const float *aug_rev, void *key_table, int P, int T, int D, int n_views, int Hi, int Wi, int Hb,
+                      int Wb, float ori_H, float ori_W, void *stream);
+/* The attention pass: writes EVERY cell of ctx (Hb,Wb,C) and valid (Hb,Wb) (no zero fill needed).  dropout_p > 0 is the
+ * training form: attention dropout on the probabilities (nn.MultiheadAttention(dropout=0.1), encoder_utils.py:223-224):
+ * key (pillar, slot) is dropped with probability dropout_p, decided by a counter-based hash of (seed, pillar, slot) that
+ * the backward regenerates; dropped keys stay in the softmax denominator.
+ * cell_order: Hb*Wb int32, a permutation of the cells (or NULL = row-major): the order in which they are walked - the
+ * host passes the cells sorted by azimuth so that each XCD gathers from one sector's image columns (results do not
+ * depend on it). */
+int di_i2p_attn_fwd(const void *img, const void *qfold, const void *key_table, const int32_t *cell_order, void *ctx,
+                    void *valid, int T, int n_views, int Hi, int Wi, int Hb, int Wb, int C, float dropout_p,
+                    unsigned long long seed, int dtype, void *stream);
 /* Backward of the above: grad_ctx (Hb,Wb,C) -> grad_img (n_views,Hi,Wi,C) and grad_qfold (Hb,Wb,C), both
  * float32, zero-filled by the caller (grad_img is accumulated with atomics).  The sampling coordinates carry
  * no gradient (points and metas are data). */

@@ -27,4 +27,28 @@ with torch.no_grad():
         b = torch.randn(128, device='cuda', generator=g) * 0.1
         for _ in range(3):
             ops.pointwise_chain(x, w, b, True, w2=w, b2=b, relu2=True)
+    if 'i2p' in which or 'bw' in which or 'xa' in which:
+        from deepinteraction_amd import synth
+        from deepinteraction_amd.geometry import SampleGeometry
+        shape = synth.SHAPE_R
+        Hi, Wi = shape['img_hw']; Hb, Wb = shape['bev_hw']
+        inp = synth.make_inputs(1, shape, seed=0)
+        geom = SampleGeometry(inp['img_metas'][0], (Hi, Wi), 'cuda')
+        pm = inp['pts_metas']
+        img, bev = cl(6, 128, Hi, Wi), cl(1, 128, Hb, Wb) * 0.2
+    if 'i2p' in which:
+        a = (pm['pillars'].cuda(), pm['pillar_coors'].cuda(), pm['pillars_num_points'].cuda(), geom.lidar2img, geom.aug_rev, geom.ori_hw)
+        for _ in range(3):
+            keys = ops.i2p_key_table(*a, (Hi, Wi), (Hb, Wb))
+            ops.i2p_attention(img, bev, *a, keys=keys)
+    if 'bw' in which:
+        pts = pm['pts'][0].cuda()
+        dense = ops.depth_complete(ops.depth_scatter(pts, geom.lidar2img, geom.aug_rev, Hi, Wi, geom.ori_hw))
+        for _ in range(3):
+            ops.bevwarp_gather(bev, dense, geom.img2lidar, geom.aug_fwd, geom.xs, geom.ys, geom.pc_range)
+    if 'xa' in which:
+        q = (torch.randn(1, 200, 128, device='cuda', generator=g) * 0.5).half()
+        kv = (torch.randn(1, 180 * 180, 256, device='cuda', generator=g) * 0.5).half()
+        for _ in range(3):
+            ops.mha_decode(q, kv, 8, 0.25)
 torch.cuda.synchronize()
