@@ -11,6 +11,7 @@
 //                    split-KV online-softmax pass + a combine pass; scores never touch HBM and
 //                    the reference's averaged (B,200,32400) weight output is not produced
 #include "di_common.h"
+#include <type_traits>
 
 namespace di {
 
@@ -307,96 +308,169 @@ __global__ __launch_bounds__(256) void mha_decode_combine_kernel(const float *__
 
 
 // ---------------------------------------------------------------------------------
-// fp16 matrix-core form of pass 1 (head dim 16): grid (chunks of 256 keys, B); the workgroup stages the
-// chunk's K and V rows of ALL heads in LDS ([head][key][K16 | V16], 64 B rows, coalesced 512-B key rows
-// from HBM); wavefront w owns head w and walks the query groups of 16:
-//   S^T = K . Q^T   one 16x16x16 MFMA per 16-key tile (A = K rows from LDS, B = Q^T from global),
-//   softmax state of the chunk per query = per lane column (two cross-row exchanges),
-//   O^T = V^T . P^T with the exp registers as B operand and V^T from ds_read_b64_tr_b16.
-// Same partial-state layout as the scalar kernel; pass 2 (combine4) spreads a query's chunks over the 64
-// lanes of a wavefront.
+// fp16 matrix-core form (head dim 16).  grid (key ranges, query splits, B), 16 wavefronts (two per head):
+//   * the workgroup walks its key range in STAGES of 128 keys, double buffered: the K and V rows of ALL heads of the
+//     next stage are in flight (registers) while the current stage is multiplied; LDS layout [head][key][K16 | V16]
+//     in 80-B rows (conflict-free 8-B fragment reads), coalesced 512-B key rows from HBM;
+//   * a wavefront owns one head and up to two query groups of 16 (four waves per SIMD hide the LDS and MFMA latencies;
+//     the query splits share the groups); per stage and
+//     group:  S^T = K . Q^T  one 16x16x16 MFMA per 16-key tile (A = K rows from LDS, B = Q^T in registers), scores in
+//     the exp2 domain (scale * log2 e folded into one multiply), running maximum per query = per lane column (two
+//     cross-row exchanges per stage), O^T += V^T . P^T with the exp registers as B operand and V^T from
+//     ds_read_b64_tr_b16; the (m, l, O) state of a (head, query) stays in registers across the stages;
+//   * one partial state per (head, query, key RANGE) - 64 ranges at 32 400 keys, a quarter of the one-state-per-256-
+//     keys layout this replaces - stored range-contiguous so that the combine pass reads 4.6 KB rows.
 namespace mh {
-constexpr int KC = 256;       // keys per workgroup
-constexpr int NT16 = KC / 16; // 16-key tiles
+constexpr int KS = 128;        // keys per stage
+constexpr int NT16 = KS / 16;  // 16-key tiles per stage
+constexpr int ROWB = 80;       // LDS bytes per (head, key): K16 | V16 | pad
+constexpr int WPH = 2;         // wavefronts per head
+constexpr int MAXQG = 2;       // query groups of 16 per wavefront (WPH * MAXQG per workgroup and head)
+constexpr int NTH = 1024;
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef float f4 __attribute__((ext_vector_type(4)));
 }  // namespace mh
 
-__global__ __launch_bounds__(512) void mha_decode_mfma_kernel(const __half *__restrict__ q,
-                                                              const __half *__restrict__ kv,
-                                                              float *__restrict__ part, int B, int Q, int S,
-                                                              int Hh, float scale) {
+// max of three without the canonicalisation (v_max x, x) that fmaxf puts in front of every operand - in a kernel that
+// is bound by VALU issue the running maximum would cost 8 instructions per 16 x 16 tile instead of 2
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+template <int HH>   // 8: the head count as a constant (index arithmetic of the staging becomes shifts); 0: run time
+__global__ __launch_bounds__(mh::NTH) void mha_decode_mfma_kernel(const __half *__restrict__ q,
+                                                                  const __half *__restrict__ kv,
+                                                                  float *__restrict__ part, int B, int Q, int S,
+                                                                  int Hh_, float scale2, int range_keys) {
   using namespace mh;
-  extern __shared__ __align__(16) unsigned char lds[];   // Hh * KC * 64 bytes
-  // grid (chunks, query splits, B): the splits of a chunk stage the same keys (second one hits L2) and
-  // share its query groups, so that the launch fills all CUs
-  const int chunk = blockIdx.x, b = blockIdx.z, nchunk = gridDim.x;
+  const int Hh = HH > 0 ? HH : Hh_;
+  extern __shared__ __align__(16) unsigned char lds[];   // 2 x Hh * KS * ROWB bytes
+  const int range = blockIdx.x, b = blockIdx.z, nrange = gridDim.x;
   const int E = Hh * kHD;
-  const int s0 = chunk * KC;
-  const int ns = min(KC, S - s0);
+  const int r0 = range * range_keys, r1 = min(r0 + range_keys, S);
+  const int nstage = (r1 - r0 + KS - 1) / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  // stage: 16-B piece p of a key row: p>>4 = K|V, (p>>1)&(Hh-1)... = head, p&1 = half of the head's 16 dims
+  const int stage_bytes = Hh * KS * ROWB;
+  // staging: 16-B piece p of a key row: p / 2Hh = K|V, (p >> 1) % Hh = head, p & 1 = half of the head's 16 dims
   const int ppk = 4 * Hh;                                // pieces per key row (2E halfs / 8)
-  for (int e = tid; e < KC * ppk; e += blockDim.x) {
-    const int key = e / ppk, p = e - key * ppk;
-    const int isv = p / (2 * Hh), hh = (p >> 1) % Hh, half8 = p & 1;
-    uint4 val = make_uint4(0, 0, 0, 0);
-    if (key < ns) val = *reinterpret_cast<const uint4 *>(kv + ((size_t)b * S + s0 + key) * 2 * E + p * 8);
-    *reinterpret_cast<uint4 *>(lds + ((hh * KC + key) * 64 + isv * 32 + half8 * 16)) = val;
-  }
+  constexpr int NPT = KS * 4 * 8 / NTH;                  // pieces per thread at 8 heads (the host caps Hh at 8)
+  const int npiece = KS * ppk;
+  uint4 stage_regs[NPT];
+  auto fetch = [&](int st) {
+    const int s0 = r0 + st * KS;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const int e = tid + j * NTH;
+      const int key = e / ppk, p = e - key * ppk;          // HH = 8: shifts
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (e < npiece && s0 + key < r1)
+        val = *reinterpret_cast<const uint4 *>(kv + ((size_t)b * S + s0 + key) * 2 * E + p * 8);
+      stage_regs[j] = val;
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const int e = tid + j * NTH;
+      if (e < npiece) {
+        const int key = e / ppk, p = e - key * ppk;
+        const int isv = p / (2 * Hh), hh = (p >> 1) % Hh, half8 = p & 1;
+        *reinterpret_cast<uint4 *>(lds + buf * stage_bytes + (hh * KS + key) * ROWB + isv * 32 + half8 * 16) = stage_regs[j];
+      }
+    }
+  };
+  fetch(0);
+  commit(0);
   __syncthreads();
+
   const int nqg = (Q + 15) / 16;
-  for (int h = wave; h < Hh; h += (int)(blockDim.x >> 6)) {
-    const unsigned char *hb = lds + (size_t)h * KC * 64;
-    for (int qg = blockIdx.y; qg < nqg; qg += gridDim.y) {
-      const int qi = qg * 16 + i;
-      const int qc = qi < Q ? qi : Q - 1;
-      const h4 qf = *reinterpret_cast<const h4 *>(q + ((size_t)b * Q + qc) * E + h * kHD + 4 * g);
-      f4 sc[NT16];
-      float m = -INFINITY;
+  // this wave's query groups (same for every head it owns): blockIdx.y, + gridDim.y, ...  (<= MAXQG, host-checked)
+  {
+    const int h = wave % Hh, part_of_head = wave / Hh;   // Hh * WPH <= 16 wavefronts (host-checked)
+    const int qg0 = blockIdx.y + part_of_head * gridDim.y, qgstep = WPH * gridDim.y;
+    h4 qf[MAXQG];
+    f4 acc[MAXQG], lacc[MAXQG];
+    float m[MAXQG];
+    const h4 ones = {(_Float16)1, (_Float16)1, (_Float16)1, (_Float16)1};
 #pragma unroll
-      for (int t = 0; t < NT16; ++t) {
-        const h4 kf = *reinterpret_cast<const h4 *>(hb + (16 * t + i) * 64 + g * 8);
-        f4 c = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    for (int j = 0; j < MAXQG; ++j) {
+      const int qg = qg0 + j * qgstep;
+      const int qi = min(qg * 16 + i, Q - 1);
+      qf[j] = part_of_head < WPH ? *reinterpret_cast<const h4 *>(q + ((size_t)b * Q + qi) * E + h * kHD + 4 * g) : h4{0, 0, 0, 0};
+      acc[j] = f4{0.f, 0.f, 0.f, 0.f};
+      lacc[j] = f4{0.f, 0.f, 0.f, 0.f};
+      m[j] = -INFINITY;
+    }
+    for (int st = 0; st < nstage; ++st) {
+      if (st + 1 < nstage) fetch(st + 1);
+      const int ns = min(KS, r1 - (r0 + st * KS));       // keys of this stage (ragged only at the very end)
+      if (part_of_head < WPH) {
+        const unsigned char *hb = lds + (st & 1) * stage_bytes + (size_t)h * KS * ROWB;
+        {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = (16 * t + 4 * g + r < ns) ? c[r] * scale : -INFINITY;   // key row 4g + r of the tile
-          c[r] = x;
-          m = fmaxf(m, x);
+          for (int j = 0; j < MAXQG; ++j) {
+            if (qg0 + j * qgstep >= nqg) break;            // wave-uniform
+            f4 sc[NT16];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) {
+              const h4 kf = *reinterpret_cast<const h4 *>(hb + (16 * t + i) * ROWB + g * 8);
+              f4 c = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[j], f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // unscaled
+              if (ns < KS) {                               // ragged stage (the very last one): keys past the end score -inf
+                asm volatile("" ::: "memory");             // keep the wave-uniform test a BRANCH (as selects it costs
+#pragma unroll                                             // 8 VALU instructions per tile in every stage)
+                for (int r = 0; r < 4; ++r)
+                  if (16 * t + 4 * g + r >= ns) c[r] = -INFINITY;
+              }
+              mx = max3_raw(c[2], c[3], max3_raw(c[0], c[1], mx));
+              sc[t] = c;
+            }
+            mx = max3_raw(mx, __shfl_xor(mx, 16), mx);
+            mx = max3_raw(mx, __shfl_xor(mx, 32), mx) * scale2;            // scale2 > 0: max(s c) = s max(c)
+            const float mn = max3_raw(m[j], mx, mx);                        // finite: a stage has at least one key
+            const float a = __builtin_amdgcn_exp2f(m[j] - mn);
+            lacc[j] *= a;
+            acc[j] *= a;
+            m[j] = mn;
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) {
+              h4 pf;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) pf[r] = (_Float16)__builtin_amdgcn_exp2f(fmaf(sc[t][r], scale2, -mn));
+              // the denominator on the matrix core too: ones . P^T sums the 16 keys of the tile for every query
+              // (every row of the result is the sum: no cross-row reduction at the end), of the SAME fp16-rounded
+              // probabilities as the numerator
+              lacc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pf, lacc[j], 0, 0, 0);
+              const hv4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                  (hv4 __attribute__((address_space(3))) *)(hb + (16 * t + 4 * g + (i >> 2)) * ROWB + 32 + (i & 3) * 8));
+              h4 vf;
+              vf[0] = vt[0]; vf[1] = vt[1]; vf[2] = vt[2]; vf[3] = vt[3];
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, acc[j], 0, 0, 0);
+            }
+          }
         }
-        sc[t] = c;
       }
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
-      float l = 0.f;
-      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (st + 1 < nstage) commit((st + 1) & 1);
+      __syncthreads();
+    }
+    if (part_of_head < WPH) {
 #pragma unroll
-      for (int t = 0; t < NT16; ++t) {
-        h4 pf;
+      for (int j = 0; j < MAXQG; ++j) {
+        const int qg = qg0 + j * qgstep;
+        const int qi = qg * 16 + i;
+        const float lj = lacc[j][0];
+        if (qg < nqg && qi < Q) {
+          float *dst = part + ((((size_t)b * Hh + h) * Q + qi) * nrange + range) * (kHD + 2);
+          if (g == 0) {
+            dst[0] = m[j];        // exp2 domain
+            dst[1] = lj;
+          }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __expf(sc[t][r] - m);
-          l += e;
-          pf[r] = (_Float16)e;
+          for (int r = 0; r < 4; ++r) dst[2 + 4 * g + r] = acc[j][r];   // O^T[dim 4g + r][query i]
         }
-        const hv4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-            (hv4 __attribute__((address_space(3))) *)(hb + (16 * t + 4 * g + (i >> 2)) * 64 + 32 + (i & 3) * 8));
-        h4 vf;
-        vf[0] = vt[0]; vf[1] = vt[1]; vf[2] = vt[2]; vf[3] = vt[3];
-        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, acc, 0, 0, 0);
-      }
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
-      if (qi < Q) {
-        float *dst = part + ((((size_t)b * Hh + h) * nchunk + chunk) * Q + qi) * (kHD + 2);
-        if (g == 0) {
-          dst[0] = m;
-          dst[1] = l;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[2 + 4 * g + r] = acc[r];   // O^T[dim 4g + r][query i]
       }
     }
   }
@@ -405,21 +479,21 @@ __global__ __launch_bounds__(512) void mha_decode_mfma_kernel(const __half *__re
 template <typename T>
 __global__ __launch_bounds__(256) void mha_decode_combine4_kernel(const float *__restrict__ part,
                                                                   T *__restrict__ out, int B, int Q, int Hh,
-                                                                  int nchunk) {
-  // one wavefront per (b, h, q): lane = (chunk slice cs of 4, head channel d)
+                                                                  int nrange) {
+  // one wavefront per (b, h, q): lane = (range slice cs of 4, head channel d); the ranges of a (b, h, q) are contiguous
   const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (w >= B * Hh * Q) return;
   const int lane = threadIdx.x & 63, d = lane & 15, cs = lane >> 4;
   const int qi = w % Q, h = (w / Q) % Hh, b = w / (Q * Hh);
-  const float *base = part + (((size_t)b * Hh + h) * nchunk) * Q * (kHD + 2) + (size_t)qi * (kHD + 2);
+  const float *base = part + (((size_t)b * Hh + h) * Q + qi) * nrange * (kHD + 2);
   float M = -INFINITY;
-  for (int c = cs; c < nchunk; c += 4) M = fmaxf(M, base[(size_t)c * Q * (kHD + 2)]);
+  for (int c = cs; c < nrange; c += 4) M = fmaxf(M, base[(size_t)c * (kHD + 2)]);
   M = fmaxf(M, __shfl_xor(M, 16));
   M = fmaxf(M, __shfl_xor(M, 32));
   float L = 0.f, O = 0.f;
-  for (int c = cs; c < nchunk; c += 4) {
-    const float *p = base + (size_t)c * Q * (kHD + 2);
-    const float wgt = __expf(p[0] - M);
+  for (int c = cs; c < nrange; c += 4) {
+    const float *p = base + (size_t)c * (kHD + 2);
+    const float wgt = __builtin_amdgcn_exp2f(p[0] - M);
     L += p[1] * wgt;
     O += p[2 + d] * wgt;
   }
@@ -428,6 +502,19 @@ __global__ __launch_bounds__(256) void mha_decode_combine4_kernel(const float *_
   O += __shfl_xor(O, 16);
   O += __shfl_xor(O, 32);
   if (cs == 0) out[((size_t)b * Q + qi) * Hh * kHD + h * kHD + d] = (T)(O / L);
+}
+
+// launch geometry of the matrix-core path: query splits so that a wave has <= MAXQG groups, key ranges (multiples of
+// the stage size) so that ~256 workgroups exist
+static void mha_plan(int B, int Q, int S, int &qsplit, int &nrange, int &range_keys) {
+  const int nqg = (Q + 15) / 16;
+  qsplit = (nqg + mh::MAXQG * mh::WPH - 1) / (mh::MAXQG * mh::WPH);
+  const int nstage_total = (S + mh::KS - 1) / mh::KS;
+  int want = (256 + qsplit * B - 1) / (qsplit * B);
+  want = std::max(1, std::min(want, nstage_total));
+  const int stages_per_range = (nstage_total + want - 1) / want;
+  range_keys = stages_per_range * mh::KS;
+  nrange = (S + range_keys - 1) / range_keys;
 }
 
 }  // namespace di
@@ -498,37 +585,48 @@ int di_roi_align_fwd(const void *feat, const float *rois, void *out, int R, int 
 }
 
 int di_mha_decode_scratch_floats(int B, int Q, int S, int num_heads) {
-  const int nchunk = (S + di::mh::KC - 1) / di::mh::KC;   // the smaller of the two kernels' chunk sizes
+  int qsplit, nrange, range_keys;
+  di::mha_plan(B, Q, S, qsplit, nrange, range_keys);
+  const int nchunk = std::max(nrange, (S + di::kChunk - 1) / di::kChunk);   // the larger of the two paths' state counts
   return B * num_heads * nchunk * Q * (di::kHD + 2);
 }
 
 int di_mha_decode_fwd(const void *q, const void *kv, void *out, float *scratch, int B, int Q, int S,
                       int num_heads, int head_dim, float scale, int dtype, void *stream) {
   DI_REQUIRE(head_dim == di::kHD, "head_dim %d unsupported (16 only)", head_dim);
-  DI_REQUIRE(B > 0 && Q > 0 && S > 0 && num_heads > 0, "bad attention shape");
+  DI_REQUIRE(B > 0 && Q > 0 && S > 0 && num_heads > 0 && scale > 0.f, "bad attention shape (scale must be positive)");
   const int nchunk = (S + di::kChunk - 1) / di::kChunk;
   const dim3 g1(nchunk, num_heads, B), blk(256);
   const dim3 g2((B * num_heads * Q + 15) / 16);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == DI_F16 && num_heads * di::mh::KC * 64 <= 160 * 1024) {
-    // matrix-core path: all heads of a 256-key chunk per workgroup
-    const int nc = (S + di::mh::KC - 1) / di::mh::KC;
-    const int lds = num_heads * di::mh::KC * 64;
+  if (dtype == DI_F16 && num_heads <= 8) {
+    // matrix-core path: all heads of a key range per workgroup
+    int qsplit, nrange, range_keys;
+    di::mha_plan(B, Q, S, qsplit, nrange, range_keys);
+    const int lds = 2 * num_heads * di::mh::KS * di::mh::ROWB;
     static bool attr_set = false;   // idempotent; a race only repeats the call
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void *)di::mha_decode_mfma_kernel,
+      hipError_t e = hipFuncSetAttribute((const void *)di::mha_decode_mfma_kernel<8>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)di::mha_decode_mfma_kernel<0>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) {
         di::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
         return DI_ERR_LAUNCH;
       }
       attr_set = true;
     }
-    const int qsplit = nc * B >= 200 ? 1 : (nc * B >= 100 ? 2 : 4);
-    hipLaunchKernelGGL(di::mha_decode_mfma_kernel, dim3(nc, qsplit, B), dim3(512), lds, s, (const __half *)q,
-                       (const __half *)kv, scratch, B, Q, S, num_heads, scale);
+    if (num_heads == 8)
+      hipLaunchKernelGGL(di::mha_decode_mfma_kernel<8>, dim3(nrange, qsplit, B), dim3(di::mh::NTH), lds, s,
+                         (const __half *)q, (const __half *)kv, scratch, B, Q, S, num_heads,
+                         scale * 1.4426950408889634f, range_keys);
+    else
+      hipLaunchKernelGGL(di::mha_decode_mfma_kernel<0>, dim3(nrange, qsplit, B), dim3(di::mh::NTH), lds, s,
+                         (const __half *)q, (const __half *)kv, scratch, B, Q, S, num_heads,
+                         scale * 1.4426950408889634f, range_keys);
     hipLaunchKernelGGL(di::mha_decode_combine4_kernel<__half>, dim3((B * num_heads * Q + 3) / 4), blk, 0, s,
-                       scratch, (__half *)out, B, Q, num_heads, nc);
+                       scratch, (__half *)out, B, Q, num_heads, nrange);
   } else if (dtype == DI_F16) {
     hipLaunchKernelGGL(di::mha_decode_partial_kernel<__half>, g1, blk, 0, s, (const __half *)q,
                        (const __half *)kv, scratch, B, Q, S, num_heads, scale);

@@ -68,17 +68,21 @@ class DeepInteractionEncoderLayer(nn.Module):
         # P_integration(cat(P_out_proj(cat(I2P, P2P)), lidar)) (:26-27): one fused kernel at inference
         return mix2(self.P_out_proj, I2P_feat, P2P_feat, self.P_integration, lidar_feat)
 
-    def _image_side(self, img_feat, img5, lidar_feat, img_metas, pts_metas):
+    def _image_side(self, img_feat, img5, lidar_feat, img_metas, pts_metas, warped=None, warped_ready=None):
         BN, I_C, I_H, I_W = img_feat.shape
         # fp16 inference: the four projections of the image map (query / key / value of I_IML and the query of P2I)
         # are ONE launch that reads it once.
         I, PL = self.I_IML, self.P2I_block.Local
         if fusable_projections(img_feat, I.query_project, I.key_project, I.value_project, PL.query_project):
             q_i, k_i, v_i, q_p = project_many([I.query_project, I.key_project, I.value_project, PL.query_project], img_feat)
-            P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas, query=q_p)
+            if warped_ready is not None:
+                torch.cuda.current_stream().wait_event(warped_ready)
+            P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas, query=q_p, warped=warped)
             I2I_feat = ops.local_attention(q_i, k_i, v_i, I.kernel_size, I.kernel_size, 1.0 / math.sqrt(k_i.size(1)))
         else:
-            P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas)
+            if warped_ready is not None:
+                torch.cuda.current_stream().wait_event(warped_ready)
+            P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas, warped=warped)
             I2I_feat = self.I_IML(img_feat, img_feat)
         return mix2(self.I_out_proj, P2I_feat.view(BN, -1, I_H, I_W), I2I_feat, self.I_integration, img_feat)
 
@@ -91,9 +95,24 @@ class DeepInteractionEncoderLayer(nn.Module):
             # precedes the BEV side; join: the caller's stream continues after both sides.  Tensors crossing the fork
             # or the join stay referenced until after the join, so neither stream's allocator pool can recycle them
             # under a kernel of the other stream.
-            return tuple(fork_join(lidar_feat.device,
-                                   lambda: self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas),
-                                   lambda: self._bev_side(lidar_feat, img5, img_metas, pts_metas)))
+            if not utils.OVERLAP & 16:
+                return tuple(fork_join(lidar_feat.device,
+                                       lambda: self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas),
+                                       lambda: self._bev_side(lidar_feat, img5, img_metas, pts_metas)))
+            # the BEV -> image warp needs the BEV map and the depth only: it opens the side stream's work and is awaited
+            # by the image side after its own projections.  `warped` stays referenced until after the join (allocator
+            # contract of fork_join).
+            main, side = torch.cuda.current_stream(lidar_feat.device), utils.side_stream(lidar_feat.device, 0)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                warped = self.P2I_block.Warp(lidar_feat, img5, img_metas, pts_metas)
+                ready = torch.cuda.Event()
+                ready.record(side)
+                new_lidar_feat = self._bev_side(lidar_feat, img5, img_metas, pts_metas)
+            new_img_feat = self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas, warped, ready)
+            main.wait_stream(side)
+            del warped
+            return new_img_feat, new_lidar_feat
         new_lidar_feat = self._bev_side(lidar_feat, img5, img_metas, pts_metas)
         new_img_feat = self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas)
         return new_img_feat, new_lidar_feat

@@ -321,8 +321,10 @@ class MMRI_P2I(nn.Module):
         self.Warp = BEVWarp()
         self.Local = LocalContextAttentionBlock(in_channels, out_channels, kernel_size, last_affine=True)
 
-    def forward(self, lidar_feats, img_feats, img_metas, pts_metas, query=None, **kwargs):
-        warped = self.Warp(lidar_feats, img_feats, img_metas, pts_metas)        # B, N, C, H, W
+    def forward(self, lidar_feats, img_feats, img_metas, pts_metas, query=None, warped=None, **kwargs):
+        """`query` / `warped`: the projected query map / the warped BEV map when the caller already has them."""
+        if warped is None:
+            warped = self.Warp(lidar_feats, img_feats, img_metas, pts_metas)    # B, N, C, H, W
         B, N, C, H, W = warped.shape
         out = self.Local(img_feats.reshape(B * N, C, H, W), warped.reshape(B * N, C, H, W), query=query)
         return out.view(B, N, C, H, W)
