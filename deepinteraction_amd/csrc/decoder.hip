@@ -604,19 +604,9 @@ int di_mha_decode_fwd(const void *q, const void *kv, void *out, float *scratch, 
     int qsplit, nrange, range_keys;
     di::mha_plan(B, Q, S, qsplit, nrange, range_keys);
     const int lds = 2 * num_heads * di::mh::KS * di::mh::ROWB;
-    static bool attr_set = false;   // idempotent; a race only repeats the call
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void *)di::mha_decode_mfma_kernel<8>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void *)di::mha_decode_mfma_kernel<0>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) {
-        di::set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-        return DI_ERR_LAUNCH;
-      }
-      attr_set = true;
-    }
+    static di::LdsRaised raised8, raised0;
+    if (int rc = di::ensure_lds(raised8, (const void *)di::mha_decode_mfma_kernel<8>, 160 * 1024)) return rc;
+    if (int rc = di::ensure_lds(raised0, (const void *)di::mha_decode_mfma_kernel<0>, 160 * 1024)) return rc;
     if (num_heads == 8)
       hipLaunchKernelGGL(di::mha_decode_mfma_kernel<8>, dim3(nrange, qsplit, B), dim3(di::mh::NTH), lds, s,
                          (const __half *)q, (const __half *)kv, scratch, B, Q, S, num_heads,

@@ -12,6 +12,14 @@ namespace di {
 // ---- host side: error plumbing (no exceptions across the C ABI)
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
+// Launch state that belongs to a DEVICE, not to the process (one process may drive several): the CU count of the current
+// device (<= 0: error set), and "the dynamic-LDS limit of this kernel has been raised on the current device" (one bit
+// per device ordinal; idempotent, a race only repeats the runtime call).
+int device_cus();
+struct LdsRaised {
+  unsigned long long done = 0;
+};
+int ensure_lds(LdsRaised &state, const void *kernel, int bytes);
 
 #define DI_REQUIRE(cond, ...)            \
   do {                                   \

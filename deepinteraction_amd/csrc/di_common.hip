@@ -37,3 +37,41 @@ long long di_graph_node_count(void *graph) {
   return (long long)n;
 }
 }
+
+namespace di {
+
+int device_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    set_error("cannot query the current device");
+    return 0;
+  }
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      set_error("cannot query the CU count of device %d", dev);
+      return 0;
+    }
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
+int ensure_lds(LdsRaised &state, const void *kernel, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    set_error("cannot query the current device");
+    return DI_ERR_LAUNCH;
+  }
+  if (state.done & (1ull << dev)) return DI_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(%d bytes of LDS): %s", bytes, hipGetErrorString(e));
+    return DI_ERR_LAUNCH;
+  }
+  state.done |= 1ull << dev;
+  return DI_OK;
+}
+
+}  // namespace di

@@ -367,8 +367,6 @@ int launch_local_attn_mfma(const void *q, const void *k, const void *v, void *ou
                            float scale, hipStream_t stream);   // local_attn_mfma.hip
 int launch_local_attn_mfma2(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                             float scale, int cfg, hipStream_t stream);   // local_attn_mfma2.hip
-int launch_local_attn_mfma4(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
-                            float scale, int cfg, hipStream_t stream);
 int launch_local_attn_mfma3(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                             float scale, int cfg, hipStream_t stream);   // local_attn_mfma3.hip
 
@@ -390,38 +388,17 @@ extern "C" {
 int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                          int C, int kH, int kW, float scale, int dtype, int variant, void *stream) {
   di::LaArgs A{q, k, v, out, n, H, W, C, scale, (hipStream_t)stream};
-  const bool mfma_ok = dtype == DI_F16 && C == 128 && kH == 9 && kW == 9 && n > 0 && H > 0 && W > 0;
-  if (variant == DI_LA_MFMA && !mfma_ok) {
-    di::set_error("MFMA local attention needs fp16, C=128, 9x9 (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
-    return DI_ERR_ARG;
-  }
-  if (variant >= DI_LA_MFMA4 && variant < DI_LA_MFMA4 + 16) {
+  const bool mfma_ok = dtype == DI_F16 && C == 128 && kH == 9 && kW == 9 && n > 0 && H > 0 && W > 0 &&
+                       (long long)n * H * W * 256 < (1ll << 31);   // 32-bit byte offsets inside the kernel
+  if (variant >= DI_LA_MFMA && variant < DI_LA_MFMA + 5) {
     if (!mfma_ok) {
-      di::set_error("the vertical-streaming kernel needs fp16, C=128, 9x9");
+      di::set_error("MFMA local attention needs fp16, C=128, 9x9, < 2^23 pixels (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
       return DI_ERR_ARG;
     }
-    return di::launch_local_attn_mfma4(q, k, v, out, n, H, W, scale, variant - DI_LA_MFMA4, (hipStream_t)stream);
+    return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, variant - DI_LA_MFMA, (hipStream_t)stream);
   }
-  if (variant >= DI_LA_MFMA3 && variant < DI_LA_MFMA3 + 3) {
-    if (!mfma_ok) {
-      di::set_error("MFMA local attention needs fp16, C=128, 9x9 (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
-      return DI_ERR_ARG;
-    }
-    return di::launch_local_attn_mfma3(q, k, v, out, n, H, W, scale, variant - DI_LA_MFMA3, (hipStream_t)stream);
-  }
-  if (variant >= DI_LA_MFMA2 && variant < DI_LA_MFMA2 + 5) {
-    if (!mfma_ok) {
-      di::set_error("MFMA local attention needs fp16, C=128, 9x9 (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
-      return DI_ERR_ARG;
-    }
-    return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, variant - DI_LA_MFMA2, (hipStream_t)stream);
-  }
-  if (mfma_ok && variant == DI_LA_MFMA)
-    return di::launch_local_attn_mfma(q, k, v, out, n, H, W, scale, (hipStream_t)stream);
-  if (mfma_ok && variant == DI_LA_AUTO && (long long)n * H * W * 256 < (1ll << 31))   // fastest measured: 16x4 tiles, 2 workgroups per CU
+  if (mfma_ok && variant == DI_LA_AUTO)   // fastest measured: 16x4 tiles, 2 workgroups per CU
     return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, 2, (hipStream_t)stream);
-  if (mfma_ok && variant == DI_LA_AUTO)
-    return di::launch_local_attn_mfma(q, k, v, out, n, H, W, scale, (hipStream_t)stream);
   return di::run_la(di::OP_FUSED, dtype, kH, kW, A);
 }
 

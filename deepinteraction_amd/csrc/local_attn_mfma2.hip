@@ -415,22 +415,10 @@ static int launch(const void *q, const void *k, const void *v, void *out, int n,
   const int tiles_x = (W + G::TW - 1) / G::TW, tiles_y = (H + G::TH - 1) / G::TH;
   const long long ntiles = (long long)n * tiles_x * tiles_y;
   DI_REQUIRE((long long)n * H * W * 256 < (1ll << 31), "map of %d x %d x %d texels exceeds the 2 GiB offset range", n, H, W);
-  static int n_cu = 0;   // idempotent initialisation; a race only repeats the queries
-  if (n_cu == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-      set_error("cannot query the CU count");
-      return DI_ERR_LAUNCH;
-    }
-    hipError_t e = hipFuncSetAttribute((const void *)local_attn_m2_kernel<G>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return DI_ERR_LAUNCH;
-    }
-    n_cu = cus;
-  }
+  static LdsRaised lds_raised;
+  if (int rc = ensure_lds(lds_raised, (const void *)local_attn_m2_kernel<G>, G::LDS_BYTES)) return rc;
+  const int n_cu = device_cus();
+  if (n_cu <= 0) return DI_ERR_LAUNCH;
   // one workgroup per resident slot, a multiple of the 8 XCDs; never more than one per tile
   long long grid = (long long)n_cu * wg_per_cu;
   if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;

@@ -230,22 +230,10 @@ static int launch(const void *x1, const void *x2, const void *x3, const void *w1
                   const void *w2, const float *b2, void *y, long long M, int relu1, int relu2,
                   const void *mask, const float *bm, hipStream_t stream) {
   constexpr int LDS = 128 * K1 * 2 + 128 * K2 * 2 + 1536;
-  static int n_cu = 0;   // idempotent initialisation; a race only repeats the queries
-  if (n_cu == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-      set_error("cannot query the CU count");
-      return DI_ERR_LAUNCH;
-    }
-    hipError_t e = hipFuncSetAttribute((const void *)pointwise_chain_kernel<K1, K2>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return DI_ERR_LAUNCH;
-    }
-    n_cu = cus;
-  }
+  static LdsRaised lds_raised;
+  if (int rc = ensure_lds(lds_raised, (const void *)pointwise_chain_kernel<K1, K2>, LDS)) return rc;
+  const int n_cu = device_cus();
+  if (n_cu <= 0) return DI_ERR_LAUNCH;
   const long long nchunk = (M + 16 * PG - 1) / (16 * PG);
   const int per_cu = LDS <= 80 * 1024 ? 2 : 1;
   long long grid = (long long)n_cu * per_cu;
@@ -430,15 +418,8 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
 template <int NG>
 static int launch_multi(const void *x, const MultiArgs &A, long long M, long long grid, hipStream_t stream) {
   constexpr int LDS = 2 * kChainImage;
-  static bool attr = false;   // idempotent
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void *)pointwise_multi_kernel<NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return DI_ERR_LAUNCH;
-    }
-    attr = true;
-  }
+  static LdsRaised lds_raised;
+  if (int rc = ensure_lds(lds_raised, (const void *)pointwise_multi_kernel<NG>, LDS)) return rc;
   hipLaunchKernelGGL((pointwise_multi_kernel<NG>), dim3((unsigned)grid), dim3(NT), LDS, stream, (const __half *)x, A, M);
   return check_launch("pointwise_multi");
 }
@@ -462,16 +443,8 @@ extern "C" int di_pointwise_multi_fwd(const void *x, int n_chains, const void *c
       A.c[c] = Chain{nullptr, nullptr, 0, 0, 0};
     }
   }
-  static int n_cu = 0;   // idempotent initialisation; a race only repeats the query
-  if (n_cu == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-      di::set_error("cannot query the CU count");
-      return DI_ERR_LAUNCH;
-    }
-    n_cu = cus;
-  }
+  const int n_cu = di::device_cus();
+  if (n_cu <= 0) return DI_ERR_LAUNCH;
   // every wave keeps its pixel groups in registers: NG in {2, 4, 5} groups per wave, one workgroup per CU when the map
   // allows it (more workgroups than CUs only beyond 5 groups per wave)
   const long long ngroups = (n_pixels + 15) / 16;

@@ -671,14 +671,8 @@ int di_token_mha(const void *qkv, int ld, const void *member, const void *view, 
 #define DI_TMHA(NT)                                                                                                  \
   do {                                                                                                               \
     constexpr int lds = 4 * NT * 16 * 64 + NT * 16;                                                                  \
-    static bool attr = false;                                                                                        \
-    if (!attr) {                                                                                                     \
-      if (hipFuncSetAttribute((const void *)tok_mha_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { \
-        di::set_error("hipFuncSetAttribute failed");                                                                 \
-        return DI_ERR_LAUNCH;                                                                                        \
-      }                                                                                                              \
-      attr = true;                                                                                                   \
-    }                                                                                                                \
+    static di::LdsRaised raised;                                                                                     \
+    if (int rc = di::ensure_lds(raised, (const void *)tok_mha_kernel<NT>, lds)) return rc;                           \
     hipLaunchKernelGGL((tok_mha_kernel<NT>), grid, blk, lds, s, (const __half *)qkv, ld, (const unsigned char *)member, \
                        (const signed char *)view, (__half *)out, ldo, Q, heads, sl2);                                \
   } while (0)

@@ -72,10 +72,8 @@ def _f32(t):
 
 
 # ------------------------------------------------------------------ local-window attention
-LA_AUTO, LA_VALU, LA_MFMA = 0, 1, 2
-LA_MFMA2 = 3          # + configuration 0..3 of the persistent pipelined row-pair kernel
-LA_MFMA3 = 8
-LA_MFMA4 = 11          # producer/consumer wavefronts + direct-to-LDS loads
+LA_AUTO, LA_VALU = 0, 1
+LA_MFMA = 3           # + configuration 0..4 of the persistent pipelined row-pair kernel (2 = the AUTO choice)
 
 
 def local_attention(q, k, v, kH, kW, scale, variant=LA_AUTO):

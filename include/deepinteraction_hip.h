@@ -60,14 +60,14 @@ long long di_graph_node_count(void *graph_host);
  * Supported windows: kH,kW odd in {3,5,7,9}. */
 int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                       int C, int kH, int kW, float scale, int dtype, void *stream);
-/* Same op with an explicit kernel choice (DI_LA_MFMA4: the vertical-streaming kernel, on par with the default on
- * the image-side maps).  DI_LA_AUTO picks, for fp16 / C=128 / 9x9, the persistent
+/* Same op with an explicit kernel choice.  DI_LA_AUTO picks, for fp16 / C=128 / 9x9, the persistent
  * software-pipelined matrix-core kernel (row-pair 16x16x32 MFMA tiles, local_attn_mfma2.hip), else the
- * generic LDS-tiled VALU kernel.  The other codes select one implementation (tests, measurements). */
-enum { DI_LA_AUTO = 0, DI_LA_VALU = 1, DI_LA_MFMA = 2,
-       DI_LA_MFMA2 = 3 /* + configuration: 3 = 16x8 tiles, 5 = 16x4 tiles (the AUTO choice), 7 = timestamps */,
-       DI_LA_MFMA3 = 8 /* producer/consumer wavefronts + direct-to-LDS loads (9, 10: measurement builds) */,
-       DI_LA_MFMA4 = 11 /* vertical streaming with the halo in an LDS ring; + k = k segments per strip (0 = fill the CUs once) */ };
+ * generic LDS-tiled VALU kernel (any C, fp32 or fp16, windows 3..9).  The other codes select one implementation
+ * (tests, measurements).  Three further matrix-core generations (one tile per workgroup; producer/consumer waves with
+ * direct-to-LDS loads; vertical streaming with an LDS halo ring) were measured in round 1, lost to this one and are
+ * gone. */
+enum { DI_LA_AUTO = 0, DI_LA_VALU = 1,
+       DI_LA_MFMA = 3 /* + configuration: 3 = 16x8 tiles, 5 = 16x4 tiles (the AUTO choice), 7 = timestamps */ };
 int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                          int C, int kH, int kW, float scale, int dtype, int variant, void *stream);
 

@@ -42,8 +42,7 @@ def main():
     for name, (n, H, W) in dict(image=(6, Hi, Wi), bev=(1, Hb, Wb)).items():
         q, k, v = rnd(n, C, H, W), rnd(n, C, H, W), rnd(n, C, H, W)
         byt = 4 * n * C * H * W * s
-        for vname, var in (('valu', ops.LA_VALU), ('auto', ops.LA_AUTO), ('mfma', ops.LA_MFMA), ('m2c0', ops.LA_MFMA2),
-                           ('m2c2', ops.LA_MFMA2 + 2), ('m3c0', ops.LA_MFMA3)):
+        for vname, var in (('valu', ops.LA_VALU), ('auto', ops.LA_AUTO), ('m2c0', ops.LA_MFMA), ('m2c2', ops.LA_MFMA + 2)):
             if var != ops.LA_VALU and dt != torch.float16:
                 continue
             us = timeit(lambda: ops.local_attention(q, k, v, 9, 9, 1 / math.sqrt(C), variant=var))
