@@ -26,6 +26,7 @@ training - the gradient all-reduce over RCCL.  Rank 0 prints ONE JSON line, with
   parity        the product's outputs on that same sample against the oracle's (same state_dict, no depth injection)
 """
 import argparse
+import contextlib
 import json
 import os
 import socket
@@ -51,6 +52,11 @@ def parse():
     ap.add_argument('--shape', default='R', choices=['R', 'A', 'TINY'])
     ap.add_argument('--model', default='v1', choices=['v1', 'pp'], help='pp = DeepInteraction++ (configs[4])')
     ap.add_argument('--mode', default='forward', choices=['forward', 'train'], help='train = configs[2]/[3]')
+    ap.add_argument('--inflight', type=int, default=2,
+                    help='samples in flight per GPU: N independent captured forwards, each load()ed with its own sample and replayed '
+                         'on its own stream (a step = N x batch samples; 2 = the reference\'s samples_per_gpu, '
+                         'Fusion_0075_refactor.py:94); 1 = one sample at a time (the latency figure, also reported as '
+                         '`single_sample` in the default line)')
     ap.add_argument('--pool', type=int, default=4, help='distinct device-resident samples cycled through the steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true',
@@ -149,6 +155,8 @@ def run_dry(args, parallel, rank, world):
 
 def main():
     args = parse()
+    if args.eager or args.dry_run or args.model != 'v1' or args.mode != 'forward':
+        args.inflight = 1          # several samples in flight exist for the graph-replayed v1 forward only
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(args))
     import torch
@@ -194,7 +202,8 @@ def _line(args, metric, value, elapsed, dtype, workload, extra_cfg):
     return dict(metric=metric, value=round(value, 3), unit='samples/s', n_gpus=args.gpus, steps=args.steps,
                 warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
                 scaling='weak', vs_baseline=None, dtype=dtype, data='synthetic',
-                config=dict(workload=workload, batch_per_gpu=args.batch, global_batch=args.batch * args.gpus,
+                config=dict(workload=workload, batch_per_gpu=args.batch * max(1, args.inflight),
+                            global_batch=args.batch * max(1, args.inflight) * args.gpus,
                             settle_ms=args.settle_ms,
                             parallelism=f'{args.gpus} replicas, sharded by sample (one process per GPU)', **extra_cfg))
 
@@ -228,19 +237,41 @@ def bench_forward(args, rank, world, device):
         else:
             from deepinteraction_amd.graphed import GraphedHotPath
             cap = max(range(len(dev_pool)), key=lambda i: n_pillars[i])     # the largest sample sets the capacity
-            g = GraphedHotPath(enc, dec, dev_pool[cap])
+            graphs = [GraphedHotPath(enc, dec, dev_pool[cap]) for _ in range(max(1, args.inflight))]
+            g = graphs[-1]                                  # (the modules' output attributes point at the last capture)
             records = [g.prepare(d) for d in dev_pool]
+            lanes = [torch.cuda.Stream() for _ in graphs] if len(graphs) > 1 else [None]
             it = [0]
 
             def step():
-                g.load(records[it[0] % len(records)])      # per-sample: copies into the captured buffers ...
-                it[0] += 1
-                g()                                         # ... and one replay of the captured forward
+                for gi, lane in zip(graphs, lanes):
+                    with torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext():
+                        gi.load(records[it[0] % len(records)])      # per-sample: copies into the captured buffers ...
+                        it[0] += 1
+                        gi()                                         # ... and one replay of the captured forward
+        if not args.eager and len(graphs) > 1:
+            for lane in lanes:                             # the lanes start after everything queued so far
+                lane.wait_stream(torch.cuda.current_stream())
         settle(step, args.settle_ms)
         for _ in range(args.warmup):
             step()
         # barrier + synchronize | K steps | barrier + synchronize, MAX over ranks
         elapsed = parallel.timed_region(step, args.steps, device)
+
+        single = None
+        if not args.eager and len(graphs) > 1:             # the one-sample-at-a-time figure beside the headline
+            torch.cuda.synchronize()
+            one = [0]
+
+            def step1():
+                g.load(records[one[0] % len(records)])
+                one[0] += 1
+                g()
+            for _ in range(max(2, args.warmup // 2)):
+                step1()
+            e1 = parallel.timed_region(step1, args.steps, device)
+            single = dict(value=round(parallel.throughput(args.batch, args.steps, e1, world), 3), unit='samples/s',
+                          ms_per_step=round(e1 / args.steps * 1e3, 3), inflight=1)
 
         # parity sample: the product's outputs on pool[0], in the benched launch mode
         product_out = None
@@ -287,15 +318,17 @@ def bench_forward(args, rank, world, device):
                     avg_launch_us=round(avg * 1e6, 2), launches=len(durs), algorithmic_bytes=alg_bytes,
                     timed_in=f'{args.roofline_steps} eager forwards right after the timed region, HIP events on the launch stream')
     out = _line(args, 'samples/sec forward (Fusion_0075 synthetic)',
-                parallel.throughput(args.batch, args.steps, elapsed, world), elapsed,
+                parallel.throughput(args.batch * max(1, args.inflight), args.steps, elapsed, world), elapsed,
                 'f16' if dtype == torch.float16 else 'f32',
                 'Full MMRI encoder (2 layers) + MMPI decoder forward, '
                 f'Fusion_0075_refactor shapes (shape {args.shape}), random-init weights',
-                dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(dev_pool),
-                     launch='eager' if args.eager else 'per step: load() of the next pool sample into the captured '
-                                                       'buffers + hipGraph replay of the captured forward',
+                dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(dev_pool), inflight=max(1, args.inflight),
+                     launch='eager' if args.eager else 'per step and sample in flight: load() of the next pool sample into the '
+                                                       'captured buffers + hipGraph replay of the captured forward',
                      graph_nodes=None if g is None else g.num_nodes()))
     out['roofline'] = roofline
+    if single is not None:
+        out['single_sample'] = single
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         state = ({k: v.float().cpu() for k, v in enc.state_dict().items()},
                  {k: v.float().cpu() for k, v in dec.state_dict().items()})

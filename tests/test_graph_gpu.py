@@ -156,3 +156,38 @@ def test_many_replays_over_a_pool_match_eager_at_the_benched_shape():
             assert torch.equal(dec.top_proposals, top) and torch.equal(dec.query_labels, labels), (it, i)
             _same(out, ref)
     assert g.num_nodes() is None or g.num_nodes() < 200
+
+
+def test_two_forwards_in_flight_match_eager_at_the_benched_shape():
+    """bench.py's default step: TWO independent captured forwards (own static buffers, shared modules and weight
+    caches), each load()ed with its own sample and replayed on its own stream at the same time - every replay
+    bit-identical to the eager forward of its sample."""
+    from deepinteraction_amd import harness, parallel
+    shape = synth.SHAPE_R
+    enc, dec = harness.build_models(shape, 200, torch.float16, 'cuda')
+    pool = [harness.to_device(synth.make_inputs(1, shape, seed=parallel.sample_seed(i)), 'cuda', torch.float16)
+            for i in range(3)]
+    with torch.no_grad():
+        eager = []
+        for d in pool:
+            _, out = harness.forward(enc, dec, d)
+            torch.cuda.synchronize()
+            eager.append({k: v.clone() for k, v in out[0][0].items()})
+        cap = max(range(3), key=lambda i: int(pool[i]['pts_metas']['pillars'].shape[0]))
+        graphs = [GraphedHotPath(enc, dec, pool[cap]) for _ in range(2)]
+        recs = [graphs[0].prepare(d) for d in pool]
+        lanes = [torch.cuda.Stream() for _ in graphs]
+        for lane in lanes:
+            lane.wait_stream(torch.cuda.current_stream())
+        it = 0
+        for rnd in range(5):
+            used, outs = [], []
+            for g, lane in zip(graphs, lanes):
+                with torch.cuda.stream(lane):
+                    g.load(recs[it % 3])
+                    outs.append(g()[0][0])
+                used.append(it % 3)
+                it += 1
+            torch.cuda.synchronize()
+            for i, out in zip(used, outs):
+                _same(out, eager[i])
