@@ -57,6 +57,9 @@ def parse():
                          'on its own stream (a step = N x batch samples; 2 = the reference\'s samples_per_gpu, '
                          'Fusion_0075_refactor.py:94); 1 = one sample at a time (the latency figure, also reported as '
                          '`single_sample` in the default line)')
+    ap.add_argument('--from-points', action='store_true',
+                    help='start every step from the raw points: the pillars of pts_metas are rebuilt by the voxeliser inside '
+                         'the captured forward (detector glue, detectors/deepinteraction.py:120-171) instead of being loaded')
     ap.add_argument('--pool', type=int, default=4, help='distinct device-resident samples cycled through the steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true',
@@ -237,7 +240,14 @@ def bench_forward(args, rank, world, device):
         else:
             from deepinteraction_amd.graphed import GraphedHotPath
             cap = max(range(len(dev_pool)), key=lambda i: n_pillars[i])     # the largest sample sets the capacity
-            graphs = [GraphedHotPath(enc, dec, dev_pool[cap]) for _ in range(max(1, args.inflight))]
+            glue = None
+            if args.from_points:
+                from deepinteraction_amd.mmdet3d_plugin import PointGlue
+                Hb, Wb = shape['bev_hw']
+                rng = list(synth.PC_RANGE)
+                glue = PointGlue(dict(max_num_points=20, max_voxels=(30000, 60000), point_cloud_range=rng,
+                                      voxel_size=[(rng[3] - rng[0]) / Wb, (rng[4] - rng[1]) / Hb, rng[5] - rng[2]])).eval()
+            graphs = [GraphedHotPath(enc, dec, dev_pool[cap], glue=glue) for _ in range(max(1, args.inflight))]
             g = graphs[-1]                                  # (the modules' output attributes point at the last capture)
             records = [g.prepare(d) for d in dev_pool]
             lanes = [torch.cuda.Stream() for _ in graphs] if len(graphs) > 1 else [None]
@@ -293,19 +303,35 @@ def bench_forward(args, rank, world, device):
                     max_abs=max(float((eg[0][0][k].float().cpu() - product_out[1][k]).abs().max()) for k in product_out[1]),
                     proposals_identical=bool(torch.equal(dec.top_proposals.cpu(), product_out[4])))
         # dominant-kernel timing: HIP events right around the launch, on the launch stream, in eager forwards of
-        # the same model and data (events cannot bracket one kernel inside a graph replay)
-        harness.forward(enc, dec, dev_pool[0])
-        torch.cuda.synchronize()
-        ops.PROFILE = []
-        for _ in range(args.roofline_steps):
-            harness.forward(enc, dec, dev_pool[0])
-        torch.cuda.synchronize()
+        # the same model and data (events cannot bracket one kernel inside a graph replay).  Single stream (the
+        # fork/join sites off): a kernel's roofline fraction is a property of the kernel running alone; under the
+        # default two-stream, two-samples-in-flight schedule its wall duration includes time-sharing with whatever
+        # runs beside it (`in_step_avg_us`).
+        from deepinteraction_amd import utils as di_utils
+
+        def kernel_times(overlap):
+            saved, di_utils.OVERLAP = di_utils.OVERLAP, overlap
+            try:
+                harness.forward(enc, dec, dev_pool[0])
+                torch.cuda.synchronize()
+                ops.PROFILE = []
+                for _ in range(args.roofline_steps):
+                    harness.forward(enc, dec, dev_pool[0])
+                torch.cuda.synchronize()
+                got, ops.PROFILE = ops.PROFILE, None
+                return got
+            finally:
+                di_utils.OVERLAP = saved
+        in_step = kernel_times(di_utils.OVERLAP)
+        ops.PROFILE = kernel_times(0)
         prof, ops.PROFILE = ops.PROFILE, None
     Hi, Wi = shape['img_hw']
     n_img = 6 * args.batch
     es = 2 if dtype == torch.float16 else 4
     alg_bytes = 4 * n_img * 128 * Hi * Wi * es
-    durs = [s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name == 'local_attn_fwd' and n == n_img]
+    def la_times(events):
+        return [s.elapsed_time(e) * 1e-3 for (name, n, s, e) in events if name == 'local_attn_fwd' and n == n_img]
+    durs, shared = la_times(prof), la_times(in_step)
     avg = sum(durs) / max(len(durs), 1)
     achieved = alg_bytes / avg / 1e9 if durs else None
     pmc = pmc_file('pmc_local_attn.json')
@@ -316,13 +342,16 @@ def bench_forward(args, rank, world, device):
                     traffic=pmc.get('hbm_bytes_per_launch'), mfma_busy=pmc.get('mfma_busy'),
                     lds_busy=pmc.get('lds_busy'), pmc_source=pmc.get('source'),
                     avg_launch_us=round(avg * 1e6, 2), launches=len(durs), algorithmic_bytes=alg_bytes,
-                    timed_in=f'{args.roofline_steps} eager forwards right after the timed region, HIP events on the launch stream')
+                    in_step_avg_us=round(sum(shared) / max(len(shared), 1) * 1e6, 2),
+                    timed_in=f'{args.roofline_steps} eager single-stream forwards right after the timed region, HIP '
+                             'events on the launch stream; in_step_avg_us: the same with the two-stream schedule')
     out = _line(args, 'samples/sec forward (Fusion_0075 synthetic)',
                 parallel.throughput(args.batch * max(1, args.inflight), args.steps, elapsed, world), elapsed,
                 'f16' if dtype == torch.float16 else 'f32',
                 'Full MMRI encoder (2 layers) + MMPI decoder forward, '
                 f'Fusion_0075_refactor shapes (shape {args.shape}), random-init weights',
                 dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(dev_pool), inflight=max(1, args.inflight),
+                     from_points=bool(args.from_points),
                      launch='eager' if args.eager else 'per step and sample in flight: load() of the next pool sample into the '
                                                        'captured buffers + hipGraph replay of the captured forward',
                      graph_nodes=None if g is None else g.num_nodes()))

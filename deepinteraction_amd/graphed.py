@@ -30,9 +30,13 @@ from .mmdet3d_plugin.models.utils.encoder_utils import GEOM_KEY
 
 
 class GraphedHotPath:
-    def __init__(self, encoder, decoder, inputs, warmup=3):
+    def __init__(self, encoder, decoder, inputs, warmup=3, glue=None):
+        """glue: a `PointGlue` (mmdet3d_plugin/models/detectors) - the captured forward then STARTS FROM THE POINTS:
+        the pillars / coordinates / counts of `pts_metas` are rebuilt by the voxeliser inside every replay (capacity-sized
+        buffers, no host synchronisation) instead of being copied in by `load()`."""
         assert not encoder.training and not decoder.training, 'graph capture is for the inference form'
         self.enc, self.dec = encoder, decoder
+        self.glue = glue
         # one map per modality (v1 neck) or a list of levels (DeepInteraction++ neck)
         self.img_feats = self._clone(inputs['img_feats'])
         self.pts_feats = self._clone(inputs['pts_feats'])
@@ -42,10 +46,16 @@ class GraphedHotPath:
         self.batch = len(inputs['img_metas'])
         self.img_metas = [dict(m) for m in inputs['img_metas']]
         self.pts = [p.clone() for p in pm['pts']]
-        self.pillars = pm['pillars'].clone()
-        self.pillar_coors = pm['pillar_coors'].clone()
-        self.pillars_num_points = pm['pillars_num_points'].clone()
-        if self.batch == 1:
+        if glue is not None:                # rebuilt from the points inside the forward: no static pillar buffers
+            self.pillars = self.pillar_coors = self.pillars_num_points = None
+            self.bounds = None
+        else:
+            self.pillars = pm['pillars'].clone()
+            self.pillar_coors = pm['pillar_coors'].clone()
+            self.pillars_num_points = pm['pillars_num_points'].clone()
+        if glue is not None:
+            pass
+        elif self.batch == 1:
             self.bounds = [0, self.pillars.shape[0]]
         else:   # fixed per-sample pillar capacity: the split of the capture-time batch
             cnt = torch.bincount(self.pillar_coors[:, 0].long(), minlength=self.batch).cpu().tolist()
@@ -74,6 +84,10 @@ class GraphedHotPath:
             dst.copy_(src, non_blocking=True)
 
     def _pts_metas(self):
+        if self.glue is not None:
+            pm = self.glue(self.pts, padded=True)           # voxelisation inside the (captured) forward
+            pm[GEOM_KEY] = self.sample_geom
+            return pm
         return {'pillars': self.pillars, 'pillar_coors': self.pillar_coors,
                 'pillars_num_points': self.pillars_num_points, 'pts': self.pts,
                 'pillar_batch_bounds': self.bounds, GEOM_KEY: self.sample_geom}
@@ -152,7 +166,9 @@ class GraphedHotPath:
         r.img_feats, r.pts_feats = inputs['img_feats'], inputs['pts_feats']
         pm = inputs['pts_metas']
         r.pts = [self._padded(src, dst, float('nan')) for dst, src in zip(self.pts, pm['pts'])]
-        if self.batch == 1:
+        if self.glue is not None:
+            r.pillars = r.pillar_coors = r.pillars_num_points = None
+        elif self.batch == 1:
             r.pillars = self._padded(pm['pillars'], self.pillars, 0.0)
             r.pillar_coors = self._padded(pm['pillar_coors'], self.pillar_coors, 0)
             r.pillars_num_points = self._padded(pm['pillars_num_points'], self.pillars_num_points, 0)
@@ -172,7 +188,7 @@ class GraphedHotPath:
                 r.pillar_coors[lo:hi, 0] = s
                 r.pillars_num_points[lo:lo + n] = pm['pillars_num_points'][sel]
         r.img_metas = [dict(m) for m in inputs['img_metas']]
-        dev = self.pillars.device
+        dev = self.pts[0].device
         r.sample_geom = [SampleGeometry._pack(m, g.img_hw).to(dev) for g, m in zip(self.sample_geom, r.img_metas)]
         r.query_geom = QueryGeometry._pack(r.img_metas)[0].to(dev)
         r.extra = []                      # per-sample constants some operators keep next to the geometry (++ rays)
@@ -189,9 +205,10 @@ class GraphedHotPath:
         self._copy(self.pts_feats, r.pts_feats)
         for dst, src in zip(self.pts, r.pts):
             dst.copy_(src, non_blocking=True)
-        self.pillars.copy_(r.pillars, non_blocking=True)
-        self.pillar_coors.copy_(r.pillar_coors, non_blocking=True)
-        self.pillars_num_points.copy_(r.pillars_num_points, non_blocking=True)
+        if self.glue is None:
+            self.pillars.copy_(r.pillars, non_blocking=True)
+            self.pillar_coors.copy_(r.pillar_coors, non_blocking=True)
+            self.pillars_num_points.copy_(r.pillars_num_points, non_blocking=True)
         self.img_metas = r.img_metas
         for g, buf in zip(self.sample_geom, r.sample_geom):
             g._buf.copy_(buf, non_blocking=True)

@@ -467,6 +467,9 @@ def mha_decode(q, kv, num_heads, scale):
 
 
 # ------------------------------------------------------------------ pillar / voxel producer
+_VOXEL_GEO = {}
+
+
 def voxelize(points, voxel_size, pc_range, max_points, max_voxels, n_feat=None):
     """Hard voxelisation (spconv PointToVoxel semantics, first-come order).  points (N,D') float32 on the device
     -> voxels (max_voxels, max_points, n_feat), coords (max_voxels, 3) int32 [z,y,x], num_points (max_voxels,)
@@ -477,7 +480,10 @@ def voxelize(points, voxel_size, pc_range, max_points, max_voxels, n_feat=None):
     D = n_feat or points.shape[1]
     dev = points.device
     grid = [int(round((pc_range[3 + a] - pc_range[a]) / voxel_size[a])) for a in range(3)]
-    geo = torch.tensor(list(pc_range) + list(voxel_size), dtype=torch.float32, device=dev)
+    gkey = (tuple(float(x) for x in pc_range), tuple(float(x) for x in voxel_size), str(dev))
+    geo = _VOXEL_GEO.get(gkey)                    # a device constant: built once (no host->device copy per call, so
+    if geo is None:                               # the op can be captured in a hipGraph)
+        geo = _VOXEL_GEO[gkey] = torch.tensor(list(pc_range) + list(voxel_size), dtype=torch.float32, device=dev)
     voxels = torch.zeros((max_voxels, max_points, D), dtype=torch.float32, device=dev)
     coords = torch.zeros((max_voxels, 3), dtype=torch.int32, device=dev)
     num = torch.zeros((max_voxels,), dtype=torch.int32, device=dev)

@@ -191,3 +191,41 @@ def test_two_forwards_in_flight_match_eager_at_the_benched_shape():
             torch.cuda.synchronize()
             for i, out in zip(used, outs):
                 _same(out, eager[i])
+
+
+def test_point_glue_rebuilds_pts_metas_and_the_graph_can_start_from_points():
+    """Detector glue (reference detectors/deepinteraction.py:120-171): `PointGlue` on the raw points reproduces the
+    `pts_metas` the inputs carry (pillars in first-come order, coordinates, counts: bit-exact), and a captured forward
+    that voxelises inside every replay (`GraphedHotPath(glue=...)`, capacity-sized buffers, no host sync) equals the
+    forward on given pillars."""
+    from deepinteraction_amd import harness, parallel
+    from deepinteraction_amd.mmdet3d_plugin import PointGlue
+    shape = synth.SHAPE_R
+    Hb, Wb = shape['bev_hw']
+    rng = list(synth.PC_RANGE)
+    glue = PointGlue(dict(max_num_points=20, max_voxels=(30000, 60000), point_cloud_range=rng,
+                          voxel_size=[(rng[3] - rng[0]) / Wb, (rng[4] - rng[1]) / Hb, rng[5] - rng[2]])).eval()
+    pool = [harness.to_device(synth.make_inputs(1, shape, seed=parallel.sample_seed(i)), 'cuda', torch.float16)
+            for i in range(2)]
+    for d in pool:
+        pm, ref = glue(d['pts_metas']['pts']), d['pts_metas']
+        assert torch.equal(pm['pillars'], ref['pillars'])
+        assert torch.equal(pm['pillars_num_points'], ref['pillars_num_points'])
+        assert torch.equal(pm['pillar_coors'], ref['pillar_coors'])
+        n = ref['pillars_num_points'].clamp(min=1).float().unsqueeze(-1)
+        assert torch.allclose(pm['pillar_center'], ref['pillars'].sum(1) / n)
+    enc, dec = harness.build_models(shape, 200, torch.float16, 'cuda')
+    with torch.no_grad():
+        eager = []
+        for d in pool:
+            _, out = harness.forward(enc, dec, d)
+            torch.cuda.synchronize()
+            eager.append({k: v.clone() for k, v in out[0][0].items()})
+        cap = max(range(2), key=lambda i: int(pool[i]['pts_metas']['pts'][0].shape[0]))
+        g = GraphedHotPath(enc, dec, pool[cap], glue=glue)
+        recs = [g.prepare(d) for d in pool]
+        for it in range(4):
+            g.load(recs[it % 2])
+            out = g()[0][0]
+            torch.cuda.synchronize()
+            _same(out, eager[it % 2])

@@ -8,6 +8,7 @@ export TMPDIR=/tmp
 echo "== bench (driver flags)"; timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; tail -c 3500 $OUT/bench_driver.json; tail -3 $OUT/bench_driver.err
 echo "== bench (defaults, no cpu)"; timeout 600 python bench.py --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 600 $OUT/bench_default.json
 if [ -n "$EXTRA" ]; then echo "== extra: $EXTRA"; ( eval "$EXTRA" ) > $OUT/extra.log 2>&1; tail -40 $OUT/extra.log; fi
+echo "== rocprof (serial: one sample at a time, one stream - per-kernel durations without time-sharing)"; ( cd /tmp && DI_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_serial -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --inflight 1 --no-cpu-baseline ) > $OUT/rocprof_serial.log 2>&1; find $OUT/prof_serial -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_serial.csv; rm -rf $OUT/prof_serial
 echo "== rocprof"; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline ) > $OUT/rocprof.log 2>&1; tail -2 $OUT/rocprof.log
 find $OUT/prof -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 find $OUT/prof -type f ! -name '*stats.csv' -delete 2>/dev/null
