@@ -16,7 +16,7 @@ from .... import ops
 from ....registry import NECKS
 from .... import utils
 from ....utils import fork_join, param_key
-from ..utils.encoder_utils import (GEOM_KEY, BEVWarp, ConvBNReLU, LocalContextAttentionBlock, MMRI_I2P, MMRI_P2I,
+from ..utils.encoder_utils import (GEOM_KEY, BEVWarp, conv3x3_module, ConvBNReLU, LocalContextAttentionBlock, MMRI_I2P, MMRI_P2I,
                                    fusable_projections, mix2, mix2_folded, pillar_batch_bounds,
                                    project_many, _fusable as _fusable_mods,
                                    sample_geometry)
@@ -144,19 +144,7 @@ class DeepInteractionEncoder(nn.Module):
                 m.momentum = self.bn_momentum
 
     def _shared_conv(self, conv, x):
-        """The shared 3x3 convolution: the HIP implicit-GEMM kernel for fp16 inference (csrc/conv3x3.hip), the library
-        convolution otherwise (float32 parity path, training)."""
-        x = ops.cl(x)
-        if (x.is_cuda and x.dtype == torch.float16 and not torch.is_grad_enabled() and conv.in_channels % 32 == 0
-                and conv.out_channels == 128 and conv.weight.dtype == torch.float16):
-            cache = self.__dict__.setdefault('_conv_cache', {})
-            key = param_key(conv)
-            hit = cache.get(id(conv))
-            if hit is None or hit[0] != key:
-                hit = (key, ops.pack_conv3x3(conv.weight, conv.bias))
-                cache[id(conv)] = hit
-            return ops.conv3x3(x, *hit[1])
-        return conv(x)
+        return conv3x3_module(self, conv, x)
 
     def forward(self, img_feats, pts_feats, img_metas, pts_metas):
         own_geom = GEOM_KEY not in pts_metas

@@ -423,9 +423,9 @@ class FusionTransformerv4(nn.Module):
     def forward(self, img_feats, pts_feats, img_metas, pts_metas):
         pts_feats = list(pts_feats)
         cl = lambda t: t.contiguous(memory_format=torch.channels_last)
-        pts_feat_conv = self.shared_conv_pts(cl(pts_feats.pop(0)))              # :85
-        ms_img = [self.multi_scale_conv_img(cl(f)) for f in img_feats]
-        ms_pts = [self.multi_scale_conv_pts(cl(f)) for f in pts_feats]
+        pts_feat_conv = eu.conv3x3_module(self, self.shared_conv_pts, cl(pts_feats.pop(0)))              # :85
+        ms_img = [eu.conv3x3_module(self, self.multi_scale_conv_img, cl(f)) for f in img_feats]
+        ms_pts = [eu.conv3x3_module(self, self.multi_scale_conv_pts, cl(f)) for f in pts_feats]
         new_img, new_pts = ms_img[0], ms_pts[0]
         dev = new_img.device
         img_flat, shapes_img = self._flatten(ms_img)

@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import ops
-from ....autograd import BEVWarpGather, I2PAttention
+from ....autograd import BEVWarpGather, I2PAttention, PixelLinear
 from ....geometry import SampleGeometry
 from ....utils import param_key
 
@@ -51,7 +51,22 @@ class ConvBNReLU(nn.Module):
     def forward(self, x):
         if not self.training and not torch.is_grad_enabled() and self.conv.kernel_size == (1, 1) and x.is_cuda:
             return pointwise(self, x)
-        x = self.conv(x)
+        c = self.conv
+        if (x.is_cuda and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.groups == 1 and c.padding == (0, 0)):
+            # training / fp32: a 1x1 convolution IS a GEMM on the (pixels, C) view of the channels-last map - and has to
+            # be run as one: MIOpen's weight-gradient solver for this shape (fp32, NHWC, 134 400 pixels, 128 -> 128) is a
+            # batched-GEMM kernel that takes 4.4 ms per call, 18 calls per training step (79 of 112 profiled ms);
+            # through F.linear the same gradient is a batched (split over pixel slabs) hipBLASLt GEMM of tens of microseconds (autograd.PixelLinear)
+            xl = ops.cl(x)
+            n, C, H, W = xl.shape
+            flat = xl.permute(0, 2, 3, 1).reshape(-1, C)
+            if torch.is_grad_enabled() and c.weight.requires_grad:
+                y = PixelLinear.apply(flat, c.weight.view(c.out_channels, C), c.bias)     # split-K weight gradient
+            else:
+                y = F.linear(flat, c.weight.view(c.out_channels, C), c.bias)
+            x = y.view(n, H, W, c.out_channels).permute(0, 3, 1, 2)
+        else:
+            x = c(x)
         if self.use_norm:
             x = self.bn(x)
         if self.use_activation:
@@ -77,6 +92,24 @@ class ConvBNReLU(nn.Module):
                    bias.to(torch.float32, copy=True).contiguous())
         self._fold_cache = (key, out)
         return out
+
+
+def conv3x3_module(owner, conv, x):
+    """A 3x3 / pad 1 / 128-output `nn.Conv2d` of a neck: the HIP implicit-GEMM kernel for fp16 inference
+    (csrc/conv3x3.hip; packed weights cached on `owner`, rebuilt when the parameters change), the library
+    convolution otherwise (float32 parity path, training)."""
+    x = ops.cl(x)
+    if (x.is_cuda and x.dtype == torch.float16 and not torch.is_grad_enabled() and conv.in_channels % 32 == 0
+            and conv.out_channels == 128 and conv.weight.dtype == torch.float16 and conv.kernel_size == (3, 3)
+            and conv.padding == (1, 1) and conv.stride == (1, 1) and conv.groups == 1):
+        cache = owner.__dict__.setdefault('_conv_cache', {})
+        key = param_key(conv)
+        hit = cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_conv3x3(conv.weight, conv.bias))
+            cache[id(conv)] = hit
+        return ops.conv3x3(x, *hit[1])
+    return conv(x)
 
 
 def pointwise(m, x, x2=None):
