@@ -13,8 +13,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdeepinteraction_hip.so')
 ARCH = 'gfx950'
+# No packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): on the MI355X boxes of this project
+# they returned wrong results in lanes 48-63 - sporadically, only while a matrix-core kernel shared the CU (two streams /
+# two samples in flight) - see DESIGN.md section 6 and tools/keys_race3.py.  Scalar fp32 ops cost the hot kernels nothing
+# measurable (they are bound by MFMA, LDS or memory).
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-cuda-compat', '-Wno-unused-result',
-         f'--offload-arch={ARCH}']
+         f'--offload-arch={ARCH}', '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+
+
+# per-file flags
+EXTRA = {}
 
 
 def sources():
@@ -38,7 +46,7 @@ def build(force=False, verbose=True):
     for src in sources():      # one hipcc per translation unit, in parallel
         obj = os.path.join(CSRC, os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
-        cmd = [hipcc] + [f for f in FLAGS if f != '-shared'] + ['-c', src, '-o', obj]
+        cmd = [hipcc] + [f for f in FLAGS if f != '-shared'] + EXTRA.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()

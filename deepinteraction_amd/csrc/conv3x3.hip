@@ -195,9 +195,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
     piece(1, bsrc1, bdst1);
     piece(2, bsrc2, bdst2);
   }
-  const int adst0 = lds_off((tid) >> 2, tid & 3), adst1 = lds_off((tid + 256) >> 2, tid & 3);
-  const int adst2 = lds_off((tid + 512) >> 2, tid & 3), adst3 = lds_off((tid + 768) >> 2, tid & 3);
-  const int adst4 = lds_off((tid + 1024) >> 2, tid & 3), adst5 = lds_off((tid + 1280) >> 2, tid & 3);
+  // the staged weights are stored in LDS order already (the slot rotation of lds_off applied by the host packing)
+  const int adst0 = tid * 16, adst1 = (tid + 256) * 16, adst2 = (tid + 512) * 16, adst3 = (tid + 768) * 16;
+  const int adst4 = (tid + 1024) * 16, adst5 = (tid + 1280) * 16;
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
 #define DI_FETCH_A(st)                                                                                                  \
   do {                                                                                                                  \
@@ -296,6 +296,176 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Third kernel, for Cout == 128 and maps of at least 16 rows: 16 x 16-pixel tiles, 8 waves (one workgroup per CU, two
+// waves per SIMD as before), and the weight tiles travel L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs,
+// asynchronous) into a ring of THREE buffers, two stages ahead of their use.  Against the 8 x 16 kernel: half the
+// weight bytes per output pixel through L2 and LDS (a 24 KB tile per stage now serves 256 pixels: weights were
+// 590 KB per 128-pixel tile, 6x the input halo), and a prefetch distance that does not cost registers.
+// vmcnt bookkeeping is static: per stage every wave issues [halo loads of the next chunk (ky == 0 only, 3 per lane)],
+// then 3 DMA instructions; at the end of a stage "all but the last 3" have landed - the DMA of the stage after next may
+// still be in flight, the tile of the next stage and the halo registers are complete.
+// ------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+template <int TH>   // tile rows: 12, 16 or 20 (the host picks the one with the fewest rounds x rows for the map)
+__global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(const __half *__restrict__ x, const __half *__restrict__ wst,
+                                                             const float *__restrict__ bias, __half *__restrict__ y,
+                                                             int H, int W, int Cin, int relu, int tiles_x, int tiles_y) {
+  constexpr int WN = 2, WM = 4, NTW = 4, RW = TH / WM;
+  static_assert(TH % WM == 0, "rows per wave");
+  constexpr int HP = (TH + 2) * (TW + 2);                  // halo pixels
+  constexpr int NLD = (HP * 4 + 511) / 512;                // halo pieces per thread and chunk: 2, 3 or 4
+  constexpr int ASZ = 3 * 128 * 64;                        // weight tile of a stage: 24 KB = 24 DMA chunks of 1 KB
+  // the ring buffers are SEPARATE objects: stage 3 ch + k always uses buffer k, so every access names its buffer at
+  // compile time and the compiler's wait-count insertion can tell a DMA into one buffer from reads of another (with
+  // one dynamic array it forces vmcnt(0) - every DMA in flight - in front of each stage's fragment reads)
+  __shared__ __align__(16) unsigned char lA0[ASZ], lA1[ASZ], lA2[ASZ];
+  __shared__ __align__(16) unsigned char lB0[HP * 64], lB1[HP * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, img = t / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const __half *xi = x + (size_t)img * H * W * Cin;
+
+  uint4 b0, b1, b2, b3;                                    // named registers (see conv3x3_lds_kernel)
+  b2 = b3 = make_uint4(0, 0, 0, 0);
+  int bsrc0, bsrc1, bsrc2, bsrc3, bdst0, bdst1, bdst2, bdst3;
+  {
+    auto piece = [&](int j, int &src, int &dst) {
+      const int e = tid + j * 512;
+      const int P = e >> 2, s4 = e & 3;
+      const int hy = P / (TW + 2), hx = P - hy * (TW + 2);
+      const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+      const bool ok = e < HP * 4 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      src = ok ? (yy * W + xx) * Cin + s4 * 8 : -1;
+      dst = e < HP * 4 ? lds_off(P, s4) : -1;
+    };
+    piece(0, bsrc0, bdst0);
+    piece(1, bsrc1, bdst1);
+    piece(2, bsrc2, bdst2);
+    piece(3, bsrc3, bdst3);
+  }
+  static_assert(NLD >= 2 && NLD <= 4, "two to four halo pieces per thread");
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const int nchunk = Cin / CK, nstage = nchunk * 3;
+  auto dma_a = [&](int st, unsigned char *buf) {           // 3 DMA instructions per wave: chunks wave*3 .. +2 of the tile
+    const int sc = st < nstage ? st : nstage - 1;          // past the end: a re-read (keeps the vmcnt arithmetic uniform)
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(wst) + (size_t)sc * ASZ + (wave * 3) * 1024 + lane * 16;
+    unsigned char *dst = buf + (wave * 3) * 1024;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 1024), (lptr_t)(dst + j * 1024), 16, 0, 0);
+  };
+#define DI_FETCH_B(c0)                                                                                                  \
+  do {                                                                                                                  \
+    b0 = bsrc0 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc0 + (c0)) : zero4;                                      \
+    b1 = bsrc1 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc1 + (c0)) : zero4;                                      \
+    if (NLD > 2) b2 = bsrc2 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc2 + (c0)) : zero4;                         \
+    if (NLD > 3) b3 = bsrc3 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc3 + (c0)) : zero4;                         \
+  } while (0)
+#define DI_COMMIT_B(d_)                                                                                                 \
+  do {                                                                                                                  \
+    if (bdst0 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst0) = b0;                                                        \
+    if (bdst1 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst1) = b1;                                                        \
+    if (NLD > 2 && bdst2 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst2) = b2;                                             \
+    if (NLD > 3 && bdst3 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst3) = b3;                                             \
+  } while (0)
+
+  f4 acc[RW][NTW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[r][n] = f4{0.f, 0.f, 0.f, 0.f};
+
+  auto multiply = [&](const unsigned char *A, int ky, const unsigned char *B) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      h8 a[NTW];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n)
+        a[n] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A + lds_off(kx * 128 + wn * 64 + n * 16 + i, g)));
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int P = (wm * RW + r + ky) * (TW + 2) + i + kx;
+        const h8 b = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(B + lds_off(P, g)));
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b, acc[r][n], 0, 0, 0);
+      }
+    }
+  };
+
+  // end of a stage: this wave's DMA of the NEXT stage's tile has landed (all but the youngest 3 vector-memory
+  // operations), its LDS writes and reads are done, then the workgroup barrier.  A plain s_barrier, not __syncthreads():
+  // the release fence of __syncthreads() makes the compiler wait for EVERY DMA in flight (vmcnt(0)).
+#define DI_STAGE_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  // prologue: halo chunk 0 and weight tiles 0, 1
+  DI_FETCH_B(0);
+  dma_a(0, lA0);
+  dma_a(1, lA1);
+  DI_COMMIT_B(lB0);                                        // (the compiler waits for the halo registers here)
+  DI_STAGE_BARRIER();                                      // tile 0 landed (tile 1 may be in flight)
+  // one chunk = stages 3 ch .. 3 ch + 2 = weight buffers 0, 1, 2; halo buffers alternate per chunk (loop unrolled by 2)
+  auto chunk = [&](int ch, unsigned char *Bcur, unsigned char *Bnext) {
+    const int st = ch * 3;
+    // ky = 0: the next halo chunk starts its trip, then the weight tile two stages ahead
+    DI_FETCH_B((ch + 1 < nchunk ? ch + 1 : ch) * CK);
+    dma_a(st + 2, lA2);
+    __builtin_amdgcn_sched_barrier(0);                     // the requests leave at the START of the stage
+    multiply(lA0, 0, Bcur);
+    DI_STAGE_BARRIER();                                    // tile st+1 and the halo registers complete
+    // ky = 1
+    dma_a(st + 3, lA0);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(lA1, 1, Bcur);
+    DI_STAGE_BARRIER();
+    // ky = 2: the halo of the next chunk goes to the other buffer (its last readers passed a barrier a chunk ago)
+    DI_COMMIT_B(Bnext);                                    // first: the wait for the halo registers (loaded two stages
+    __builtin_amdgcn_sched_barrier(0);                     // ago) must not cover the DMA issued next
+    dma_a(st + 4, lA1);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(lA2, 2, Bcur);
+    DI_STAGE_BARRIER();
+  };
+  for (int ch = 0; ch < nchunk; ch += 2) {
+    chunk(ch, lB0, lB1);
+    if (ch + 1 < nchunk) chunk(ch + 1, lB1, lB0);
+  }
+#undef DI_FETCH_B
+#undef DI_COMMIT_B
+#undef DI_STAGE_BARRIER
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no DMA may outlive the workgroup's LDS
+
+  // epilogue (row permutation of the staged weights: a lane's fragment pair = 8 consecutive channels = one 16-B store)
+  const int xx = x0 + i;
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int yy = y0 + wm * RW + r;
+    if (yy >= H || xx >= W) continue;
+#pragma unroll
+    for (int p2 = 0; p2 < NTW / 2; ++p2) {
+      const int c0 = 32 * ((wn * NTW) / 2 + p2) + 8 * g;
+      h8 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v0 = acc[r][2 * p2][q] + bias[c0 + q], v1 = acc[r][2 * p2 + 1][q] + bias[c0 + 4 + q];
+        if (relu) {
+          v0 = fmaxf(v0, 0.f);
+          v1 = fmaxf(v1, 0.f);
+        }
+        o[q] = (_Float16)v0;
+        o[4 + q] = (_Float16)v1;
+      }
+      *reinterpret_cast<h8 *>(y + (((size_t)img * H + yy) * W + xx) * 128 + c0) = o;
+    }
+  }
+}
+
 }  // namespace cv
 }  // namespace di
 
@@ -318,7 +488,31 @@ extern "C" int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w
     // weights through LDS.  8-row tiles whenever the map has at least 8 rows: the kernel is latency bound per
     // stage, so fewer, larger tiles that fit the resident slots in one round beat more, smaller ones
     // (180 x 180: 276 tiles of 8 x 16 in one round instead of 540 of 4 x 16 in two)
-    if (H >= 8) {
+    static const int no_dma = getenv("DI_CONV_NO_DMA") ? atoi(getenv("DI_CONV_NO_DMA")) : 0;
+    if (H >= 12 && !no_dma) {
+      // one workgroup per CU: the tile height with the fewest (rounds of tiles over the CUs) x (rows per tile) -
+      // 6 x 112 x 200: 20 rows = 468 tiles = 2 rounds (16 rows: 546 tiles = 3 rounds); 180 x 180: 12 rows = 180 tiles
+      const int cus = di::device_cus();
+      if (cus <= 0) return DI_ERR_LAUNCH;
+      static const int force_th = getenv("DI_CONV_TH") ? atoi(getenv("DI_CONV_TH")) : 0;
+      int best = 0;
+      long long best_cost = 0;
+      for (int th : {12, 16, 20}) {
+        if (force_th ? th != force_th : th > H + 3) continue;
+        const long long tiles = (long long)tiles_x * ((H + th - 1) / th) * n;
+        const long long cost = ((tiles + cus - 1) / cus) * th;
+        if (best == 0 || cost < best_cost) best = th, best_cost = cost;
+      }
+      if (best == 0) best = 12;
+      static const int lds_pad = getenv("DI_CONV_PAD") ? atoi(getenv("DI_CONV_PAD")) : 0;
+#define DI_DMA(TH_)                                                                                               \
+  hipLaunchKernelGGL(conv3x3_dma_kernel<TH_>, dim3(tiles_x * ((H + TH_ - 1) / TH_) * n), dim3(512),                \
+                     lds_pad ? 160 * 1024 - (3 * 3 * 128 * 64 + 2 * (TH_ + 2) * 18 * 64) : 0, s,                  \
+                     (const __half *)x, (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x,     \
+                     (H + TH_ - 1) / TH_)
+      if (best == 12) DI_DMA(12); else if (best == 16) DI_DMA(16); else DI_DMA(20);
+#undef DI_DMA
+    } else if (H >= 8) {
       const int tiles_y = (H + 7) / 8;
       hipLaunchKernelGGL((conv3x3_lds_kernel<8>), dim3(tiles_x * tiles_y * n), dim3(256), 0, s, (const __half *)x,
                          (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x, tiles_y);

@@ -653,7 +653,8 @@ def polar_bev_sample_bwd(grad_out, proj, aug_rev, cam_xy, params, polar_shape):
 # ------------------------------------------------------------------ 3x3 convolutions (implicit GEMM on the matrix cores)
 def pack_conv3x3(weight, bias=None, bn=None):
     """Constants of `conv3x3` from a torch Conv2d weight (Cout,Cin,3,3) [+ bias] [+ a following eval-mode BatchNorm2d,
-    folded in]: (w_packed fp16 (Cout_pad, 9, Cin), w_staged fp16 (Cin/32, 3, 3, 128, 32) or None, bias float32 (Cout))."""
+    folded in]: (w_packed fp16 (Cout_pad, 9, Cin), w_staged fp16 (Cin/32, 3, 3, 128, 32) in LDS slot order or None, bias float32
+    (Cout))."""
     with torch.no_grad():
         w = weight.detach().float()
         Cout = w.shape[0]
@@ -675,6 +676,15 @@ def pack_conv3x3(weight, bias=None, bn=None):
             nb, gq, rq = rr // 16, (rr % 16) // 4, rr % 4
             wr = w[32 * (nb // 2) + 8 * gq + 4 * (nb % 2) + rq]
             ws = wr.view(128, Cin // 32, 32, 3, 3).permute(1, 3, 4, 0, 2).to(torch.float16).contiguous()
+            # ... stored in LDS order: the 16-B slot s of row R = kx * 128 + n of a (chunk, ky) tile sits at slot
+            # (s + 2 * (R >> 2)) & 3 (the conflict-free rotation of csrc/conv3x3.hip lds_off), so that the tile can be
+            # moved by linear copies / LDS-DMA
+            t = ws.view(Cin // 32, 3, 384, 4, 8)
+            R = torch.arange(384, device=w.device).view(384, 1)
+            sl = torch.arange(4, device=w.device).view(1, 4)
+            rot = torch.empty_like(t)
+            rot[:, :, R.expand(384, 4), (sl + 2 * (R >> 2)) & 3] = t
+            ws = rot.view(Cin // 32, 3, 3, 128, 32).contiguous()
         return wp.to(torch.float16).contiguous(), ws, b.contiguous()
 
 
