@@ -51,6 +51,7 @@ SIGNATURES = {
     'di_roi_align_fwd': [_c_p] * 3 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
     'di_mha_decode_fwd': [_c_p] * 4 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
     'di_pointwise_multi_fwd': [_c_p, _c_i] + [_c_p] * 5 + [ctypes.c_longlong, _c_p],
+    'di_ffn_ln_fwd': [_c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, ctypes.c_longlong, _c_p],
     'di_conv3x3_fwd': [_c_p] * 5 + [_c_i] * 7 + [_c_p],
     'di_token_linear': [_c_p, _c_i, _c_p, _c_i, _c_i, _c_p, _c_i, _c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_p, _c_i, _c_p, _c_i,
                         _c_p, _c_p, _c_f, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p],

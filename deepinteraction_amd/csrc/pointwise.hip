@@ -415,6 +415,170 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Transformer FFN + post-norm in one pass over the tokens (DeepInteraction++ layers, mmcv FFN + the following
+// LayerNorm: fusion_transformerv4.py operation_order (..., 'ffn', 'norm')):
+//     y = LayerNorm(x + W2 . relu(W1 . x + b1) + b2),      x: (M, 128) fp16, hidden = 128 * n_chunks
+// The hidden layer is walked in chunks of 128 channels: chunk c is a two-link chain (W1[c] : 128 x 128, then the columns
+// c of W2 : 128 x 128) whose second link ACCUMULATES into the output registers - the (M, hidden) activation never exists
+// in memory (274 MB of traffic per call at 134 400 tokens and hidden 512), ReLU / bias / residual / LayerNorm run on
+// the fp32 accumulators.  Same machinery as pointwise_multi_kernel: a wave keeps its 2 x 16 tokens in registers as MFMA
+// B operands, the chunk images (ops.chain_image of the chunk) arrive by LDS-DMA in a double buffer.
+// ------------------------------------------------------------------------------------------------------------
+struct FfnArgs {
+  const unsigned char *img[8];   // chunk images (kChainImage bytes each); b2 lives in chunk 0's image, zeros elsewhere
+  int n;
+  const __half *ln_w, *ln_b;
+  float eps;
+  // single-link form  y = LayerNorm(res + W . x + b)  (the output projection of an attention block + its post-norm):
+  // one image holding a one-link chain (ops.chain_image(w, b)), the residual from `res` instead of x
+  const __half *res;
+  int single;
+};
+
+__global__ __launch_bounds__(NT, 2) void ffn_ln_kernel(const __half *__restrict__ x, __half *__restrict__ y, FfnArgs A, long long M) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int Mi = (int)M;
+  const int ngroups = (Mi + 15) / 16;
+  const int g0 = (blockIdx.x * NW + wave) * 2;                // this wave's pair of token groups
+  auto dma_chunk = [&](const unsigned char *img, unsigned char *buf) {
+    const unsigned char *src = img + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                              // W1 | W2: KiB chunks 0..63, 8 per wave
+      const int chunk = wave * 8 + j;
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + chunk * 1024), (lptr_t)(buf + chunk * 1024), 16, 0, 0);
+    }
+    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(src + 64 * 1024), (lptr_t)(buf + 64 * 1024), 16, 0, 0);   // biases
+  };
+  dma_chunk(A.img[0], lds);
+  h8 xb[2][4];
+  int pix[2];
+#pragma unroll
+  for (int pg = 0; pg < 2; ++pg) {
+    const int grp = g0 + pg;
+    pix[pg] = grp < ngroups ? grp * 16 + i : Mi;
+    const int pc = pix[pg] < Mi ? pix[pg] : Mi - 1;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      xb[pg][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(x + (size_t)pc * 128 + kk * 32 + g * 8));
+  }
+  f4 out[2][8];
+#pragma unroll
+  for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) out[pg][nb] = f4{0.f, 0.f, 0.f, 0.f};
+
+  for (int c = 0; c < A.n; ++c) {
+    unsigned char *buf = lds + (c & 1) * kChainImage;
+    const unsigned char *lw1 = buf, *lw2 = buf + 128 * 128 * 2;
+    const float *lb = reinterpret_cast<const float *>(buf + 2 * 128 * 128 * 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // chunk c's image has landed (issued a whole chunk ago)
+    __syncthreads();
+    if (c + 1 < A.n) dma_chunk(A.img[c + 1], lds + ((c + 1) & 1) * kChainImage);
+    // ---- link 1: hidden chunk = relu(W1[c] . x + b1[c])
+    f4 acc[2][8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+      for (int pg = 0; pg < 2; ++pg) acc[pg][nb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(16 * nb + i, 4 * kk + g)));
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) acc[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[pg][kk], acc[pg][nb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (A.single) {                                            // the link's accumulators (+ bias) ARE the output
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        const f4 bias = *reinterpret_cast<const f4 *>(lb + 16 * nb + 4 * g);
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) out[pg][nb] = acc[pg][nb] + bias;
+      }
+      break;
+    }
+    h8 hb[2][4];
+#pragma unroll
+    for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const f4 ba = *reinterpret_cast<const f4 *>(lb + 16 * (2 * kk) + 4 * g), bb = *reinterpret_cast<const f4 *>(lb + 16 * (2 * kk + 1) + 4 * g);
+        h8 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          t[r] = (_Float16)fmaxf(acc[pg][2 * kk][r] + ba[r], 0.f);
+          t[4 + r] = (_Float16)fmaxf(acc[pg][2 * kk + 1][r] + bb[r], 0.f);
+        }
+        hb[pg][kk] = t;
+      }
+    // ---- link 2: out += W2[:, chunk c] . hidden chunk  (+ the chunk image's b2: the real bias in chunk 0, zeros after)
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(16 * nb + i, 4 * kk + g)));
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) out[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, hb[pg][kk], out[pg][nb], 0, 0, 0);
+      }
+      const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
+#pragma unroll
+      for (int pg = 0; pg < 2; ++pg) out[pg][nb] += bias;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- epilogue: residual + LayerNorm over the 128 channels of a token (32 per lane, 4 lanes per token), 16-B stores.
+  // Image row 16nb + 4g + r of the last link is channel 32(nb/2) + 8g + 4(nb%2) + r = element 4(nb%2) + r of xb[.][nb/2].
+#pragma unroll
+  for (int pg = 0; pg < 2; ++pg) {
+    if (A.single) {                                            // residual from its own tensor, same channel layout
+      const int pc = pix[pg] < Mi ? pix[pg] : Mi - 1;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        xb[pg][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A.res + (size_t)pc * 128 + kk * 32 + g * 8));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = out[pg][nb][r] + (float)xb[pg][nb >> 1][4 * (nb & 1) + r];
+        out[pg][nb][r] = v;
+        sum += v;
+      }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.f / 128.f);
+    float var = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = out[pg][nb][r] - mean;
+        var += d * d;
+      }
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    const float rstd = rsqrtf(var * (1.f / 128.f) + A.eps);
+    if (pix[pg] < Mi) {
+#pragma unroll
+      for (int p2 = 0; p2 < 4; ++p2) {
+        const h8 lw = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A.ln_w + 32 * p2 + 8 * g));
+        const h8 lbv = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A.ln_b + 32 * p2 + 8 * g));
+        h8 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (_Float16)((out[pg][2 * p2][r] - mean) * rstd * (float)lw[r] + (float)lbv[r]);
+          o[4 + r] = (_Float16)((out[pg][2 * p2 + 1][r] - mean) * rstd * (float)lw[4 + r] + (float)lbv[4 + r]);
+        }
+        *reinterpret_cast<h8 *>(y + (size_t)pix[pg] * 128 + 32 * p2 + 8 * g) = o;
+      }
+    }
+  }
+}
+
 template <int NG>
 static int launch_multi(const void *x, const MultiArgs &A, long long M, long long grid, hipStream_t stream) {
   constexpr int LDS = 2 * kChainImage;
@@ -426,6 +590,31 @@ static int launch_multi(const void *x, const MultiArgs &A, long long M, long lon
 
 }  // namespace pw
 }  // namespace di
+
+extern "C" int di_ffn_ln_fwd(const void *x, int n_chunks, const void *const *image, const void *residual, const void *ln_w,
+                             const void *ln_b, float eps, void *y, long long n_tokens, void *stream) {
+  using namespace di::pw;
+  DI_REQUIRE(n_tokens > 0 && n_tokens < (1ll << 24) && x && y && ln_w && ln_b, "bad token count (1 .. 2^24 - 1)");
+  DI_REQUIRE(n_chunks >= 1 && n_chunks <= 8 && image, "hidden width = 128 x (1 .. 8)");
+  FfnArgs A;
+  for (int c = 0; c < 8; ++c) A.img[c] = c < n_chunks ? (const unsigned char *)image[c] : nullptr;
+  for (int c = 0; c < n_chunks; ++c) DI_REQUIRE(A.img[c], "chunk image %d missing", c);
+  A.n = n_chunks;
+  A.ln_w = (const __half *)ln_w;
+  A.ln_b = (const __half *)ln_b;
+  A.eps = eps;
+  A.res = (const __half *)residual;
+  A.single = residual != nullptr;
+  DI_REQUIRE(!A.single || n_chunks == 1, "the single-link form takes one image");
+  constexpr int LDS = 2 * kChainImage;
+  static di::LdsRaised raised;
+  if (int rc = di::ensure_lds(raised, (const void *)ffn_ln_kernel, LDS)) return rc;
+  const long long groups = (n_tokens + 15) / 16;
+  const long long grid = (groups + 2 * NW - 1) / (2 * NW);
+  hipLaunchKernelGGL(ffn_ln_kernel, dim3((unsigned)grid), dim3(NT), LDS, (hipStream_t)stream, (const __half *)x, (__half *)y, A,
+                     n_tokens);
+  return di::check_launch("ffn_ln");
+}
 
 extern "C" int di_pointwise_multi_fwd(const void *x, int n_chains, const void *const *image, void *const *y,
                                       const int *relu1, const int *relu2, const int *two_links, long long n_pixels,

@@ -47,8 +47,27 @@ class TransFFN(nn.Module):
             return out
         return (x if identity is None else identity) + out
 
+    def _fusable(self, norm, x):
+        return (x.is_cuda and x.dtype == torch.float16 and not torch.is_grad_enabled() and not self.training
+                and self.add_identity and self.num_fcs == 2 and self.embed_dims == 128
+                and self.feedforward_channels % 128 == 0 and self.feedforward_channels <= 1024
+                and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and norm.normalized_shape == (128,)
+                and norm.weight.dtype == torch.float16 and self.layers[0][0].weight.dtype == torch.float16)
+
     def then_norm(self, norm, x):
-        """norm(self(x)) with the identity add folded into the normalisation kernel."""
+        """norm(self(x)) with the identity add folded into the normalisation kernel; fp16 inference with 128-channel
+        tokens: the whole FFN + norm is ONE kernel (ops.ffn_ln: the hidden activation never reaches memory)."""
+        if self._fusable(norm, x):
+            l1, l2 = self.layers[0][0], self.layers[1]
+            key = param_key(self)
+            hit = self.__dict__.get('_ffn_images')
+            if hit is None or hit[0] != key:
+                with torch.no_grad():
+                    hit = (key, ops.ffn_images(l1.weight, l1.bias, l2.weight, l2.bias))
+                self.__dict__['_ffn_images'] = hit
+            shape = x.shape
+            y = ops.ffn_ln(x.reshape(-1, 128).contiguous(), hit[1], norm.weight, norm.bias, norm.eps)
+            return y.view(shape)
         if not self.add_identity:
             return post_norm(norm, self.layers(x))
         return post_norm(norm, x, self.layers(x))
@@ -129,6 +148,20 @@ class MultiScaleDeformableAttention(nn.Module):
             out = MSDeformAttn.apply(v.contiguous(), proj, ref, shapes, self.num_points)
         else:
             out = ops.ms_deform_attn(v.contiguous(), proj[..., :n_off], proj[..., n_off:], ref, shapes, self.num_points)
+        if (then_norm is not None and self.batch_first and out.is_cuda and out.dtype == torch.float16
+                and not torch.is_grad_enabled() and not self.training and self.embed_dims == 128
+                and isinstance(then_norm, nn.LayerNorm) and then_norm.elementwise_affine
+                and then_norm.weight.dtype == torch.float16 and identity.shape == out.shape):
+            # output projection + residual + post-norm in one kernel (ops.linear_ln)
+            key = param_key(self.output_proj)
+            hit = self.__dict__.get('_out_image')
+            if hit is None or hit[0] != key:
+                with torch.no_grad():
+                    hit = (key, ops.chain_image(self.output_proj.weight.float(), self.output_proj.bias.float()))
+                self.__dict__['_out_image'] = hit
+            y = ops.linear_ln(out.reshape(-1, 128).contiguous(), hit[1], identity.reshape(-1, 128).contiguous(),
+                              then_norm.weight, then_norm.bias, then_norm.eps)
+            return y.view(out.shape)
         out = self.output_proj(out)
         if not self.batch_first:
             out = out.permute(1, 0, 2)

@@ -211,6 +211,43 @@ def chain_image(w1, b1, w2=None, b2=None):
     return torch.cat(parts).contiguous()
 
 
+def ffn_images(w1, b1, w2, b2):
+    """Chunk images of `ffn_ln` from the two Linear layers of an FFN (w1 (hidden,128), w2 (128,hidden), hidden = 128 k):
+    chunk c = chain_image(W1[128c:128c+128], b1[128c:..], W2[:, 128c:128c+128], b2 for c == 0 else 0)."""
+    hidden = w1.shape[0]
+    assert w1.shape[1] == 128 and w2.shape == (128, hidden) and hidden % 128 == 0 and hidden // 128 <= 8
+    zero = torch.zeros(128, dtype=torch.float32, device=w1.device)
+    return [chain_image(w1[128 * c:128 * c + 128].float(), b1[128 * c:128 * c + 128].float(),
+                        w2[:, 128 * c:128 * c + 128].float(), b2.float() if c == 0 else zero)
+            for c in range(hidden // 128)]
+
+
+def ffn_ln(x, images, ln_w, ln_b, eps=1e-5):
+    """LayerNorm(x + W2 . relu(W1 . x + b1) + b2) over (M,128) fp16 tokens in one launch (`images` = ffn_images(...))."""
+    _dev(x)
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.shape[1] == 128 and x.is_contiguous()
+    assert ln_w.dtype == torch.float16 and ln_b.dtype == torch.float16 and ln_w.numel() == 128
+    y = torch.empty_like(x)
+    arr = (ctypes.c_void_p * len(images))(*[t.data_ptr() for t in images])
+    _profiled('ffn_ln_fwd', x.shape[0], lambda: _lib.call(
+        'di_ffn_ln_fwd', x.data_ptr(), len(images), ctypes.addressof(arr), None, ln_w.data_ptr(), ln_b.data_ptr(),
+        float(eps), y.data_ptr(), x.shape[0], _stream()))
+    return y
+
+
+def linear_ln(x, image, residual, ln_w, ln_b, eps=1e-5):
+    """LayerNorm(residual + x @ W^T + b) over (M,128) fp16 tokens in one launch; image = chain_image(W, b) (128 x 128)."""
+    _dev(x, residual)
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.shape[1] == 128 and x.is_contiguous()
+    assert residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous()
+    assert ln_w.dtype == torch.float16 and ln_b.dtype == torch.float16 and ln_w.numel() == 128
+    y = torch.empty_like(x)
+    arr = (ctypes.c_void_p * 1)(image.data_ptr())
+    _lib.call('di_ffn_ln_fwd', x.data_ptr(), 1, ctypes.addressof(arr), residual.data_ptr(), ln_w.data_ptr(),
+              ln_b.data_ptr(), float(eps), y.data_ptr(), x.shape[0], _stream())
+    return y
+
+
 def pointwise_multi(x, chains):
     """Several chains over one fp16 channels-last map (C = 128) in ONE launch, x read once.  chains: list of
     (image, relu1, relu2, two_links) with image = chain_image(...).  Returns one map per chain."""

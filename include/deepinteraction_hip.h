@@ -298,6 +298,17 @@ int di_pointwise_multi_fwd(const void *x, int n_chains, const void *const *image
                            const int *relu1_host, const int *relu2_host, const int *two_links_host, long long n_pixels,
                            void *stream);
 
+/* Transformer FFN + post-norm of the DeepInteraction++ layers (mmcv FFN followed by LayerNorm: necks/fusion_transformerv4.py
+ * operation_order (..., 'ffn', 'norm')) in one pass over the tokens:
+ *     y = LayerNorm(x + W2 . relu(W1 . x + b1) + b2)         x, y (n_tokens, 128) fp16; hidden width 128 * n_chunks
+ * image: HOST array of n_chunks <= 8 DEVICE pointers, chunk c = the chain image (layout as di_pointwise_multi_fwd) of the
+ * two-link chain (W1[128c : 128c+128, :], b1[128c : ..], W2[:, 128c : 128c+128], b2 in chunk 0 / zeros elsewhere);
+ * ln_w, ln_b (128) fp16.  The (n_tokens, hidden) activation never exists in memory; fp32 accumulation throughout.
+ * residual != NULL selects the single-link form  y = LayerNorm(residual + W . x + b)  (output projection of an attention
+ * block + its post-norm): n_chunks = 1, image[0] = the one-link chain image of (W, b). */
+int di_ffn_ln_fwd(const void *x, int n_chunks, const void *const *image, const void *residual, const void *ln_w,
+                  const void *ln_b, float eps, void *y, long long n_tokens, void *stream);
+
 /* ---------------------------------------------------------------- 3x3 convolutions (stride 1, pad 1), implicit GEMM
  * The shared convolutions of the MMRI encoder (necks/deepinteraction_encoder.py:45-62) and the heat-map heads of the
  * decoder (dense_heads/deepinteraction_decoder.py:96-119) on fp16 channels-last maps:

@@ -216,3 +216,45 @@ def test_v2_block_first_query_quirk():
         roi = torch.randn(32, 49, 128, device=DEV)
         out = blk._refine_all(x, roi)
     assert torch.allclose(out, out[:, :1].expand_as(out)) and not torch.allclose(out[0], out[1])
+
+
+@pytest.mark.parametrize('M,hidden', [(1000, 512), (37, 128), (134400, 512)])
+def test_fused_ffn_layernorm(M, hidden):
+    """ops.ffn_ln (FFN + residual + LayerNorm in one kernel, the hidden activation kept in registers chunk by chunk)
+    against the float64 evaluation on the same fp16 operands (the kernel rounds the hidden activation to fp16, as the
+    unfused fp16 path does): 1e-3 of the output scale (outputs are normalised: O(1))."""
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+    from deepinteraction_amd import ops
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, 128, generator=g) * 0.7).half()
+    w1 = (torch.randn(hidden, 128, generator=g) / 128 ** 0.5).half()
+    b1 = (torch.randn(hidden, generator=g) * 0.1).half()
+    w2 = (torch.randn(128, hidden, generator=g) / hidden ** 0.5).half()
+    b2 = (torch.randn(128, generator=g) * 0.1).half()
+    lw, lb = (1 + 0.1 * torch.randn(128, generator=g)).half(), (0.1 * torch.randn(128, generator=g)).half()
+    dev = 'cuda'
+    imgs = ops.ffn_images(w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev))
+    got = ops.ffn_ln(x.to(dev), imgs, lw.to(dev), lb.to(dev), 1e-5).double().cpu()
+    xd = x.to(dev).double()
+    h = (xd @ w1.to(dev).double().t() + b1.to(dev).double()).relu().half().double()
+    o = xd + h @ w2.to(dev).double().t() + b2.to(dev).double()
+    ref = torch.nn.functional.layer_norm(o, (128,), lw.to(dev).double(), lb.to(dev).double(), 1e-5).cpu()
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+
+
+def test_fused_linear_layernorm():
+    """ops.linear_ln: LayerNorm(residual + x W^T + b) in one kernel (output projection of the deformable attention +
+    its post-norm) against float64."""
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+    from deepinteraction_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M = 4099
+    x, res = (torch.randn(M, 128, generator=g) * 0.7).half().cuda(), (torch.randn(M, 128, generator=g)).half().cuda()
+    w, b = (torch.randn(128, 128, generator=g) / 11).half().cuda(), (torch.randn(128, generator=g) * 0.1).half().cuda()
+    lw, lb = (1 + 0.1 * torch.randn(128, generator=g)).half().cuda(), (0.1 * torch.randn(128, generator=g)).half().cuda()
+    got = ops.linear_ln(x, ops.chain_image(w.float(), b.float()), res, lw, lb, 1e-5).double()
+    ref = torch.nn.functional.layer_norm(res.double() + x.double() @ w.double().t() + b.double(), (128,), lw.double(),
+                                         lb.double(), 1e-5)
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
