@@ -302,9 +302,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
 // asynchronous) into a ring of THREE buffers, two stages ahead of their use.  Against the 8 x 16 kernel: half the
 // weight bytes per output pixel through L2 and LDS (a 24 KB tile per stage now serves 256 pixels: weights were
 // 590 KB per 128-pixel tile, 6x the input halo), and a prefetch distance that does not cost registers.
-// vmcnt bookkeeping is static: per stage every wave issues [halo loads of the next chunk (ky == 0 only, 3 per lane)],
-// then 3 DMA instructions; at the end of a stage "all but the last 3" have landed - the DMA of the stage after next may
-// still be in flight, the tile of the next stage and the halo registers are complete.
+// Per stage every wave issues [halo loads of the next chunk (ky == 0 only)], then 3 DMA instructions at the START of the
+// stage; they have the stage's 48 MFMAs per wave to land.
 // ------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -400,16 +399,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(const __half *__res
     }
   };
 
-  // end of a stage: this wave's DMA of the NEXT stage's tile has landed (all but the youngest 3 vector-memory
-  // operations), its LDS writes and reads are done, then the workgroup barrier.  A plain s_barrier, not __syncthreads():
-  // the release fence of __syncthreads() makes the compiler wait for EVERY DMA in flight (vmcnt(0)).
+  // end of a stage: this wave's DMA requests (the next stage's tile, and the one after it that left at the start of this
+  // stage - a whole stage of MFMAs ago) have landed, its LDS writes and reads are done, then the workgroup barrier.
+  // A counted wait (vmcnt(3): all but the youngest tile) measured the same, so the plain one stays.  s_barrier, not
+  // __syncthreads(): its release fence would be placed by the compiler where it also stalls the fragment reads.
 #define DI_STAGE_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
   // prologue: halo chunk 0 and weight tiles 0, 1
   DI_FETCH_B(0);
   dma_a(0, lA0);
   dma_a(1, lA1);
   DI_COMMIT_B(lB0);                                        // (the compiler waits for the halo registers here)
-  DI_STAGE_BARRIER();                                      // tile 0 landed (tile 1 may be in flight)
+  DI_STAGE_BARRIER();
   // one chunk = stages 3 ch .. 3 ch + 2 = weight buffers 0, 1, 2; halo buffers alternate per chunk (loop unrolled by 2)
   auto chunk = [&](int ch, unsigned char *Bcur, unsigned char *Bnext) {
     const int st = ch * 3;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(const __half *__res
     dma_a(st + 2, lA2);
     __builtin_amdgcn_sched_barrier(0);                     // the requests leave at the START of the stage
     multiply(lA0, 0, Bcur);
-    DI_STAGE_BARRIER();                                    // tile st+1 and the halo registers complete
+    DI_STAGE_BARRIER();
     // ky = 1
     dma_a(st + 3, lA0);
     __builtin_amdgcn_sched_barrier(0);
@@ -504,10 +504,8 @@ extern "C" int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w
         if (best == 0 || cost < best_cost) best = th, best_cost = cost;
       }
       if (best == 0) best = 12;
-      static const int lds_pad = getenv("DI_CONV_PAD") ? atoi(getenv("DI_CONV_PAD")) : 0;
 #define DI_DMA(TH_)                                                                                               \
-  hipLaunchKernelGGL(conv3x3_dma_kernel<TH_>, dim3(tiles_x * ((H + TH_ - 1) / TH_) * n), dim3(512),                \
-                     lds_pad ? 160 * 1024 - (3 * 3 * 128 * 64 + 2 * (TH_ + 2) * 18 * 64) : 0, s,                  \
+  hipLaunchKernelGGL(conv3x3_dma_kernel<TH_>, dim3(tiles_x * ((H + TH_ - 1) / TH_) * n), dim3(512), 0, s,          \
                      (const __half *)x, (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x,     \
                      (H + TH_ - 1) / TH_)
       if (best == 12) DI_DMA(12); else if (best == 16) DI_DMA(16); else DI_DMA(20);
