@@ -323,7 +323,9 @@ __global__ __launch_bounds__(256) void mha_decode_combine_kernel(const float *__
 namespace mh {
 constexpr int KS = 128;        // keys per stage
 constexpr int NT16 = KS / 16;  // 16-key tiles per stage
-constexpr int ROWB = 80;       // LDS bytes per (head, key): K16 | V16 | pad
+constexpr int KROW = 48;       // LDS bytes per (head, key) of K: 32 + 16 pad - conflict-free 8-B fragment reads
+constexpr int VROW = 32;       // ... of V: the transposing reads take 8 rows x 32 B = all 64 banks, no padding
+constexpr int ROWB = KROW + VROW;
 constexpr int WPH = 2;         // wavefronts per head
 constexpr int MAXQG = 2;       // query groups of 16 per wavefront (WPH * MAXQG per workgroup and head)
 constexpr int NTH = 1024;
@@ -378,7 +380,9 @@ __global__ __launch_bounds__(mh::NTH) void mha_decode_mfma_kernel(const __half *
       if (e < npiece) {
         const int key = e / ppk, p = e - key * ppk;
         const int isv = p / (2 * Hh), hh = (p >> 1) % Hh, half8 = p & 1;
-        *reinterpret_cast<uint4 *>(lds + buf * stage_bytes + (hh * KS + key) * ROWB + isv * 32 + half8 * 16) = stage_regs[j];
+        unsigned char *dst = lds + buf * stage_bytes + (isv ? Hh * KS * KROW + (hh * KS + key) * VROW
+                                                             : (hh * KS + key) * KROW);
+        *reinterpret_cast<uint4 *>(dst + half8 * 16) = stage_regs[j];
       }
     }
   };
@@ -408,7 +412,8 @@ __global__ __launch_bounds__(mh::NTH) void mha_decode_mfma_kernel(const __half *
       if (st + 1 < nstage) fetch(st + 1);
       const int ns = min(KS, r1 - (r0 + st * KS));       // keys of this stage (ragged only at the very end)
       if (part_of_head < WPH) {
-        const unsigned char *hb = lds + (st & 1) * stage_bytes + (size_t)h * KS * ROWB;
+        const unsigned char *kb = lds + (st & 1) * stage_bytes + (size_t)h * KS * KROW;
+        const unsigned char *vb = lds + (st & 1) * stage_bytes + (size_t)Hh * KS * KROW + (size_t)h * KS * VROW;
         {
 #pragma unroll
           for (int j = 0; j < MAXQG; ++j) {
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(mh::NTH) void mha_decode_mfma_kernel(const __half *
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < NT16; ++t) {
-              const h4 kf = *reinterpret_cast<const h4 *>(hb + (16 * t + i) * ROWB + g * 8);
+              const h4 kf = *reinterpret_cast<const h4 *>(kb + (16 * t + i) * KROW + g * 8);
               f4 c = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qf[j], f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // unscaled
               if (ns < KS) {                               // ragged stage (the very last one): keys past the end score -inf
                 asm volatile("" ::: "memory");             // keep the wave-uniform test a BRANCH (as selects it costs
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(mh::NTH) void mha_decode_mfma_kernel(const __half *
               // probabilities as the numerator
               lacc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(ones, pf, lacc[j], 0, 0, 0);
               const hv4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                  (hv4 __attribute__((address_space(3))) *)(hb + (16 * t + 4 * g + (i >> 2)) * ROWB + 32 + (i & 3) * 8));
+                  (hv4 __attribute__((address_space(3))) *)(vb + (16 * t + 4 * g + (i >> 2)) * VROW + (i & 3) * 8));
               h4 vf;
               vf[0] = vt[0]; vf[1] = vt[1]; vf[2] = vt[2]; vf[3] = vt[3];
               acc[j] = __builtin_amdgcn_mfma_f32_16x16x16f16(vf, pf, acc[j], 0, 0, 0);
