@@ -317,8 +317,11 @@ int di_ffn_ln_fwd(const void *x, int n_chunks, const void *const *image, const v
  * (Cout,3,3,Cin), rows zero-padded to 16 when Cout <= 16; bias float32 (Cout) (a following BatchNorm folded in by the
  * caller); Cout == 128 or Cout <= 16; y (n,H,W,Cout) fp16, or (n,Cout,H,W) when out_nchw.
  * w_staged (optional, Cout == 128): the same weights as (Cin/32, 3 ky, 3 kx, 128, 32) fp16 with the 128 rows
- * permuted (row 16nb+4g+r = output channel 32(nb/2)+8g+4(nb%2)+r, for 16-B stores) - with it the kernel
- * that stages the weights through LDS runs (the fast one); NULL selects the weights-from-L2 kernel. */
+ * permuted (row 16nb+4g+r = output channel 32(nb/2)+8g+4(nb%2)+r, for 16-B stores) and, inside every (chunk, ky) tile of
+ * 384 rows x 64 B, the 16-B slot s of row R stored at slot (s + 2 * (R >> 2)) & 3 - the kernel's conflict-free LDS order,
+ * so that a tile moves by LDS-DMA / linear copies.  With it the kernels that stage the weights through LDS run (16/12/20-row
+ * tiles with an LDS-DMA weight ring for maps of >= 12 rows, the fast path); NULL selects the weights-from-L2 kernel.
+ * `ops.pack_conv3x3` builds all three tensors from a torch Conv2d (+ BatchNorm2d). */
 int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w_staged, const float *bias, void *y, int n, int H,
                    int W, int Cin, int Cout, int relu, int out_nchw, void *stream);
 
