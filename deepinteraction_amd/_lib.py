@@ -62,7 +62,7 @@ SIGNATURES = {
     'di_pred_heads': [_c_p] * 11 + [_c_i, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
 }
 # helpers that return a value instead of an error code
-VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_i2p_key_table_bytes': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 2,
+VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_i2p_key_table_bytes': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 3,
                'di_token_linear_workspace_bytes': [_c_i] * 3,
                'di_graph_node_count': [_c_p]}
 _LONGLONG = {'di_topk_workspace_bytes', 'di_i2p_key_table_bytes', 'di_graph_node_count', 'di_token_linear_workspace_bytes'}

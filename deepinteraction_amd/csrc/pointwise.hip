@@ -19,9 +19,18 @@
 // Weights live in LDS (XOR-swizzled 16-B chunks: conflict-free ds_read_b128 fragments), staged once per
 // persistent workgroup.  fp32 accumulation, bias add in fp32.
 #include "di_common.h"
+#include <type_traits>
 
 namespace di {
 namespace pw {
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -49,20 +58,28 @@ __device__ __forceinline__ int out_row(int rl) {
 template <int K, bool PERM, bool ROWPERM = false>
 __device__ __forceinline__ void stage_w(const __half *__restrict__ w, unsigned char *lds, int tid) {
   constexpr int CH = K / 8;            // 16-B chunks per row
-  for (int e = tid; e < 128 * CH; e += NT) {
+  constexpr int N = 128 * CH / NT;     // chunks per thread
+  static_assert(128 * CH % NT == 0, "whole rounds of chunks");
+  // ALL loads of the thread first, then the LDS writes: one L2 round trip instead of N dependent ones
+  uint2 lo[N], hi[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const int e = tid + j * NT;
     const int rl = e / CH, c = e - rl * CH;
     const int r = ROWPERM ? out_row(rl) : rl;                // source row
-    uint4 val;
-    if (PERM && c < 16) {
-      // destination chunk c = 4kk + g holds columns 32kk + 8g + (4t + r'), i.e. two 8-B pieces of the source
-      const int kk = c >> 2, g = c & 3;
-      const uint2 lo = *reinterpret_cast<const uint2 *>(w + (size_t)r * K + 32 * kk + 4 * g);        // t = 0
-      const uint2 hi = *reinterpret_cast<const uint2 *>(w + (size_t)r * K + 32 * kk + 16 + 4 * g);   // t = 1
-      val = make_uint4(lo.x, lo.y, hi.x, hi.y);
-    } else {
-      val = *reinterpret_cast<const uint4 *>(w + (size_t)r * K + c * 8);
-    }
-    *reinterpret_cast<uint4 *>(lds + w_off<K>(rl, c)) = val;
+    // PERM: destination chunk c = 4kk + g (c < 16) holds columns 32kk + 8g + (4t + r'), i.e. two 8-B pieces of the
+    // source (t = 0, 1); every other chunk is 16 contiguous bytes
+    const bool perm = PERM && c < 16;
+    const int kk = c >> 2, g = c & 3;
+    const int c_lo = perm ? 32 * kk + 4 * g : c * 8, c_hi = perm ? 32 * kk + 16 + 4 * g : c * 8 + 4;
+    lo[j] = *reinterpret_cast<const uint2 *>(w + (size_t)r * K + c_lo);
+    hi[j] = *reinterpret_cast<const uint2 *>(w + (size_t)r * K + c_hi);
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const int e = tid + j * NT;
+    const int rl = e / CH, c = e - rl * CH;
+    *reinterpret_cast<uint4 *>(lds + w_off<K>(rl, c)) = make_uint4(lo[j].x, lo[j].y, hi[j].x, hi[j].y);
   }
 }
 
@@ -80,8 +97,12 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
   const int i = lane & 15, g = lane >> 4;
 
   constexpr int KK1 = K1 / 32;
+  // weights > 80 KB: one workgroup per CU (2 waves per SIMD, 256 VGPRs each) - room to read the weight fragments of the
+  // next row block under the MFMAs of the current one; the small variants run two workgroups per CU at <= 128 VGPRs
+  constexpr bool PIPE = 128 * K1 * 2 + 128 * K2 * 2 + 1536 > 80 * 1024;
   const long long nchunk = (M + 16 * PG - 1) / (16 * PG);
-  const long long ch0 = (long long)blockIdx.x * NW + wave, chstep = (long long)gridDim.x * NW;
+  // wave-major numbering: the ragged last round of chunks lands on wave 0 of many workgroups, not on all waves of a few
+  const long long ch0 = (long long)wave * gridDim.x + blockIdx.x, chstep = (long long)gridDim.x * NW;
   // B operands of link 1: pixel i of each group, channels 32kk + 8g .. +7 (x1 then x2).  The FIRST chunk's loads are
   // issued before the weights are staged (a launch gives a wave one or two chunks: its HBM round trip then overlaps
   // the 64 KB weight staging instead of following it).
@@ -102,33 +123,63 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
   };
   if (ch0 < nchunk) load_x(ch0);
 
+  // biases first (their loads then share the weights' L2 round trip instead of adding two of their own)
+  float bv1 = 0.f, bv2 = 0.f, bvm = 0.f;
+  if (tid < 128) {
+    bv1 = b1[K2 == 0 ? out_row(tid) : tid];
+    if (K2 > 0) bv2 = b2[out_row(tid)];
+    if (bm != nullptr) bvm = bm[K2 == 0 ? out_row(tid) : tid];
+  }
   stage_w<K1, false, K2 == 0>(w1, lw1, tid);                  // the rows of the LAST link are permuted (16-B stores)
   if (K2 > 0) stage_w<(K2 > 0 ? K2 : 128), true, true>(w2, lw2, tid);
   if (tid < 128) {
-    lb[tid] = b1[K2 == 0 ? out_row(tid) : tid];
-    lb[128 + tid] = K2 > 0 ? b2[out_row(tid)] : 0.f;
-    lb[256 + tid] = bm != nullptr ? bm[K2 == 0 ? out_row(tid) : tid] : 0.f;
+    lb[tid] = bv1;
+    lb[128 + tid] = bv2;
+    lb[256 + tid] = bvm;
   }
   __syncthreads();
 
+  // ReLU as a floor (0 or -inf): no branch inside the MFMA loops
+  const float fl1 = relu1 ? 0.f : -INFINITY, fl2 = relu2 ? 0.f : -INFINITY;
+  const f4 floor1 = f4{fl1, fl1, fl1, fl1}, floor2 = f4{fl2, fl2, fl2, fl2};
   for (long long ch = ch0; ch < nchunk; ch += chstep) {
     const long long p0 = ch * (16 * PG);
     long long pix[PG];
 #pragma unroll
     for (int pg = 0; pg < PG; ++pg) pix[pg] = p0 + pg * 16 + i;
     // ---- link 1: H^T[oc][px] = W1 . X^T
+    // the weight fragments of row block nb + 1 are read while the MFMAs of row block nb run (two blocks live at a time)
     f4 acc[PG][8];
+    {
+      h8 a[KK1], an[KK1];
+      if constexpr (PIPE) {
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-#pragma unroll
-      for (int pg = 0; pg < PG; ++pg) acc[pg][nb] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < KK1; ++kk) {
-        const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<K1>(16 * nb + i, 4 * kk + g)));
-#pragma unroll
-        for (int pg = 0; pg < PG; ++pg) acc[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[pg][kk], acc[pg][nb], 0, 0, 0);
+        for (int kk = 0; kk < KK1; ++kk) a[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<K1>(i, 4 * kk + g)));
       }
-      __builtin_amdgcn_sched_barrier(0);   // keep the weight fragments of one output block live at a time
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        if constexpr (PIPE) {
+          if (nb < 7) {
+#pragma unroll
+            for (int kk = 0; kk < KK1; ++kk)
+              an[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<K1>(16 * (nb + 1) + i, 4 * kk + g)));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) acc[pg][nb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK1; ++kk) {
+          if constexpr (!PIPE) a[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<K1>(16 * nb + i, 4 * kk + g)));
+#pragma unroll
+          for (int pg = 0; pg < PG; ++pg) acc[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk], xb[pg][kk], acc[pg][nb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PIPE) {
+#pragma unroll
+          for (int kk = 0; kk < KK1; ++kk) a[kk] = an[kk];
+        }
+      }
     }
     // bias + activation: lane holds output channels 16nb + 4g + r of pixel i
 #pragma unroll
@@ -139,8 +190,7 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
       for (int pg = 0; pg < PG; ++pg) {
         f4 t = acc[pg][nb] + bias;
         if (mask != nullptr) t += mb * (float)xm[pg];           // bias that applies to the masked pixels only
-        if (relu1) t = __builtin_elementwise_max(t, f4{0.f, 0.f, 0.f, 0.f});
-        acc[pg][nb] = t;
+        acc[pg][nb] = __builtin_elementwise_max(t, floor1);
       }
     }
     if (K2 == 0) {
@@ -186,27 +236,44 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
           xb[pg][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(x3 + pc * 128 + kk * 32 + g * 8));
       }
     }
+    constexpr int KW2 = K2 > 0 ? K2 : 128;
+    h8 a2[KK2], an2[KK2];
+    if constexpr (PIPE) {
+#pragma unroll
+      for (int kk = 0; kk < KK2; ++kk) a2[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<KW2>(i, 4 * kk + g)));
+    }
 #pragma unroll
     for (int p2 = 0; p2 < 4; ++p2) {
       f4 o2[2][PG];                                            // [fragment of the pair][pixel group]
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int nb = 2 * p2 + e;
+        if constexpr (PIPE) {
+          if (nb < 7) {
+#pragma unroll
+            for (int kk = 0; kk < KK2; ++kk)
+              an2[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<KW2>(16 * (nb + 1) + i, 4 * kk + g)));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < KK2; ++kk) a2[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<KW2>(16 * nb + i, 4 * kk + g)));
+        }
 #pragma unroll
         for (int pg = 0; pg < PG; ++pg) o2[e][pg] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < KK2; ++kk) {
-          const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<(K2 > 0 ? K2 : 128)>(16 * nb + i, 4 * kk + g)));
+        for (int kk = 0; kk < KK2; ++kk)
 #pragma unroll
           for (int pg = 0; pg < PG; ++pg)
-            o2[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, kk < 4 ? hb[pg][kk] : xb[pg][kk & 3], o2[e][pg], 0, 0, 0);
+            o2[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[kk], kk < 4 ? hb[pg][kk] : xb[pg][kk & 3], o2[e][pg], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PIPE) {
+#pragma unroll
+          for (int kk = 0; kk < KK2; ++kk) a2[kk] = an2[kk];
         }
         const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
 #pragma unroll
-        for (int pg = 0; pg < PG; ++pg) {
-          o2[e][pg] += bias;
-          if (relu2) o2[e][pg] = __builtin_elementwise_max(o2[e][pg], f4{0.f, 0.f, 0.f, 0.f});
-        }
+        for (int pg = 0; pg < PG; ++pg) o2[e][pg] = __builtin_elementwise_max(o2[e][pg] + bias, floor2);
       }
 #pragma unroll
       for (int pg = 0; pg < PG; ++pg)
@@ -275,7 +342,9 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
   const int i = lane & 15, g = lane >> 4;
   const int Mi = (int)M;                                       // < 2^24 pixels (checked by the host): 32-bit offsets
   const int ngroups = (Mi + 15) / 16;
-  const int wg = blockIdx.x * NW + wave, stride = gridDim.x * NW;
+  // wave-major numbering: the ragged last round of groups (wg < ngroups mod stride) lands on wave 0 of MANY workgroups
+  // instead of on all eight waves of a few
+  const int wg = wave * gridDim.x + blockIdx.x, stride = gridDim.x * NW;
 
   auto dma_chain = [&](const Chain &ch, unsigned char *buf) {
     const unsigned char *src = ch.img + lane * 16;
@@ -318,39 +387,49 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (c + 1 < A.n) dma_chain(A.c[c + 1], lds + ((c + 1) & 1) * kChainImage);
+
+    // one step = the chain on NP (2, or 1 for the odd last one) pixel groups of this wave, sharing every weight fragment
+    // ReLU as a floor (0 or -inf): no branch inside the MFMA loops
+    const float fl1 = ch.relu1 ? 0.f : -INFINITY, fl2 = ch.relu2 ? 0.f : -INFINITY;
+    const f4 floor1 = f4{fl1, fl1, fl1, fl1}, floor2 = f4{fl2, fl2, fl2, fl2};
+    auto step = [&](auto J0, auto NPc) {
+      constexpr int j0 = decltype(J0)::value, NP = decltype(NPc)::value;
+      // ---- link 1
+      // the weight fragments of row block nb + 1 are read while the MFMAs of row block nb run
+      f4 acc[NP][8];
+      h8 a[4], an[4];
 #pragma unroll
-    for (int j0 = 0; j0 < NG; j0 += 2) {                      // (odd NG: the last pair's second slot repeats the last group, unstored)
-      if (wg + j0 * stride >= ngroups) break;                 // wave-uniform: no barrier inside
-      // ---- link 1 on the pair of groups (j0, j0 + 1)
-      f4 acc[2][8];
+      for (int kk = 0; kk < 4; ++kk) a[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(i, 4 * kk + g)));
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) {
+        if (nb < 7) {
 #pragma unroll
-        for (int pg = 0; pg < 2; ++pg) acc[pg][nb] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(16 * nb + i, 4 * kk + g)));
-#pragma unroll
-          for (int pg = 0; pg < 2; ++pg) acc[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[j0 + pg < NG ? j0 + pg : NG - 1][kk], acc[pg][nb], 0, 0, 0);
+          for (int kk = 0; kk < 4; ++kk)
+            an[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(16 * (nb + 1) + i, 4 * kk + g)));
+          __builtin_amdgcn_sched_barrier(0);                     // reads first: they fly under this block's MFMAs
         }
+#pragma unroll
+        for (int pg = 0; pg < NP; ++pg) acc[pg][nb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int pg = 0; pg < NP; ++pg) acc[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk], xb[j0 + pg][kk], acc[pg][nb], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[kk] = an[kk];
       }
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) {
         const f4 bias = *reinterpret_cast<const f4 *>(lb + 16 * nb + 4 * g);
 #pragma unroll
-        for (int pg = 0; pg < 2; ++pg) {
-          f4 t = acc[pg][nb] + bias;
-          if (ch.relu1) t = __builtin_elementwise_max(t, f4{0.f, 0.f, 0.f, 0.f});
-          acc[pg][nb] = t;
-        }
+        for (int pg = 0; pg < NP; ++pg) acc[pg][nb] = __builtin_elementwise_max(acc[pg][nb] + bias, floor1);
       }
       if (!two) {
         // output rows of the LAST link are permuted in the image: fragment pair (2p, 2p+1) of lane group g holds
         // channels 32p + 8g + 0..7 -> one 16-B store per pair (8-B stores are store-issue bound: ~7 B/clk/CU)
 #pragma unroll
-        for (int pg = 0; pg < 2; ++pg)
-          if (j0 + pg < NG && pix[j0 + pg < NG ? j0 + pg : NG - 1] < Mi) {
+        for (int pg = 0; pg < NP; ++pg)
+          if (pix[j0 + pg] < Mi) {
 #pragma unroll
             for (int p2 = 0; p2 < 4; ++p2) {
               h8 o;
@@ -359,15 +438,15 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
                 o[r] = (_Float16)acc[pg][2 * p2][r];
                 o[4 + r] = (_Float16)acc[pg][2 * p2 + 1][r];
               }
-              *reinterpret_cast<h8 *>(ch.y + (size_t)pix[j0 + pg < NG ? j0 + pg : NG - 1] * 128 + 32 * p2 + 8 * g) = o;
+              *reinterpret_cast<h8 *>(ch.y + (size_t)pix[j0 + pg] * 128 + 32 * p2 + 8 * g) = o;
             }
           }
-        continue;
+        return;
       }
       // ---- link 2: the hidden activations in registers are the B operand (k = 8g + 4t + r <-> channel 32kk + 16t + 4g + r)
-      h8 hb[2][4];
+      h8 hb[NP][4];
 #pragma unroll
-      for (int pg = 0; pg < 2; ++pg)
+      for (int pg = 0; pg < NP; ++pg)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           h8 t;
@@ -379,39 +458,60 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
           hb[pg][kk] = t;
         }
 #pragma unroll
+      for (int kk = 0; kk < 4; ++kk) a[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(i, 4 * kk + g)));
+#pragma unroll
       for (int p2 = 0; p2 < 4; ++p2) {
-        f4 o2[2][2];                                           // [fragment of the pair][pixel group]
+        f4 o2[2][NP];                                          // [fragment of the pair][pixel group]
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int nb = 2 * p2 + e;
-          o2[e][0] = o2[e][1] = f4{0.f, 0.f, 0.f, 0.f};
+          if (nb < 7) {
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(16 * nb + i, 4 * kk + g)));
-#pragma unroll
-            for (int pg = 0; pg < 2; ++pg) o2[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, hb[pg][kk], o2[e][pg], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk)
+              an[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(16 * (nb + 1) + i, 4 * kk + g)));
+            __builtin_amdgcn_sched_barrier(0);
           }
+#pragma unroll
+          for (int pg = 0; pg < NP; ++pg) o2[e][pg] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int pg = 0; pg < NP; ++pg) o2[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk], hb[pg][kk], o2[e][pg], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) a[kk] = an[kk];
           const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
 #pragma unroll
-          for (int pg = 0; pg < 2; ++pg) {
-            o2[e][pg] += bias;
-            if (ch.relu2) o2[e][pg] = __builtin_elementwise_max(o2[e][pg], f4{0.f, 0.f, 0.f, 0.f});
-          }
+          for (int pg = 0; pg < NP; ++pg) o2[e][pg] = __builtin_elementwise_max(o2[e][pg] + bias, floor2);
         }
 #pragma unroll
-        for (int pg = 0; pg < 2; ++pg)
-          if (j0 + pg < NG && pix[j0 + pg < NG ? j0 + pg : NG - 1] < Mi) {
+        for (int pg = 0; pg < NP; ++pg)
+          if (pix[j0 + pg] < Mi) {
             h8 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               o[r] = (_Float16)o2[0][pg][r];
               o[4 + r] = (_Float16)o2[1][pg][r];
             }
-            *reinterpret_cast<h8 *>(ch.y + (size_t)pix[j0 + pg < NG ? j0 + pg : NG - 1] * 128 + 32 * p2 + 8 * g) = o;   // channels 32p + 8g + 0..7
+            *reinterpret_cast<h8 *>(ch.y + (size_t)pix[j0 + pg] * 128 + 32 * p2 + 8 * g) = o;   // channels 32p + 8g + 0..7
           }
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
+    };
+
+    // groups in pairs; a wave with an odd number of groups runs its last one alone (half the MFMA work).  All
+    // conditions are wave-uniform and there is no barrier inside a step.
+    static_for<0, (NG + 1) / 2>([&](auto S) {
+      constexpr int j0 = 2 * decltype(S)::value;
+      if (wg + j0 * stride < ngroups) {
+        if constexpr (j0 + 1 < NG) {
+          if (wg + (j0 + 1) * stride < ngroups) step(std::integral_constant<int, j0>{}, std::integral_constant<int, 2>{});
+          else step(std::integral_constant<int, j0>{}, std::integral_constant<int, 1>{});
+        } else {
+          step(std::integral_constant<int, j0>{}, std::integral_constant<int, 1>{});
+        }
+      }
+    });
   }
 }
 
@@ -638,7 +738,7 @@ extern "C" int di_pointwise_multi_fwd(const void *x, int n_chains, const void *c
   // allows it (more workgroups than CUs only beyond 5 groups per wave)
   const long long ngroups = (n_pixels + 15) / 16;
   long long grid = n_cu;
-  if (ngroups < (long long)grid * NW * 2) grid = (ngroups + NW * 2 - 1) / (NW * 2);
+  if (ngroups < (long long)grid * NW) grid = (ngroups + NW - 1) / NW;        // small map: one group per wave, every CU busy
   int ng = (int)((ngroups + grid * NW - 1) / (grid * NW));
   if (ng > 5) {
     grid = (ngroups + NW * 5 - 1) / (NW * 5);

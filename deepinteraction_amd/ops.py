@@ -430,7 +430,7 @@ def topk(scores, k, with_values=False):
     B, N = scores.shape
     idx = torch.empty((B, k), dtype=torch.int64, device=scores.device)
     val = torch.empty((B, k), dtype=torch.float32, device=scores.device) if with_values else None
-    ws = torch.empty((int(_lib.lib().di_topk_workspace_bytes(B, k)),), dtype=torch.uint8, device=scores.device)
+    ws = torch.empty((int(_lib.lib().di_topk_workspace_bytes(B, N, k)),), dtype=torch.uint8, device=scores.device)
     _lib.call('di_topk_fwd', scores.data_ptr(), idx.data_ptr(), 0 if val is None else val.data_ptr(), ws.data_ptr(),
               B, N, k, _stream())
     return (idx, val) if with_values else idx

@@ -186,9 +186,9 @@ int di_bevwarp_gather_bwd(const void *grad_out, const float *depth, const float 
 /* Top-k of non-negative float32 scores per row (the proposal pick of deepinteraction_decoder.py:242, where the
  * reference arg-sorts all 324 000 scores): indices (B,k) int64 in the order "value descending, lower index first on
  * ties" (deterministic; the reference leaves ties unspecified), optionally the values (may be NULL).  Radix select on
- * a composite (value, index) key + a k-element sort; k <= 1024, N <= 2^20; `workspace` = di_topk_workspace_bytes(B, k)
- * bytes of device memory, 64-byte aligned.  No host synchronisation. */
-long long di_topk_workspace_bytes(int B, int k);
+ * a composite (value, index) key + a k-element sort (4 launches); k <= 1024, N <= 2^20; `workspace` =
+ * di_topk_workspace_bytes(B, N, k) bytes of device memory, 64-byte aligned.  No host synchronisation. */
+long long di_topk_workspace_bytes(int B, int N, int k);
 int di_topk_fwd(const float *scores, long long *out_idx, float *out_val, void *workspace, int B, int N, int k,
                 void *stream);
 int di_heatmap_nms(const void *a, const void *b, float *out, int B, int num_classes, int H, int W,

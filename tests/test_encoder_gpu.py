@@ -367,6 +367,34 @@ def test_pointwise_chain(k1, k2, relu, npix):
     assert err <= 1e-3 * max(ref.abs().max().item(), 1.0), err
 
 
+@pytest.mark.parametrize('k2', [0, 256])
+@pytest.mark.parametrize('npix', [(1, 9, 13), (1, 180, 180)])
+def test_pointwise_chain_masked_bias(k2, npix):
+    """The masked link-1 bias (the folded output projection of the pillar attention inside P_out_proj):
+    h = W1 . [x1 ; x2] + b1 + mask * bm, against float64 on the same fp16 operands."""
+    _require_gpu()
+    n, H, W = npix
+    g = torch.Generator().manual_seed(5)
+    mk = lambda: torch.randn(n, 128, H, W, generator=g).half()
+    x1, x2, x3 = mk(), mk(), (mk() if k2 else None)
+    w1 = (torch.randn(128, 256, generator=g) / 16).half()
+    b1, bm = torch.randn(128, generator=g) * 0.1, torch.randn(128, generator=g)
+    w2 = (torch.randn(128, 256, generator=g) / 16).half() if k2 else None
+    b2 = torch.randn(128, generator=g) * 0.1 if k2 else None
+    mask = (torch.rand(n, 1, H, W, generator=g) < 0.4).half()
+    dev = lambda t: None if t is None else t.to(DEV)
+    cl = lambda t: None if t is None else t.to(DEV).contiguous(memory_format=torch.channels_last)
+    out = ops.pointwise_chain(cl(x1), dev(w1), dev(b1), False, x2=cl(x2), w2=dev(w2), b2=dev(b2), relu2=False, x3=cl(x3),
+                              mask=dev(mask).contiguous(), bm=dev(bm)).float().cpu()
+    flat = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).double()
+    h = torch.cat([flat(x1), flat(x2)], 1) @ w1.double().t() + b1.double() + flat(mask) * bm.double()
+    if k2:
+        h = torch.cat([h.half().double(), flat(x3)], 1) @ w2.double().t() + b2.double()
+    ref = h.float().view(n, H, W, 128).permute(0, 3, 1, 2)
+    err = (out - ref).abs().max().item()
+    assert err <= 1e-3 * max(ref.abs().max().item(), 1.0), err
+
+
 @pytest.mark.parametrize('npix', [(1, 7, 5), (2, 33, 61), (1, 180, 180), (6, 112, 200), (12, 112, 200)])
 def test_pointwise_multi_equals_single_chains(npix):
     """Several projections of one map in one launch (ops.pointwise_multi: the map is read once, the chains' weights are
