@@ -4,11 +4,21 @@
 // Radix SELECT instead of a sort.  Every element gets the 52-bit key
 //        K = float_bits(score) << 20 | (0xFFFFF - index)          (scores >= 0: their bit patterns are ordered)
 // so all keys are distinct and "value descending, lower index first on ties" is plain descending K - a
-// deterministic rule where the reference's argsort leaves ties unspecified.  Five digit levels (11+11+10 value bits,
-// 10+10 index bits), each a multi-block histogram of the elements that still match the selected prefix and a
-// one-block pick of the digit that holds the k-th largest key; then the blocks collect the exactly k keys >= K*
-// into per-block segments and one block bitonic-sorts them.  12 small launches, no host synchronisation, no global atomics,
-// bit-reproducible.
+// deterministic rule where the reference's argsort leaves ties unspecified.
+//
+// Four launches (round 2, second version; the first one walked all five digit levels over the whole score map: 12
+// launches, 95 us of kernel time):
+//   1. hist     64 blocks: per-block LDS histogram of the TOP digit (11 value bits), stored as SUFFIX sums (plain stores)
+//   2. pick     1 block:   sums the 64 suffix arrays: the digit T that holds the k-th largest key is where the total
+//                          crosses k; the per-block suffix sums at T and T + 1 say how many keys of every slice lie
+//                          above T and inside T -> exclusive scans = where every block of step 3 writes
+//   3. collect  64 blocks: keys with digit > T (fewer than k) -> `above`, keys with digit == T -> `bin`, both FLAT
+//   4. final    1 block:   above + bin fit 1024 slots -> sort them all; otherwise radix select with in-place compaction
+//                          over `bin` (cached in LDS up to 16 384 keys): per level histogram, pick, keys above the
+//                          picked digit -> selected, keys inside it -> compacted to the front; stops as soon as what
+//                          is left fits the sort.  Then a bitonic sort of the <= 1024 survivors.
+// No host synchronisation, no global atomics, no buffer zeroed by one kernel and accumulated into by another (see
+// below), bit-reproducible.
 #include "di_common.h"
 
 namespace di {
@@ -20,141 +30,357 @@ namespace tk {
 // went wrong from the second replay on - atomics and plain stores to the same lines do not meet in the same cache
 // level across the XCDs - while eager launches, with their full cache maintenance at every boundary, were fine.)
 constexpr int kBins = 2048;
-constexpr int kHistBlocks = 32;      // partial histograms per sample
+constexpr int kBlocks = 64;          // slices of the score row = partial histograms per sample (one wave scans them)
+constexpr int kTopShift = 41;        // the top digit: key bits 41..51 = score bits 21..31
+constexpr int kNT = 1024;            // threads of every kernel here
+constexpr int kCache = 16384;        // keys of the selected top bin the final kernel caches in LDS (128 KB)
+typedef unsigned long long u64;
+
 struct State {
-  unsigned long long prefix;   // the digits selected so far, right aligned
-  int need;                    // how many keys of the selected bin are still to be taken
-  int pad;
+  int T;                     // the top digit that holds the k-th largest key
+  int above;                 // keys with a larger top digit (< k): all selected
+  int take;                  // k - above: how many keys of digit T are selected
+  int M;                     // keys with top digit T
+  int above_off[kBlocks];    // where slice p writes its keys inside `above` / `bin`
+  int bin_off[kBlocks];
 };
+constexpr int kStateBytes = (sizeof(State) + 63) / 64 * 64;
 
-__device__ __forceinline__ unsigned long long make_key(float v, int idx) {
-  return ((unsigned long long)__float_as_uint(v) << 20) | (unsigned long long)(0xFFFFFu - (unsigned)idx);
+__device__ __forceinline__ u64 make_key(float v, int idx) {
+  return ((u64)__float_as_uint(v) << 20) | (u64)(0xFFFFFu - (unsigned)idx);
+}
+__device__ __forceinline__ int lanes_below(u64 m, int lane) { return __popcll(m & ((1ull << lane) - 1ull)); }
+
+// LDS counter += 1 for every lane with `on`.  The lanes that share the bin of the first active lane are counted with
+// ONE atomic, then the same once more for what is left (a row that is mostly zeros, or equal scores, would otherwise
+// serialise up to 64 atomics on one address); the remaining lanes add one each.
+__device__ __forceinline__ void count_digit(int *h, bool on, int d, int lane) {
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const u64 act = __ballot(on);
+    if (act == 0) return;
+    const int first = __ffsll((long long)act) - 1;
+    const int d0 = __shfl(d, first);
+    const bool mine = on && d == d0;
+    const u64 same = __ballot(mine);
+    if (lane == first) atomicAdd(&h[d0], __popcll(same));
+    on = on && !mine;
+  }
+  if (on) atomicAdd(&h[d], 1);
 }
 
-// partial histogram of digit (K >> shift) & (2^bits - 1) over this block's slice of the elements whose higher bits
-// equal state.prefix
-__global__ __launch_bounds__(256) void hist_kernel(const float *__restrict__ scores, const State *__restrict__ st,
-                                                   int *__restrict__ part, int N, int shift, int bits, int first) {
+// wave-aggregated append: every lane with `on` gets a distinct slot counted from *counter (LDS), one atomic per wave
+__device__ __forceinline__ int append_slot(int *counter, bool on, int lane) {
+  const u64 m = __ballot(on);
+  if (m == 0) return 0;
+  const int first = __ffsll((long long)m) - 1;
+  int pos = 0;
+  if (lane == first) pos = atomicAdd(counter, __popcll(m));
+  return __shfl(pos, first) + lanes_below(m, lane);
+}
+
+// 1024 threads; h: LDS counts of nb <= 2048 bins.  Inclusive suffix sums (number of keys in bins >= b) of this
+// thread's two bins b0 = nb-1-2t and b1 = b0-1 (reversed order: two per thread, wave scan, wave totals in wt[16]).
+__device__ __forceinline__ void block_suffix(const int *h, int nb, int *wt, int &b0, int &b1, int &v0, int &v1, int &incl0,
+                                             int &incl1) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  b0 = nb - 1 - 2 * t;
+  b1 = b0 - 1;
+  v0 = b0 >= 0 ? h[b0] : 0;
+  v1 = b1 >= 0 ? h[b1] : 0;
+  const int s = v0 + v1;
+  int inc = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wt[wave] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wt[w];
+  incl1 = base + inc;
+  incl0 = incl1 - v1;
+}
+
+// the bin T with  #(bins > T) < need <= #(bins >= T);  res[0] = T, res[1] = #(bins > T).  Ends with a barrier.
+__device__ __forceinline__ void block_pick(const int *h, int nb, int need, int *wt, int *res) {
+  int b0, b1, v0, v1, incl0, incl1;
+  block_suffix(h, nb, wt, b0, b1, v0, v1, incl0, incl1);
+  if (incl0 - v0 < need && need <= incl0) {
+    res[0] = b0;
+    res[1] = incl0 - v0;
+  }
+  if (incl0 < need && need <= incl1) {
+    res[0] = b1;
+    res[1] = incl0;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void slice_of(int blk, int N, int &lo, int &hi) {
+  const int per = (N + kBlocks - 1) / kBlocks;
+  lo = min(blk * per, N);
+  hi = min(lo + per, N);
+}
+
+// step 1: histogram of the top digit over this block's slice, stored as suffix sums
+__global__ __launch_bounds__(kNT) void hist_kernel(const float *__restrict__ scores, int *__restrict__ part, int N) {
   __shared__ int lh[kBins];
-  const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < kBins; i += 256) lh[i] = 0;
-  __syncthreads();
-  const unsigned long long prefix = first ? 0ull : st[b].prefix;
-  const unsigned mask = (1u << bits) - 1u;
-  const float *s = scores + (size_t)b * N;
-  const int per = (N + kHistBlocks - 1) / kHistBlocks;
-  const int lo = blockIdx.x * per, hi = min(lo + per, N);
-  for (int i = lo + threadIdx.x; i < hi; i += 256) {
-    const unsigned long long K = make_key(s[i], i);
-    if ((K >> (shift + bits)) == prefix) atomicAdd(&lh[(unsigned)(K >> shift) & mask], 1);
-  }
-  __syncthreads();
-  int *dst = part + ((size_t)b * kHistBlocks + blockIdx.x) * kBins;
-  for (int i = threadIdx.x; i < kBins; i += 256) dst[i] = lh[i];
-}
-
-// one block per sample: the bin T with  #(bins > T) < need <= #(bins >= T); prefix <- prefix:T, need -= #(bins > T)
-__global__ __launch_bounds__(1024) void pick_kernel(State *__restrict__ st, const int *__restrict__ part, int bits, int k,
-                                                    int first) {
-  __shared__ int suf[kBins];
-  const int b = blockIdx.x, nb = 1 << bits, t = threadIdx.x;
-  const int *h = part + (size_t)b * kHistBlocks * kBins;
-  // the previous level's selection is read ahead of the scan: its barriers separate these loads from the single
-  // thread that rewrites st[b] at the end
-  const int need = first ? k : st[b].need;
-  const unsigned long long prefix = first ? 0ull : st[b].prefix;
-  // suffix sums over reversed bins (Hillis-Steele on <= 2048 entries, two per thread)
-  for (int i = t; i < kBins; i += 1024) {
-    int c = 0;
-    if (i < nb)
-      for (int p = 0; p < kHistBlocks; ++p) c += h[p * kBins + nb - 1 - i];
-    suf[i] = c;                                                                  // suf[r]: bin nb-1-r
-  }
-  __syncthreads();
-  for (int d = 1; d < nb; d <<= 1) {
-    int v0 = 0, v1 = 0;
-    const int i0 = t, i1 = t + 1024;
-    if (i0 >= d) v0 = suf[i0 - d];
-    if (i1 < kBins && i1 >= d) v1 = suf[i1 - d];
-    __syncthreads();
-    suf[i0] += v0;
-    if (i1 < kBins) suf[i1] += v1;
-    __syncthreads();
-  }
-  for (int r = t; r < nb; r += 1024) {
-    const int incl = suf[r], excl = r ? suf[r - 1] : 0;
-    if (excl < need && need <= incl) {
-      st[b].prefix = (prefix << bits) | (unsigned long long)(nb - 1 - r);
-      st[b].need = need - excl;
-    }
-  }
-}
-
-// every block gathers the keys >= K* of its slice (all keys are distinct; exactly k exist in total) into its own
-// segment of `cand` (LDS counter, plain stores) and records how many it found
-__global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ scores, const State *__restrict__ st,
-                                                      unsigned long long *__restrict__ cand, int *__restrict__ cand_n,
-                                                      int N, int k) {
-  __shared__ int cnt;
-  const int b = blockIdx.y;
-  const unsigned long long Kstar = st[b].prefix;   // all 52 bits selected
-  if (threadIdx.x == 0) cnt = 0;
+  __shared__ int wt[16];
+  const int b = blockIdx.y, t = threadIdx.x, lane = t & 63;
+  for (int i = t; i < kBins; i += kNT) lh[i] = 0;
   __syncthreads();
   const float *s = scores + (size_t)b * N;
-  const int per = (N + kHistBlocks - 1) / kHistBlocks;
-  const int lo = blockIdx.x * per, hi = min(lo + per, N);
-  unsigned long long *dst = cand + ((size_t)b * kHistBlocks + blockIdx.x) * k;
-  for (int i = lo + threadIdx.x; i < hi; i += 256) {
-    const unsigned long long K = make_key(s[i], i);
-    if (K >= Kstar) {
-      const int pos = atomicAdd(&cnt, 1);          // LDS atomic: order irrelevant, the sort follows
-      if (pos < k) dst[pos] = K;
+  int lo, hi;
+  slice_of(blockIdx.x, N, lo, hi);
+  constexpr int U = 4;
+  for (int base = lo; base < hi; base += kNT * U) {                        // wave-uniform trip count; loads first
+    unsigned bits[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * kNT + t;
+      bits[u] = __float_as_uint(s[min(i, hi - 1)]);                         // clamped, not predicated: the loads stay batched
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) count_digit(lh, base + u * kNT + t < hi, (int)(bits[u] >> 21), lane);
   }
   __syncthreads();
-  if (threadIdx.x == 0) cand_n[b * kHistBlocks + blockIdx.x] = min(cnt, k);
+  int b0, b1, v0, v1, incl0, incl1;
+  block_suffix(lh, kBins, wt, b0, b1, v0, v1, incl0, incl1);
+  int *dst = part + ((size_t)b * kBlocks + blockIdx.x) * kBins;
+  dst[b0] = incl0;                                                         // kBins = 2 * kNT: both bins exist
+  dst[b1] = incl1;
 }
 
-// one block per sample: concatenate the segments (k keys in total), bitonic-sort them (descending), write the indices
-__global__ __launch_bounds__(1024) void sort_kernel(const unsigned long long *__restrict__ cand, const int *__restrict__ cand_n,
-                                                    long long *__restrict__ out_idx, float *__restrict__ out_val, int k) {
-  __shared__ unsigned long long a[1024];
-  __shared__ int off[kHistBlocks + 1];
+// step 2: one block per sample
+__global__ __launch_bounds__(kNT) void pick_kernel(const int *__restrict__ part, unsigned char *__restrict__ states, int k) {
+  __shared__ __align__(16) int h[kBins + 4];                               // total suffix sums; h[kBins] = 0
+  __shared__ int res[2];
   const int b = blockIdx.x, t = threadIdx.x;
-  a[t] = 0ull;
-  if (t == 0) {
-    int o = 0;
-    for (int p = 0; p < kHistBlocks; ++p) {
-      off[p] = o;
-      o += cand_n[b * kHistBlocks + p];
+  const int *p = part + (size_t)b * kBlocks * kBins;
+  State *st = reinterpret_cast<State *>(states + (size_t)b * kStateBytes);
+  {
+    // thread = (half of the slices, four adjacent bins): 32 independent 16-B loads in two batches, each issued before its adds
+    const int half = t >> 9, b4 = (t & 511) * 4;
+    const int *src = p + (size_t)half * 32 * kBins + b4;
+    int4 c = make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int q0 = 0; q0 < 32; q0 += 16) {
+      int4 v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = *reinterpret_cast<const int4 *>(src + (q0 + q) * kBins);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        c.x += v[q].x;
+        c.y += v[q].y;
+        c.z += v[q].z;
+        c.w += v[q].w;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    off[kHistBlocks] = o;
+    if (half == 0) *reinterpret_cast<int4 *>(&h[b4]) = c;
+    __syncthreads();
+    if (half == 1) {
+      int4 o = *reinterpret_cast<int4 *>(&h[b4]);
+      o.x += c.x;
+      o.y += c.y;
+      o.z += c.z;
+      o.w += c.w;
+      *reinterpret_cast<int4 *>(&h[b4]) = o;
+    }
+  }
+  if (t == 0) h[kBins] = 0;
+  __syncthreads();
+  // the suffix sums fall with the bin index: T is the last bin whose suffix sum still reaches k
+#pragma unroll
+  for (int j = 0; j < kBins / kNT; ++j) {
+    const int i = t + j * kNT;
+    if (h[i] >= k && h[i + 1] < k) {
+      res[0] = i;
+      res[1] = h[i + 1];
+    }
   }
   __syncthreads();
-  for (int e = t; e < kHistBlocks * k; e += 1024) {
-    const int p = e / k, j = e - p * k;
-    if (j < off[p + 1] - off[p] && off[p] + j < 1024) a[off[p] + j] = cand[((size_t)b * kHistBlocks + p) * k + j];
+  const int T = res[0], above = res[1];
+  if (t < kBlocks) {                                                       // one wave: two exclusive scans over the slices
+    const int a = T + 1 < kBins ? p[t * kBins + T + 1] : 0, m = p[t * kBins + T] - a;
+    int ia = a, im = m;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int oa = __shfl_up(ia, d), om = __shfl_up(im, d);
+      if (t >= d) {
+        ia += oa;
+        im += om;
+      }
+    }
+    st->above_off[t] = ia - a;
+    st->bin_off[t] = im - m;
+    if (t == kBlocks - 1) st->M = im;
+    if (t == 0) {
+      st->T = T;
+      st->above = above;
+      st->take = k - above;
+    }
+  }
+}
+
+// step 3: every block moves the keys of its slice that lie above / inside digit T to their flat positions
+__global__ __launch_bounds__(kNT) void collect_kernel(const float *__restrict__ scores, const unsigned char *__restrict__ states,
+                                                      u64 *__restrict__ above, u64 *__restrict__ bin, int N, int k) {
+  __shared__ int n_above, n_bin;
+  const int b = blockIdx.y, t = threadIdx.x, lane = t & 63;
+  const State *st = reinterpret_cast<const State *>(states + (size_t)b * kStateBytes);
+  const int T = st->T;
+  u64 *ab = above + (size_t)b * k + st->above_off[blockIdx.x];
+  u64 *bn = bin + (size_t)b * N + st->bin_off[blockIdx.x];
+  if (t == 0) n_above = n_bin = 0;
+  __syncthreads();
+  const float *s = scores + (size_t)b * N;
+  int lo, hi;
+  slice_of(blockIdx.x, N, lo, hi);
+  constexpr int U = 4;
+  for (int base = lo; base < hi; base += kNT * U) {                        // wave-uniform trip count; loads first
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * kNT + t;
+      v[u] = s[min(i, hi - 1)];                                            // clamped, not predicated: the loads stay batched
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * kNT + t;
+      const bool on = i < hi;
+      const u64 K = make_key(v[u], i);
+      const int d = (int)(K >> kTopShift);
+      const bool in_bin = on && d == T, is_above = on && d > T;
+      const int pb = append_slot(&n_bin, in_bin, lane);
+      if (in_bin) bn[pb] = K;
+      const int pa = append_slot(&n_above, is_above, lane);                // fewer than k in total
+      if (is_above) ab[pa] = K;
+    }
+  }
+}
+
+// step 4: one block per sample
+__global__ __launch_bounds__(kNT) void final_kernel(const unsigned char *__restrict__ states, const u64 *__restrict__ above,
+                                                    u64 *__restrict__ bin, long long *__restrict__ out_idx,
+                                                    float *__restrict__ out_val, int N, int k) {
+  extern __shared__ __align__(16) unsigned char dyn_lds[];                 // kCache keys
+  __shared__ u64 sel[1024];
+  __shared__ int h[kBins];
+  __shared__ int wt[16], res[2], n_sel, n_keep;
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
+  const State *st = reinterpret_cast<const State *>(states + (size_t)b * kStateBytes);
+  const int a = st->above, M = st->M;
+  const u64 *ab = above + (size_t)b * k;
+  u64 *bn = bin + (size_t)b * N;
+  sel[t] = 0ull;
+  __syncthreads();
+  if (t < a) sel[t] = ab[t];
+  int n;
+  if (a + M <= 1024) {
+    if (t < M) sel[a + t] = bn[t];                                         // everything still in play fits the sort
+    n = a + M;
+  } else {
+    // radix select with compaction.  `ck[0 .. cur)` = the keys that still match the digits picked so far (LDS copy of
+    // the bin, or the bin itself in global memory when it is larger than the cache: same code through a flat pointer)
+    u64 *ck = bn;
+    if (M <= kCache) {
+      u64 *cache = reinterpret_cast<u64 *>(dyn_lds);
+      constexpr int U = 8;
+      for (int base = 0; base < M; base += kNT * U) {                      // loads first: one round trip per 8192 keys
+        u64 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = bn[min(base + u * kNT + t, M - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (base + u * kNT + t < M) cache[base + u * kNT + t] = v[u];
+      }
+      ck = cache;
+    }
+    if (t == 0) n_sel = a;
+    int cur = M, need = st->take;
+    const int shifts[4] = {30, 20, 10, 0}, nbits[4] = {11, 10, 10, 10};
+    n = k;
+    for (int l = 0; l < 4; ++l) {
+      const int shift = shifts[l], bits = nbits[l];
+      const unsigned mask = (1u << bits) - 1u;
+      for (int i = t; i < kBins; i += kNT) h[i] = 0;
+      if (t == 0) n_keep = 0;
+      __syncthreads();                                                     // also: the cache / the last compaction is complete
+      for (int base = 0; base < cur; base += kNT) {                        // wave-uniform trip count
+        const int e = base + t;
+        const bool on = e < cur;
+        const u64 K = ck[min(e, cur - 1)];
+        count_digit(h, on, (int)((unsigned)(K >> shift) & mask), lane);
+      }
+      __syncthreads();
+      block_pick(h, 1 << bits, need, wt, res);
+      const int T = res[0];
+      need -= res[1];
+      // keys above the picked digit are selected, keys inside it move to the front (a round reads its 1024 keys, then -
+      // after the barrier - writes to positions below everything already read)
+      for (int base = 0; base < cur; base += kNT) {
+        const int e = base + t;
+        const bool on = e < cur;
+        const u64 K = ck[min(e, cur - 1)];
+        const int d = (int)((unsigned)(K >> shift) & mask);
+        __syncthreads();
+        const bool up = on && d > T, keep = on && d == T;
+        const int ps = append_slot(&n_sel, up, lane);
+        if (up) sel[ps] = K;
+        const int pk = append_slot(&n_keep, keep, lane);
+        if (keep) ck[pk] = K;
+      }
+      __syncthreads();
+      cur = n_keep;
+      const int have = n_sel;
+      __syncthreads();                                                     // everybody has read n_keep before the next level resets it
+      if (have + cur <= 1024) {                                            // what is left fits the sort (have + need = k <= have + cur)
+        for (int e = t; e < cur; e += kNT) sel[have + e] = ck[e];
+        n = have + cur;
+        break;
+      }
+    }
   }
   __syncthreads();
-  for (int len = 2; len <= 1024; len <<= 1) {
+  int P = 64;
+  while (P < n) P <<= 1;
+  for (int len = 2; len <= P; len <<= 1) {
     for (int j = len >> 1; j > 0; j >>= 1) {
       const int p = t ^ j;
-      if (p > t) {
+      if (t < P && p > t) {
         const bool desc = (t & len) == 0;
-        const unsigned long long x = a[t], y = a[p];
+        const u64 x = sel[t], y = sel[p];
         if ((x < y) == desc) {
-          a[t] = y;
-          a[p] = x;
+          sel[t] = y;
+          sel[p] = x;
         }
       }
       __syncthreads();
     }
   }
   if (t < k) {
-    const unsigned long long K = a[t];
+    const u64 K = sel[t];
     out_idx[(size_t)b * k + t] = (long long)(0xFFFFFu - (unsigned)(K & 0xFFFFFull));
     if (out_val != nullptr) out_val[(size_t)b * k + t] = __uint_as_float((unsigned)(K >> 20));
   }
+}
+
+struct Layout {
+  size_t part, states, above, bin, total;
+};
+static Layout layout(int B, int N, int k) {
+  Layout L;
+  auto up = [](size_t v) { return (v + 63) / 64 * 64; };
+  L.part = 0;
+  L.states = up((size_t)B * kBlocks * kBins * sizeof(int));
+  L.above = L.states + (size_t)B * kStateBytes;
+  L.bin = L.above + up((size_t)B * k * sizeof(u64));
+  L.total = L.bin + up((size_t)B * N * sizeof(u64));
+  return L;
 }
 
 }  // namespace tk
@@ -162,8 +388,9 @@ __global__ __launch_bounds__(1024) void sort_kernel(const unsigned long long *__
 
 extern "C" {
 
-long long di_topk_workspace_bytes(int B, int k) {
-  return (long long)B * ((long long)di::tk::kHistBlocks * (di::tk::kBins * (long long)sizeof(int) + (long long)k * 8 + 4) + 64) + 64;
+long long di_topk_workspace_bytes(int B, int N, int k) {
+  if (B <= 0 || N <= 0 || k <= 0) return 0;
+  return (long long)di::tk::layout(B, N, k).total + 64;
 }
 
 int di_topk_fwd(const float *scores, long long *out_idx, float *out_val, void *workspace, int B, int N, int k,
@@ -171,19 +398,20 @@ int di_topk_fwd(const float *scores, long long *out_idx, float *out_val, void *w
   using namespace di::tk;
   DI_REQUIRE(B > 0 && N > 0 && k > 0 && k <= 1024 && k <= N, "bad top-k shape (k <= min(N, 1024))");
   DI_REQUIRE(N <= (1 << 20), "N=%d exceeds the 2^20 indices of the composite key", N);
+  DI_REQUIRE(scores && out_idx && workspace, "scores, out_idx and workspace are required");
   hipStream_t s = (hipStream_t)stream;
   unsigned char *w = reinterpret_cast<unsigned char *>(workspace);
-  int *part = reinterpret_cast<int *>(w);
-  State *st = reinterpret_cast<State *>(w + (size_t)B * kHistBlocks * kBins * sizeof(int));
-  unsigned long long *cand = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(st) + (size_t)B * 64);
-  int *cand_n = reinterpret_cast<int *>(cand + (size_t)B * kHistBlocks * k);
-  const int shifts[5] = {41, 30, 20, 10, 0}, nbits[5] = {11, 11, 10, 10, 10};
-  for (int l = 0; l < 5; ++l) {
-    hipLaunchKernelGGL(hist_kernel, dim3(kHistBlocks, B), dim3(256), 0, s, scores, st, part, N, shifts[l], nbits[l], l == 0);
-    hipLaunchKernelGGL(pick_kernel, dim3(B), dim3(1024), 0, s, st, part, nbits[l], k, l == 0);
-  }
-  hipLaunchKernelGGL(collect_kernel, dim3(kHistBlocks, B), dim3(256), 0, s, scores, st, cand, cand_n, N, k);
-  hipLaunchKernelGGL(sort_kernel, dim3(B), dim3(1024), 0, s, cand, cand_n, out_idx, out_val, k);
+  const Layout L = layout(B, N, k);
+  int *part = reinterpret_cast<int *>(w + L.part);
+  unsigned char *states = w + L.states;
+  u64 *above = reinterpret_cast<u64 *>(w + L.above), *bin = reinterpret_cast<u64 *>(w + L.bin);
+  constexpr int cache_bytes = kCache * (int)sizeof(u64);
+  static di::LdsRaised lds_raised;
+  if (int rc = di::ensure_lds(lds_raised, (const void *)final_kernel, cache_bytes)) return rc;
+  hipLaunchKernelGGL(hist_kernel, dim3(kBlocks, B), dim3(kNT), 0, s, scores, part, N);
+  hipLaunchKernelGGL(pick_kernel, dim3(B), dim3(kNT), 0, s, part, states, k);
+  hipLaunchKernelGGL(collect_kernel, dim3(kBlocks, B), dim3(kNT), 0, s, scores, states, above, bin, N, k);
+  hipLaunchKernelGGL(final_kernel, dim3(B), dim3(kNT), cache_bytes, s, states, above, bin, out_idx, out_val, N, k);
   return di::check_launch("topk_fwd");
 }
 

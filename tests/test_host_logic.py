@@ -44,3 +44,38 @@ def test_chain_and_ffn_images_have_the_kernel_layout_size():
     # b2 rides in chunk 0 only
     tail = lambda t: t[2 * 128 * 128 * 2 + 512:].view(torch.float32)
     assert float(tail(imgs[0]).abs().sum()) > 0 and all(float(tail(t).abs().sum()) == 0 for t in imgs[1:])
+
+
+def test_graph_input_arena_layout():
+    """GraphedHotPath keeps every per-sample input in one allocation: the views keep shape, strides (channels-last maps
+    stay channels-last), dtype and content; a second arena with the same layout (a prepared record) switches all of them
+    with ONE copy."""
+    import torch
+    from deepinteraction_amd.graphed import GraphedHotPath
+    g = GraphedHotPath.__new__(GraphedHotPath)
+    g.glue = None
+    gen = torch.Generator().manual_seed(0)
+    g.img_feats = torch.randn(2, 8, 5, 7, generator=gen).half().contiguous(memory_format=torch.channels_last)
+    g.pts_feats = [torch.randn(1, 4, 6, 6, generator=gen), torch.randn(1, 4, 3, 3, generator=gen).contiguous(memory_format=torch.channels_last)]
+    g.pts = [torch.randn(11, 5, generator=gen)]
+    g.pillars = torch.randn(9, 20, 5, generator=gen)
+    g.pillar_coors = torch.randint(0, 50, (9, 4), generator=gen, dtype=torch.int32)
+    g.pillars_num_points = torch.randint(0, 20, (9,), generator=gen, dtype=torch.int32)
+    before = [t.clone() for t in g._input_list()]
+    strides = [t.stride() for t in g._input_list()]
+    g._build_arena()
+    after = g._input_list()
+    assert isinstance(g.pts_feats, list) and len(g.pts_feats) == 2 and g.pillars_num_points.dtype == torch.int32
+    base = g._arena.untyped_storage().data_ptr()
+    for b, a, st in zip(before, after, strides):
+        assert torch.equal(a, b) and a.stride() == st and a.dtype == b.dtype
+        assert a.untyped_storage().data_ptr() == base and a.data_ptr() % 256 == base % 256
+    assert g.img_feats.is_contiguous(memory_format=torch.channels_last)
+    # a record arena: same layout, other content; one copy switches every view
+    other = torch.empty_like(g._arena)
+    views = g._arena_views(other)
+    for v, b in zip(views, before):
+        v.copy_(b * 2 if b.is_floating_point() else b + 1)
+    g._arena.copy_(other)
+    for a, b in zip(g._input_list(), before):
+        assert torch.equal(a, b * 2 if b.is_floating_point() else b + 1)
