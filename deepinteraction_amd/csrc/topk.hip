@@ -273,99 +273,112 @@ __global__ __launch_bounds__(kNT) void final_kernel(const unsigned char *__restr
   __shared__ int wt[16], res[2], n_sel, n_keep;
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
   const State *st = reinterpret_cast<const State *>(states + (size_t)b * kStateBytes);
-  const int a = st->above, M = st->M;
+  const int a = st->above, M = st->M, take = st->take;
   const u64 *ab = above + (size_t)b * k;
   u64 *bn = bin + (size_t)b * N;
+  int Pk = 64;                                                             // the sort network covers the next power of two >= k
+  while (Pk < k) Pk <<= 1;
   sel[t] = 0ull;
   __syncthreads();
   if (t < a) sel[t] = ab[t];
-  int n;
-  if (a + M <= 1024) {
-    if (t < M) sel[a + t] = bn[t];                                         // everything still in play fits the sort
-    n = a + M;
-  } else {
-    // radix select with compaction.  `ck[0 .. cur)` = the keys that still match the digits picked so far (LDS copy of
-    // the bin, or the bin itself in global memory when it is larger than the cache: same code through a flat pointer)
-    u64 *ck = bn;
-    if (M <= kCache) {
-      u64 *cache = reinterpret_cast<u64 *>(dyn_lds);
-      constexpr int U = 8;
-      for (int base = 0; base < M; base += kNT * U) {                      // loads first: one round trip per 8192 keys
-        u64 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = bn[min(base + u * kNT + t, M - 1)];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (base + u * kNT + t < M) cache[base + u * kNT + t] = v[u];
-      }
-      ck = cache;
-    }
+  constexpr int U = 4;                                                     // keys per thread and round: loads first
+  // Radix select with compaction over ck[0 .. cur): per level histogram of the digit, pick, then the keys above the
+  // picked digit are selected and the keys inside it move to the front (a round reads its 4096 keys, then - after the
+  // barrier - writes to positions below everything already read).  Stops when what is left fits the sort network.
+  // Returns how many keys `sel` holds.  Instantiated for the LDS cache and for global memory.
+  auto select = [&](u64 *ck) __attribute__((always_inline)) {
     if (t == 0) n_sel = a;
-    int cur = M, need = st->take;
+    int cur = M, need = take, n = k;
     const int shifts[4] = {30, 20, 10, 0}, nbits[4] = {11, 10, 10, 10};
-    n = k;
     for (int l = 0; l < 4; ++l) {
       const int shift = shifts[l], bits = nbits[l];
       const unsigned mask = (1u << bits) - 1u;
       for (int i = t; i < kBins; i += kNT) h[i] = 0;
       if (t == 0) n_keep = 0;
       __syncthreads();                                                     // also: the cache / the last compaction is complete
-      for (int base = 0; base < cur; base += kNT) {                        // wave-uniform trip count
-        const int e = base + t;
-        const bool on = e < cur;
-        const u64 K = ck[min(e, cur - 1)];
-        count_digit(h, on, (int)((unsigned)(K >> shift) & mask), lane);
+      for (int base = 0; base < cur; base += kNT * U) {                    // wave-uniform trip count
+        u64 K[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) K[u] = ck[min(base + u * kNT + t, cur - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) count_digit(h, base + u * kNT + t < cur, (int)((unsigned)(K[u] >> shift) & mask), lane);
       }
       __syncthreads();
       block_pick(h, 1 << bits, need, wt, res);
       const int T = res[0];
       need -= res[1];
-      // keys above the picked digit are selected, keys inside it move to the front (a round reads its 1024 keys, then -
-      // after the barrier - writes to positions below everything already read)
-      for (int base = 0; base < cur; base += kNT) {
-        const int e = base + t;
-        const bool on = e < cur;
-        const u64 K = ck[min(e, cur - 1)];
-        const int d = (int)((unsigned)(K >> shift) & mask);
+      for (int base = 0; base < cur; base += kNT * U) {
+        u64 K[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) K[u] = ck[min(base + u * kNT + t, cur - 1)];
         __syncthreads();
-        const bool up = on && d > T, keep = on && d == T;
-        const int ps = append_slot(&n_sel, up, lane);
-        if (up) sel[ps] = K;
-        const int pk = append_slot(&n_keep, keep, lane);
-        if (keep) ck[pk] = K;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool on = base + u * kNT + t < cur;
+          const int d = (int)((unsigned)(K[u] >> shift) & mask);
+          const bool up = on && d > T, keep = on && d == T;
+          const int ps = append_slot(&n_sel, up, lane);
+          if (up) sel[ps] = K[u];
+          const int pk = append_slot(&n_keep, keep, lane);
+          if (keep) ck[pk] = K[u];
+        }
       }
       __syncthreads();
       cur = n_keep;
       const int have = n_sel;
       __syncthreads();                                                     // everybody has read n_keep before the next level resets it
-      if (have + cur <= 1024) {                                            // what is left fits the sort (have + need = k <= have + cur)
+      if (have + cur <= Pk) {                                              // what is left fits the sort (have + need = k <= have + cur)
         for (int e = t; e < cur; e += kNT) sel[have + e] = ck[e];
         n = have + cur;
         break;
       }
     }
+    return n;
+  };
+  int n;
+  if (a + M <= Pk) {
+    if (t < M) sel[a + t] = bn[t];                                         // everything still in play fits the sort
+    n = a + M;
+  } else if (M <= kCache) {
+    u64 *cache = reinterpret_cast<u64 *>(dyn_lds);
+    for (int base = 0; base < M; base += kNT * 8) {                        // loads first: one round trip per 8192 keys
+      u64 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = bn[min(base + u * kNT + t, M - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u * kNT + t < M) cache[base + u * kNT + t] = v[u];
+    }
+    n = select(cache);
+  } else {
+    n = select(bn);                                                        // a bin beyond the cache: same steps in global memory
   }
   __syncthreads();
+  // bitonic sort (descending) of sel[0 .. P): a key per thread in a register; partners closer than a wave meet through
+  // lane shuffles, the others through LDS
   int P = 64;
   while (P < n) P <<= 1;
+  u64 x = sel[t];
   for (int len = 2; len <= P; len <<= 1) {
     for (int j = len >> 1; j > 0; j >>= 1) {
-      const int p = t ^ j;
-      if (t < P && p > t) {
-        const bool desc = (t & len) == 0;
-        const u64 x = sel[t], y = sel[p];
-        if ((x < y) == desc) {
-          sel[t] = y;
-          sel[p] = x;
-        }
+      u64 y;
+      if (j >= 64) {
+        __syncthreads();
+        sel[t] = x;
+        __syncthreads();
+        y = sel[t ^ j];
+      } else {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)x, j), hi = (unsigned)__shfl_xor((int)(unsigned)(x >> 32), j);
+        y = ((u64)hi << 32) | lo;
       }
-      __syncthreads();
+      const bool desc = (t & len) == 0, lower = (t & j) == 0;             // lower: this thread is the partner with the smaller index
+      const bool want_max = lower == desc;
+      x = want_max ? (x > y ? x : y) : (x < y ? x : y);
     }
   }
   if (t < k) {
-    const u64 K = sel[t];
-    out_idx[(size_t)b * k + t] = (long long)(0xFFFFFu - (unsigned)(K & 0xFFFFFull));
-    if (out_val != nullptr) out_val[(size_t)b * k + t] = __uint_as_float((unsigned)(K >> 20));
+    out_idx[(size_t)b * k + t] = (long long)(0xFFFFFu - (unsigned)(x & 0xFFFFFull));
+    if (out_val != nullptr) out_val[(size_t)b * k + t] = __uint_as_float((unsigned)(x >> 20));
   }
 }
 

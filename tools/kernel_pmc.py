@@ -27,6 +27,23 @@ with torch.no_grad():
         b = torch.randn(128, device='cuda', generator=g) * 0.1
         for _ in range(3):
             ops.pointwise_chain(x, w, b, True, w2=w, b2=b, relu2=True)
+    if 'mix' in which:                       # out_proj + integration pair of an encoder layer, image side (chain<256,256>)
+        x1, x2, x3 = cl(6, 128, 112, 200), cl(6, 128, 112, 200), cl(6, 128, 112, 200)
+        w1 = (torch.randn(128, 256, device='cuda', generator=g) / 16).half()
+        w2 = (torch.randn(128, 256, device='cuda', generator=g) / 16).half()
+        b = torch.randn(128, device='cuda', generator=g) * 0.1
+        for _ in range(3):
+            ops.pointwise_chain(x1, w1, b, False, x2=x2, w2=w2, b2=b, relu2=False, x3=x3)
+    if 'multi' in which:                     # the four projections of the image map (q, k two links; v one; q of P2I two)
+        x = cl(6, 128, 112, 200)
+        mk = lambda: ((torch.randn(128, 128, device='cuda', generator=g) / 11).half(), torch.randn(128, device='cuda', generator=g) * 0.1)
+        chains = []
+        for two in (True, True, False, True):
+            w1, b1 = mk()
+            w2, b2 = mk() if two else (None, None)
+            chains.append((ops.chain_image(w1, b1, w2, b2), True, True, two))
+        for _ in range(3):
+            ops.pointwise_multi(x, chains)
     if 'i2p' in which or 'bw' in which or 'xa' in which:
         from deepinteraction_amd import synth
         from deepinteraction_amd.geometry import SampleGeometry
