@@ -53,19 +53,38 @@ SIGNATURES = {
     'di_pointwise_multi_fwd': [_c_p, _c_i] + [_c_p] * 5 + [ctypes.c_longlong, _c_p],
     'di_ffn_ln_fwd': [_c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, ctypes.c_longlong, _c_p],
     'di_conv3x3_fwd': [_c_p] * 5 + [_c_i] * 7 + [_c_p],
-    'di_token_linear': [_c_p, _c_i, _c_p, _c_i, _c_i, _c_p, _c_i, _c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_p, _c_i, _c_p, _c_i,
-                        _c_p, _c_p, _c_f, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p],
-    'di_token_mha': [_c_p, _c_i, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_f, _c_p],
+    'di_token_program': [_c_p, _c_i, _c_p, _c_i, _c_i, _c_p],
+    'di_token_wide': [_c_p, _c_i, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_i, _c_i, _c_p],
+    'di_token_splitk': [_c_p, ctypes.c_longlong, _c_p, _c_p, _c_i, _c_i, _c_p, _c_p],
     'di_dynconv_fwd': [_c_p] * 7 + [_c_i, _c_f, _c_p],
     'di_roi_select': [_c_p] * 7 + [_c_i] * 3 + [_c_p],
     'di_query_init': [_c_p] * 12 + [_c_i] * 5 + [_c_p],
-    'di_pred_heads': [_c_p] * 11 + [_c_i, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p],
+    'di_roi_align_x_fwd': [_c_p] * 3 + [_c_i] * 5 + [_c_f, _c_i, _c_i, _c_p],
+    'di_kv_project_fwd': [_c_p] * 6 + [_c_i, _c_i, _c_p],
+    'di_mha_decode_x_fwd': [_c_p] * 3 + [_c_i] * 3 + [_c_f, _c_p],
 }
 # helpers that return a value instead of an error code
 VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_i2p_key_table_bytes': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 3,
-               'di_token_linear_workspace_bytes': [_c_i] * 3,
+               'di_token_splitk_workspace_bytes': [_c_i] * 2, 'di_mha_decode_x_ranges': [_c_i] * 3,
                'di_graph_node_count': [_c_p]}
-_LONGLONG = {'di_topk_workspace_bytes', 'di_i2p_key_table_bytes', 'di_graph_node_count', 'di_token_linear_workspace_bytes'}
+_LONGLONG = {'di_topk_workspace_bytes', 'di_i2p_key_table_bytes', 'di_graph_node_count', 'di_token_splitk_workspace_bytes'}
+
+# ---- the step program of di_token_program (structs of include/deepinteraction_hip.h)
+TOK_LOAD, TOK_LOAD_PARTS, TOK_ATTN, TOK_COMBINE, TOK_LINEAR, TOK_ROWOP, TOK_STORE, TOK_HEADS = range(1, 9)
+TOK_MAX_STEPS, TOK_MAX_HEADS = 20, 8
+
+
+class TokStep(ctypes.Structure):
+    _fields_ = [('kind', _c_i), ('src', _c_i), ('dst', _c_i), ('aux', _c_i), ('K', _c_i), ('N', _c_i), ('a', _c_i),
+                ('b', _c_i), ('f', _c_f), ('pad', _c_i), ('p0', _c_p), ('p1', _c_p), ('p2', _c_p), ('p3', _c_p),
+                ('ld0', ctypes.c_longlong), ('ld1', ctypes.c_longlong)]
+
+
+class TokHeads(ctypes.Structure):
+    _fields_ = [('w2', _c_p), ('b2', _c_p), ('qpos', _c_p), ('keep', _c_p), ('pos_out', _c_p),
+                ('out', _c_p * TOK_MAX_HEADS), ('first', _c_p * TOK_MAX_HEADS), ('cls', _c_i * TOK_MAX_HEADS),
+                ('nheads', _c_i), ('center_head', _c_i), ('ldo', _c_i), ('col0', _c_i)]
+
 
 _lib = None
 

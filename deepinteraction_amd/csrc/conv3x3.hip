@@ -138,7 +138,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const __half *__restric
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (n0 + q < Cout) y[(((size_t)img * Cout + n0 + q) * H + yy) * W + xx] = __float2half(v[q]);
+          if (n0 + q < Cout) {
+            const size_t o = (((size_t)img * Cout + n0 + q) * H + yy) * W + xx;
+            if (nchw == 2) reinterpret_cast<float *>(y)[o] = v[q];      // float32 logits (heat-map heads)
+            else y[o] = __float2half(v[q]);
+          }
       }
     }
   }

@@ -159,10 +159,10 @@ __device__ __forceinline__ void roi_sample8(const T *__restrict__ map, int H, in
   for (int i = 0; i < 8; ++i) acc[i] = fmaf(w4, f[i], acc[i]);
 }
 
-template <typename T, bool FULLC>
+template <typename T, bool FULLC, typename TO = T>
 __global__ __launch_bounds__(256) void roi_align_kernel(const T *__restrict__ feat,
                                                         const float *__restrict__ rois,
-                                                        T *__restrict__ out, int R, int N, int H, int W,
+                                                        TO *__restrict__ out, int R, int N, int H, int W,
                                                         int C, float scale) {
   constexpr int PB = 7, G = 2;
   const int l16 = threadIdx.x & 15;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T *__restrict__ fe
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] *= 1.f / (G * G);
-      st8(out + (size_t)g * C + ch0, pack8f(acc, T()));
+      st8(out + (size_t)g * C + ch0, pack8f(acc, TO()));
     }
   }
 }
@@ -573,7 +573,13 @@ int di_query_geometry_ld(const float *center, const float *height, const float *
 
 int di_roi_align_fwd(const void *feat, const float *rois, void *out, int R, int N, int H, int W, int C,
                      float spatial_scale, int dtype, void *stream) {
+  return di_roi_align_x_fwd(feat, rois, out, R, N, H, W, C, spatial_scale, dtype, dtype, stream);
+}
+
+int di_roi_align_x_fwd(const void *feat, const float *rois, void *out, int R, int N, int H, int W, int C,
+                       float spatial_scale, int dtype, int out_dtype, void *stream) {
   DI_REQUIRE(R >= 0 && N > 0 && H > 0 && W > 0, "bad roi_align shape");
+  DI_REQUIRE(out_dtype == dtype || out_dtype == DI_F32, "roi_align writes the map's type or float32");
   DI_REQUIRE(C > 0 && C % 8 == 0 && C <= 128, "C=%d must be a multiple of 8, <= 128", C);
   if (R == 0) return DI_OK;
   const int total = R * 49;
@@ -582,7 +588,14 @@ int di_roi_align_fwd(const void *feat, const float *rois, void *out, int R, int 
 #define DI_ROI(TT, FULL)                                                                              \
   hipLaunchKernelGGL((di::roi_align_kernel<TT, FULL>), dim3(blocks), dim3(256), 0, s, (const TT *)feat, \
                      rois, (TT *)out, R, N, H, W, C, spatial_scale)
-  if (dtype == DI_F16) { if (C == 128) DI_ROI(__half, true); else DI_ROI(__half, false); }
+  if (dtype == DI_F16 && out_dtype == DI_F32) {           // fp16 map, float32 RoI features (the decoder's token path)
+    if (C == 128)
+      hipLaunchKernelGGL((di::roi_align_kernel<__half, true, float>), dim3(blocks), dim3(256), 0, s, (const __half *)feat,
+                         rois, (float *)out, R, N, H, W, C, spatial_scale);
+    else
+      hipLaunchKernelGGL((di::roi_align_kernel<__half, false, float>), dim3(blocks), dim3(256), 0, s, (const __half *)feat,
+                         rois, (float *)out, R, N, H, W, C, spatial_scale);
+  } else if (dtype == DI_F16) { if (C == 128) DI_ROI(__half, true); else DI_ROI(__half, false); }
   else if (dtype == DI_F32) { if (C == 128) DI_ROI(float, true); else DI_ROI(float, false); }
   else { di::set_error("unsupported dtype %d", dtype); return DI_ERR_ARG; }
 #undef DI_ROI

@@ -20,7 +20,8 @@ def randomize_bn(mods, seed=5):
 
 
 def build_models(shape, num_proposals, dtype, device, seed=1234, train_cfg=None):
-    """(DeepInteractionEncoder, DeepInteractionDecoder) of Fusion_0075_refactor.py:185-224 at `shape`, eval mode."""
+    """(DeepInteractionEncoder, DeepInteractionDecoder) of Fusion_0075_refactor.py:185-224 at `shape`, eval mode; dtype
+    float16 = the benched mixed mode of `precision.half_maps_` (fp16 maps, float32 token path)."""
     from .mmdet3d_plugin import DeepInteractionDecoder, DeepInteractionEncoder
     torch.manual_seed(seed)
     enc = DeepInteractionEncoder(num_layers=2, in_channels_img=shape['c_img'], in_channels_pts=shape['c_pts'],
@@ -30,7 +31,9 @@ def build_models(shape, num_proposals, dtype, device, seed=1234, train_cfg=None)
         cfg['train_cfg'] = train_cfg
     dec = DeepInteractionDecoder(**cfg)
     randomize_bn([enc, dec])
-    return enc.to(device, dtype).eval(), dec.to(device, dtype).eval()
+    from .precision import to_inference
+    enc, dec = to_inference(enc.to(device), dec.to(device), dtype)       # fp16: maps fp16, token path float32
+    return enc.eval(), dec.eval()
 
 
 def to_device(inp, device, dtype):

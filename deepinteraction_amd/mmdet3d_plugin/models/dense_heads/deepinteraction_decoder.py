@@ -135,14 +135,16 @@ class DeepInteractionDecoder(nn.Module):
             self._bev_pos_dev = self.bev_pos.to(device)
         return self._bev_pos_dev
 
-    def _heatmap(self, head, feat):
+    def _heatmap(self, head, feat, out_f32=False):
         """(B,num_classes,H,W) NCHW heat-map logits: ConvModule(3x3 + BN + ReLU) + Conv 3x3 (reference :96-119).  fp16
-        inference: two launches of the HIP implicit-GEMM kernel (BatchNorm folded)."""
+        maps at inference: two launches of the HIP implicit-GEMM kernel (BatchNorm folded; weights of either float type
+        are packed to fp16 once); `out_f32`: float32 logits (they feed the NMS comparison and the top-Q pick)."""
         feat = ops.cl(feat)
         cm, last = head[0], head[1]
-        if (feat.is_cuda and feat.dtype == torch.float16 and not torch.is_grad_enabled() and not self.training
-                and feat.shape[1] % 32 == 0 and cm.conv.out_channels == 128 and last.out_channels <= 16
-                and cm.conv.weight.dtype == torch.float16):
+        if (feat.is_cuda and torch.float16 in (feat.dtype, cm.conv.weight.dtype) and not torch.is_grad_enabled()
+                and not self.training and feat.shape[1] % 32 == 0 and cm.conv.out_channels == 128
+                and last.out_channels <= 16):
+            feat = feat.half()                      # mixed mode off the fused path: fp16 heads on widened maps
             cache = self.__dict__.setdefault('_heat_cache', {})
             key = param_key(head)
             hit = cache.get(id(head))
@@ -151,8 +153,9 @@ class DeepInteractionDecoder(nn.Module):
                        ops.pack_conv3x3(last.weight, last.bias))
                 cache[id(head)] = hit
             mid = ops.conv3x3(feat, *hit[1], relu=True)
-            return ops.conv3x3(mid, *hit[2], out_nchw=True)
-        return head(feat).contiguous()
+            return ops.conv3x3(mid, *hit[2], out_nchw=True, out_f32=out_f32)
+        out = head(feat.to(cm.conv.weight.dtype)).contiguous()
+        return out.float() if out_f32 else out
 
     def forward(self, pts_inputs, img_inputs, img_metas):
         if self.fused and type(self)._mmpi is DeepInteractionDecoder._mmpi \
@@ -160,6 +163,9 @@ class DeepInteractionDecoder(nn.Module):
             if self._fused_path is None:
                 self._fused_path = decoder_fused.FusedDecoder()
             return self._fused_path.forward(self, pts_inputs, img_inputs, img_metas)
+        wd = self.class_encoding.weight.dtype
+        if pts_inputs[0].dtype != wd:                 # mixed mode (precision.half_maps_) off the fused path: widen the maps
+            pts_inputs, img_inputs = [p.to(wd) for p in pts_inputs], img_inputs.to(wd)
         lidar_feat, new_lidar_feat = ops.cl(pts_inputs[0]), ops.cl(pts_inputs[1])
         B, C, H, W = lidar_feat.shape
         HW = H * W
@@ -169,8 +175,8 @@ class DeepInteractionDecoder(nn.Module):
         lidar_flat = lidar_feat.view(B, C, HW)                                   # strided view of channels-last
         bev_pos = self._bev_pos(dev)                                             # (1,HW,2)
 
-        dense_heatmap = self._heatmap(self.heatmap_head, lidar_feat)
-        dense_heatmap_img = self._heatmap(self.heatmap_head_img, new_lidar_feat)
+        dense_heatmap = self._heatmap(self.heatmap_head, lidar_feat, out_f32=True)
+        dense_heatmap_img = self._heatmap(self.heatmap_head_img, new_lidar_feat, out_f32=True)
         k1 = {'nuScenes': (8, 9), 'Waymo': (1, 2)}.get(self.test_cfg['dataset'], ())
         heatmap = ops.heatmap_nms(dense_heatmap.detach(), dense_heatmap_img.detach(), self.nms_kernel_size,
                                   [c for c in k1 if c < self.num_classes]).view(B, self.num_classes, HW)

@@ -461,17 +461,17 @@ def query_geometry(res, proj, aug_rev, per_sample, cell, pc_xy, bev_cell, dim_sc
     return on, ri, rb
 
 
-def roi_align(feat, rois, spatial_scale):
-    """feat (N,C,H,W) channels-last; rois (R,5) f32 [n,x0,y0,x1,y1] -> (R,49,C)."""
+def roi_align(feat, rois, spatial_scale, out_f32=False):
+    """feat (N,C,H,W) channels-last; rois (R,5) f32 [n,x0,y0,x1,y1] -> (R,49,C) (float32 with out_f32)."""
     _dev(feat, rois)
     feat = cl(feat)
     N, C, H, W = feat.shape
     rois = rois.contiguous()
     assert rois.dtype == torch.float32 and rois.shape[1] == 5
     R = rois.shape[0]
-    out = torch.empty((R, 49, C), dtype=feat.dtype, device=feat.device)
-    _lib.call('di_roi_align_fwd', feat.data_ptr(), rois.data_ptr(), out.data_ptr(), R, N, H, W, C,
-              float(spatial_scale), _code(feat), _stream())
+    out = torch.empty((R, 49, C), dtype=torch.float32 if out_f32 else feat.dtype, device=feat.device)
+    _lib.call('di_roi_align_x_fwd', feat.data_ptr(), rois.data_ptr(), out.data_ptr(), R, N, H, W, C,
+              float(spatial_scale), _code(feat), _lib.DI_F32 if out_f32 else _code(feat), _stream())
     return out
 
 
@@ -725,78 +725,144 @@ def pack_conv3x3(weight, bias=None, bn=None):
         return wp.to(torch.float16).contiguous(), ws, b.contiguous()
 
 
-def conv3x3(x, w_packed, w_staged, bias, relu=False, out_nchw=False, use_staged=True):
-    """x (n,Cin,H,W) channels-last fp16 -> (n,Cout,H,W), channels-last (or contiguous NCHW when out_nchw)."""
+def conv3x3(x, w_packed, w_staged, bias, relu=False, out_nchw=False, use_staged=True, out_f32=False):
+    """x (n,Cin,H,W) channels-last fp16 -> (n,Cout,H,W), channels-last (or contiguous NCHW when out_nchw; float32 with
+    out_f32 - NCHW only)."""
     _dev(x, w_packed, bias)
     x = cl(x)
     n, Cin, H, W = x.shape
     Cout = bias.numel()
     assert x.dtype == torch.float16 and w_packed.dtype == torch.float16 and w_packed.shape[1:] == (9, Cin)
     assert bias.dtype == torch.float32
+    assert out_nchw or not out_f32
     if out_nchw:
-        y = torch.empty((n, Cout, H, W), dtype=x.dtype, device=x.device)
+        y = torch.empty((n, Cout, H, W), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     else:
         y = empty_cl(n, Cout, H, W, x)
     ws = 0 if (w_staged is None or not use_staged) else w_staged.data_ptr()
     _profiled('conv3x3_fwd', n * Cin, lambda: _lib.call('di_conv3x3_fwd', x.data_ptr(), w_packed.data_ptr(), ws,
                                                        bias.data_ptr(), y.data_ptr(), n, H, W, Cin, Cout, int(bool(relu)),
-                                                       int(bool(out_nchw)), _stream()))
+                                                       (2 if out_f32 else 1) if out_nchw else 0, _stream()))
     return y
 
 
-# ------------------------------------------------------------------ token-level kernels of the MMPI decoder (fp16)
-def _h16(t):
-    assert t.dtype == torch.float16 and t.stride(-1) == 1, 'token kernels take row-major fp16'
+# ------------------------------------------------------------------ token-level kernels of the MMPI decoder (float32)
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.stride(-1) == 1, 'token kernels take row-major float32'
     return t
 
 
-def token_linear(x, w, bias=None, x2=None, pos=None, act1=0, res1=None, ln1=None, act2=False, res2=None, ln2=None,
-                 keep=None, eps=1e-5, out=None):
-    """Y = epilogue(([x ; x2] + pos) @ w.T): bias, act1 (0 none / 1 ReLU / 2 GELU), LN1(. + res1), ReLU (act2),
-    LN2(. + res2), rows with keep == 0 zeroed.  x (M,K1) [x2 (M,K-K1)], w (N,K) fp16; bias float32 (N); ln* = (weight,
-    bias) fp16 (128); keep uint8 (M).  Returns (M,N) fp16."""
+class TokenProgram:
+    """One launch of `di_token_program` (csrc/token32.hip): a short program of steps that every group of 16 consecutive
+    tokens of a sample runs on rows held in LDS buffers 0..2 (512 floats wide).  The builder keeps the tensors it was
+    given alive until `run` has launched."""
+
+    def __init__(self):
+        self.steps, self.refs, self.head_desc = [], [], None
+
+    def _add(self, kind, src=0, dst=0, aux=-1, K=0, N=0, a=0, b=0, f=0.0, p0=None, p1=None, p2=None, ld0=0, ld1=0):
+        st = _lib.TokStep()
+        st.kind, st.src, st.dst, st.aux, st.K, st.N, st.a, st.b, st.f = kind, src, dst, aux, K, N, a, b, float(f)
+        for name, t in (('p0', p0), ('p1', p1), ('p2', p2)):
+            if t is not None:
+                _dev(t)
+                setattr(st, name, t.data_ptr())
+                self.refs.append(t)
+        st.ld0, st.ld1 = ld0, ld1
+        self.steps.append(st)
+        return self
+
+    def load(self, dst, x, pos=None, col=0):
+        """buf[dst][:, col:col+K] = x (+ pos); x, pos (M,K) float32."""
+        _f32c(x)
+        if pos is not None:
+            assert _f32c(pos).shape == x.shape
+        return self._add(_lib.TOK_LOAD, dst=dst, K=x.shape[1], a=col, p0=x, p1=pos, ld0=x.stride(0),
+                         ld1=0 if pos is None else pos.stride(0))
+
+    def load_parts(self, dst, workspace, nslices, total_rows, bias=None):
+        """buf[dst][:, :128] = sum of the split-K partial sums (+ bias)."""
+        return self._add(_lib.TOK_LOAD_PARTS, dst=dst, a=nslices, b=total_rows, p0=workspace, p1=bias)
+
+    def attn(self, dst, qkv, scale, member=None, view=None):
+        """buf[dst][:, :128] = self attention (8 heads x 16) among the sample's tokens from qkv (M, 384) = [q|k|v]."""
+        assert _f32c(qkv).shape[1] == 384 and (member is None) == (view is None)
+        return self._add(_lib.TOK_ATTN, dst=dst, f=scale * 1.4426950408889634, p0=qkv, p1=member, p2=view,
+                         ld0=qkv.stride(0))
+
+    def combine(self, dst, scratch, nrange):
+        """buf[dst][:, :128] = merged key-range states of `mha_decode_x`."""
+        return self._add(_lib.TOK_COMBINE, dst=dst, a=nrange, p0=scratch)
+
+    def linear(self, src, dst, w, bias=None, act=0):
+        """buf[dst][:, :N] = act(buf[src][:, :K] @ w.T + bias); w (N,K) float32; act 0 none / 1 ReLU / 2 GELU."""
+        assert _f32c(w).is_contiguous() and (bias is None or (_f32c(bias).numel() == w.shape[0]))
+        return self._add(_lib.TOK_LINEAR, src=src, dst=dst, K=w.shape[1], N=w.shape[0], a=act, p0=w, p1=bias)
+
+    def rowop(self, src, dst, aux=-1, ln=None, eps=1e-5, relu=False, keep=None):
+        """buf[dst][:, :128] = keep * relu?(LayerNorm?(buf[src] + buf[aux]?))."""
+        lw, lb = ln if ln is not None else (None, None)
+        return self._add(_lib.TOK_ROWOP, src=src, dst=dst, aux=aux, b=int(bool(relu)), f=eps, p0=lw, p1=lb, p2=keep)
+
+    def store(self, src, y, col=0):
+        """y (M,N) = buf[src][:, col:col+N]."""
+        return self._add(_lib.TOK_STORE, src=src, N=_f32c(y).shape[1], a=col, p0=y, ld0=y.stride(0))
+
+    def heads(self, src, w2, b2, qpos, outs, cls, center_head, ldo, col0, keep=None, first=None, pos_out=None):
+        """Second layers of the prediction heads on the hidden rows in buf[src] (see include/deepinteraction_hip.h)."""
+        h = _lib.TokHeads()
+        n = len(cls)
+        assert n <= _lib.TOK_MAX_HEADS and (keep is None or first is not None)
+        h.w2, h.b2, h.qpos = w2.data_ptr(), b2.data_ptr(), qpos.data_ptr()
+        h.keep = None if keep is None else keep.data_ptr()
+        h.pos_out = None if pos_out is None else pos_out.data_ptr()
+        for i in range(n):
+            h.out[i] = outs[i].data_ptr()
+            h.first[i] = first[i].data_ptr() if first is not None else None
+            h.cls[i] = int(cls[i])
+        h.nheads, h.center_head, h.ldo, h.col0 = n, center_head, ldo, col0
+        self.refs += [w2, b2, qpos, keep, pos_out] + list(outs) + (list(first) if first is not None else [])
+        self.head_desc = h
+        return self._add(_lib.TOK_HEADS, src=src)
+
+    def run(self, B, Q):
+        n = len(self.steps)
+        arr = (_lib.TokStep * n)(*self.steps)
+        hp = ctypes.addressof(self.head_desc) if self.head_desc is not None else 0
+        _lib.call('di_token_program', ctypes.addressof(arr), n, hp, B, Q, _stream())
+
+
+def token_wide(x, w, bias=None):
+    """x (M,128) @ w (N,128).T + bias -> (M,N) float32, weight stationary (DynamicConv's parameter generator)."""
     _dev(x, w)
-    _h16(x), _h16(w)
-    M, K1 = x.shape
-    N, K = w.shape
-    assert w.is_contiguous() and (x2 is None) == (K1 == K)
-    if x2 is not None:
-        _h16(x2)
-        assert x2.shape == (M, K - K1)
-    if bias is not None:
-        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
-    y = torch.empty((M, N), dtype=torch.float16, device=x.device) if out is None else out
-    ptr = lambda t: 0 if t is None else t.data_ptr()
-    ld = lambda t: 0 if t is None else t.stride(0)
-    nws = int(_lib.lib().di_token_linear_workspace_bytes(M, N, K))
-    ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws else None
-    l1w, l1b = ln1 if ln1 is not None else (None, None)
-    l2w, l2b = ln2 if ln2 is not None else (None, None)
-    _lib.call('di_token_linear', x.data_ptr(), x.stride(0), ptr(x2), ld(x2), K1, ptr(pos), ld(pos), w.data_ptr(),
-              ptr(bias), int(act1), ptr(res1), ld(res1), ptr(l1w), ptr(l1b), int(bool(act2)), ptr(res2), ld(res2),
-              ptr(l2w), ptr(l2b), float(eps), ptr(keep), y.data_ptr(), y.stride(0), M, N, K, ptr(ws), _stream())
+    _f32c(x), _f32c(w)
+    M, N = x.shape[0], w.shape[0]
+    assert x.shape[1] == 128 and w.shape[1] == 128 and w.is_contiguous()
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _lib.call('di_token_wide', x.data_ptr(), x.stride(0), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
+              y.data_ptr(), y.stride(0), M, N, _stream())
     return y
 
 
-def token_mha(qkv, B, Q, heads, scale, member=None, view=None):
-    """qkv (B*Q, 3E) = [q | k | v] fp16 -> (B*Q, E): per-head soft-max attention among the Q tokens of each sample;
-    optional visibility (member uint8 (B*Q), view int8 (B*Q)), see include/deepinteraction_hip.h."""
-    _dev(qkv)
-    _h16(qkv)
-    E = heads * 16
-    assert qkv.shape == (B * Q, 3 * E)
-    out = torch.empty((B * Q, E), dtype=torch.float16, device=qkv.device)
-    _lib.call('di_token_mha', qkv.data_ptr(), qkv.stride(0), 0 if member is None else member.data_ptr(),
-              0 if view is None else view.data_ptr(), out.data_ptr(), out.stride(0), B, Q, heads, float(scale), _stream())
-    return out
+def token_splitk(x, w):
+    """Partial sums of x (M,K) @ w (128,K).T over K slices -> (workspace float32 (slices, M, 128), slices)."""
+    _dev(x, w)
+    _f32c(x), _f32c(w)
+    M, K = x.shape
+    assert w.shape == (128, K) and w.is_contiguous()
+    ws = torch.empty(int(_lib.lib().di_token_splitk_workspace_bytes(M, K)) // 4, dtype=torch.float32, device=x.device)
+    ns = ctypes.c_int(0)
+    _lib.call('di_token_splitk', x.data_ptr(), x.stride(0), w.data_ptr(), ws.data_ptr(), M, K, ctypes.addressof(ns), _stream())
+    return ws, ns.value
 
 
 def dynconv(roi, params, n1, n2, eps=1e-5):
-    """roi (R,49,128), params (R,32768) in the fused layout, n1/n2 = (weight, bias) fp16 of DynamicConv.norm1/2
+    """roi (R,49,128), params (R,32768) = [p1^T | p2^T], n1/n2 = (weight, bias) of DynamicConv.norm1/2, all float32
     -> relu(LN2(relu(LN1(roi @ p1)) @ p2)) (R,49,128)."""
     _dev(roi, params)
     R = roi.shape[0]
     assert roi.shape == (R, 49, 128) and roi.is_contiguous() and params.shape == (R, 32768) and params.is_contiguous()
+    assert roi.dtype == torch.float32 and params.dtype == torch.float32 and n1[0].dtype == torch.float32
     out = torch.empty_like(roi)
     _lib.call('di_dynconv_fwd', roi.data_ptr(), params.data_ptr(), n1[0].data_ptr(), n1[1].data_ptr(), n2[0].data_ptr(),
               n2[1].data_ptr(), out.data_ptr(), R, float(eps), _stream())
@@ -827,15 +893,16 @@ def roi_select(rect, on=None):
 
 def query_init(bev, top, ce_w, ce_b, pe):
     """bev (B,128,H,W) channels-last fp16, top (B,Q) int64 flattened (class, cell) picks, ce_w (128,ncls) / ce_b (128)
-    fp16, pe = float32 (w1 (128,2), b1, w2 (128,128), b2) -> feat (B*Q,128), pos_embed (B*Q,128) fp16, pos (B,Q,2)
-    float32, labels (B,Q) int64."""
+    float32, pe = float32 (w1 (128,2), b1, w2 (128,128), b2) -> feat (B*Q,128), pos_embed (B*Q,128) float32, pos
+    (B,Q,2) float32, labels (B,Q) int64."""
     _dev(bev, top)
     B, C, H, W = bev.shape
     Q = top.shape[1]
     assert C == 128 and _is_cl(bev) and bev.dtype == torch.float16 and top.dtype == torch.int64 and top.is_contiguous()
+    assert ce_w.dtype == torch.float32 and ce_w.is_contiguous() and ce_b.dtype == torch.float32
     dev = bev.device
-    feat = torch.empty((B * Q, 128), dtype=torch.float16, device=dev)
-    pemb = torch.empty((B * Q, 128), dtype=torch.float16, device=dev)
+    feat = torch.empty((B * Q, 128), dtype=torch.float32, device=dev)
+    pemb = torch.empty((B * Q, 128), dtype=torch.float32, device=dev)
     pos = torch.empty((B, Q, 2), dtype=torch.float32, device=dev)
     labels = torch.empty((B, Q), dtype=torch.int64, device=dev)
     _lib.call('di_query_init', bev.data_ptr(), top.data_ptr(), ce_w.data_ptr(), ce_b.data_ptr(), pe[0].data_ptr(),
@@ -844,16 +911,37 @@ def query_init(bev, top, ce_w, ce_b, pe):
     return feat, pemb, pos, labels
 
 
-def pred_heads(x1, x2, folded, qpos, outs, B, Q, ldo, col0, center_head, keep=None, first=None, pos_out=None):
-    """All prediction heads of one stage: x1 (B*Q,128) [x2 (B*Q,128)] fp16; folded = (w1 fp16 (nheads*64, K), b1, w2
-    (sum cls, 64), b2 float32, cls list); outs / first = lists of float32 (B, cls_h, ldo | Q) tensors."""
-    w1, b1, w2, b2, cls = folded
-    n = len(cls)
-    arr_out = (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs])
-    arr_first = (ctypes.c_void_p * n)(*[t.data_ptr() for t in first]) if first is not None else None
-    arr_cls = (ctypes.c_int * n)(*cls)
-    _lib.call('di_pred_heads', x1.data_ptr(), 0 if x2 is None else x2.data_ptr(), w1.data_ptr(), b1.data_ptr(),
-              w2.data_ptr(), b2.data_ptr(), qpos.data_ptr(), 0 if keep is None else keep.data_ptr(),
-              ctypes.addressof(arr_out), 0 if arr_first is None else ctypes.addressof(arr_first),
-              ctypes.addressof(arr_cls), n, center_head, 0 if pos_out is None else pos_out.data_ptr(), B, Q, ldo, col0,
-              _stream())
+def split_hi_lo(w):
+    """float32 tensor -> (hi, lo) fp16 with w = hi + lo / 2048 to ~2^-22 (the low half pre-scaled out of the fp16
+    subnormals): the operand form of the float32-accurate fp16 MFMA passes (csrc/cross_attn.hip)."""
+    w = w.detach().float()
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    return hi.contiguous(), lo.contiguous()
+
+
+def kv_project(x_tokens, w_hi, w_lo, kbias, vbias):
+    """x_tokens (B,S,128) fp16 (a view of the channels-last BEV map) -> (B,S,384) fp16 = [Khi | Klo | V]
+    (K = Khi + Klo / 2048 = Wk x + kbias, V = Wv x + vbias; kbias / vbias (S,128) float32)."""
+    _dev(x_tokens, w_hi)
+    B, S, C = x_tokens.shape
+    assert C == 128 and x_tokens.dtype == torch.float16 and x_tokens.is_contiguous()
+    assert w_hi.shape == (256, 128) and w_lo.shape == (256, 128) and w_hi.dtype == torch.float16
+    assert kbias.shape == (S, 128) and vbias.shape == (S, 128) and kbias.dtype == torch.float32 and kbias.is_contiguous()
+    out = torch.empty((B, S, 384), dtype=torch.float16, device=x_tokens.device)
+    _lib.call('di_kv_project_fwd', x_tokens.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(), kbias.data_ptr(),
+              vbias.contiguous().data_ptr(), out.data_ptr(), B, S, _stream())
+    return out
+
+
+def mha_decode_x(q, kx, scale):
+    """q (B,Q,128) float32 (unscaled), kx (B,S,384) from `kv_project` -> (scratch, nrange): the partial soft-max states a
+    `TokenProgram.combine` step merges."""
+    _dev(q, kx)
+    B, Q, E = q.shape
+    S = kx.shape[1]
+    assert E == 128 and q.dtype == torch.float32 and q.is_contiguous() and kx.shape == (B, S, 384) and kx.is_contiguous()
+    nrange = int(_lib.lib().di_mha_decode_x_ranges(B, Q, S))
+    scratch = torch.empty(B * 8 * Q * nrange * 18, dtype=torch.float32, device=q.device)
+    _lib.call('di_mha_decode_x_fwd', q.data_ptr(), kx.data_ptr(), scratch.data_ptr(), B, Q, S, float(scale), _stream())
+    return scratch, nrange

@@ -218,6 +218,10 @@ int di_query_geometry_ld(const float *center, const float *height, const float *
  *     DynamicConv without the reference's flatten/permute). */
 int di_roi_align_fwd(const void *feat, const float *rois, void *out, int R, int N, int H, int W, int C,
                      float spatial_scale, int dtype, void *stream);
+/* ... with the output type chosen separately (out_dtype = dtype, or DI_F32 RoI features from an fp16 map: the
+ * decoder's float32 token path). */
+int di_roi_align_x_fwd(const void *feat, const float *rois, void *out, int R, int N, int H, int W, int C,
+                       float spatial_scale, int dtype, int out_dtype, void *stream);
 
 /* Backward of (3) w.r.t. the feature maps: grad_out (R,49,C) -> grad_feat (N,H,W,C) float32, zero-filled by
  * the caller, accumulated with atomics (the boxes carry no gradient: they come from detached predictions,
@@ -232,6 +236,20 @@ int di_roi_align_bwd(const void *grad_out, const float *rois, float *grad_feat, 
 int di_mha_decode_scratch_floats(int B, int Q, int S, int num_heads);
 int di_mha_decode_fwd(const void *q, const void *kv, void *out, float *scratch, int B, int Q, int S,
                       int num_heads, int head_dim, float scale, int dtype, void *stream);
+
+/* (4x) the same cross attention with float32-accurate logits (round 3; the logits of this attention reach |s| ~ 500,
+ *     so K and q in fp16 alone break the 1e-3 contract - DESIGN.md "Numerics"):
+ *   di_kv_project_fwd: K = Wk x + kbias, V = Wv x + vbias for the B*S tokens x (fp16, 128 channels) of the BEV map
+ *     (decoder_utils.py:98-100 with `key + key_pos` folded: kbias = Wk kpe + bk is constant, float32 (S,128));
+ *     the float32 weight arrives split, W = w_hi + w_lo / 2048 (fp16 (256,128) each, rows [K ; V]);
+ *     out (B*S, 384) fp16 = [Khi | Klo | V] with K = Khi + Klo / 2048.
+ *   di_mha_decode_x_fwd: q (B,Q,128) float32, UNSCALED; kx from di_kv_project_fwd; 8 heads x 16; writes one partial
+ *     soft-max state [m (exp2 domain), l, O[16]] per (sample, head, query, key range) to scratch
+ *     (B*8*Q*di_mha_decode_x_ranges(B,Q,S)*18 floats), merged by a DI_TOK_COMBINE step of di_token_program. */
+int di_kv_project_fwd(const void *x, const void *w_hi, const void *w_lo, const float *kbias, const float *vbias,
+                      void *out, int B, int S, void *stream);
+int di_mha_decode_x_ranges(int B, int Q, int S);
+int di_mha_decode_x_fwd(const float *q, const void *kx, float *scratch, int B, int Q, int S, float scale, void *stream);
 
 /* ---------------------------------------------------------------- DeepInteraction++ operators (row a20)
  * di_ms_deform_attn_fwd: the core of mmcv-full 1.3.18 `MultiScaleDeformableAttention` (CUDA op `ms_deform_attn`,
@@ -315,7 +333,8 @@ int di_ffn_ln_fwd(const void *x, int n_chunks, const void *const *image, const v
  *   y[p][n] = act(sum_{ky,kx,c} w[n][ky*3+kx][c] * x[p + (ky-1, kx-1)][c] + bias[n])
  * x (n,H,W,Cin) fp16, Cin % 32 == 0; w_packed (Cout_pad, 9, Cin) fp16 = the torch weight (Cout,Cin,3,3) permuted to
  * (Cout,3,3,Cin), rows zero-padded to 16 when Cout <= 16; bias float32 (Cout) (a following BatchNorm folded in by the
- * caller); Cout == 128 or Cout <= 16; y (n,H,W,Cout) fp16, or (n,Cout,H,W) when out_nchw.
+ * caller); Cout == 128 or Cout <= 16; y (n,H,W,Cout) fp16, or (n,Cout,H,W) when out_nchw
+ * (1: fp16, 2: float32 - the heat-map logits that feed the NMS comparison and the top-Q pick).
  * w_staged (optional, Cout == 128): the same weights as (Cin/32, 3 ky, 3 kx, 128, 32) fp16 with the 128 rows
  * permuted (row 16nb+4g+r = output channel 32(nb/2)+8g+4(nb%2)+r, for 16-B stores) and, inside every (chunk, ky) tile of
  * 384 rows x 64 B, the 16-B slot s of row R stored at slot (s + 2 * (R >> 2)) & 3 - the kernel's conflict-free LDS order,
@@ -325,48 +344,74 @@ int di_ffn_ln_fwd(const void *x, int n_chunks, const void *const *image, const v
 int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w_staged, const float *bias, void *y, int n, int H,
                    int W, int Cin, int Cout, int relu, int out_nchw, void *stream);
 
-/* ---------------------------------------------------------------- token-level kernels of the MMPI decoder
- * fp16 inference form of the reference's decoder layer / RoI blocks / prediction heads on the B*Q query tokens
- * (models/utils/decoder_utils.py:35-113, 498-581, 584-629, 632-841; dense_heads/deepinteraction_decoder.py:242-297).
- * Token matrices are row-major fp16 with an explicit row stride (`ld*`, in elements); weights are fp16 (N, K)
- * row-major as `nn.Linear.weight`; biases float32; LayerNorm weights fp16 (as the half() module holds them).
+/* ---------------------------------------------------------------- token-level kernels of the MMPI decoder (float32)
+ * Inference form of the reference's decoder layer / RoI blocks / prediction heads on the B*Q query tokens
+ * (models/utils/decoder_utils.py:35-113, 498-581, 584-629, 632-841; dense_heads/deepinteraction_decoder.py:242-313).
+ * The token state, the RoI features, the generated DynamicConv parameters and every weight of this path are FLOAT32
+ * (float32 MFMA): with fp16 anywhere on this path the box outputs leave the 1e-3 contract (DESIGN.md "Numerics");
+ * only the feature MAPS the tokens gather from are fp16.  Token matrices are row-major with an explicit row stride
+ * (`ld*`, in elements); weights (N, K) row-major as `nn.Linear.weight`.
  *
- * di_token_linear: Y = epilogue((X | [X ; X2]) + P) . W^T):
- *     v = acc + bias; v = act1(v) (0 none, 1 ReLU, 2 GELU-erf); v = LN1(v + res1); v = relu(v) if act2;
- *     v = LN2(v + res2); rows with keep[m] == 0 are written as zeros.    Every stage optional (null pointers).
- *   N, K multiples of 128; a LayerNorm needs N == 128; [X ; X2] = channel concat split at k1 (multiple of 32).
- *   Shapes with K >= 2048 (DynamicConv out_layer) run split-K and need `workspace` of
- *   di_token_linear_workspace_bytes(M, N, K) bytes; K == 128, N >= 2048 with no epilogue runs weight-stationary.
- * di_token_mha: softmax(q k^T scale) v per head (16 dims) among the Q <= 512 tokens of each sample, from the packed
- *   projection qkv (B*Q, >= 3E) = [q | k | v]; optional visibility mask: key k is visible to query q when bit
- *   view[q] of member[k] is set or view[q] < 0 (the per-view self attention of ImageRCNNBlock, :745).
+ * di_token_program: ONE launch runs a short program on every group of 16 consecutive tokens of a sample (grid
+ *   ceil(Q/16) x B; the rows live in three LDS buffers of 16 x 512 floats, `src` / `dst` / `aux` name them):
+ *     DI_TOK_LOAD        dst[:, a:a+K] = p0[m, :K] (+ p1[m, :K])                       rows of ld0 (ld1) floats
+ *     DI_TOK_LOAD_PARTS  dst[:, :128]  = sum_{s<a} p0[(s*b + m)*128 : +128] + p1       split-K partial sums (b = B*Q)
+ *     DI_TOK_ATTN        dst[:, :128]  = softmax(q k^T) v per head (8 heads x 16) among the Q tokens of the sample,
+ *                        from the packed projection p0 = [q | k | v] (rows of ld0 floats), f = scale * log2(e);
+ *                        optional visibility p1 = member (uint8), p2 = view (int8): key k is visible to query q when
+ *                        bit view[q] of member[k] is set or view[q] < 0 (ImageRCNNBlock's per-view attention, :745)
+ *     DI_TOK_COMBINE     dst[:, :128]  = merge of the a key-range states of di_mha_decode_x_fwd (p0 = scratch)
+ *     DI_TOK_LINEAR      dst[:, :N]    = act_a(src[:, :K] . p0^T + p1)    a: 0 none, 1 ReLU, 2 GELU(erf); K, N <= 512
+ *     DI_TOK_ROWOP       dst[:, :128]  = mask_p2(relu_{b&1}(LayerNorm_{p0,p1,eps=f}(src + buf[aux])))   each part optional
+ *     DI_TOK_STORE       p0[m, :N]     = src[:, a:a+N]
+ *     DI_TOK_HEADS       second layers of the prediction heads on the hidden rows in src (first layers: a LINEAR step
+ *                        with the BatchNorm-folded, stacked (nheads*64, K) weight), `center += query_pos`, the
+ *                        on-the-image merge with the first stage (`keep`), written at column col0 of the
+ *                        (B, cls_h, ldo) float32 outputs; pos_out = the new centres (B,Q,2)   (:498-581, head :265-311)
+ * di_token_wide: Y = X . W^T + bias for K = 128, N >> M (DynamicConv's parameter generator, :608), weight stationary.
+ * di_token_splitk: partial sums of X (M,K) . W^T (128,K) over K slices of 448 into workspace (slices, M, 128)
+ *   (DynamicConv's out_layer, :624); a DI_TOK_LOAD_PARTS step of the next program sums them.
  * di_dynconv_fwd: F2 = relu(LN2(relu(LN1(roi . p1)) . p2)) per RoI (:617-622); roi (R,49,128); params (R, 32768) =
- *   [p1^T (d,c) | p2^T (e, d permuted as k = 32kk+8g+4t+r <-> d = 32kk+16t+4g+r)]; out (R,49,128).
+ *   [p1^T (d,c) | p2^T (e,d)] (the generating Linear's rows permuted on the host); out (R,49,128).
  * di_roi_select: image block (on != null): last valid view per query, membership bits, RoIs, keep mask, float view
  *   id (:681-759 bookkeeping); point block (on == null): rois = (b, BEV rect).
- * di_query_init: query features = BEV token + class encoding, positions, learned positional embedding (float32
- *   MLP, BatchNorm folded) and labels of the top-Q proposals (deepinteraction_decoder.py:242-253).
- * di_pred_heads: all prediction heads of one stage (folded first layers stacked (nheads*64, K) fp16, second layers
- *   stacked (sum cls, 64) float32), `center += query_pos`, the on-the-image merge with the first stage (`keep`),
- *   written at column offset col0 of (B, cls_h, ldo) float32 outputs; pos_out = the new centres (B,Q,2). */
-int di_token_linear(const void *x, int ldx, const void *x2, int ldx2, int k1, const void *p, int ldp, const void *w,
-                    const float *bias, int act1, const void *res1, int ldr1, const void *ln1_w, const void *ln1_b,
-                    int act2, const void *res2, int ldr2, const void *ln2_w, const void *ln2_b, float eps,
-                    const void *keep, void *y, int ldy, int M, int N, int K, void *workspace, void *stream);
-long long di_token_linear_workspace_bytes(int M, int N, int K);
-int di_token_mha(const void *qkv, int ld, const void *member, const void *view, void *out, int ldo, int B, int Q,
-                 int heads, float scale, void *stream);
-int di_dynconv_fwd(const void *roi, const void *params, const void *n1w, const void *n1b, const void *n2w,
-                   const void *n2b, void *out, int R, float eps, void *stream);
+ * di_query_init: query features = BEV token (fp16 map) + class encoding, positions, learned positional embedding
+ *   (BatchNorm folded) and labels of the top-Q proposals (deepinteraction_decoder.py:242-253); float32 out. */
+enum { DI_TOK_LOAD = 1, DI_TOK_LOAD_PARTS = 2, DI_TOK_ATTN = 3, DI_TOK_COMBINE = 4, DI_TOK_LINEAR = 5,
+       DI_TOK_ROWOP = 6, DI_TOK_STORE = 7, DI_TOK_HEADS = 8 };
+#define DI_TOK_MAX_STEPS 20
+#define DI_TOK_MAX_HEADS 8
+typedef struct di_tok_step {
+  int kind, src, dst, aux;
+  int K, N, a, b;
+  float f;
+  int pad;
+  const void *p0, *p1, *p2, *p3;
+  long long ld0, ld1;
+} di_tok_step;
+typedef struct di_tok_heads {
+  const float *w2, *b2, *qpos;     /* stacked second layers (sum cls, 64), their biases, query positions (B,Q,2) */
+  const unsigned char *keep;       /* (B,Q) or NULL */
+  float *pos_out;                  /* (B,Q,2) or NULL */
+  float *out[DI_TOK_MAX_HEADS];    /* (B, cls_h, ldo) each */
+  const float *first[DI_TOK_MAX_HEADS];   /* (B, cls_h, Q) of the first stage (needed with keep) */
+  int cls[DI_TOK_MAX_HEADS];
+  int nheads, center_head, ldo, col0;
+} di_tok_heads;
+int di_token_program(const di_tok_step *steps_host, int nsteps, const di_tok_heads *heads_host, int B, int Q,
+                     void *stream);
+int di_token_wide(const float *x, int ldx, const float *w, const float *bias, float *y, long long ldy, int M, int N,
+                  void *stream);
+long long di_token_splitk_workspace_bytes(int M, int K);
+int di_token_splitk(const float *x, long long ldx, const float *w, float *workspace, int M, int K, int *nslices_host,
+                    void *stream);
+int di_dynconv_fwd(const float *roi, const float *params, const float *n1w, const float *n1b, const float *n2w,
+                   const float *n2b, float *out, int R, float eps, void *stream);
 int di_roi_select(const int *on, const float *rect, float *rois, void *view, void *member, void *keep, float *on_img,
                   int B, int V, int Q, void *stream);
-int di_query_init(const void *bev, const long long *top, const void *ce_w, const void *ce_b, const float *w1,
-                  const float *b1, const float *w2, const float *b2, void *feat, void *pe, float *pos,
+int di_query_init(const void *bev, const long long *top, const float *ce_w, const float *ce_b, const float *w1,
+                  const float *b1, const float *w2, const float *b2, float *feat, float *pe, float *pos,
                   long long *labels, int B, int Q, int Hb, int Wb, int ncls, void *stream);
-int di_pred_heads(const void *x1, const void *x2, const void *w1, const float *b1, const float *w2, const float *b2,
-                  const float *qpos, const void *keep, float *const *out_host, const float *const *first_host,
-                  const int *cls_host, int nheads, int center_head, float *pos_out, int B, int Q, int ldo, int col0,
-                  void *stream);
 
 /* ---------------------------------------------------------------- pillar / voxel producer
  * Hard voxelisation (spconv PointToVoxel as wrapped by models/updated_modules/sparse_voxelize.py:9-70), three

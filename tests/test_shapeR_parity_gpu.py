@@ -86,7 +86,9 @@ def _ref_slice(ref_enc, b):
 def _product(c, q, dtype):
     enc, dec = c['models'][q]
     import copy
-    return copy.deepcopy(enc).to(DEV, dtype).eval(), copy.deepcopy(dec).to(DEV, dtype).eval()
+    from deepinteraction_amd import precision
+    enc, dec = precision.to_inference(copy.deepcopy(enc).to(DEV), copy.deepcopy(dec).to(DEV), dtype)
+    return enc.eval(), dec.eval()          # fp16 = the benched mixed mode: fp16 maps, float32 token path
 
 
 def _run(enc, dec, d):

@@ -1,9 +1,10 @@
-"""GPU: the token-level kernels of the MMPI decoder (csrc/token.hip, C ABI di_token_* / di_dynconv_fwd / di_roi_select /
-di_query_init / di_pred_heads) against the same arithmetic in float64 on the same fp16 operands, and the fused decoder
-forward (deepinteraction_amd/decoder_fused.py) against the module-by-module product path it replaces.
+"""GPU: the float32 token-level kernels of the MMPI decoder (csrc/token32.hip: di_token_program / di_token_wide /
+di_token_splitk / di_dynconv_fwd / di_roi_select / di_query_init; csrc/cross_attn.hip: di_kv_project_fwd /
+di_mha_decode_x_fwd) against the same arithmetic in float64, and the fused decoder forward
+(deepinteraction_amd/decoder_fused.py) against the module-by-module float32 path of the same head.
 
-Tolerance: fp16 storage of every stage output (2^-11 relative), float32 accumulation: 2e-3 of the value scale per
-kernel (a LayerNorm output is O(1), so this is absolute there)."""
+Tolerance: float32 products and accumulation: 2e-5 of the value scale per kernel (the cross attention: 1e-4 - its
+probabilities and values pass the matrix cores as fp16)."""
 import math
 
 import pytest
@@ -12,14 +13,15 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from deepinteraction_amd import decoder_fused, ops, synth
+from deepinteraction_amd import decoder_fused, ops, precision, synth
 from deepinteraction_amd.configs import decoder_cfg
 
 DEV = 'cuda'
 
 
-def _close(got, ref, tol=2e-3):
+def _close(got, ref, tol=2e-5):
     got, ref = got.double().cpu(), ref.double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
     err = (got - ref).abs().max().item()
     assert err <= tol * max(1.0, ref.abs().max().item()), (err, ref.abs().max().item())
 
@@ -28,65 +30,67 @@ def _ln(x, w, b, eps=1e-5):
     return F.layer_norm(x, (x.shape[-1],), w.double(), b.double(), eps)
 
 
-@pytest.mark.parametrize('M', [1, 37, 200, 400])
-@pytest.mark.parametrize('case', ['plain384', 'pos', 'relu256', 'gelu512', 'res_ln', 'concat', 'two_ln', 'keep'])
-def test_token_linear(M, case):
+def _gen(seed):
+    g = torch.Generator().manual_seed(seed)
+    return g, (lambda *s: torch.randn(*s, generator=g))
+
+
+D = lambda t: None if t is None else t.to(DEV)
+
+
+@pytest.mark.parametrize('B,Q', [(1, 1), (1, 37), (1, 200), (2, 200), (1, 400)])
+@pytest.mark.parametrize('case', ['plain384', 'pos', 'relu256', 'gelu512', 'res_ln', 'concat', 'chain', 'keep'])
+def test_program_linear_steps(B, Q, case):
+    """LOAD / LINEAR / ROWOP / STORE steps in the combinations the decoder uses."""
     assert torch.cuda.is_available(), 'gpu tests need a HIP device'
-    cases = ['plain384', 'pos', 'relu256', 'gelu512', 'res_ln', 'concat', 'two_ln', 'keep']
-    g = torch.Generator().manual_seed(cases.index(case) * 1000 + M)
-    r = lambda *s: torch.randn(*s, generator=g)
+    cases = ['plain384', 'pos', 'relu256', 'gelu512', 'res_ln', 'concat', 'chain', 'keep']
+    g, r = _gen(cases.index(case) * 1000 + Q + B)
+    M = B * Q
     K, N = dict(plain384=(128, 384), pos=(128, 128), relu256=(128, 256), gelu512=(128, 512), res_ln=(512, 128),
-                concat=(256, 384), two_ln=(6272, 128), keep=(256, 128))[case]
-    x, w, b = r(M, K).half(), (r(N, K) / math.sqrt(K)).half(), r(N) * 0.1
-    d = lambda t: None if t is None else t.to(DEV)
-    kw, ref = {}, None
+                concat=(256, 384), chain=(128, 128), keep=(256, 128))[case]
+    x, w, b = r(M, K), r(N, K) / math.sqrt(K), r(N) * 0.1
     xd = x.double()
+    p = ops.TokenProgram()
+    y_dev = torch.empty((M, N), dtype=torch.float32, device=DEV)
     if case == 'pos':
-        p = r(M, K).half()
-        kw['pos'] = d(p)
-        xd = (x + p).double()                               # the add is an fp16 add, as in the module path
-    if case == 'concat':
-        kw['x2'] = d(x[:, 128:].contiguous())
-        x_dev = d(x[:, :128].contiguous())
+        pe = r(M, K)
+        p.load(0, D(x), pos=D(pe))
+        xd = xd + pe.double()
+    elif case == 'concat':
+        p.load(0, D(x[:, :128].contiguous())).load(0, D(x[:, 128:].contiguous()), col=128)
     else:
-        x_dev = d(x)
+        p.load(0, D(x))
     y = xd @ w.double().t() + b.double()
-    if case == 'relu256':
-        kw['act1'], y = 1, y.relu()
-    if case == 'gelu512':
-        kw['act1'], y = 2, F.gelu(y)
+    act = dict(relu256=1, gelu512=2).get(case, 0)
+    if act == 1:
+        y = y.relu()
+    if act == 2:
+        y = F.gelu(y)
+    p.linear(0, 1, D(w), D(b), act=act)
     if case in ('res_ln', 'keep'):
-        res, lw, lb = r(M, 128).half(), (1 + 0.2 * r(128)).half(), (0.1 * r(128)).half()
-        kw.update(res1=d(res), ln1=(d(lw), d(lb)))
+        res, lw, lb = r(M, 128), 1 + 0.2 * r(128), 0.1 * r(128)
+        keep = (torch.rand(M, generator=g) > 0.3).to(torch.uint8) if case == 'keep' else None
+        p.load(2, D(res)).rowop(1, 1, aux=2, ln=(D(lw), D(lb)), keep=D(keep))
         y = _ln(y + res.double(), lw, lb)
-    if case == 'keep':
-        keep = (torch.rand(M, generator=g) > 0.3).to(torch.uint8)
-        kw['keep'] = d(keep)
-        y = y * keep.double()[:, None]
-    if case == 'two_ln':                                      # DynamicConv out_layer: LN3 -> relu -> +res -> LN2
-        res, lw, lb = r(M, 128).half(), (1 + 0.2 * r(128)).half(), (0.1 * r(128)).half()
-        lw2, lb2 = (1 + 0.2 * r(128)).half(), (0.1 * r(128)).half()
-        kw.update(ln1=(d(lw), d(lb)), act2=True, res2=d(res), ln2=(d(lw2), d(lb2)))
-        y = _ln(_ln(y, lw, lb).relu() + res.double(), lw2, lb2)
-    got = ops.token_linear(x_dev, d(w), d(b), **kw)
-    assert got.shape == (M, N)
-    _close(got, y)
-
-
-def test_token_linear_wide_generator():
-    """K = 128 -> N = 32768 (DynamicConv.dynamic_layer), weight-stationary kernel."""
-    g = torch.Generator().manual_seed(5)
-    x, w, b = torch.randn(200, 128, generator=g).half(), (torch.randn(32768, 128, generator=g) / 11).half(), \
-        torch.randn(32768, generator=g) * 0.1
-    got = ops.token_linear(x.to(DEV), w.to(DEV), b.to(DEV))
-    _close(got, x.double() @ w.double().t() + b.double())
+        if keep is not None:
+            y = y * keep.double()[:, None]
+    if case == 'chain':              # DynamicConv tail: LN -> relu -> + res -> LN -> FFN (512) -> + -> LN
+        res, lw, lb, lw2, lb2 = r(M, 128), 1 + 0.2 * r(128), 0.1 * r(128), 1 + 0.2 * r(128), 0.1 * r(128)
+        w1, b1, w2, b2 = r(512, 128) / 11, r(512) * 0.1, r(128, 512) / 22, r(128) * 0.1
+        p.rowop(1, 1, ln=(D(lw), D(lb)), relu=True).load(2, D(res)).rowop(1, 1, aux=2, ln=(D(lw2), D(lb2)))
+        p.linear(1, 0, D(w1), D(b1), act=2).linear(0, 2, D(w2), D(b2)).rowop(2, 1, aux=1, ln=(D(lw), D(lb)))
+        z = _ln(_ln(y, lw, lb).relu() + res.double(), lw2, lb2)
+        y = _ln(z + F.gelu(z @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double(), lw, lb)
+    p.store(1, y_dev)
+    p.run(B, Q)
+    _close(y_dev, y)
 
 
 @pytest.mark.parametrize('B,Q,masked', [(1, 200, False), (2, 200, True), (1, 400, True), (2, 37, True), (1, 512, False)])
-def test_token_mha(B, Q, masked):
-    g = torch.Generator().manual_seed(Q + B)
+def test_program_attention(B, Q, masked):
+    g, r = _gen(Q + B)
     E, H = 128, 8
-    qkv = torch.randn(B * Q, 3 * E, generator=g).half()
+    qkv = r(B * Q, 3 * E)
     member = view = None
     allowed = torch.ones(B, Q, Q, dtype=torch.bool)
     if masked:
@@ -99,31 +103,73 @@ def test_token_mha(B, Q, masked):
                     member[b, q] |= (1 << v)                                  # a query is a member of its own view
         bits = (member.long()[:, None, :] >> view.long().clamp(min=0)[:, :, None]) & 1
         allowed = (bits == 1) | (view.long()[:, :, None] < 0)
-    got = ops.token_mha(qkv.to(DEV), B, Q, H, 0.25, None if member is None else member.view(-1).to(DEV),
-                        None if view is None else view.view(-1).to(DEV))
+    out = torch.empty((B * Q, E), dtype=torch.float32, device=DEV)
+    p = ops.TokenProgram()
+    p.attn(0, D(qkv), 0.25, None if member is None else D(member.view(-1)), None if view is None else D(view.view(-1)))
+    p.store(0, out)
+    p.run(B, Q)
     q, k, v = (t.double().view(B, Q, H, 16).transpose(1, 2) for t in qkv.split(E, dim=1))
     sc = (q @ k.transpose(-1, -2)) * 0.25
     sc = sc.masked_fill(~allowed[:, None], float('-inf'))
     ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * Q, E)
-    _close(got, ref)
+    _close(out, ref)
+
+
+def test_wide_generator():
+    """K = 128 -> N = 32768 (DynamicConv.dynamic_layer), weight-stationary kernel."""
+    g, r = _gen(5)
+    x, w, b = r(200, 128), r(32768, 128) / 11, r(32768) * 0.1
+    got = ops.token_wide(D(x), D(w), D(b))
+    _close(got, x.double() @ w.double().t() + b.double())
+    got = ops.token_wide(D(x[:37]), D(w[:256]), None)
+    _close(got, x[:37].double() @ w[:256].double().t())
+
+
+@pytest.mark.parametrize('M', [1, 37, 200, 400])
+def test_splitk_and_parts(M):
+    """DynamicConv out_layer: split-K partial sums + the LOAD_PARTS step that sums them."""
+    g, r = _gen(M)
+    x, w, b = r(M, 6272), r(128, 6272) / 80, r(128) * 0.1
+    ws, ns = ops.token_splitk(D(x), D(w))
+    assert ns == 14
+    out = torch.empty((M, 128), dtype=torch.float32, device=DEV)
+    ops.TokenProgram().load_parts(0, ws, ns, M, D(b)).store(0, out).run(1, M)
+    _close(out, x.double() @ w.double().t() + b.double())
 
 
 def test_dynconv_core():
-    """relu(LN2(relu(LN1(roi @ p1)) @ p2)) with the parameters in the kernel's permuted layout (decoder_fused._dyn_perm)."""
-    g = torch.Generator().manual_seed(2)
+    """relu(LN2(relu(LN1(roi @ p1)) @ p2)) with the parameters in the kernel's transposed layout (decoder_fused._dyn_perm)."""
+    g, r = _gen(2)
     R = 23
-    roi = torch.randn(R, 49, 128, generator=g).half()
-    params = (torch.randn(R, 32768, generator=g) / 11).half()                       # reference layout
-    n = lambda: ((1 + 0.2 * torch.randn(128, generator=g)).half(), (0.1 * torch.randn(128, generator=g)).half())
+    roi = r(R, 49, 128)
+    params = r(R, 32768) / 11                                                       # reference layout
+    n = lambda: (1 + 0.2 * r(128), 0.1 * r(128))
     n1, n2 = n(), n()
     perm = decoder_fused._dyn_perm('cpu')
-    got = ops.dynconv(roi.to(DEV), params[:, perm].contiguous().to(DEV), tuple(t.to(DEV) for t in n1),
-                      tuple(t.to(DEV) for t in n2))
+    got = ops.dynconv(D(roi), D(params[:, perm].contiguous()), tuple(D(t) for t in n1), tuple(D(t) for t in n2))
     p1 = params[:, :16384].double().view(R, 128, 128)
     p2 = params[:, 16384:].double().view(R, 128, 128)
-    f1 = _ln(torch.bmm(roi.double(), p1), *n1).relu().half().double()               # the kernel keeps F1 in fp16
+    f1 = _ln(torch.bmm(roi.double(), p1), *n1).relu()
     ref = _ln(torch.bmm(f1, p2), *n2).relu()
-    _close(got, ref, 4e-3)
+    _close(got, ref, 5e-5)
+
+
+def test_query_init():
+    g, r = _gen(9)
+    B, Q, H, W, ncls = 2, 37, 12, 12, 10
+    bev = r(B, 128, H, W).half().to(DEV).contiguous(memory_format=torch.channels_last)
+    top = torch.randint(0, ncls * H * W, (B, Q), generator=g)
+    ce_w, ce_b = r(128, ncls), r(128)
+    pe = (r(128, 2), r(128), r(128, 128) / 11, r(128))
+    feat, pemb, pos, labels = ops.query_init(bev, D(top), D(ce_w), D(ce_b), tuple(D(t) for t in pe))
+    cls, cell = top // (H * W), top % (H * W)
+    tok = bev.float().cpu().permute(0, 2, 3, 1).reshape(B, H * W, 128).double()
+    want = tok.gather(1, cell[:, :, None].expand(-1, -1, 128)) + ce_w.double().t()[cls] + ce_b.double()
+    _close(feat.view(B, Q, 128), want)
+    xy = torch.stack([(cell % W).double() + 0.5, (cell // W).double() + 0.5], -1)
+    wpe = (xy @ pe[0].double().t() + pe[1].double()).relu() @ pe[2].double().t() + pe[3].double()
+    _close(pemb.view(B, Q, 128), wpe)
+    assert torch.equal(pos.cpu().double(), xy) and torch.equal(labels.cpu(), cls)
 
 
 @pytest.mark.parametrize('B,V,Q', [(1, 6, 200), (2, 6, 37), (1, 3, 400)])
@@ -152,6 +198,44 @@ def test_roi_select(B, V, Q):
     assert torch.equal(ops.roi_select(rb.to(DEV)).cpu(), want)
 
 
+@pytest.mark.parametrize('B,Q,S', [(1, 200, 32400), (2, 37, 1000), (1, 400, 5000)])
+def test_cross_attention_x(B, Q, S):
+    """kv_project (float32 weight split in two fp16 halves, positional bias) + mha_decode_x (float32-accurate logits of
+    magnitude ~300) + the COMBINE step, against float64 on the same fp16 map."""
+    g, r = _gen(S + Q)
+    E, H = 128, 8
+    x = (r(B, S, E) * 2).half()
+    w = r(2 * E, E) * 0.4
+    kb, vb = r(S, E) * 8, r(S, E)
+    q = r(B, Q, E) * 6
+    hi, lo = ops.split_hi_lo(D(w))
+    kx = ops.kv_project(D(x), hi, lo, D(kb), D(vb))
+    K = x.double() @ w[:E].double().t() + kb.double()
+    Vv = x.double() @ w[E:].double().t() + vb.double()
+    got_k = kx[..., :E].double().cpu() + kx[..., E:2 * E].double().cpu() / 2048.0
+    _close(got_k, K, 2e-6)
+    _close(kx[..., 2 * E:], Vv, 1e-3)
+    scratch, nr = ops.mha_decode_x(D(q), kx, 0.25)
+    out = torch.empty((B * Q, E), dtype=torch.float32, device=DEV)
+    ops.TokenProgram().combine(0, scratch, nr).store(0, out).run(B, Q)
+    qh = q.double().view(B, Q, H, 16).transpose(1, 2)
+    kh = K.view(B, S, H, 16).transpose(1, 2)
+    vh = kx[..., 2 * E:].double().cpu().view(B, S, H, 16).transpose(1, 2)          # the fp16 V the kernel read
+    sc = (qh @ kh.transpose(-1, -2)) * 0.25
+    assert sc.abs().max().item() > 100                                               # the regime that needs float32 logits
+    ref = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B * Q, E)
+    _close(out, ref, 1e-3)
+
+
+def test_roi_align_float32_out():
+    g, r = _gen(4)
+    feat = r(3, 128, 20, 30).half().to(DEV).contiguous(memory_format=torch.channels_last)
+    rois = torch.tensor([[0, 1.5, 2.0, 9.0, 12.0], [2, -3.0, -1.0, 40.0, 25.0], [1, 5.0, 5.0, 5.5, 5.2]])
+    a = ops.roi_align(feat, D(rois), 0.5)
+    b = ops.roi_align(feat, D(rois), 0.5, out_f32=True)
+    assert b.dtype == torch.float32 and torch.equal(b.half(), a)
+
+
 def _decoder(Q, seed=7):
     from deepinteraction_amd import harness
     from deepinteraction_amd.mmdet3d_plugin import DeepInteractionDecoder
@@ -162,15 +246,19 @@ def _decoder(Q, seed=7):
     for n, p in dec.named_parameters():                         # biases / LayerNorm affine off their trivial init
         if p.dim() == 1:
             p.data.add_(torch.randn(p.shape, generator=g) * 0.05)
-    return dec.to(DEV).half().eval()
+    return dec.to(DEV).eval()
 
 
 @pytest.mark.parametrize('B,Q', [(1, 40), (2, 24), (1, 200)])
 def test_fused_decoder_matches_module_path(B, Q):
-    """The fused forward against the module-by-module path of the same head (same weights, fp16): identical INT
-    outputs (proposals, labels, on-the-image masks), continuous outputs within fp16 noise of ~40 stacked stages."""
+    """The fused forward (fp16 maps, float32 token path) against the module-by-module path of the same head in float32 on
+    the same fp16-representable maps: identical INT outputs (proposals, labels, on-the-image masks), continuous outputs
+    within 1e-3 (the module path's heat-map heads are fp16 too, so the proposals are the same set)."""
+    import copy
     torch.backends.cudnn.deterministic = True
-    dec = _decoder(Q)
+    dec32 = _decoder(Q)
+    dec = copy.deepcopy(dec32)
+    dec.heatmap_head.half(), dec.heatmap_head_img.half()            # precision.half_maps_ for the head
     shape = synth.SHAPE_TINY
     Hi, Wi = shape['img_hw']
     g = torch.Generator().manual_seed(0)
@@ -186,12 +274,12 @@ def test_fused_decoder_matches_module_path(B, Q):
         ref = dec([p0, p1], img, metas)[0][0]
     assert torch.equal(f_top, dec.top_proposals) and torch.equal(f_labels, dec.query_labels)
     agree = [float((a == b).float().mean()) for a, b in zip(f_masks, dec.on_the_image_mask)]
-    assert min(agree) >= 0.97, agree                              # a centre within fp16 noise of an image border may flip
+    assert min(agree) == 1.0, agree
     assert set(fused) == set(ref)
     for k in ref:
         a, b = fused[k].float(), ref[k].float()
         assert a.shape == b.shape, k
         d = (a - b).abs()
         scale = max(1.0, b.abs().max().item())
-        assert d.median().item() <= 3e-3 * scale, (k, d.median().item())
-        assert (d > 3e-2 * scale).float().mean().item() <= 0.1, (k, (d > 3e-2 * scale).float().mean().item())
+        print(k, 'max', d.max().item() / scale, 'median', d.median().item() / scale)
+        assert d.median().item() <= 1e-4 * scale and d.max().item() <= 1e-2 * scale, (k, d.max().item(), scale)
