@@ -87,7 +87,7 @@ def self_launch(args):
 
 
 # ------------------------------------------------------------------------------------------------ CPU side
-def cpu_baseline(shape, num_proposals, state, sample, product_out, budget_s=60.0):
+def cpu_baseline(shape, num_proposals, state, sample, product_out, budget_s=60.0, state_same=None):
     """The CPU oracle (kind "port": PyTorch fp32 restatement of the reference path, its per-sample and per-view
     Python loops and scipy depth completion included) on this box's host cores, BOUNDED: a 1/16-area probe of the
     workload is timed first; when the predicted full-size time fits `budget_s` the oracle runs the full-size
@@ -123,9 +123,21 @@ def cpu_baseline(shape, num_proposals, state, sample, product_out, budget_s=60.0
             forced = parity.oracle_decoder(D, ref_enc, sample['img_metas'], top_override=top.cpu())
             par = parity.summarize(parity.compare_encoder(got_enc, ref_enc),
                                    parity.compare_decoder(out, labels, masks, top, free, forced))
-            par['vs'] = ('CPU oracle full forward on the same sample and state_dict, no depth injection; continuous '
-                         'outputs as |got-ref|/max(1,max|ref|); decoder outputs against the oracle decoder run on '
-                         'the product\'s proposals')
+            par['vs'] = ('CPU oracle full forward on the same sample with the FLOAT32 parameters of the model (before the '
+                         'fp16 conversion of the map side), no depth injection; continuous outputs as '
+                         '|got-ref|/max(1,max|ref|) (abs_max in the output\'s unit: BEV cells for center); decoder outputs '
+                         'against the oracle decoder run on the product\'s proposals')
+            if state_same is not None:        # the arithmetic alone: the oracle holds the product's own parameter values
+                E2, D2 = parity.build_oracle(shape, num_proposals, state=state_same)
+                ref2 = parity.oracle_encoder(E2, sample)
+                free2 = parity.oracle_decoder(D2, ref2, sample['img_metas'])
+                forced2 = parity.oracle_decoder(D2, ref2, sample['img_metas'], top_override=top.cpu())
+                same = parity.summarize(parity.compare_encoder(got_enc, ref2),
+                                        parity.compare_decoder(out, labels, masks, top, free2, forced2))
+                same.pop('first_proposals', None)
+                same['vs'] = ('the same with the oracle holding the product\'s parameter VALUES (encoder and heat-map '
+                              'heads rounded through fp16, token path float32 on both sides): arithmetic only')
+                par['identical_parameters'] = same
     else:
         div = 2 if t16 * 4.0 * 1.3 <= budget_s else 4
         dt, sh = probe(div) if div != 4 else (t16, sh)
@@ -359,9 +371,13 @@ def bench_forward(args, rank, world, device):
     if single is not None:
         out['single_sample'] = single
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        state = ({k: v.float().cpu() for k, v in enc.state_dict().items()},
-                 {k: v.float().cpu() for k, v in dec.state_dict().items()})
-        base, par = cpu_baseline(shape, args.proposals, state, host_pool[0], product_out)
+        same = ({k: v.float().cpu() for k, v in enc.state_dict().items()},
+                {k: v.float().cpu() for k, v in dec.state_dict().items()})
+        # the model as built, before precision.half_maps_ rounded its map side: same seed, same init, float32 on the host
+        e32, d32 = harness.build_models(shape, args.proposals, torch.float32, 'cpu')
+        state = (e32.state_dict(), d32.state_dict())
+        base, par = cpu_baseline(shape, args.proposals, state, host_pool[0], product_out,
+                                 state_same=same if dtype == torch.float16 else None)
         out['cpu_baseline'] = base
         if par is not None and g is not None:
             par['graph_vs_eager'] = graph_vs_eager

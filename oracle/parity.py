@@ -34,7 +34,9 @@ def randomize_bn(mods, seed=5):
 
 def build_oracle(shape, num_proposals, seed=1234, state=None, round_fp16=False):
     """Oracle encoder + decoder (fp32, CPU, eval).  `state` = (encoder state_dict, decoder state_dict) to load
-    (e.g. the product's); round_fp16 rounds every floating parameter / buffer through fp16."""
+    (e.g. the product's); round_fp16: True rounds every floating parameter / buffer through fp16, 'maps' only those the
+    product's fp16 mode holds in fp16 (`deepinteraction_amd.precision.half_maps_`: the encoder and the two heat-map
+    heads) - the "identical parameters" comparison that isolates the arithmetic."""
     torch.manual_seed(seed)
     E = oenc.DeepInteractionEncoder(2, shape['c_img'], shape['c_pts'], 128)
     D = odec.DeepInteractionDecoder(**configs.decoder_cfg(bev=shape['bev_hw'][0], num_proposals=num_proposals))
@@ -44,7 +46,8 @@ def build_oracle(shape, num_proposals, seed=1234, state=None, round_fp16=False):
         E.load_state_dict({k: v.detach().float().cpu() for k, v in state[0].items()})
         D.load_state_dict({k: v.detach().float().cpu() for k, v in state[1].items()})
     if round_fp16:
-        for m in (E, D):
+        mods = (E, D) if round_fp16 is True else (E, D.heatmap_head, D.heatmap_head_img)
+        for m in mods:
             for t in list(m.parameters()) + list(m.buffers()):
                 if t.is_floating_point():
                     t.data = t.data.half().float()
@@ -75,7 +78,8 @@ def rel_stats(got, ref):
     d = ((got - ref).abs() / scale).flatten()
     ds = d[:: d.numel() // 4_000_000 + 1] if d.numel() > 4_000_000 else d      # quantiles on a strided subsample
     return dict(max=float(d.max()), median=float(ds.median()), p999=float(torch.quantile(ds.double(), 0.999)),
-                scale=scale, frac_gt_1e3=float((d > 1e-3).float().mean()), frac_gt_1e2=float((d > 1e-2).float().mean()))
+                scale=scale, frac_gt_1e3=float((d > 1e-3).float().mean()), frac_gt_1e2=float((d > 1e-2).float().mean()),
+                abs_max=float(d.max()) * scale)          # in the output's own unit (`center`: BEV cells)
 
 
 def compare_encoder(got, ref):
@@ -106,7 +110,8 @@ def summarize(enc_stats, dec_stats):
     """Compact form for the bench JSON line."""
     r3 = lambda x: float(f'{x:.3g}')
     out = {k: dict(max=r3(v['max']), median=r3(v['median']), p999=r3(v['p999'])) for k, v in enc_stats.items()}
-    out.update({f'dec.{k}': dict(max=r3(v['max']), median=r3(v['median']), p999=r3(v['p999']))
+    out.update({f'dec.{k}': dict(max=r3(v['max']), median=r3(v['median']), p999=r3(v['p999']),
+                                 frac_gt_1e3=r3(v['frac_gt_1e3']), abs_max=r3(v['abs_max']))
                 for k, v in dec_stats['keys'].items()})
     out['proposal_set_overlap'] = r3(dec_stats['proposal_set_overlap'])
     out['label_agreement'] = r3(dec_stats['label_agreement'])

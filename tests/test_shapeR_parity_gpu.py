@@ -107,13 +107,24 @@ def _check_fp32(name, es, ds):
         assert s['max'] <= 2e-3, (name, k, s)
 
 
-def _check_fp16(name, es, ds):
-    for k, s in es.items():                                  # measured: median ~3e-4, p99.9 ~3e-3 of the value scale
-        assert s['median'] <= 1e-3 and s['p999'] <= 1e-2 and s['frac_gt_1e2'] <= 2e-3, (name, k, s)
-    assert ds['proposal_set_overlap'] >= 0.9, (name, ds['proposal_set_overlap'])
+def _check_fp16(name, es, ds, same_params=False):
+    """Round 3 (float32 token path): measured against the float32-parameter oracle - encoder maps max 3.8e-4 (median
+    4e-5), decoder outputs median 0.7-1.3e-4, p99.9 1.3-3.4e-3, max 5e-3, 0.2-1.2 % beyond 1e-3, none beyond 1e-2 -
+    which is the floor the fp16 ENCODER sets: the oracle itself, its encoder weights rounded to fp16 and its maps
+    rounded once, puts p99.9 at 1.0-1.9e-3 and 0.1-1 % beyond 1e-3 with exact arithmetic everywhere
+    (tests/tools/fp16_error_budget.py).  Bounds = measured with head-room."""
+    for k, s in es.items():
+        assert s['median'] <= 1e-4 and s['p999'] <= 5e-4 and s['frac_gt_1e3'] <= 1e-5, (name, k, s)
+    assert ds['proposal_set_overlap'] >= 0.995, (name, ds['proposal_set_overlap'])
     assert ds['labels_equal_on_same_proposals']
+    assert all(m >= 0.995 for m in ds['mask_agreement']), (name, ds['mask_agreement'])
     for k, s in ds['keys'].items():
-        assert s['median'] <= 5e-3 and s['p999'] <= 1e-1, (name, k, s)
+        if k == 'query_heatmap_score':           # a score is 0 or the heat value: an NMS near-tie flips it whole
+            assert s['p999'] <= 1e-3 and s['frac_gt_1e3'] <= 2e-3, (name, k, s)
+            continue
+        assert s['median'] <= 2.5e-4 and s['p999'] <= 6e-3 and s['frac_gt_1e3'] <= 2.5e-2 and s['frac_gt_1e2'] <= 1e-3, \
+            (name, k, s)
+    assert ds['keys']['center']['abs_max'] <= 0.05, ds['keys']['center']       # BEV cells (0.6 m each)
 
 
 def test_fp32_eager_B2_Q200(ctx):
@@ -135,6 +146,23 @@ def test_fp16_eager_B2_Q200(ctx):
     ds = parity.compare_decoder(out, labels, masks, top, ctx['free'][200], forced)
     _report('fp16_eager_B2_Q200', dict(encoder=es, decoder=ds))
     _check_fp16('fp16_B2_Q200', es, ds)
+
+
+def test_fp16_identical_parameters_B1_Q200(ctx):
+    """The arithmetic alone: the oracle holds the SAME parameters as the fp16 product (encoder and heat-map heads
+    rounded through fp16, token path float32 on both sides), sample 0."""
+    enc, dec = _product(ctx, 200, torch.float16)
+    s0 = _sample(ctx['inp'], 0)
+    d = harness.to_device(s0, DEV, torch.float16)
+    got_enc, out, labels, masks, top = _run(enc, dec, d)
+    E, D = parity.build_oracle(SHAPE, 200, state=ctx['state'], round_fp16='maps')
+    ref = parity.oracle_encoder(E, s0)
+    es = parity.compare_encoder(got_enc, ref)
+    free = parity.oracle_decoder(D, ref, s0['img_metas'])
+    forced = parity.oracle_decoder(D, ref, s0['img_metas'], top_override=top.cpu())
+    ds = parity.compare_decoder(out, labels, masks, top, free, forced)
+    _report('fp16_identical_parameters_B1_Q200', dict(encoder=es, decoder=ds))
+    _check_fp16('fp16_same_params', es, ds)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
