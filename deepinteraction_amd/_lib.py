@@ -54,8 +54,9 @@ SIGNATURES = {
     'di_ffn_ln_fwd': [_c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, ctypes.c_longlong, _c_p],
     'di_conv3x3_fwd': [_c_p] * 5 + [_c_i] * 7 + [_c_p],
     'di_token_program': [_c_p, _c_i, _c_p, _c_i, _c_i, _c_p],
-    'di_token_wide': [_c_p, _c_i, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_i, _c_i, _c_p],
-    'di_token_splitk': [_c_p, ctypes.c_longlong, _c_p, _c_p, _c_i, _c_i, _c_p, _c_p],
+    'di_token_program_timed': [_c_p, _c_i, _c_p, _c_i, _c_i, _c_p, _c_p],
+    'di_token_wide': [_c_p, _c_i, _c_p, _c_p, _c_p, _c_i, _c_p],
+    'di_token_splitk': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_p, _c_p],
     'di_dynconv_fwd': [_c_p] * 7 + [_c_i, _c_f, _c_p],
     'di_roi_select': [_c_p] * 7 + [_c_i] * 3 + [_c_p],
     'di_query_init': [_c_p] * 12 + [_c_i] * 5 + [_c_p],
@@ -76,8 +77,9 @@ TOK_MAX_STEPS, TOK_MAX_HEADS = 20, 8
 
 class TokStep(ctypes.Structure):
     _fields_ = [('kind', _c_i), ('src', _c_i), ('dst', _c_i), ('aux', _c_i), ('K', _c_i), ('N', _c_i), ('a', _c_i),
-                ('b', _c_i), ('f', _c_f), ('pad', _c_i), ('p0', _c_p), ('p1', _c_p), ('p2', _c_p), ('p3', _c_p),
-                ('ld0', ctypes.c_longlong), ('ld1', ctypes.c_longlong)]
+                ('b', _c_i), ('f', _c_f), ('role_lo', _c_i), ('role_hi', _c_i), ('rt', _c_i), ('rc', _c_i), ('nch', _c_i),
+                ('p0', _c_p), ('p1', _c_p), ('p2', _c_p), ('p3', _c_p), ('ld0', ctypes.c_longlong),
+                ('ld1', ctypes.c_longlong), ('roff', ctypes.c_longlong)]
 
 
 class TokHeads(ctypes.Structure):

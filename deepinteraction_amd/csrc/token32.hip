@@ -1,23 +1,32 @@
-// Token-level kernels of the MMPI decoder in FLOAT32 for gfx950 (round 3).
+// Token-level kernels of the MMPI decoder with FLOAT32 accuracy for gfx950 (round 3).
 //
 // The decoder works on B*Q <= ~1000 query tokens of 128 channels (reference decoder_utils.py:35-113 decoder layer,
 // :498-581 prediction FFN, :584-629 DynamicConv, :632-841 RoI blocks).  The work is tiny (a few MFLOP per linear layer)
 // and numerically touchy: with random-init weights the 200 x 32 400 cross attention has logits of magnitude ~500 and
 // the DynamicConv chain amplifies a 2^-11 perturbation of any operand to 1e-2 of the box outputs
 // (tests/tools/fp16_error_budget.py).  So the token state, the RoI features, the generated DynamicConv parameters and
-// every weight of this path are float32, multiplied on the matrix cores with the float32 MFMA (16x16x4, full fp32
-// products and accumulation); only the BEV / image MAPS the tokens gather from stay fp16.
+// every weight of this path carry float32 accuracy; only the BEV / image MAPS the tokens gather from stay fp16.
 //
-// Launch count is what the path is bound by (5-15 us of latency per launch for < 1 us of work), so the token-parallel
-// parts are ONE kernel per dependency level: `program_kernel` gives a workgroup 16 token rows in LDS and runs a short
-// PROGRAM of steps on them (load / self attention among the sample's queries / merge of the cross attention's partial
-// states / linear / residual + LayerNorm / store / prediction heads), every linear layer reading its weights straight
-// from L2.  What cannot be row-parallel stays its own kernel: the DynamicConv parameter generator (weight stationary,
-// 128 -> 32 768 per query), the DynamicConv core (one workgroup per RoI) and the split-K out_layer (6 272 -> 128).
+// Matrix products: the float32 MFMA (16x16x4) runs at 1/16 of the fp16 rate and made the first version of these
+// kernels MFMA-bound (program 41 us, generator 25 us, DynamicConv 25 us).  Every operand is therefore SPLIT into two
+// fp16 numbers, x = hi + lo / 2048 (hi = fp16(x), lo = fp16((x - hi) * 2048): the low half pre-scaled so that it never
+// lands in the fp16 subnormals), and a product runs as three fp16 MFMAs (16x16x32) with float32 accumulation:
+//     a . b  =  ahi . bhi  +  (ahi . blo + alo . bhi) / 2048          (+ alo . blo / 2^22, dropped: 2^-22 relative)
+// - 16/3 times the float32 MFMA rate, weights pre-split once on the host, activations split in registers, products
+// that feed another kernel's matrix operand (generated parameters, DynamicConv output) written as hi / lo pairs.
 //
-// All GEMMs run TRANSPOSED, Y^T = W . X^T: the A operand of `v_mfma_f32_16x16x4_f32` is one weight row per lane, the
-// B operand one token row per lane, both read as float4 (4 consecutive k, consumed by 4 MFMAs whose k index g maps to
-// k = 16c + 4g + t), and a lane ends with 4 consecutive output channels of one token.
+// Launch count and dependent round trips are what the path is bound by, so the token-parallel parts are ONE kernel
+// per dependency level: `program_kernel` gives a workgroup 16 token rows in LDS and runs a short PROGRAM of steps on
+// them (load / self attention among the sample's queries / merge of the cross attention's partial states / linear /
+// residual + LayerNorm / store / prediction heads); a linear step issues ALL weight fragments of up to four (tile,
+// K-chunk) items before its first MFMA, and the first group of the NEXT linear step before the barrier that ends the
+// current step; consecutive loads are one round trip; the attention keeps four key tiles in flight.  What cannot be
+// row-parallel stays its own kernel: the DynamicConv parameter generator (weight stationary, 128 -> 32 768 per
+// query), the DynamicConv core (one workgroup per RoI) and the split-K out_layer (6 272 -> 128).
+//
+// All GEMMs run TRANSPOSED, Y^T = W . X^T: the A operand is 8 consecutive k of one weight row per lane, the B operand
+// 8 consecutive k of one token row, and a lane ends with 4 consecutive output channels of one token.
+#include <stdlib.h>
 #include <string.h>
 
 #include "di_common.h"
@@ -26,21 +35,53 @@ namespace di {
 namespace t32 {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
 
 __device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
-__device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 c) {
+__device__ __forceinline__ h8 ld_h8(const __half *p) { return __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(p)); }
+__device__ __forceinline__ f4 mfma4(f4 a, f4 b, f4 c) {       // float32 MFMA, 4 consecutive k (the attention's 16-dim heads)
 #pragma unroll
   for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], c, 0, 0, 0);
   return c;
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
+// 8 floats -> the hi / lo fp16 pair
+struct HL {
+  h8 hi, lo;
+};
+__device__ __forceinline__ void split1(float x, _Float16 &hi, _Float16 &lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * kLoScale);
+}
+__device__ __forceinline__ HL split8(f4 a, f4 b) {
+  HL r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    _Float16 h, l;
+    split1(a[j], h, l);
+    r.hi[j] = h; r.lo[j] = l;
+    split1(b[j], h, l);
+    r.hi[4 + j] = h; r.lo[4 + j] = l;
+  }
+  return r;
+}
+// one k-step (32) of the three-pass product: (ah, al) += (whi, wlo) x (b.hi, b.lo)
+__device__ __forceinline__ void mfma3(h8 whi, h8 wlo, const HL &b, f4 &ah, f4 &al) {
+  al = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, b.lo, al, 0, 0, 0);
+  al = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, b.hi, al, 0, 0, 0);
+  ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi, b.hi, ah, 0, 0, 0);
+}
+
 constexpr int TM = 16;          // token rows per workgroup
 constexpr int NW = 8;           // wavefronts per workgroup
 constexpr int NTH = NW * 64;
 constexpr int LDW = 516;        // floats per LDS row: 512 + 4 (float4 reads of 16 rows spread over the banks)
 constexpr int NBUF = 3;
-constexpr int LDS_BYTES = NBUF * TM * LDW * 4;
+constexpr int LDS_BYTES = NBUF * TM * LDW * 4 + 256;
 
 // ------------------------------------------------------------------------------------------------------------
 // The steps of a program.  `src` / `dst` / `aux` name LDS row buffers (0..2); widths are in floats.
@@ -49,9 +90,11 @@ struct Step {           // mirrors di_tok_step of include/deepinteraction_hip.h
   int kind, src, dst, aux;
   int K, N, a, b;
   float f;
-  int pad;
+  int role_lo, role_hi;   // the step runs in the workgroups whose role (blockIdx.z) lies in [role_lo, role_hi]
+  int rt, rc, nch;        // LINEAR: tiles / K-chunks added per role to the packed weight's block index; chunks of the weight
   const void *p0, *p1, *p2, *p3;
   long long ld0, ld1;
+  long long roff;         // elements added to p0 per role (LOAD / LOAD_PARTS / STORE)
 };
 struct Heads {          // mirrors di_tok_heads
   const float *w2, *b2, *qpos;
@@ -67,30 +110,78 @@ struct Program {
   Step s[DI_TOK_MAX_STEPS];
 };
 
-// K_LOAD: dst[r][a + c] = p0[m * ld0 + c] (+ p1[m * ld1 + c]),  c < K
-__device__ __forceinline__ void step_load(const Step &s, float *buf, long long m0, int rows, int tid) {
-  const float *x = (const float *)s.p0, *p = (const float *)s.p1;
-  float *d = buf + s.dst * TM * LDW + s.a;
-  const int k4 = s.K >> 2;
-  for (int e = tid; e < TM * k4; e += NTH) {
-    const int r = e / k4, c = (e - r * k4) * 4;
-    f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < rows) {
-      v = ld4(x + (m0 + r) * s.ld0 + c);
-      if (p != nullptr) v += ld4(p + (m0 + r) * s.ld1 + c);
+// The program arrives as a kernel argument.  The kernarg segment is host memory: the first version indexed it per
+// step (`prog.s[si].field` = scalar loads over the fabric) and paid 1 500 shader cycles of fixed cost per step, 7 000
+// per linear step (measured with the stamps below).  So the whole argument block is copied to LDS once, by all
+// threads in one round trip, and a step's fields are pulled into SGPRs (readfirstlane) when the step starts.
+__device__ __forceinline__ Step fetch_step(const Step *ls) {
+  Step s;
+  const unsigned *src = reinterpret_cast<const unsigned *>(ls);
+  unsigned *dst = reinterpret_cast<unsigned *>(&s);
+#pragma unroll
+  for (int j = 0; j < (int)(sizeof(Step) / 4); ++j) dst[j] = __builtin_amdgcn_readfirstlane(src[j]);
+  return s;
+}
+
+// K_LOAD: dst[r][a + c] = (p0 + role * roff)[m * ld0 + c] (+ p1[m * ld1 + c]),  c < K.  Up to three CONSECUTIVE load
+// steps run as one phase: every global load of all of them is issued before the first LDS write (one round trip).
+constexpr int kMaxLoadRun = 3;
+__device__ __forceinline__ void steps_load(const Program &prog, int si, int nrun, float *buf, long long m0, int rows, int tid,
+                                           int role) {
+  Step s[kMaxLoadRun];
+  bool on[kMaxLoadRun];
+#pragma unroll
+  for (int q = 0; q < kMaxLoadRun; ++q) {
+    s[q] = fetch_step(&prog.s[min(si + q, DI_TOK_MAX_STEPS - 1)]);
+    on[q] = q < nrun && role >= s[q].role_lo && role <= s[q].role_hi;
+  }
+  f4 v[kMaxLoadRun][4];
+#pragma unroll
+  for (int q = 0; q < kMaxLoadRun; ++q) {
+    if (!on[q]) continue;
+    const float *x = (const float *)s[q].p0 + (role - s[q].role_lo) * s[q].roff, *p = (const float *)s[q].p1;
+    const int k4 = s[q].K >> 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + j * NTH;
+      const int r = e / k4, c = (e - r * k4) * 4;
+      v[q][j] = f4{0.f, 0.f, 0.f, 0.f};
+      if (e < TM * k4 && r < rows) {
+        v[q][j] = ld4(x + (m0 + r) * s[q].ld0 + c);
+        if (p != nullptr) v[q][j] += ld4(p + (m0 + r) * s[q].ld1 + c);
+      }
     }
-    *reinterpret_cast<f4 *>(d + r * LDW + c) = v;
+  }
+#pragma unroll
+  for (int q = 0; q < kMaxLoadRun; ++q) {
+    if (!on[q]) continue;
+    float *d = buf + s[q].dst * TM * LDW + s[q].a;
+    const int k4 = s[q].K >> 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + j * NTH;
+      const int r = e / k4, c = (e - r * k4) * 4;
+      if (e < TM * k4) *reinterpret_cast<f4 *>(d + r * LDW + c) = v[q][j];
+    }
   }
 }
 
 // K_LOAD_PARTS: dst[r][c] = sum_{s < a} p0[(s * b + m) * 128 + c] + p1[c]   (split-K partial sums, b = total rows)
-__device__ __forceinline__ void step_load_parts(const Step &s, float *buf, long long m0, int rows, int tid) {
-  const float *part = (const float *)s.p0, *bias = (const float *)s.p1;
+__device__ __forceinline__ void step_load_parts(const Step &s, float *buf, long long m0, int rows, int tid, int rr) {
+  const float *part = (const float *)s.p0 + rr * s.roff, *bias = (const float *)s.p1;
   float *d = buf + s.dst * TM * LDW;
   const int r = tid >> 5, c = (tid & 31) * 4;
   f4 v = bias != nullptr ? ld4(bias + c) : f4{0.f, 0.f, 0.f, 0.f};
   if (r < rows) {
-    for (int sl = 0; sl < s.a; ++sl) v += ld4(part + ((size_t)sl * s.b + m0 + r) * 128 + c);
+    const float *p = part + (size_t)(m0 + r) * 128 + c;
+    const size_t st = (size_t)s.b * 128;
+    for (int s0 = 0; s0 < s.a; s0 += 8) {                  // 8 slices in flight
+      f4 t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = s0 + j < s.a ? ld4(p + (size_t)(s0 + j) * st) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v += t[j];
+    }
   } else {
     v = f4{0.f, 0.f, 0.f, 0.f};
   }
@@ -101,43 +192,75 @@ __device__ __forceinline__ void step_load_parts(const Step &s, float *buf, long 
 // decoder_utils.py:743-746 / :824-826 and :91-95): wave = head (8 heads x 16 dims), packed projection p0 = [q | k | v]
 // rows of ld0 floats.  Optional visibility (image RoI block: the attention runs among the queries of ONE view): key k
 // is visible to query q when bit view[q] of member[k] is set, or when view[q] < 0.  f = scale * log2(e).
+// Key tiles go in chunks of 8: all loads of a chunk are issued first; the 8 score tiles are independent three-pass
+// products (16x16x16 fp16 MFMA on the hi / lo halves: the head dim is the 16 of k), ONE maximum exchange per chunk
+// (the first version did the online soft-max tile by tile: a dependent chain of MFMA -> 2 cross-lane exchanges ->
+// exp -> MFMA per tile, 28 000 cycles for 13 tiles), then the probabilities and O^T += V^T P^T, again three-pass.
+struct HL4 {
+  h4 hi, lo;
+};
+__device__ __forceinline__ HL4 split4(f4 a) {
+  HL4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    _Float16 h, l;
+    split1(a[j], h, l);
+    r.hi[j] = h;
+    r.lo[j] = l;
+  }
+  return r;
+}
+__device__ __forceinline__ void mfma3s(const HL4 &a, const HL4 &b, f4 &ch, f4 &cl) {
+  cl = __builtin_amdgcn_mfma_f32_16x16x16f16(a.lo, b.hi, cl, 0, 0, 0);
+  cl = __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.lo, cl, 0, 0, 0);
+  ch = __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.hi, ch, 0, 0, 0);
+}
 __device__ __forceinline__ void step_attn(const Step &s, float *buf, int b, int q0, int Q, int lane, int wave) {
   const float *base = (const float *)s.p0 + (size_t)b * Q * s.ld0;
   const unsigned char *member = (const unsigned char *)s.p1;
   const signed char *view = (const signed char *)s.p2;
   const int ld = (int)s.ld0, h = wave, i = lane & 15, g = lane >> 4;
   const int qc = min(q0 + i, Q - 1);
-  const f4 qv = ld4(base + (size_t)qc * ld + h * 16 + 4 * g);
+  const HL4 qv = split4(ld4(base + (size_t)qc * ld + h * 16 + 4 * g));        // B[k = dim 4g + j][col = query i]
   const int vq = member != nullptr ? (int)view[(size_t)b * Q + qc] : -1;
   const float sl2 = s.f;
   float m = -INFINITY, l = 0.f;
-  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  f4 oh = {0.f, 0.f, 0.f, 0.f}, ol = {0.f, 0.f, 0.f, 0.f};
   const int ntile = (Q + 15) >> 4;
-  // tile t: K row of key 16t + i (dims 4g..4g+3), V[key 16t + 4g + r][dim i], membership bytes of keys 16t + 4g + r
-  auto fetch = [&](int t, f4 &kk, f4 &vv, unsigned &mem) {
-    const int ki = min(16 * t + i, Q - 1);
-    kk = ld4(base + (size_t)ki * ld + 128 + h * 16 + 4 * g);
-    mem = 0xFFFFFFFFu;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int t0 = 0; t0 < ntile; t0 += 8) {
+    // tile t: K row of key 16t + i (dims 4g..4g+3), V[key 16t + 4g + r][dim i], membership bytes of keys 16t + 4g + r;
+    // keys past the end clamp to the last one (masked below)
+    f4 kk[8], vv[8];
+    unsigned mem[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int kr = min(16 * t + 4 * g + r, Q - 1);
-      vv[r] = base[(size_t)kr * ld + 256 + h * 16 + i];
-      if (member != nullptr) mem = (mem & ~(0xFFu << (8 * r))) | ((unsigned)member[(size_t)b * Q + kr] << (8 * r));
+    for (int j = 0; j < 8; ++j) {
+      const int t = t0 + j, k4 = 16 * t + 4 * g;
+      kk[j] = ld4(base + (size_t)min(16 * t + i, Q - 1) * ld + 128 + h * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vv[j][r] = base[(size_t)min(k4 + r, Q - 1) * ld + 256 + h * 16 + i];
+      mem[j] = 0xFFFFFFFFu;
+      if (member != nullptr) {
+        unsigned mm = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mm |= (unsigned)member[(size_t)b * Q + min(k4 + r, Q - 1)] << (8 * r);
+        mem[j] = mm;
+      }
     }
-  };
-  f4 kk, vv, kn, vn;
-  unsigned mem, memn;
-  fetch(0, kk, vv, mem);
-  for (int t = 0; t < ntile; ++t) {
-    if (t + 1 < ntile) fetch(t + 1, kn, vn, memn);
-    f4 c = mfma4(kk, qv, f4{0.f, 0.f, 0.f, 0.f});          // S^T[key 4g + r][query i]
+    f4 sc[8];
     float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = 16 * t + 4 * g + r;
-      const bool vis = key < Q && (vq < 0 || ((mem >> (8 * r + vq)) & 1u));
-      c[r] = vis ? c[r] * sl2 : -INFINITY;
-      mx = fmaxf(mx, c[r]);
+    for (int j = 0; j < 8; ++j) {
+      f4 ch = zero, cl = zero;
+      mfma3s(split4(kk[j]), qv, ch, cl);                     // S^T[key 4g + r][query i]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * (t0 + j) + 4 * g + r;
+        const bool vis = key < Q && (vq < 0 || ((mem[j] >> (8 * r + vq)) & 1u));
+        const float x = vis ? fmaf(cl[r], kLoInv, ch[r]) * sl2 : -INFINITY;
+        sc[j][r] = x;
+        mx = fmaxf(mx, x);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -145,25 +268,30 @@ __device__ __forceinline__ void step_attn(const Step &s, float *buf, int b, int 
     const float ms = mn == -INFINITY ? 0.f : mn;             // nothing visible so far: keep everything at zero
     const float a = exp2f(m - ms);
     l *= a;
-    acc *= a;
+    oh *= a;
+    ol *= a;
     m = mn;
-    f4 p;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      p[r] = exp2f(c[r] - ms);
-      l += p[r];
+    for (int j = 0; j < 8; ++j) {
+      f4 p;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] = exp2f(sc[j][r] - ms);
+        l += p[r];
+      }
+      mfma3s(split4(vv[j]), split4(p), oh, ol);              // O^T[dim 4g + r'][query i]: A = V^T[dim i][key 4g + r]
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[r], p[r], acc, 0, 0, 0);   // O^T[dim 4g+r'][query i]
-    kk = kn; vv = vn; mem = memn;
   }
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
   const float inv = l > 0.f ? 1.f / l : 0.f;
-  *reinterpret_cast<f4 *>(buf + s.dst * TM * LDW + i * LDW + h * 16 + 4 * g) = acc * inv;
+  f4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = fmaf(ol[r], kLoInv, oh[r]) * inv;
+  *reinterpret_cast<f4 *>(buf + s.dst * TM * LDW + i * LDW + h * 16 + 4 * g) = o;
 }
 
-// K_COMBINE: merge of the cross attention's partial softmax states (csrc/decoder.hip mha_decode_*: one state
+// K_COMBINE: merge of the cross attention's partial softmax states (csrc/cross_attn.hip mha_decode_x_kernel: one state
 // [m (exp2 domain), l, O[16]] per (sample, head, query, key range), range-contiguous): wave = head.  a = ranges.
 __device__ __forceinline__ void step_combine(const Step &s, float *buf, int b, int q0, int Q, int lane, int wave) {
   const int h = wave, i = lane & 15, g = lane >> 4, nrange = s.a;
@@ -198,35 +326,79 @@ __device__ __forceinline__ void step_combine(const Step &s, float *buf, int b, i
   *reinterpret_cast<f4 *>(buf + s.dst * TM * LDW + i * LDW + h * 16 + 4 * g) = O * inv;
 }
 
-// K_LINEAR: dst[r][n] = act(sum_k src[r][k] * W[n][k] + bias[n]),  n < N, k < K (multiples of 16; W row-major (N,K))
-__device__ __forceinline__ void step_linear(const Step &s, float *buf, int lane, int wave) {
-  const float *W = (const float *)s.p0, *bias = (const float *)s.p1;
+// K_LINEAR: dst[r][n] = act(sum_k src[r][k] * W[n][k] + bias[n]),  n < N (multiple of 16), k < K (multiple of 128);
+// W = hi + lo / 2048 packed in fragment order (p0, see linear_issue).  Work items = (16-channel tile of this wave, 128-wide K
+// chunk), tile-major; the weight fragments of FOUR items (8 x 16 B per lane each) are issued before the first MFMA of
+// the group.  (Holding the next step's first group in registers across the barrier made the compiler spill 529
+// VGPRs; the kernel's prologue warms L2 with every weight line instead, see `touch_weights`.)
+struct WFrag {
+  h8 w[8];              // k-step kk: w[2kk] = hi, w[2kk + 1] = lo
+  f4 bias;
+};
+// The weight arrives PACKED in fragment order (ops.pack_linear): block (tile t, chunk c) = 8 pieces of 1 KiB,
+// piece 2kk + h = [lane 16g + i][8 halfs] = W_h[16t + i][128c + 32kk + 8g .. + 7] - one load instruction of a wave reads
+// one contiguous KiB (row-major weights made every instruction touch 16 half cache lines: 25 GB/s per workgroup).
+__device__ __forceinline__ void linear_issue(const Step &s, int it0, WFrag (&A)[4], int lane, int wave, int rr) {
+  const __half *wp = (const __half *)s.p0;
+  const float *bias = (const float *)s.p1;
+  const int g = lane >> 4, nch = s.K >> 7, nchw = s.nch > 0 ? s.nch : nch;
+  const int ntile = s.N >> 4;
+  const int mine = wave < ntile ? (ntile - wave + NW - 1) / NW : 0;
+  const int total = mine * nch;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int it = min(it0 + j, total - 1);                  // past the end: the last item again (never used)
+    const int tt = it / nch, c = it - tt * nch, t = wave + NW * tt + rr * s.rt;
+    const __half *blk = wp + ((size_t)(t * nchw + c + rr * s.rc) * 8) * 512 + lane * 8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) A[j].w[q] = ld_h8(blk + q * 512);
+    A[j].bias = bias != nullptr ? ld4(bias + 16 * t + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+__device__ __forceinline__ void step_linear(const Step &s, float *buf, int lane, int wave, int rr) {
   const float *x = buf + s.src * TM * LDW;
   float *d = buf + s.dst * TM * LDW;
-  const int i = lane & 15, g = lane >> 4, K = s.K;
-  for (int t = wave; t < (s.N >> 4); t += NW) {
-    const float *wr = W + (size_t)(16 * t + i) * K + 4 * g;
-    const float *xr = x + i * LDW + 4 * g;
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 128) {                 // 8 weight fragments in flight per lane
-      f4 a[8];
-      const int nc = min(8, (K - k0) >> 4);
+  const int i = lane & 15, g = lane >> 4, nch = s.K >> 7;
+  const int ntile = s.N >> 4;
+  const int mine = wave < ntile ? (ntile - wave + NW - 1) / NW : 0;
+  const int total = mine * nch;
+  if (total == 0) return;
+  const float *xr = x + i * LDW + 8 * g;
+  f4 ah = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
+  HL bq[4];
+  WFrag A[4];
+  for (int it0 = 0; it0 < total; it0 += 4) {
+    linear_issue(s, it0, A, lane, wave, rr);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) a[c] = c < nc ? ld4(wr + k0 + 16 * c) : f4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) {
+      const int it = it0 + j;
+      if (it >= total) break;                               // wave-uniform
+      const int tt = it / nch, c = it - tt * nch;
+      if (c == 0) {
+        ah = f4{0.f, 0.f, 0.f, 0.f};
+        al = f4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (nch > 1 || it == 0) {                             // the B operands of chunk c: token rows from LDS, split
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (c < nc) acc = mfma4(a[c], ld4(xr + k0 + 16 * c), acc);
+        for (int kk = 0; kk < 4; ++kk) bq[kk] = split8(ld4(xr + 128 * c + 32 * kk), ld4(xr + 128 * c + 32 * kk + 4));
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) mfma3(A[j].w[2 * kk], A[j].w[2 * kk + 1], bq[kk], ah, al);
+      if (c == nch - 1) {
+        const int n = 16 * (wave + NW * tt) + 4 * g;
+        f4 v = A[j].bias;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += fmaf(al[r], kLoInv, ah[r]);
+        if (s.a == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (s.a == 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        }
+        *reinterpret_cast<f4 *>(d + i * LDW + n) = v;       // Y^T[channel 4g + r][token i]
+      }
     }
-    const int n = 16 * t + 4 * g;
-    if (bias != nullptr) acc += ld4(bias + n);
-    if (s.a == 1) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
-    } else if (s.a == 2) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = gelu_erf(acc[r]);
-    }
-    *reinterpret_cast<f4 *>(d + i * LDW + n) = acc;       // Y^T[channel 4g + r][token i]
   }
 }
 
@@ -235,6 +407,12 @@ __device__ __forceinline__ void step_linear(const Step &s, float *buf, int lane,
 __device__ __forceinline__ void step_rowop(const Step &s, float *buf, long long m0, int rows, int tid) {
   if (tid >= 256) return;
   const int r = tid >> 4, c0 = (tid & 15) * 8;
+  float w[8], bb[8];
+  if (s.p0 != nullptr) {                                    // issued first: their round trip overlaps the row reads
+    unpack8(ld8((const float *)s.p0 + c0), w);
+    unpack8(ld8((const float *)s.p1 + c0), bb);
+  }
+  const bool kept = s.p2 == nullptr || r >= rows || ((const unsigned char *)s.p2)[m0 + r] != 0;
   const float *x = buf + s.src * TM * LDW + r * LDW + c0;
   float v[8];
   unpack8(ld8(x), v);
@@ -255,9 +433,6 @@ __device__ __forceinline__ void step_rowop(const Step &s, float *buf, long long 
       ss += d * d;
     }
     const float inv = rsqrtf(row16_sum(ss) * (1.f / 128.f) + s.f);
-    float w[8], bb[8];
-    unpack8(ld8((const float *)s.p0 + c0), w);
-    unpack8(ld8((const float *)s.p1 + c0), bb);
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (v[j] - mean) * inv * w[j] + bb[j];
   }
@@ -265,7 +440,7 @@ __device__ __forceinline__ void step_rowop(const Step &s, float *buf, long long 
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
   }
-  if (s.p2 != nullptr && r < rows && !((const unsigned char *)s.p2)[m0 + r]) {
+  if (!kept) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
   }
@@ -273,8 +448,8 @@ __device__ __forceinline__ void step_rowop(const Step &s, float *buf, long long 
 }
 
 // K_STORE: p0[m * ld0 + c] = src[r][a + c],  c < N
-__device__ __forceinline__ void step_store(const Step &s, const float *buf, long long m0, int rows, int tid) {
-  float *y = (float *)s.p0;
+__device__ __forceinline__ void step_store(const Step &s, const float *buf, long long m0, int rows, int tid, int rr) {
+  float *y = (float *)s.p0 + rr * s.roff;
   const float *x = buf + s.src * TM * LDW + s.a;
   const int n4 = s.N >> 2;
   for (int e = tid; e < rows * n4; e += NTH) {
@@ -287,223 +462,356 @@ __device__ __forceinline__ void step_store(const Step &s, const float *buf, long
 // BN + ReLU - a K_LINEAR step into `src`, BatchNorm folded, heads stacked - then Conv1d(64 -> classes)), and what
 // follows every call in deepinteraction_decoder.py: `center += query_pos` (:265,:288), the on-the-image merge with the
 // first stage's result (:292-295), the placement at column col0 of the (B, classes, ldo) output tensors (:304-311).
-__device__ __forceinline__ void step_heads(const Step &s, const Heads &ho, const float *buf, int b, int q0, int Q, int tid) {
+__device__ __forceinline__ void step_heads(const Step &s, const Heads &ho, const float *buf, int b, int q0, int Q, int tid, int rr) {
+  // s.a == 1: this workgroup evaluates head `rr` only, its 64 hidden channels at columns 0..63 of src
   const float *hid = buf + s.src * TM * LDW;
-  int total = 0;
+  int total = 0, first_row = 0;
 #pragma unroll
-  for (int h = 0; h < DI_TOK_MAX_HEADS; ++h) total += h < ho.nheads ? ho.cls[h] : 0;
+  for (int h = 0; h < DI_TOK_MAX_HEADS; ++h) {
+    const int n = h < ho.nheads ? ho.cls[h] : 0;
+    if (s.a == 1) {
+      if (h < rr) first_row += n;
+      if (h == rr) total = n;
+    } else {
+      total += n;
+    }
+  }
   for (int e = tid; e < TM * total; e += NTH) {
-    const int r = e / total, o = e - r * total;
+    const int r = e / total, o = first_row + e - r * total;
     const int q = q0 + r;
     if (q >= Q) continue;
     int h = 0, row0 = 0;
     while (h + 1 < ho.nheads && o >= row0 + ho.cls[h]) row0 += ho.cls[h++];
     const int cidx = o - row0, ncls = ho.cls[h];
     const float *wr = ho.w2 + (size_t)o * 64;
-    const float *hr = hid + r * LDW + h * 64;
+    const float *hr = hid + r * LDW + (s.a == 1 ? 0 : h * 64);
+    const size_t bq = (size_t)b * Q + q;
+    f4 wv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wv[j] = ld4(wr + 4 * j);
     float a = ho.b2[o];
+    const float qp = h == ho.center_head ? ho.qpos[bq * 2 + cidx] : 0.f;
+    const bool merge = ho.keep != nullptr && !ho.keep[bq];
+    const float fv = merge ? ho.first[h][((size_t)b * ncls + cidx) * Q + q] : 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const f4 w = ld4(wr + 4 * j), x = ld4(hr + 4 * j);
-      a = fmaf(w[0], x[0], a);
-      a = fmaf(w[1], x[1], a);
-      a = fmaf(w[2], x[2], a);
-      a = fmaf(w[3], x[3], a);
+      const f4 x = ld4(hr + 4 * j);
+      a = fmaf(wv[j][0], x[0], a);
+      a = fmaf(wv[j][1], x[1], a);
+      a = fmaf(wv[j][2], x[2], a);
+      a = fmaf(wv[j][3], x[3], a);
     }
-    const size_t bq = (size_t)b * Q + q;
-    if (h == ho.center_head) a += ho.qpos[bq * 2 + cidx];
-    if (ho.keep != nullptr && !ho.keep[bq]) a = ho.first[h][((size_t)b * ncls + cidx) * Q + q];
+    a += qp;
+    if (merge) a = fv;
     ho.out[h][((size_t)b * ncls + cidx) * ho.ldo + ho.col0 + q] = a;
     if (h == ho.center_head && ho.pos_out != nullptr) ho.pos_out[bq * 2 + cidx] = a;
   }
 }
 
-__global__ __launch_bounds__(NTH) void program_kernel(Program prog, Heads heads, int Q) {
-  extern __shared__ __align__(16) float buf[];          // NBUF x TM x LDW
+// Prologue: every weight line this wave will read in ANY linear step of the program is requested once, by LDS-DMA
+// into a junk area (no VGPRs, nothing waits for it): the steps' own loads then hit L2 instead of HBM - a program is a
+// chain of dependent round trips, and the weights (constants) are the part of it that can be started early.
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+__device__ __forceinline__ void touch_weights(const Program &prog, int nsteps, float *junk, int lane, int wave, int role) {
+  for (int si = 0; si < nsteps; ++si) {
+    if (__builtin_amdgcn_readfirstlane(prog.s[si].kind) != DI_TOK_LINEAR) continue;
+    const Step s = fetch_step(&prog.s[si]);
+    if (role < s.role_lo || role > s.role_hi) continue;
+    const int rr = role - s.role_lo;
+    const __half *wp = (const __half *)s.p0;
+    const int nch = s.K >> 7, ntile = s.N >> 4, nchw = s.nch > 0 ? s.nch : nch;
+    for (int t = wave; t < ntile; t += NW)
+      for (int c = 0; c < nch; ++c)     // an 8 KiB block = 64 lines of 128 B: one lane each
+        __builtin_amdgcn_global_load_lds((gptr_t)(wp + ((size_t)((t + rr * s.rt) * nchw + c + rr * s.rc) * 8) * 512 + lane * 64),
+                                         (lptr_t)junk, 4, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(NTH) void program_kernel(Program prog, Heads heads, int Q, int touch, unsigned long long *stamps) {
+  extern __shared__ __align__(16) float buf[];          // NBUF x TM x LDW, + 256 B of junk for the prologue's DMA
+  __shared__ Program lp;
+  __shared__ Heads lh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y, q0 = blockIdx.x * TM;
   const int rows = min(TM, Q - q0);
   const long long m0 = (long long)b * Q + q0;
-  for (int si = 0; si < prog.n; ++si) {
-    const Step &s = prog.s[si];
-    switch (s.kind) {
-      case DI_TOK_LOAD: step_load(s, buf, m0, rows, tid); break;
-      case DI_TOK_LOAD_PARTS: step_load_parts(s, buf, m0, rows, tid); break;
-      case DI_TOK_ATTN: step_attn(s, buf, b, q0, Q, lane, wave); break;
-      case DI_TOK_COMBINE: step_combine(s, buf, b, q0, Q, lane, wave); break;
-      case DI_TOK_LINEAR: step_linear(s, buf, lane, wave); break;
-      case DI_TOK_ROWOP: step_rowop(s, buf, m0, rows, tid); break;
-      case DI_TOK_STORE: step_store(s, buf, m0, rows, tid); break;
-      case DI_TOK_HEADS: step_heads(s, heads, buf, b, q0, Q, tid); break;
-      default: break;
+  const bool stamp = stamps != nullptr && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+  if (stamp) stamps[0] = __builtin_readcyclecounter();
+  {
+    const unsigned *src = reinterpret_cast<const unsigned *>(&prog);
+    unsigned *dst = reinterpret_cast<unsigned *>(&lp);
+    for (int j = tid; j < (int)(sizeof(Program) / 4); j += NTH) dst[j] = src[j];
+    const unsigned *hs = reinterpret_cast<const unsigned *>(&heads);
+    unsigned *hd = reinterpret_cast<unsigned *>(&lh);
+    if (tid < (int)(sizeof(Heads) / 4)) hd[tid] = hs[tid];
+  }
+  __syncthreads();
+  const int nsteps = __builtin_amdgcn_readfirstlane(lp.n);
+  const int role = blockIdx.z;
+  if (touch) touch_weights(lp, nsteps, buf + NBUF * TM * LDW, lane, wave, role);
+  for (int si = 0; si < nsteps; ++si) {
+    const Step s = fetch_step(&lp.s[si]);
+    const bool mine = role >= s.role_lo && role <= s.role_hi;
+    const int rr = role - s.role_lo;
+    if (s.kind == DI_TOK_LOAD) {                           // (a run of loads checks the roles step by step)
+      int nrun = 1;
+      while (nrun < kMaxLoadRun && si + nrun < nsteps && __builtin_amdgcn_readfirstlane(lp.s[si + nrun].kind) == DI_TOK_LOAD) ++nrun;
+      steps_load(lp, si, nrun, buf, m0, rows, tid, role);
+      si += nrun - 1;
+    } else if (mine) {
+      switch (s.kind) {
+        case DI_TOK_LOAD_PARTS: step_load_parts(s, buf, m0, rows, tid, rr); break;
+        case DI_TOK_ATTN: step_attn(s, buf, b, q0, Q, lane, wave); break;
+        case DI_TOK_COMBINE: step_combine(s, buf, b, q0, Q, lane, wave); break;
+        case DI_TOK_LINEAR: step_linear(s, buf, lane, wave, rr); break;
+        case DI_TOK_ROWOP: step_rowop(s, buf, m0, rows, tid); break;
+        case DI_TOK_STORE: step_store(s, buf, m0, rows, tid, rr); break;
+        case DI_TOK_HEADS: step_heads(s, lh, buf, b, q0, Q, tid, rr); break;
+        default: break;
+      }
     }
     __syncthreads();
+    if (stamp) stamps[si + 1] = __builtin_readcyclecounter();      // profiling aid (di_token_program_timed)
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Wide linear (N >> M, K == 128), weight stationary: DynamicConv's parameter generator (decoder_utils.py:608:
-// Linear 128 -> 2*128*128 per query).  A workgroup owns 128 output columns, a wave 32 of them with its 16 weight
-// fragments in registers, and walks all the token rows.  Rows of W map to MFMA rows so that a lane holds 8
-// consecutive output columns (32-B stores, 128 B per token row and wave quarter).
+// DynamicConv, three kernels (decoder_utils.py:608-624).  Everything here is bound by how fast a CU takes in matrix
+// operands (~64 B/clk at best), so every operand is laid out for ONE contiguous KiB per wave-level load and no byte is
+// read twice by a workgroup:
+//
+//   wide_kernel     params = Linear 128 -> 2*128*128 of the query feature, weight stationary: a wave owns 64 output
+//                   values (4 fragments x hi/lo = 32 KiB of packed weight, read once) and walks the 13 row tiles.
+//   dynconv_kernel  F2 = relu(LN2(relu(LN1(roi . p1)) . p2)), one workgroup per RoI: each WAVE owns 32 of the 128
+//                   output channels for all 64 (49 valid) positions, so the RoI's 256 KiB of generated parameters are
+//                   read exactly once; the LayerNorm statistics and F1 cross the waves through LDS.
+//   splitk_kernel   partial sums of out_layer (6 272 -> 128) over 14 K slices.
+//
+// Layouts (host side: decoder_fused._dyn_layout):
+//   params[m] (65 536 halfs) = fragments (product p, channel block nb, k-step kk, half h) of 512 halfs =
+//       [lane 16g + i][8] :  p = 0: p1^T[d = 16nb + i][c = 32kk + 8g + j];  p = 1: p2^T[e = 16nb + i][d = 32kk + 8g + j]
+//     (the rows of the generating Linear are permuted so that its 32 768 outputs come out in this order: value index
+//      V = fragment * 512 + lane * 8 + j without the half bit);
+//   F2 leaves as f2p[k-step ks = 4s + e/32][m][hi 32 | lo 32] (k = s*128 + e of the flattened RoI feature): the B
+//     operand of the split-K kernel, 16 rows x 128 B per (row tile, k-step);
+//   out_layer's weight in k-step order: [tile t][k-step ks][half h][lane][8] (ops.pack_ksteps).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wide_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W,
-                                                   const float *__restrict__ bias, float *__restrict__ Y,
-                                                   long long ldy, int M, int N) {
+__global__ __launch_bounds__(256) void wide_kernel(const float *__restrict__ X, int ldx, const __half *__restrict__ wp,
+                                                   const float *__restrict__ bias, __half *__restrict__ Y, int M) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 128 + wave * 32;
-  // MFMA row i of fragment nb <-> output column n0 + 8 (i >> 2) + 4 nb + (i & 3)
-  f4 a[2][8];
+  // a workgroup = 2 groups of 64 values x 2 halves of the row tiles: 64 values per wave make 128-B stores, and the
+  // kernel is MFMA-issue bound (13 row tiles x 48 three-pass MFMAs per wave), so all four SIMDs of every CU work
+  const int wq = blockIdx.x * 2 + (wave & 1);             // this wave's 64 values V0 .. V0 + 63
+  const int half = wave >> 1;
+  const int ntile = (M + 15) >> 4, t_lo = half * ((ntile + 1) >> 1), t_hi = half ? ntile : (ntile + 1) >> 1;
+  const int V0 = wq * 64;
+  // packed weight: tile T = 4 wq + nb, row i' <-> value V0 + 16 (i' >> 2) + 4 nb + (i' & 3): a lane ends with the 16
+  // consecutive values V0 + 16 g + 4 nb + r
+  h8 a[4][8];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = n0 + 8 * (i >> 2) + 4 * nb + (i & 3);
+  for (int nb = 0; nb < 4; ++nb) {
+    const __half *blk = wp + (size_t)(4 * wq + nb) * 4096 + lane * 8;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) a[nb][c] = ld4(W + (size_t)n * 128 + 16 * c + 4 * g);
+    for (int q = 0; q < 8; ++q) a[nb][q] = ld_h8(blk + q * 512);
   }
-  f4 bs[2];
-  bs[0] = bias ? ld4(bias + n0 + 8 * g) : f4{0.f, 0.f, 0.f, 0.f};
-  bs[1] = bias ? ld4(bias + n0 + 8 * g + 4) : f4{0.f, 0.f, 0.f, 0.f};
+  f4 bs[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) bs[nb] = bias ? ld4(bias + V0 + 16 * g + 4 * nb) : f4{0.f, 0.f, 0.f, 0.f};
   f4 xb[8], xn[8];
   auto fetch = [&](int m0, f4 (&x)[8]) {
-    const int mr = min(m0 + i, M - 1);
+    const float *p = X + (size_t)min(m0 + i, M - 1) * ldx + 8 * g;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) x[c] = ld4(X + (size_t)mr * ldx + 16 * c + 4 * g);
+    for (int kk = 0; kk < 4; ++kk) {
+      x[2 * kk] = ld4(p + 32 * kk);
+      x[2 * kk + 1] = ld4(p + 32 * kk + 4);
+    }
   };
-  fetch(0, xb);
-  for (int m0 = 0; m0 < M; m0 += 16) {
-    if (m0 + 16 < M) fetch(m0 + 16, xn);
-    f4 acc[2] = {bs[0], bs[1]};
+  fetch(16 * t_lo, xb);
+  const size_t ooff = ((size_t)(V0 >> 9) * 2) * 512 + (V0 & 511) + 16 * g;
+  for (int m0 = 16 * t_lo; m0 < 16 * t_hi; m0 += 16) {
+    if (m0 + 16 < 16 * t_hi) fetch(m0 + 16, xn);
+    f4 hi[4], lo[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      acc[0] = mfma4(a[0][c], xb[c], acc[0]);
-      acc[1] = mfma4(a[1][c], xb[c], acc[1]);
+    for (int nb = 0; nb < 4; ++nb) {
+      hi[nb] = bs[nb];
+      lo[nb] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const HL b = split8(xb[2 * kk], xb[2 * kk + 1]);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) mfma3(a[nb][2 * kk], a[nb][2 * kk + 1], b, hi[nb], lo[nb]);
     }
     if (m0 + i < M) {
-      float *y = Y + (size_t)(m0 + i) * ldy + n0 + 8 * g;
-      *reinterpret_cast<f4 *>(y) = acc[0];
-      *reinterpret_cast<f4 *>(y + 4) = acc[1];
+      const HL o0 = split8(hi[0] + lo[0] * kLoInv, hi[1] + lo[1] * kLoInv);
+      const HL o1 = split8(hi[2] + lo[2] * kLoInv, hi[3] + lo[3] * kLoInv);
+      __half *y = Y + (size_t)(m0 + i) * 65536 + ooff;
+      *reinterpret_cast<h8 *>(y) = o0.hi;
+      *reinterpret_cast<h8 *>(y + 8) = o1.hi;
+      *reinterpret_cast<h8 *>(y + 512) = o0.lo;
+      *reinterpret_cast<h8 *>(y + 520) = o1.lo;
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) xb[c] = xn[c];
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Split-K linear (K >> 128, N == 128): DynamicConv's out_layer (decoder_utils.py:624: Linear 49*128 -> 128 on the
-// flattened RoI feature).  grid (row blocks of 16, K slices); a wave owns 32 output columns; partial sums go to a
-// float32 workspace (slice, M, 128), summed by a K_LOAD_PARTS step of the program that follows.
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void splitk_kernel(const float *__restrict__ X, long long ldx,
-                                                     const float *__restrict__ W, float *__restrict__ part, int M,
-                                                     int K, int kslice) {
+constexpr int DC_LD = 132;      // floats per LDS row of the (64 positions x 128 channels) exchange buffer
+__global__ __launch_bounds__(256) void dynconv_kernel(const float *__restrict__ roi, const __half *__restrict__ params,
+                                                      const float *__restrict__ n1w, const float *__restrict__ n1b,
+                                                      const float *__restrict__ n2w, const float *__restrict__ n2b,
+                                                      __half *__restrict__ f2p, int M, float eps) {
+  __shared__ __align__(16) float xs[64 * DC_LD];          // RoI feature, then F1 (position-major)
+  __shared__ float red[4][64];                            // per (wave, position) partial sums
+  const int q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const long long m0 = (long long)blockIdx.x * 16;
-  const long long mr = m0 + i < M ? m0 + i : M - 1;
-  const int kb = blockIdx.y * kslice, ke = min(kb + kslice, K);
-  const float *xr = X + mr * ldx + 4 * g;
-  const float *w0 = W + (size_t)(wave * 32 + i) * K + 4 * g, *w1 = w0 + (size_t)16 * K;
-  f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
-  for (int k0 = kb; k0 < ke; k0 += 64) {                  // 4 chunks of 16 in flight
-    f4 xa[4], wa[4], wb[4];
+  const __half *pq = params + (size_t)q * 65536 + lane * 8;
+  // the wave's parameter fragments of product p: channel blocks nb = 2 wave + nbl, k-steps kk, halves h
+  auto frags = [&](int prod, h8 (&a)[2][8]) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int k = min(k0 + 16 * c, ke - 16);
-      xa[c] = ld4(xr + k);
-      wa[c] = ld4(w0 + k);
-      wb[c] = ld4(w1 + k);
+    for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) a[nbl][qq] = ld_h8(pq + (size_t)(((prod * 8 + 2 * wave + nbl) * 4) * 2 + qq) * 512);
+  };
+  h8 a[2][8];
+  frags(0, a);
+  {                                                       // RoI feature -> LDS (rows >= 49 zero)
+    const float *rq = roi + (size_t)q * 49 * 128;
+    for (int e = tid; e < 64 * 32; e += 256) {
+      const int s = e >> 5, c = (e & 31) * 4;
+      *reinterpret_cast<f4 *>(&xs[s * DC_LD + c]) = s < 49 ? ld4(rq + s * 128 + c) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  f4 acc[2][4];                                           // [channel block][position group]: channel 32 wave + 16 nbl + 4g + r, position 16 pg + i
+  auto product = [&]() {
+#pragma unroll
+    for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+      for (int pg = 0; pg < 4; ++pg) acc[nbl][pg] = f4{0.f, 0.f, 0.f, 0.f};
+    f4 lo[2][4];
+#pragma unroll
+    for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+      for (int pg = 0; pg < 4; ++pg) lo[nbl][pg] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg) {
+      const float *xr = &xs[(16 * pg + i) * DC_LD + 8 * g];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const HL b = split8(ld4(xr + 32 * kk), ld4(xr + 32 * kk + 4));
+#pragma unroll
+        for (int nbl = 0; nbl < 2; ++nbl) mfma3(a[nbl][2 * kk], a[nbl][2 * kk + 1], b, acc[nbl][pg], lo[nbl][pg]);
+      }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (k0 + 16 * c < ke) {
-        acc[0] = mfma4(wa[c], xa[c], acc[0]);
-        acc[1] = mfma4(wb[c], xa[c], acc[1]);
+    for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+      for (int pg = 0; pg < 4; ++pg) acc[nbl][pg] += lo[nbl][pg] * kLoInv;
+  };
+  // LayerNorm over the 128 channels of every position + ReLU: this wave holds 32 channels of each position
+  auto ln_relu = [&](const float *w, const float *b) {
+    float mean[4], inv[4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int pg = 0; pg < 4; ++pg) {
+        float sum = 0.f;
+#pragma unroll
+        for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = pass == 0 ? acc[nbl][pg][r] : acc[nbl][pg][r] - mean[pg];
+            sum += pass == 0 ? d : d * d;
+          }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (g == 0) red[wave][16 * pg + i] = sum;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int pg = 0; pg < 4; ++pg) {
+        const int pp = 16 * pg + i;
+        const float t = (red[0][pp] + red[1][pp]) + (red[2][pp] + red[3][pp]);
+        if (pass == 0) mean[pg] = t * (1.f / 128.f);
+        else inv[pg] = rsqrtf(t * (1.f / 128.f) + eps);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int nbl = 0; nbl < 2; ++nbl) {
+      const int ch = 32 * wave + 16 * nbl + 4 * g;
+      const f4 wv = ld4(w + ch), bv = ld4(b + ch);
+#pragma unroll
+      for (int pg = 0; pg < 4; ++pg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[nbl][pg][r] = fmaxf((acc[nbl][pg][r] - mean[pg]) * inv[pg] * wv[r] + bv[r], 0.f);
+    }
+  };
+  product();                                              // F1^T
+  frags(1, a);                                            // (in flight under the LayerNorm)
+  ln_relu(n1w, n1b);                                      // its last barrier: every wave is done reading the RoI rows
+#pragma unroll
+  for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg) *reinterpret_cast<f4 *>(&xs[(16 * pg + i) * DC_LD + 32 * wave + 16 * nbl + 4 * g]) = acc[nbl][pg];
+  __syncthreads();
+  product();                                              // F2^T
+  ln_relu(n2w, n2b);
+  // f2p[ks = 4 s + wave][q][h * 32 + 16 nbl + 4 g + r]
+#pragma unroll
+  for (int pg = 0; pg < 4; ++pg) {
+    const int sp = 16 * pg + i;
+    if (sp < 49) {
+      __half *o = f2p + ((size_t)(4 * sp + wave) * M + q) * 64 + 4 * g;
+#pragma unroll
+      for (int nbl = 0; nbl < 2; ++nbl) {
+        const HL4 v = split4(acc[nbl][pg]);
+        *reinterpret_cast<h4 *>(o + 16 * nbl) = v.hi;
+        *reinterpret_cast<h4 *>(o + 32 + 16 * nbl) = v.lo;
+      }
+    }
+  }
+}
+
+// Split-K out_layer: grid (row blocks of 16, K slices); a wave owns 32 output columns (2 tiles); k-steps of 32.
+__global__ __launch_bounds__(256) void splitk_kernel(const __half *__restrict__ f2p, const __half *__restrict__ wp,
+                                                     float *__restrict__ part, int M, int nks, int ks_per_slice) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int mr = min(m0 + i, M - 1);
+  const int kb = blockIdx.y * ks_per_slice, ke = min(kb + ks_per_slice, nks);
+  f4 ah[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, al[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+  const __half *w0 = wp + (size_t)(2 * wave) * nks * 1024 + lane * 8, *w1 = w0 + (size_t)nks * 1024;
+  for (int k0 = kb; k0 < ke; k0 += 7) {                    // 7 k-steps in flight (42 x 16 B per lane)
+    HL xb[7];
+    h8 a0h[7], a0l[7], a1h[7], a1l[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+      const int ks = min(k0 + c, ke - 1);
+      const __half *xr = f2p + ((size_t)ks * M + mr) * 64 + 8 * g;
+      xb[c].hi = ld_h8(xr);
+      xb[c].lo = ld_h8(xr + 32);
+      a0h[c] = ld_h8(w0 + (size_t)ks * 1024);
+      a0l[c] = ld_h8(w0 + (size_t)ks * 1024 + 512);
+      a1h[c] = ld_h8(w1 + (size_t)ks * 1024);
+      a1l[c] = ld_h8(w1 + (size_t)ks * 1024 + 512);
+    }
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+      if (k0 + c < ke) {
+        mfma3(a0h[c], a0l[c], xb[c], ah[0], al[0]);
+        mfma3(a1h[c], a1l[c], xb[c], ah[1], al[1]);
       }
   }
   if (m0 + i < M) {
     float *dst = part + ((size_t)blockIdx.y * M + m0 + i) * 128 + wave * 32 + 4 * g;
-    *reinterpret_cast<f4 *>(dst) = acc[0];
-    *reinterpret_cast<f4 *>(dst + 16) = acc[1];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// DynamicConv core (decoder_utils.py:617-622), one workgroup per RoI:
-//     F1 = relu(LN1(roi (49x128) . p1 (128x128)));   F2 = relu(LN2(F1 . p2))         -> F2 (49x128)
-// computed transposed, F1^T = p1^T . roi^T: the accumulators of the first product (4 consecutive channels d of one
-// spatial position per lane) ARE the B operands of the second one (MFMA (nb, r) consumes k <-> d = 16nb + 4g + r).
-// The generated parameters arrive as params[q] = [ p1^T (d, c) | p2^T (e, d) ]: the rows of the generating Linear are
-// permuted once on the host, so both A operands are plain float4 loads.  A wave owns 16 spatial positions.
-// ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dynconv_kernel(const float *__restrict__ roi, const float *__restrict__ params,
-                                                      const float *__restrict__ n1w, const float *__restrict__ n1b,
-                                                      const float *__restrict__ n2w, const float *__restrict__ n2b,
-                                                      float *__restrict__ out, float eps) {
-  const int q = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 15, g = lane >> 4;
-  const int s = wave * 16 + i;                          // spatial position of this lane's column (49 valid)
-  const int sr = s < 49 ? s : 48;
-  const float *rq = roi + ((size_t)q * 49 + sr) * 128 + 4 * g;
-  const float *p1 = params + (size_t)q * 32768 + 4 * g, *p2 = p1 + 16384;
-  f4 xb[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) xb[c] = ld4(rq + 16 * c);
-  f4 acc[8];
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb) {
-    f4 a[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) a[c] = ld4(p1 + (16 * nb + i) * 128 + 16 * c);
-    f4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 8; ++c) v = mfma4(a[c], xb[c], v);
-    acc[nb] = v;                                        // F1^T[d = 16nb + 4g + r][position i]
-  }
-  // LayerNorm over the 128 channels of position s: lane holds d = 16nb + 4g + r; the other 96 live in lanes i + 16g'
-  auto ln_relu = [&](f4 (&v)[8], const float *w, const float *b) {
-    float sum = 0.f;
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) sum += v[nb][0] + v[nb][1] + v[nb][2] + v[nb][3];
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.f / 128.f);
-    float ss = 0.f;
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = v[nb][r] - mean;
-        ss += d * d;
-      }
-    ss += __shfl_xor(ss, 16);
-    ss += __shfl_xor(ss, 32);
-    const float inv = rsqrtf(ss * (1.f / 128.f) + eps);
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      const f4 wv = ld4(w + 16 * nb + 4 * g), bv = ld4(b + 16 * nb + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[nb][r] = fmaxf((v[nb][r] - mean) * inv * wv[r] + bv[r], 0.f);
-    }
-  };
-  ln_relu(acc, n1w, n1b);
-  f4 acc2[8];
-#pragma unroll
-  for (int ne = 0; ne < 8; ++ne) {
-    f4 a[8];
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) a[nb] = ld4(p2 + (16 * ne + i) * 128 + 16 * nb);   // p2^T[e = 16ne + i][d = 16nb + 4g + r]
-    f4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) v = mfma4(a[nb], acc[nb], v);
-    acc2[ne] = v;
-  }
-  ln_relu(acc2, n2w, n2b);
-  if (s < 49) {
-    float *o = out + ((size_t)q * 49 + s) * 128 + 4 * g;
-#pragma unroll
-    for (int ne = 0; ne < 8; ++ne) *reinterpret_cast<f4 *>(o + 16 * ne) = acc2[ne];
+    *reinterpret_cast<f4 *>(dst) = ah[0] + al[0] * kLoInv;
+    *reinterpret_cast<f4 *>(dst + 16) = ah[1] + al[1] * kLoInv;
   }
 }
 
@@ -601,6 +909,7 @@ static int check_program(const di_tok_step *steps, int n, const di_tok_heads *he
   for (int i = 0; i < n; ++i) {
     const di_tok_step &s = steps[i];
     auto okbuf = [](int b) { return b >= 0 && b < NBUF; };
+    DI_REQUIRE(s.role_lo >= 0 && s.role_hi >= s.role_lo && s.role_hi < 16, "step %d: bad role range [%d, %d]", i, s.role_lo, s.role_hi);
     switch (s.kind) {
       case DI_TOK_LOAD:
         DI_REQUIRE(okbuf(s.dst) && s.p0 && s.K > 0 && s.K % 4 == 0 && s.a >= 0 && s.a % 4 == 0 && s.a + s.K <= 512,
@@ -617,9 +926,9 @@ static int check_program(const di_tok_step *steps, int n, const di_tok_heads *he
         DI_REQUIRE(okbuf(s.dst) && s.p0 && s.a > 0, "step %d (combine): bad arguments", i);
         break;
       case DI_TOK_LINEAR:
-        DI_REQUIRE(okbuf(s.src) && okbuf(s.dst) && s.src != s.dst && s.p0 && s.K > 0 && s.K % 16 == 0 && s.K <= 512 &&
-                       s.N > 0 && s.N % 16 == 0 && s.N <= 512 && s.a >= 0 && s.a <= 2,
-                   "step %d (linear): K, N multiples of 16 up to 512, src != dst", i);
+        DI_REQUIRE(okbuf(s.src) && okbuf(s.dst) && s.src != s.dst && s.p0 && s.K > 0 && s.K % 128 == 0 &&
+                       s.K <= 512 && s.N > 0 && s.N % 16 == 0 && s.N <= 512 && s.a >= 0 && s.a <= 2,
+                   "step %d (linear): K multiple of 128, N of 16, both <= 512, src != dst, packed weight in p0", i);
         break;
       case DI_TOK_ROWOP:
         DI_REQUIRE(okbuf(s.src) && okbuf(s.dst) && s.aux < NBUF && (s.p0 == nullptr) == (s.p1 == nullptr),
@@ -647,7 +956,8 @@ static int check_program(const di_tok_step *steps, int n, const di_tok_heads *he
 
 extern "C" {
 
-int di_token_program(const di_tok_step *steps, int nsteps, const di_tok_heads *heads, int B, int Q, void *stream) {
+static int launch_program(const di_tok_step *steps, int nsteps, const di_tok_heads *heads, int B, int Q,
+                          unsigned long long *stamps, void *stream) {
   using namespace di::t32;
   static_assert(sizeof(Step) == sizeof(di_tok_step) && sizeof(Heads) == sizeof(di_tok_heads), "C ABI structs");
   DI_REQUIRE(B > 0 && Q > 0, "bad token program shape B=%d Q=%d", B, Q);
@@ -660,34 +970,48 @@ int di_token_program(const di_tok_step *steps, int nsteps, const di_tok_heads *h
   if (heads != nullptr) memcpy(&h, heads, sizeof(h));
   static di::LdsRaised raised;
   if (int rc = di::ensure_lds(raised, (const void *)program_kernel, LDS_BYTES)) return rc;
-  hipLaunchKernelGGL(program_kernel, dim3((Q + TM - 1) / TM, B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, prog, h, Q);
+  static const int touch = getenv("DI_TOK_TOUCH") ? atoi(getenv("DI_TOK_TOUCH")) : 1;
+  int roles = 1;
+  for (int i = 0; i < nsteps; ++i) roles = steps[i].role_hi + 1 > roles ? steps[i].role_hi + 1 : roles;
+  hipLaunchKernelGGL(program_kernel, dim3((Q + TM - 1) / TM, B, roles), dim3(NTH), LDS_BYTES, (hipStream_t)stream, prog, h, Q,
+                     touch, stamps);
   return di::check_launch("token_program");
 }
 
-int di_token_wide(const float *x, int ldx, const float *w, const float *bias, float *y, long long ldy, int M, int N,
-                  void *stream) {
-  DI_REQUIRE(x && w && y && M > 0 && N > 0 && N % 128 == 0, "bad wide linear shape M=%d N=%d (N multiple of 128, K = 128)", M, N);
-  hipLaunchKernelGGL(di::t32::wide_kernel, dim3(N / 128), dim3(256), 0, (hipStream_t)stream, x, ldx, w, bias, y, ldy, M, N);
+int di_token_program(const di_tok_step *steps, int nsteps, const di_tok_heads *heads, int B, int Q, void *stream) {
+  return launch_program(steps, nsteps, heads, B, Q, nullptr, stream);
+}
+
+int di_token_program_timed(const di_tok_step *steps, int nsteps, const di_tok_heads *heads, int B, int Q,
+                           unsigned long long *stamps, void *stream) {
+  DI_REQUIRE(stamps != nullptr, "di_token_program_timed needs nsteps + 1 stamps");
+  return launch_program(steps, nsteps, heads, B, Q, stamps, stream);
+}
+
+int di_token_wide(const float *x, int ldx, const void *w_packed, const float *bias, void *params, int M, void *stream) {
+  DI_REQUIRE(x && w_packed && params && M > 0, "bad parameter generator call M=%d", M);
+  hipLaunchKernelGGL(di::t32::wide_kernel, dim3(32768 / 128), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     (const __half *)w_packed, bias, (__half *)params, M);
   return di::check_launch("token_wide");
 }
 
-long long di_token_splitk_workspace_bytes(int M, int K) { return (long long)((K + 447) / 448) * M * 128 * 4; }
+long long di_token_splitk_workspace_bytes(int M, int K) { return (long long)((K / 32 + 13) / 14) * M * 128 * 4; }
 
-int di_token_splitk(const float *x, long long ldx, const float *w, float *workspace, int M, int K, int *nslices,
-                    void *stream) {
-  DI_REQUIRE(x && w && workspace && M > 0 && K > 0 && K % 16 == 0, "bad split-K shape M=%d K=%d (N = 128)", M, K);
-  const int kslice = 448, ns = (K + kslice - 1) / kslice;
-  hipLaunchKernelGGL(di::t32::splitk_kernel, dim3((M + 15) / 16, ns), dim3(256), 0, (hipStream_t)stream, x, ldx, w,
-                     workspace, M, K, kslice);
+int di_token_splitk(const void *f2p, const void *w_packed, float *workspace, int M, int K, int *nslices, void *stream) {
+  DI_REQUIRE(f2p && w_packed && workspace && M > 0 && K >= 32 && K % 32 == 0,
+             "bad split-K shape M=%d K=%d (N = 128, K multiple of 32)", M, K);
+  const int nks = K / 32, per = 14, ns = (nks + per - 1) / per;
+  hipLaunchKernelGGL(di::t32::splitk_kernel, dim3((M + 15) / 16, ns), dim3(256), 0, (hipStream_t)stream,
+                     (const __half *)f2p, (const __half *)w_packed, workspace, M, nks, per);
   if (nslices) *nslices = ns;
   return di::check_launch("token_splitk");
 }
 
-int di_dynconv_fwd(const float *roi, const float *params, const float *n1w, const float *n1b, const float *n2w,
-                   const float *n2b, float *out, int R, float eps, void *stream) {
-  DI_REQUIRE(R > 0 && roi && params && out && n1w && n1b && n2w && n2b, "bad DynamicConv call R=%d", R);
-  hipLaunchKernelGGL(di::t32::dynconv_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, roi, params, n1w, n1b, n2w, n2b,
-                     out, eps);
+int di_dynconv_fwd(const float *roi, const void *params, const float *n1w, const float *n1b, const float *n2w,
+                   const float *n2b, void *f2p, int R, float eps, void *stream) {
+  DI_REQUIRE(R > 0 && roi && params && f2p && n1w && n1b && n2w && n2b, "bad DynamicConv call R=%d", R);
+  hipLaunchKernelGGL(di::t32::dynconv_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, roi, (const __half *)params, n1w,
+                     n1b, n2w, n2b, (__half *)f2p, R, eps);
   return di::check_launch("dynconv_fwd");
 }
 

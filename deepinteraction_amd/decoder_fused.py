@@ -37,12 +37,12 @@ def usable(dec, lidar_feat, img_feat):
         if type(blk) is not (ImageRCNNBlock if l % 2 == 0 else PointRCNNBlock):
             return False
         sfx = '' if l % 2 == 0 else '_pts'
-        if getattr(blk, 'linear1' + sfx).out_features > 512:
+        if getattr(blk, 'linear1' + sfx).out_features not in (128, 256, 384, 512):
             return False
     layer = dec.decoder[0]
     if layer.cross_only or layer.self_posembed is None or layer.cross_posembed is None:
         return False
-    if layer.activation is not F.relu or layer.linear1.out_features > 512 or layer.linear1.out_features % 16:
+    if layer.activation is not F.relu or layer.linear1.out_features not in (128, 256, 384, 512):
         return False
     for head in (dec.heatmap_head, dec.heatmap_head_img):
         cm, last = head[0], head[1]
@@ -72,19 +72,44 @@ def _f32(t):
     return t.detach().float().contiguous()
 
 
-def _dyn_perm(device):
-    """Row permutation of DynamicConv.dynamic_layer that makes the generated parameters arrive as
-    [p1^T (d, c) | p2^T (e, d)] (csrc/token32.hip dynconv_kernel): mine[d*128 + c] = ref[c*128 + d],
-    mine[16384 + e*128 + d] = ref[16384 + d*128 + e]."""
-    a = torch.arange(128).view(128, 1)
-    b = torch.arange(128).view(1, 128)
-    t = (b * 128 + a).reshape(-1)
-    return torch.cat([t, 16384 + t]).to(device)
+def _dyn_value_order(device):
+    """ref[V]: the index into DynamicConv.dynamic_layer's 32 768 outputs of value V of the fragment order
+    (csrc/token32.hip): V = (((p*8 + nb)*4 + kk)*64 + 16g + i)*8 + j;  p = 0: p1[c = 32kk + 8g + j][d = 16nb + i] (index
+    c*128 + d), p = 1: p2[d = 32kk + 8g + j][e = 16nb + i] (index 16384 + d*128 + e)."""
+    V = torch.arange(32768)
+    j, lane, kk, nb, pr = V % 8, (V // 8) % 64, (V // 512) % 4, (V // 2048) % 8, V // 16384
+    i, g = lane % 16, lane // 16
+    k = 32 * kk + 8 * g + j
+    n = 16 * nb + i
+    return (pr * 16384 + k * 128 + n).to(device)
+
+
+def _dyn_layout(weight, bias):
+    """(w_packed, bias_v) of `ops.token_wide` from DynamicConv.dynamic_layer: rows in value order, then the MFMA row
+    mapping of the generator kernel (a wave's 64 values V0..: row i' of tile nb <-> V0 + 16 (i' >> 2) + 4 nb + (i' & 3)),
+    then `ops.pack_linear`."""
+    dev = weight.device
+    ref = _dyn_value_order(dev)
+    wv, bv = weight.detach().float()[ref], bias.detach().float()[ref].contiguous()
+    r = torch.arange(32768, device=dev)
+    wq, nb, ip = r // 64, (r % 64) // 16, r % 16
+    rows = 64 * wq + 16 * (ip // 4) + 4 * nb + (ip % 4)
+    return ops.pack_linear(wv[rows]), bv
+
+
+def _split(w):
+    """float32 weight -> the (hi, lo) fp16 pair of the three-pass MFMA product."""
+    return ops.split_hi_lo(w)
+
+
+def _pack(w):
+    """float32 weight of a program's linear step, packed in MFMA fragment order (hi / lo split)."""
+    return ops.pack_linear(w.detach().float())
 
 
 def _mha_consts(mha):
-    """(in_proj_weight (3E,E), in_proj_bias, out_proj.weight, out_proj.bias), float32."""
-    return (_f32(mha.in_proj_weight), _f32(mha.in_proj_bias), _f32(mha.out_proj.weight), _f32(mha.out_proj.bias))
+    """(in_proj_weight (3E,E) packed, in_proj_bias, out_proj.weight packed, out_proj.bias)."""
+    return (_pack(mha.in_proj_weight), _f32(mha.in_proj_bias), _pack(mha.out_proj.weight), _f32(mha.out_proj.bias))
 
 
 def _ln(norm):
@@ -97,7 +122,7 @@ def _heads_consts(ffn):
     for h, n in enumerate(sizes):
         rows.append(W2[col:col + n, h * 64:(h + 1) * 64])
         col += n
-    return (W1.contiguous(), b1.contiguous(), torch.cat(rows).contiguous(), b2.contiguous(), list(sizes))
+    return (_pack(W1), b1.contiguous(), torch.cat(rows).contiguous(), b2.contiguous(), list(sizes))
 
 
 class FusedDecoder:
@@ -115,15 +140,15 @@ class FusedDecoder:
 
         def build():
             sa, dy = g('dyconv_pre_self_attn'), g('dyconv')
-            perm = _dyn_perm(dy.dynamic_layer.weight.device)
+            wd, bd = _dyn_layout(dy.dynamic_layer.weight, dy.dynamic_layer.bias)
             return dict(sa=_mha_consts(sa), scale=float(sa.head_dim) ** -0.5,
                         n1=_ln(g('norm1')), n2=_ln(g('norm2')), n3=_ln(g('norm3')),
                         eps=(g('norm1').eps, g('norm2').eps, g('norm3').eps),
-                        wd=_f32(dy.dynamic_layer.weight)[perm].contiguous(), bd=_f32(dy.dynamic_layer.bias)[perm].contiguous(),
+                        wd=wd, bd=bd,
                         dn1=_ln(dy.norm1), dn2=_ln(dy.norm2), dn3=_ln(dy.norm3), deps=(dy.norm1.eps, dy.norm3.eps),
-                        wout=_f32(dy.out_layer.weight), bout=_f32(dy.out_layer.bias),
-                        w1=_f32(g('linear1').weight), b1=_f32(g('linear1').bias),
-                        w2=_f32(g('linear2').weight), b2=_f32(g('linear2').bias))
+                        wout=ops.pack_ksteps(dy.out_layer.weight.detach().float()), bout=_f32(dy.out_layer.bias),
+                        w1=_pack(g('linear1').weight), b1=_f32(g('linear1').bias),
+                        w2=_pack(g('linear2').weight), b2=_f32(g('linear2').bias))
         return self._c(('blk', id(blk)), blk, build)
 
     def _layer_consts(self, layer):
@@ -133,8 +158,9 @@ class FusedDecoder:
                         ca_scale=float(ca.head_dim) ** -0.5,
                         n1=_ln(layer.norm1), n2=_ln(layer.norm2), n3=_ln(layer.norm3),
                         eps=(layer.norm1.eps, layer.norm2.eps, layer.norm3.eps),
-                        w1=_f32(layer.linear1.weight), b1=_f32(layer.linear1.bias),
-                        w2=_f32(layer.linear2.weight), b2=_f32(layer.linear2.bias))
+                        w1=_pack(layer.linear1.weight), b1=_f32(layer.linear1.bias),
+                        w2=_pack(layer.linear2.weight), b2=_f32(layer.linear2.bias),
+                        wq=_pack(_f32(ca.in_proj_weight)[:ca.embed_dim]), bq=_f32(ca.in_proj_bias)[:ca.embed_dim].contiguous())
         return self._c('layer', layer, build)
 
     def _kv_consts(self, layer, bev_pos):
@@ -161,13 +187,28 @@ class FusedDecoder:
         return (w1, b1, _f32(c2.weight[:, :, 0]), _f32(c2.bias))
 
     # ------------------------------------------------------------------ pieces
+    @staticmethod
+    def _heads_and_next(p, x_buf, hid_buf, qkv_buf, heads, nxt, qkv_out):
+        """Tail of a stage on the rows in buf[x_buf] (`K` = 128, or 256 with the previous tokens at columns 128..255):
+        roles 0..nheads-1 evaluate one prediction head each (hidden 64 channels), roles nheads..nheads+2 one 128-column
+        third of the NEXT block's packed self-attention projection."""
+        nh = len(heads['cls'])
+        hw1, hb1 = heads.pop('w1'), heads.pop('b1')
+        p.linear(x_buf, hid_buf, hw1, hb1, act=1, roles=(0, nh - 1), n_per_role=64)
+        p.heads(hid_buf, roles=(0, nh - 1), per_role=True, **heads)
+        if nxt is not None:
+            p.linear(x_buf, qkv_buf, nxt[0], nxt[1], roles=(nh, nh + 2), n_per_role=128)
+            p.store(qkv_buf, qkv_out, roles=(nh, nh + 2), n=128, role_offset=128)
+
     def _block(self, blk, sfx, x, qkv, roi, B, Q, heads, next_qkv_w, member=None, view=None, keep=None):
         """decoder_utils.py:743-756 / :824-837 on tokens x (B*Q,128) whose packed self-attention projection `qkv` the
         previous program wrote, then this stage's prediction heads (`heads` = the arguments of TokenProgram.heads, on
-        [x' ; x]) and the next block's packed projection.  Returns (x', qkv')."""
+        [x' ; x]) and the next block's packed projection.  Returns (x', qkv').  Three programs around the DynamicConv
+        kernels; the weights of a token group are spread over the roles (<= 128 KB per workgroup)."""
         c = self._block_consts(blk, sfx)
         M, dev = B * Q, x.device
-        y = torch.empty((M, 128), dtype=torch.float32, device=dev)
+        f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        y = f32e(M, 128)
         p = ops.TokenProgram()
         p.attn(0, qkv, c['scale'], member, view)
         p.linear(0, 1, c['sa'][2], c['sa'][3])
@@ -175,27 +216,32 @@ class FusedDecoder:
         p.rowop(1, 1, aux=2, ln=c['n1'], eps=c['eps'][0])
         p.store(1, y)
         p.run(B, Q)
-        params = ops.token_wide(y, c['wd'], c['bd'])                                 # (M, 2*128*128), fused layout
-        f2 = ops.dynconv(roi, params, c['dn1'], c['dn2'], c['deps'][0])
-        ws, ns = ops.token_splitk(f2.view(M, -1), c['wout'])
-        xn = torch.empty((M, 128), dtype=torch.float32, device=dev)
-        qkv_n = torch.empty((M, 384), dtype=torch.float32, device=dev) if next_qkv_w is not None else None
-        p = ops.TokenProgram()
+        params = ops.token_wide(y, c['wd'], c['bd'])                                 # (M, 65536) hi / lo fragments
+        f2p = ops.dynconv(roi, params, c['dn1'], c['dn2'], c['deps'][0])
+        ws, ns = ops.token_splitk(f2p, c['wout'])
+        # FFN with the hidden dimension split over the roles: role r holds hidden channels [128r, 128r + 128)
+        nh = c['w1'].shape[0] * 16 // 128
+        z, ws2 = f32e(M, 128), f32e(nh, M, 128)
+        p = ops.TokenProgram(roles=nh)
         p.load_parts(0, ws, ns, M, c['bout'])
         p.rowop(0, 0, ln=c['dn3'], eps=c['deps'][1], relu=True)
         p.load(1, y)
         p.rowop(0, 0, aux=1, ln=c['n2'], eps=c['eps'][1])                            # z
-        p.linear(0, 1, c['w1'], c['b1'], act=2)
-        p.linear(1, 2, c['w2'], c['b2'])
+        p.store(0, z, roles=(0, 0))
+        p.linear(0, 1, c['w1'], c['b1'], act=2, n_per_role=128)
+        p.linear(1, 2, c['w2'], None, k_per_role=128)
+        p.store(2, ws2, n=128, role_offset=M * 128)
+        p.run(B, Q)
+        nhd = len(heads['cls'])
+        xn = f32e(M, 128)
+        qkv_n = f32e(M, 384) if next_qkv_w is not None else None
+        p = ops.TokenProgram(roles=nhd + (3 if next_qkv_w is not None else 0))
+        p.load_parts(2, ws2, nh, M, c['b2'])
+        p.load(0, z)
         p.rowop(2, 2, aux=0, ln=c['n3'], eps=c['eps'][2], keep=keep)                 # x'
-        p.store(2, xn)
+        p.store(2, xn, roles=(0, 0))
         p.load(2, x, col=128)                                                        # [x' ; x]
-        hw1, hb1 = heads.pop('w1'), heads.pop('b1')
-        p.linear(2, 0, hw1, hb1, act=1)
-        p.heads(0, **heads)
-        if next_qkv_w is not None:
-            p.linear(2, 1, next_qkv_w[0], next_qkv_w[1])
-            p.store(1, qkv_n)
+        self._heads_and_next(p, 2, 0, 1, heads, next_qkv_w, qkv_n)
         p.run(B, Q)
         return xn, qkv_n
 
@@ -246,37 +292,47 @@ class FusedDecoder:
         # ---- decoder layer (decoder_utils.py:83-113: post-norm; positional embeddings added to q, k and v)
         c = self._layer_consts(layer)
         qkv = f32e(M, 384)
-        p = ops.TokenProgram()
-        p.load(0, x, pos=qpe).linear(0, 1, c['sa'][0], c['sa'][1]).store(1, qkv)
+        p = ops.TokenProgram(roles=3)                                                # a third of the packed projection each
+        p.load(0, x, pos=qpe).linear(0, 1, c['sa'][0], c['sa'][1], n_per_role=128).store(1, qkv, n=128, role_offset=128)
         p.run(B, Q)
         x1, qc = f32e(M, 128), f32e(M, 128)
         p = ops.TokenProgram()
         p.attn(0, qkv, c['sa_scale'])
         p.linear(0, 1, c['sa'][2], c['sa'][3])
-        p.load(2, x)
+        p.load(2, x).load(0, qpe)
         p.rowop(1, 1, aux=2, ln=c['n1'], eps=c['eps'][0])                            # x1
         p.store(1, x1)
-        p.load(0, qpe)
         p.rowop(0, 0, aux=1)                                                         # x1 + qpe
-        p.linear(0, 2, c['ca'][0][:128], c['ca'][1][:128])
+        p.linear(0, 2, c['wq'], c['bq'])
         p.store(2, qc)
         p.run(B, Q)
         scratch, nrange = ops.mha_decode_x(qc.view(B, Q, 128), kx, c['ca_scale'])
-        x3, qkv_b = f32e(M, 128), f32e(M, 384)
-        pos1 = f32e(B, Q, 2)
+        x2 = f32e(M, 128)
         p = ops.TokenProgram()
         p.combine(0, scratch, nrange)
         p.linear(0, 1, c['ca'][2], c['ca'][3])
         p.load(2, x1)
         p.rowop(1, 1, aux=2, ln=c['n2'], eps=c['eps'][1])                            # x2
-        p.linear(1, 0, c['w1'], c['b1'], act=1)
-        p.linear(0, 2, c['w2'], c['b2'])
+        p.store(1, x2)
+        p.run(B, Q)
+        nh = c['w1'].shape[0] * 16 // 128                                            # FFN: hidden dimension split over the roles
+        wsf = f32e(nh, M, 128)
+        p = ops.TokenProgram(roles=nh)
+        p.load(0, x2)
+        p.linear(0, 1, c['w1'], c['b1'], act=1, n_per_role=128)
+        p.linear(1, 2, c['w2'], None, k_per_role=128)
+        p.store(2, wsf, n=128, role_offset=M * 128)
+        p.run(B, Q)
+        x3, qkv_b = f32e(M, 128), f32e(M, 384)
+        pos1 = f32e(B, Q, 2)
+        p = ops.TokenProgram(roles=len(cls) + 3)
+        p.load_parts(2, wsf, nh, M, c['b2'])
+        p.load(1, x2)
         p.rowop(2, 2, aux=1, ln=c['n3'], eps=c['eps'][2])                            # x3
-        p.store(2, x3)
-        p.linear(2, 0, heads0[0], heads0[1], act=1)
-        p.heads(0, w2=heads0[2], b2=heads0[3], qpos=pos, outs=first, cls=cls, center_head=ic, ldo=Q, col0=0, pos_out=pos1)
-        p.linear(2, 1, blk_consts[0]['sa'][0], blk_consts[0]['sa'][1])
-        p.store(1, qkv_b)
+        p.store(2, x3, roles=(0, 0))
+        self._heads_and_next(p, 2, 0, 1, dict(w1=heads0[0], b1=heads0[1], w2=heads0[2], b2=heads0[3], qpos=pos, outs=first,
+                                              cls=cls, center_head=ic, ldo=Q, col0=0, pos_out=pos1),
+                             (blk_consts[0]['sa'][0], blk_consts[0]['sa'][1]), qkv_b)
         p.run(B, Q)
         x, pos = x3, pos1
 

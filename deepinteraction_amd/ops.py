@@ -754,15 +754,20 @@ def _f32c(t):
 
 class TokenProgram:
     """One launch of `di_token_program` (csrc/token32.hip): a short program of steps that every group of 16 consecutive
-    tokens of a sample runs on rows held in LDS buffers 0..2 (512 floats wide).  The builder keeps the tensors it was
-    given alive until `run` has launched."""
+    tokens of a sample runs on rows held in LDS buffers 0..2 (512 floats wide).  `roles` > 1 launches that many
+    workgroups per token group; a step runs in the roles of its `roles=(lo, hi)` range (default: all) - see
+    include/deepinteraction_hip.h.  The builder keeps the tensors it was given alive until `run` has launched."""
 
-    def __init__(self):
-        self.steps, self.refs, self.head_desc = [], [], None
+    def __init__(self, roles=1):
+        self.steps, self.refs, self.head_desc, self.roles = [], [], None, roles
 
-    def _add(self, kind, src=0, dst=0, aux=-1, K=0, N=0, a=0, b=0, f=0.0, p0=None, p1=None, p2=None, ld0=0, ld1=0):
+    def _add(self, kind, src=0, dst=0, aux=-1, K=0, N=0, a=0, b=0, f=0.0, p0=None, p1=None, p2=None, ld0=0, ld1=0,
+             roles=None, rt=0, rc=0, nch=0, roff=0):
         st = _lib.TokStep()
         st.kind, st.src, st.dst, st.aux, st.K, st.N, st.a, st.b, st.f = kind, src, dst, aux, K, N, a, b, float(f)
+        st.role_lo, st.role_hi = (0, self.roles - 1) if roles is None else roles
+        assert 0 <= st.role_lo <= st.role_hi < self.roles
+        st.rt, st.rc, st.nch, st.roff = rt, rc, nch, roff
         for name, t in (('p0', p0), ('p1', p1), ('p2', p2)):
             if t is not None:
                 _dev(t)
@@ -772,44 +777,62 @@ class TokenProgram:
         self.steps.append(st)
         return self
 
-    def load(self, dst, x, pos=None, col=0):
+    def load(self, dst, x, pos=None, col=0, roles=None):
         """buf[dst][:, col:col+K] = x (+ pos); x, pos (M,K) float32."""
         _f32c(x)
         if pos is not None:
             assert _f32c(pos).shape == x.shape
         return self._add(_lib.TOK_LOAD, dst=dst, K=x.shape[1], a=col, p0=x, p1=pos, ld0=x.stride(0),
-                         ld1=0 if pos is None else pos.stride(0))
+                         ld1=0 if pos is None else pos.stride(0), roles=roles)
 
-    def load_parts(self, dst, workspace, nslices, total_rows, bias=None):
-        """buf[dst][:, :128] = sum of the split-K partial sums (+ bias)."""
-        return self._add(_lib.TOK_LOAD_PARTS, dst=dst, a=nslices, b=total_rows, p0=workspace, p1=bias)
+    def load_parts(self, dst, workspace, nslices, total_rows, bias=None, roles=None):
+        """buf[dst][:, :128] = sum of the partial sums workspace (nslices, total_rows, 128) (+ bias)."""
+        return self._add(_lib.TOK_LOAD_PARTS, dst=dst, a=nslices, b=total_rows, p0=workspace, p1=bias, roles=roles)
 
-    def attn(self, dst, qkv, scale, member=None, view=None):
+    def attn(self, dst, qkv, scale, member=None, view=None, roles=None):
         """buf[dst][:, :128] = self attention (8 heads x 16) among the sample's tokens from qkv (M, 384) = [q|k|v]."""
         assert _f32c(qkv).shape[1] == 384 and (member is None) == (view is None)
         return self._add(_lib.TOK_ATTN, dst=dst, f=scale * 1.4426950408889634, p0=qkv, p1=member, p2=view,
-                         ld0=qkv.stride(0))
+                         ld0=qkv.stride(0), roles=roles)
 
-    def combine(self, dst, scratch, nrange):
+    def combine(self, dst, scratch, nrange, roles=None):
         """buf[dst][:, :128] = merged key-range states of `mha_decode_x`."""
-        return self._add(_lib.TOK_COMBINE, dst=dst, a=nrange, p0=scratch)
+        return self._add(_lib.TOK_COMBINE, dst=dst, a=nrange, p0=scratch, roles=roles)
 
-    def linear(self, src, dst, w, bias=None, act=0):
-        """buf[dst][:, :N] = act(buf[src][:, :K] @ w.T + bias); w (N,K) float32; act 0 none / 1 ReLU / 2 GELU."""
-        assert _f32c(w).is_contiguous() and (bias is None or (_f32c(bias).numel() == w.shape[0]))
-        return self._add(_lib.TOK_LINEAR, src=src, dst=dst, K=w.shape[1], N=w.shape[0], a=act, p0=w, p1=bias)
+    def linear(self, src, dst, w, bias=None, act=0, roles=None, n_per_role=None, k_per_role=None):
+        """buf[dst][:, :N] = act(buf[src][:, :K] @ W.T + bias); w = `pack_linear(W)` for W (N,K) float32; act 0 none / 1 ReLU
+        / 2 GELU.  n_per_role: role r of `roles` computes output channels [r*n, (r+1)*n) (into buf[dst][:, :n]);
+        k_per_role: role r multiplies input channels [r*k, (r+1)*k) (from buf[src][:, :k]) - a partial sum, no bias."""
+        assert w.dtype == torch.float16 and w.dim() == 6 and w.is_contiguous()
+        N, K = w.shape[0] * 16, w.shape[1] * 128
+        assert bias is None or (_f32c(bias).numel() == N)
+        rt = rc = 0
+        if n_per_role is not None:
+            assert n_per_role % 16 == 0
+            rt, N = n_per_role // 16, n_per_role
+        if k_per_role is not None:
+            assert k_per_role % 128 == 0 and bias is None
+            rc, K = k_per_role // 128, k_per_role
+        return self._add(_lib.TOK_LINEAR, src=src, dst=dst, K=K, N=N, a=act, p0=w, p1=bias, roles=roles, rt=rt, rc=rc,
+                         nch=w.shape[1])
 
-    def rowop(self, src, dst, aux=-1, ln=None, eps=1e-5, relu=False, keep=None):
+    def rowop(self, src, dst, aux=-1, ln=None, eps=1e-5, relu=False, keep=None, roles=None):
         """buf[dst][:, :128] = keep * relu?(LayerNorm?(buf[src] + buf[aux]?))."""
         lw, lb = ln if ln is not None else (None, None)
-        return self._add(_lib.TOK_ROWOP, src=src, dst=dst, aux=aux, b=int(bool(relu)), f=eps, p0=lw, p1=lb, p2=keep)
+        return self._add(_lib.TOK_ROWOP, src=src, dst=dst, aux=aux, b=int(bool(relu)), f=eps, p0=lw, p1=lb, p2=keep,
+                         roles=roles)
 
-    def store(self, src, y, col=0):
-        """y (M,N) = buf[src][:, col:col+N]."""
-        return self._add(_lib.TOK_STORE, src=src, N=_f32c(y).shape[1], a=col, p0=y, ld0=y.stride(0))
+    def store(self, src, y, col=0, roles=None, n=None, role_offset=0):
+        """y (M,N) = buf[src][:, col:col+N]; with n / role_offset: role r stores n columns at y + r * role_offset elements
+        (columns r*n.. of a wider row, or slice r of a (roles, M, n) workspace)."""
+        _f32c(y)
+        return self._add(_lib.TOK_STORE, src=src, N=y.shape[-1] if n is None else n, a=col, p0=y, ld0=y.stride(-2),
+                         roles=roles, roff=role_offset)
 
-    def heads(self, src, w2, b2, qpos, outs, cls, center_head, ldo, col0, keep=None, first=None, pos_out=None):
-        """Second layers of the prediction heads on the hidden rows in buf[src] (see include/deepinteraction_hip.h)."""
+    def heads(self, src, w2, b2, qpos, outs, cls, center_head, ldo, col0, keep=None, first=None, pos_out=None, roles=None,
+              per_role=False):
+        """Second layers of the prediction heads on the hidden rows in buf[src] (see include/deepinteraction_hip.h);
+        per_role: role r evaluates head r only, its 64 hidden channels at columns 0..63."""
         h = _lib.TokHeads()
         n = len(cls)
         assert n <= _lib.TOK_MAX_HEADS and (keep is None or first is not None)
@@ -823,50 +846,73 @@ class TokenProgram:
         h.nheads, h.center_head, h.ldo, h.col0 = n, center_head, ldo, col0
         self.refs += [w2, b2, qpos, keep, pos_out] + list(outs) + (list(first) if first is not None else [])
         self.head_desc = h
-        return self._add(_lib.TOK_HEADS, src=src)
+        return self._add(_lib.TOK_HEADS, src=src, a=int(bool(per_role)), roles=roles)
 
-    def run(self, B, Q):
+    def run(self, B, Q, stamps=None):
+        """Launch.  `stamps` (int64 (nsteps + 1,), device): profiling aid - shader-clock stamps of workgroup (0,0,0)."""
         n = len(self.steps)
         arr = (_lib.TokStep * n)(*self.steps)
         hp = ctypes.addressof(self.head_desc) if self.head_desc is not None else 0
-        _lib.call('di_token_program', ctypes.addressof(arr), n, hp, B, Q, _stream())
+        if stamps is None:
+            _lib.call('di_token_program', ctypes.addressof(arr), n, hp, B, Q, _stream())
+        else:
+            assert stamps.dtype == torch.int64 and stamps.numel() >= n + 1
+            _lib.call('di_token_program_timed', ctypes.addressof(arr), n, hp, B, Q, stamps.data_ptr(), _stream())
 
 
-def token_wide(x, w, bias=None):
-    """x (M,128) @ w (N,128).T + bias -> (M,N) float32, weight stationary (DynamicConv's parameter generator)."""
-    _dev(x, w)
-    _f32c(x), _f32c(w)
-    M, N = x.shape[0], w.shape[0]
-    assert x.shape[1] == 128 and w.shape[1] == 128 and w.is_contiguous()
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    _lib.call('di_token_wide', x.data_ptr(), x.stride(0), w.data_ptr(), 0 if bias is None else bias.data_ptr(),
-              y.data_ptr(), y.stride(0), M, N, _stream())
+def token_wide(x, w_packed, bias):
+    """DynamicConv's parameter generator (weight stationary): x (M,128) float32 -> params (M, 65536) fp16, the hi / lo
+    fragments `dynconv` reads; w_packed, bias from `decoder_fused._dyn_layout`."""
+    _dev(x, w_packed)
+    _f32c(x)
+    M = x.shape[0]
+    assert x.shape[1] == 128 and w_packed.dtype == torch.float16 and w_packed.numel() == 32768 * 128 * 2 and w_packed.is_contiguous()
+    assert bias.dtype == torch.float32 and bias.numel() == 32768
+    y = torch.empty((M, 65536), dtype=torch.float16, device=x.device)
+    _lib.call('di_token_wide', x.data_ptr(), x.stride(0), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), M, _stream())
     return y
 
 
-def token_splitk(x, w):
-    """Partial sums of x (M,K) @ w (128,K).T over K slices -> (workspace float32 (slices, M, 128), slices)."""
-    _dev(x, w)
-    _f32c(x), _f32c(w)
-    M, K = x.shape
-    assert w.shape == (128, K) and w.is_contiguous()
-    ws = torch.empty(int(_lib.lib().di_token_splitk_workspace_bytes(M, K)) // 4, dtype=torch.float32, device=x.device)
+def token_splitk(f2p, w_packed):
+    """Partial sums of DynamicConv's out_layer over K slices: f2p (K/32, M, 64) fp16 from `dynconv`, w_packed =
+    `pack_ksteps(W)` for W (128, K) -> (workspace float32 (slices, M, 128), slices)."""
+    _dev(f2p, w_packed)
+    nks, M, _ = f2p.shape
+    K = nks * 32
+    assert f2p.dtype == torch.float16 and f2p.is_contiguous() and f2p.shape[2] == 64
+    assert w_packed.dtype == torch.float16 and w_packed.numel() == 128 * K * 2 and w_packed.is_contiguous()
+    ws = torch.empty(int(_lib.lib().di_token_splitk_workspace_bytes(M, K)) // 4, dtype=torch.float32, device=f2p.device)
     ns = ctypes.c_int(0)
-    _lib.call('di_token_splitk', x.data_ptr(), x.stride(0), w.data_ptr(), ws.data_ptr(), M, K, ctypes.addressof(ns), _stream())
+    _lib.call('di_token_splitk', f2p.data_ptr(), w_packed.data_ptr(), ws.data_ptr(), M, K, ctypes.addressof(ns), _stream())
     return ws, ns.value
 
 
 def dynconv(roi, params, n1, n2, eps=1e-5):
-    """roi (R,49,128), params (R,32768) = [p1^T | p2^T], n1/n2 = (weight, bias) of DynamicConv.norm1/2, all float32
-    -> relu(LN2(relu(LN1(roi @ p1)) @ p2)) (R,49,128)."""
+    """roi (R,49,128) float32, params (R, 65536) fp16 from `token_wide`, n1/n2 = (weight, bias) float32 of
+    DynamicConv.norm1/2 -> relu(LN2(relu(LN1(roi @ p1)) @ p2)) as f2p (196, R, 64) fp16 (k-step major, hi | lo)."""
     _dev(roi, params)
     R = roi.shape[0]
-    assert roi.shape == (R, 49, 128) and roi.is_contiguous() and params.shape == (R, 32768) and params.is_contiguous()
-    assert roi.dtype == torch.float32 and params.dtype == torch.float32 and n1[0].dtype == torch.float32
-    out = torch.empty_like(roi)
+    assert roi.shape == (R, 49, 128) and roi.is_contiguous() and roi.dtype == torch.float32
+    assert params.shape == (R, 65536) and params.is_contiguous() and params.dtype == torch.float16
+    assert n1[0].dtype == torch.float32
+    f2p = torch.empty((196, R, 64), dtype=torch.float16, device=roi.device)
     _lib.call('di_dynconv_fwd', roi.data_ptr(), params.data_ptr(), n1[0].data_ptr(), n1[1].data_ptr(), n2[0].data_ptr(),
-              n2[1].data_ptr(), out.data_ptr(), R, float(eps), _stream())
-    return out
+              n2[1].data_ptr(), f2p.data_ptr(), R, float(eps), _stream())
+    return f2p
+
+
+def f2p_to_dense(f2p):
+    """(K/32, M, 64) hi | lo fp16 -> (M, K) float64 (tests)."""
+    nks, M, _ = f2p.shape
+    v = f2p[..., :32].double() + f2p[..., 32:].double() / 2048.0
+    return v.permute(1, 0, 2).reshape(M, nks * 32)
+
+
+def dense_to_f2p(x):
+    """(M, K) float32 -> (K/32, M, 64) hi | lo fp16 (tests)."""
+    M, K = x.shape
+    hi, lo = split_hi_lo(x)
+    return torch.cat([hi.view(M, K // 32, 32), lo.view(M, K // 32, 32)], -1).permute(1, 0, 2).contiguous()
 
 
 def roi_select(rect, on=None):
@@ -909,6 +955,29 @@ def query_init(bev, top, ce_w, ce_b, pe):
               pe[1].data_ptr(), pe[2].data_ptr(), pe[3].data_ptr(), feat.data_ptr(), pemb.data_ptr(), pos.data_ptr(),
               labels.data_ptr(), B, Q, H, W, ce_w.shape[1], _stream())
     return feat, pemb, pos, labels
+
+
+def pack_linear(w):
+    """(N,K) float32 weight (N multiple of 16, K of 128) -> fp16 (N/16, K/128, 4, 2, 64, 8): the hi / lo split of
+    `split_hi_lo` in MFMA fragment order - block (t, c) holds, per k-step kk and half h, the 64 lanes' 8 halfs
+    W_h[16t + i][128c + 32kk + 8g + j] at lane 16g + i (csrc/token32.hip linear_issue: every load instruction of a wave
+    reads one contiguous KiB)."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 128 == 0
+    hi, lo = split_hi_lo(w)
+    x = torch.stack([hi, lo])                                             # (h, N, K)
+    x = x.view(2, N // 16, 16, K // 128, 4, 4, 8)                         # (h, t, i, c, kk, g, j)
+    return x.permute(1, 3, 4, 0, 5, 2, 6).contiguous().view(N // 16, K // 128, 4, 2, 64, 8)
+
+
+def pack_ksteps(w):
+    """(N,K) float32 weight (N multiple of 16, K of 32) -> fp16 (N/16, K/32, 2, 64, 8): hi / lo split in k-step order -
+    [tile t][k-step ks][half h][lane 16g + i][j] = W_h[16t + i][32ks + 8g + j] (csrc/token32.hip splitk_kernel)."""
+    N, K = w.shape
+    assert N % 16 == 0 and K % 32 == 0
+    hi, lo = split_hi_lo(w)
+    x = torch.stack([hi, lo]).view(2, N // 16, 16, K // 32, 4, 8)          # (h, t, i, ks, g, j)
+    return x.permute(1, 3, 0, 4, 2, 5).contiguous().view(N // 16, K // 32, 2, 64, 8)
 
 
 def split_hi_lo(w):

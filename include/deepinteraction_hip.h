@@ -347,13 +347,19 @@ int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w_staged, co
 /* ---------------------------------------------------------------- token-level kernels of the MMPI decoder (float32)
  * Inference form of the reference's decoder layer / RoI blocks / prediction heads on the B*Q query tokens
  * (models/utils/decoder_utils.py:35-113, 498-581, 584-629, 632-841; dense_heads/deepinteraction_decoder.py:242-313).
- * The token state, the RoI features, the generated DynamicConv parameters and every weight of this path are FLOAT32
- * (float32 MFMA): with fp16 anywhere on this path the box outputs leave the 1e-3 contract (DESIGN.md "Numerics");
- * only the feature MAPS the tokens gather from are fp16.  Token matrices are row-major with an explicit row stride
- * (`ld*`, in elements); weights (N, K) row-major as `nn.Linear.weight`.
+ * The token state, the RoI features, the generated DynamicConv parameters and every weight of this path carry FLOAT32
+ * accuracy: with fp16 anywhere on this path the box outputs leave the 1e-3 contract (DESIGN.md "Numerics"); only the
+ * feature MAPS the tokens gather from are fp16.  Matrix operands travel as SPLIT fp16 pairs, x = hi + lo / 2048
+ * (hi = fp16(x), lo = fp16((x - hi) * 2048)): a product is three fp16 MFMAs with float32 accumulation, 2^-22 relative.
+ * Weights are split once on the host (`*_hi`, `*_lo`, (N, K) row-major as `nn.Linear.weight`); token matrices are
+ * float32, row-major with an explicit row stride (`ld*`, in elements), split in registers.
  *
  * di_token_program: ONE launch runs a short program on every group of 16 consecutive tokens of a sample (grid
- *   ceil(Q/16) x B; the rows live in three LDS buffers of 16 x 512 floats, `src` / `dst` / `aux` name them):
+ *   ceil(Q/16) x B x roles; the rows live in three LDS buffers of 16 x 512 floats, `src` / `dst` / `aux` name them).
+ *   ROLES spread one token group's weights over several CUs: the workgroup of role r executes the steps whose
+ *   [role_lo, role_hi] contains r; a LINEAR step takes the weight tiles r*rt.. / K-chunks r*rc.. (an N-split - packed
+ *   projections, one prediction head per role - or a hidden-dimension split whose partial sums the next launch adds),
+ *   LOAD / STORE / LOAD_PARTS add r*roff to p0, HEADS with a = 1 evaluates head r only (hidden at columns 0..63).
  *     DI_TOK_LOAD        dst[:, a:a+K] = p0[m, :K] (+ p1[m, :K])                       rows of ld0 (ld1) floats
  *     DI_TOK_LOAD_PARTS  dst[:, :128]  = sum_{s<a} p0[(s*b + m)*128 : +128] + p1       split-K partial sums (b = B*Q)
  *     DI_TOK_ATTN        dst[:, :128]  = softmax(q k^T) v per head (8 heads x 16) among the Q tokens of the sample,
@@ -361,18 +367,24 @@ int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w_staged, co
  *                        optional visibility p1 = member (uint8), p2 = view (int8): key k is visible to query q when
  *                        bit view[q] of member[k] is set or view[q] < 0 (ImageRCNNBlock's per-view attention, :745)
  *     DI_TOK_COMBINE     dst[:, :128]  = merge of the a key-range states of di_mha_decode_x_fwd (p0 = scratch)
- *     DI_TOK_LINEAR      dst[:, :N]    = act_a(src[:, :K] . p0^T + p1)    a: 0 none, 1 ReLU, 2 GELU(erf); K, N <= 512
+ *     DI_TOK_LINEAR      dst[:, :N]    = act_a(src[:, :K] . W^T + p1), W (hi + lo / 2048) packed in MFMA fragment order
+ *                        (blocks (N/16, K/128) of 8 x 1 KiB: `ops.pack_linear`); a: 0 none, 1 ReLU, 2 GELU(erf);
+ *                        K multiple of 128, N of 16, both <= 512
  *     DI_TOK_ROWOP       dst[:, :128]  = mask_p2(relu_{b&1}(LayerNorm_{p0,p1,eps=f}(src + buf[aux])))   each part optional
  *     DI_TOK_STORE       p0[m, :N]     = src[:, a:a+N]
  *     DI_TOK_HEADS       second layers of the prediction heads on the hidden rows in src (first layers: a LINEAR step
  *                        with the BatchNorm-folded, stacked (nheads*64, K) weight), `center += query_pos`, the
  *                        on-the-image merge with the first stage (`keep`), written at column col0 of the
  *                        (B, cls_h, ldo) float32 outputs; pos_out = the new centres (B,Q,2)   (:498-581, head :265-311)
- * di_token_wide: Y = X . W^T + bias for K = 128, N >> M (DynamicConv's parameter generator, :608), weight stationary.
- * di_token_splitk: partial sums of X (M,K) . W^T (128,K) over K slices of 448 into workspace (slices, M, 128)
- *   (DynamicConv's out_layer, :624); a DI_TOK_LOAD_PARTS step of the next program sums them.
- * di_dynconv_fwd: F2 = relu(LN2(relu(LN1(roi . p1)) . p2)) per RoI (:617-622); roi (R,49,128); params (R, 32768) =
- *   [p1^T (d,c) | p2^T (e,d)] (the generating Linear's rows permuted on the host); out (R,49,128).
+ * DynamicConv (:608-624) as three kernels whose operands are laid out for one contiguous KiB per wave-level load
+ * (layouts: csrc/token32.hip, host side `decoder_fused._dyn_layout` / `ops.pack_linear` / `ops.pack_ksteps`):
+ * di_token_wide: params (M, 65536) fp16 = the generator Linear 128 -> 2*128*128 of x (M,128) float32, weight stationary,
+ *   written as hi / lo fragments in the order di_dynconv_fwd reads them; w_packed = the generator's weight, rows
+ *   permuted to that order, in MFMA fragment order; bias (32768) in value order.
+ * di_dynconv_fwd: F2 = relu(LN2(relu(LN1(roi . p1)) . p2)) per RoI (:617-622); roi (R,49,128) float32; F2 leaves as
+ *   f2p (196, R, 64) fp16 = [k-step of the flattened (49*128) feature][RoI][hi 32 | lo 32].
+ * di_token_splitk: partial sums of out_layer (:624) over 14 K slices into workspace (slices, M, 128) float32 from f2p
+ *   and the weight in k-step order; a DI_TOK_LOAD_PARTS step of the next program sums them.
  * di_roi_select: image block (on != null): last valid view per query, membership bits, RoIs, keep mask, float view
  *   id (:681-759 bookkeeping); point block (on == null): rois = (b, BEV rect).
  * di_query_init: query features = BEV token (fp16 map) + class encoding, positions, learned positional embedding
@@ -385,9 +397,11 @@ typedef struct di_tok_step {
   int kind, src, dst, aux;
   int K, N, a, b;
   float f;
-  int pad;
+  int role_lo, role_hi;     /* the step runs in the workgroups whose role (grid z) lies in [role_lo, role_hi] */
+  int rt, rc, nch;          /* LINEAR: tiles / K-chunks added per role to the packed weight's block index; chunks of the weight (0: K/128) */
   const void *p0, *p1, *p2, *p3;
   long long ld0, ld1;
+  long long roff;           /* LOAD / LOAD_PARTS / STORE: elements added to p0 per role */
 } di_tok_step;
 typedef struct di_tok_heads {
   const float *w2, *b2, *qpos;     /* stacked second layers (sum cls, 64), their biases, query positions (B,Q,2) */
@@ -400,13 +414,15 @@ typedef struct di_tok_heads {
 } di_tok_heads;
 int di_token_program(const di_tok_step *steps_host, int nsteps, const di_tok_heads *heads_host, int B, int Q,
                      void *stream);
-int di_token_wide(const float *x, int ldx, const float *w, const float *bias, float *y, long long ldy, int M, int N,
-                  void *stream);
+/* profiling aid: the same launch; workgroup (0,0) writes the shader clock at kernel start and after every step's
+ * barrier to stamps[0 .. nsteps] (device memory). */
+int di_token_program_timed(const di_tok_step *steps_host, int nsteps, const di_tok_heads *heads_host, int B, int Q,
+                           unsigned long long *stamps, void *stream);
+int di_token_wide(const float *x, int ldx, const void *w_packed, const float *bias, void *params, int M, void *stream);
 long long di_token_splitk_workspace_bytes(int M, int K);
-int di_token_splitk(const float *x, long long ldx, const float *w, float *workspace, int M, int K, int *nslices_host,
-                    void *stream);
-int di_dynconv_fwd(const float *roi, const float *params, const float *n1w, const float *n1b, const float *n2w,
-                   const float *n2b, float *out, int R, float eps, void *stream);
+int di_token_splitk(const void *f2p, const void *w_packed, float *workspace, int M, int K, int *nslices_host, void *stream);
+int di_dynconv_fwd(const float *roi, const void *params, const float *n1w, const float *n1b, const float *n2w,
+                   const float *n2b, void *f2p, int R, float eps, void *stream);
 int di_roi_select(const int *on, const float *rect, float *rois, void *view, void *member, void *keep, float *on_img,
                   int B, int V, int Q, void *stream);
 int di_query_init(const void *bev, const long long *top, const float *ce_w, const float *ce_b, const float *w1,

@@ -36,6 +36,9 @@ def _gen(seed):
 
 
 D = lambda t: None if t is None else t.to(DEV)
+PK = lambda w: ops.pack_linear(w.to(DEV))              # weight of a program's linear step
+SP = lambda w: ops.split_hi_lo(w.to(DEV))            # float32 weight -> (hi, lo) fp16 pair on the device
+JOIN = lambda p: p[0].double().cpu() + p[1].double().cpu() / 2048.0
 
 
 @pytest.mark.parametrize('B,Q', [(1, 1), (1, 37), (1, 200), (2, 200), (1, 400)])
@@ -66,7 +69,7 @@ def test_program_linear_steps(B, Q, case):
         y = y.relu()
     if act == 2:
         y = F.gelu(y)
-    p.linear(0, 1, D(w), D(b), act=act)
+    p.linear(0, 1, PK(w), D(b), act=act)
     if case in ('res_ln', 'keep'):
         res, lw, lb = r(M, 128), 1 + 0.2 * r(128), 0.1 * r(128)
         keep = (torch.rand(M, generator=g) > 0.3).to(torch.uint8) if case == 'keep' else None
@@ -78,12 +81,35 @@ def test_program_linear_steps(B, Q, case):
         res, lw, lb, lw2, lb2 = r(M, 128), 1 + 0.2 * r(128), 0.1 * r(128), 1 + 0.2 * r(128), 0.1 * r(128)
         w1, b1, w2, b2 = r(512, 128) / 11, r(512) * 0.1, r(128, 512) / 22, r(128) * 0.1
         p.rowop(1, 1, ln=(D(lw), D(lb)), relu=True).load(2, D(res)).rowop(1, 1, aux=2, ln=(D(lw2), D(lb2)))
-        p.linear(1, 0, D(w1), D(b1), act=2).linear(0, 2, D(w2), D(b2)).rowop(2, 1, aux=1, ln=(D(lw), D(lb)))
+        p.linear(1, 0, PK(w1), D(b1), act=2).linear(0, 2, PK(w2), D(b2)).rowop(2, 1, aux=1, ln=(D(lw), D(lb)))
         z = _ln(_ln(y, lw, lb).relu() + res.double(), lw2, lb2)
         y = _ln(z + F.gelu(z @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double(), lw, lb)
     p.store(1, y_dev)
     p.run(B, Q)
     _close(y_dev, y)
+
+
+@pytest.mark.parametrize('B,Q', [(1, 37), (2, 200)])
+def test_program_roles(B, Q):
+    """Roles: an N-split linear (each role a 128-column third, stored side by side) and an FFN whose hidden dimension is
+    split over the roles (partial sums in a workspace, added by LOAD_PARTS of a second program)."""
+    g, r = _gen(Q)
+    M = B * Q
+    x, wq, bq = r(M, 128), r(384, 128) / 11, r(384) * 0.1
+    w1, b1, w2, b2 = r(512, 128) / 11, r(512) * 0.1, r(128, 512) / 22, r(128) * 0.1
+    qkv = torch.empty((M, 384), dtype=torch.float32, device=DEV)
+    ws = torch.empty((4, M, 128), dtype=torch.float32, device=DEV)
+    out = torch.empty((M, 128), dtype=torch.float32, device=DEV)
+    xd = D(x)
+    p = ops.TokenProgram(roles=4)
+    p.load(0, xd)
+    p.linear(0, 1, PK(wq), D(bq), roles=(1, 3), n_per_role=128).store(1, qkv, roles=(1, 3), n=128, role_offset=128)
+    p.linear(0, 1, PK(w1), D(b1), act=2, n_per_role=128).linear(1, 2, PK(w2), None, k_per_role=128)
+    p.store(2, ws, n=128, role_offset=M * 128)
+    p.run(B, Q)
+    ops.TokenProgram().load_parts(0, ws, 4, M, D(b2)).store(0, out).run(B, Q)
+    _close(qkv, x.double() @ wq.double().t() + bq.double())
+    _close(out, F.gelu(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double())
 
 
 @pytest.mark.parametrize('B,Q,masked', [(1, 200, False), (2, 200, True), (1, 400, True), (2, 37, True), (1, 512, False)])
@@ -115,14 +141,28 @@ def test_program_attention(B, Q, masked):
     _close(out, ref)
 
 
+def _ref_params(w, b, x):
+    """The generator's output in the reference layout: (M, 32768) float64."""
+    return x.double() @ w.double().t() + b.double()
+
+
+def _join_params(params):
+    """(M, 65536) hi / lo fragments -> (M, 32768) float64 in the reference layout."""
+    M = params.shape[0]
+    f = params.double().cpu().view(M, 64, 2, 512)
+    v = (f[:, :, 0] + f[:, :, 1] / 2048.0).reshape(M, 32768)                       # value order
+    out = torch.empty_like(v)
+    out[:, decoder_fused._dyn_value_order('cpu')] = v
+    return out
+
+
 def test_wide_generator():
-    """K = 128 -> N = 32768 (DynamicConv.dynamic_layer), weight-stationary kernel."""
+    """K = 128 -> N = 32768 (DynamicConv.dynamic_layer), weight-stationary kernel, hi / lo fragment output."""
     g, r = _gen(5)
     x, w, b = r(200, 128), r(32768, 128) / 11, r(32768) * 0.1
-    got = ops.token_wide(D(x), D(w), D(b))
-    _close(got, x.double() @ w.double().t() + b.double())
-    got = ops.token_wide(D(x[:37]), D(w[:256]), None)
-    _close(got, x[:37].double() @ w[:256].double().t())
+    wp, bv = decoder_fused._dyn_layout(D(w), D(b))
+    _close(_join_params(ops.token_wide(D(x), wp, bv)), _ref_params(w, b, x), 1e-6)
+    _close(_join_params(ops.token_wide(D(x[:37]), wp, bv)), _ref_params(w, b, x[:37]), 1e-6)
 
 
 @pytest.mark.parametrize('M', [1, 37, 200, 400])
@@ -130,28 +170,30 @@ def test_splitk_and_parts(M):
     """DynamicConv out_layer: split-K partial sums + the LOAD_PARTS step that sums them."""
     g, r = _gen(M)
     x, w, b = r(M, 6272), r(128, 6272) / 80, r(128) * 0.1
-    ws, ns = ops.token_splitk(D(x), D(w))
+    ws, ns = ops.token_splitk(ops.dense_to_f2p(D(x)), ops.pack_ksteps(D(w)))
     assert ns == 14
     out = torch.empty((M, 128), dtype=torch.float32, device=DEV)
     ops.TokenProgram().load_parts(0, ws, ns, M, D(b)).store(0, out).run(1, M)
-    _close(out, x.double() @ w.double().t() + b.double())
+    _close(out, x.double() @ w.double().t() + b.double(), 2e-6)
 
 
 def test_dynconv_core():
-    """relu(LN2(relu(LN1(roi @ p1)) @ p2)) with the parameters in the kernel's transposed layout (decoder_fused._dyn_perm)."""
+    """relu(LN2(relu(LN1(roi @ p1)) @ p2)) from the generator's fragments."""
     g, r = _gen(2)
     R = 23
-    roi = r(R, 49, 128)
-    params = r(R, 32768) / 11                                                       # reference layout
+    roi, y = r(R, 49, 128), r(R, 128)
+    w, b = r(32768, 128) / 120, r(32768) * 0.02
     n = lambda: (1 + 0.2 * r(128), 0.1 * r(128))
     n1, n2 = n(), n()
-    perm = decoder_fused._dyn_perm('cpu')
-    got = ops.dynconv(D(roi), D(params[:, perm].contiguous()), tuple(D(t) for t in n1), tuple(D(t) for t in n2))
-    p1 = params[:, :16384].double().view(R, 128, 128)
-    p2 = params[:, 16384:].double().view(R, 128, 128)
+    wp, bv = decoder_fused._dyn_layout(D(w), D(b))
+    params_dev = ops.token_wide(D(y), wp, bv)
+    got = ops.dynconv(D(roi), params_dev, tuple(D(t) for t in n1), tuple(D(t) for t in n2))
+    params = _join_params(params_dev)                                               # what the kernel multiplied by
+    p1 = params[:, :16384].view(R, 128, 128)
+    p2 = params[:, 16384:].view(R, 128, 128)
     f1 = _ln(torch.bmm(roi.double(), p1), *n1).relu()
     ref = _ln(torch.bmm(f1, p2), *n2).relu()
-    _close(got, ref, 5e-5)
+    _close(ops.f2p_to_dense(got).view(R, 49, 128), ref, 2e-5)
 
 
 def test_query_init():
