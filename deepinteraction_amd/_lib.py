@@ -62,7 +62,7 @@ SIGNATURES = {
     'di_query_init': [_c_p] * 12 + [_c_i] * 5 + [_c_p],
     'di_roi_align_x_fwd': [_c_p] * 3 + [_c_i] * 5 + [_c_f, _c_i, _c_i, _c_p],
     'di_kv_project_fwd': [_c_p] * 6 + [_c_i, _c_i, _c_p],
-    'di_mha_decode_x_fwd': [_c_p] * 3 + [_c_i] * 3 + [_c_f, _c_p],
+    'di_mha_decode_x_fwd': [_c_p] * 4 + [_c_i] * 3 + [_c_f, _c_p],
 }
 # helpers that return a value instead of an error code
 VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_i2p_key_table_bytes': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 3,

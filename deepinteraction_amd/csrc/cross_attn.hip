@@ -260,6 +260,34 @@ __global__ __launch_bounds__(NTH) void mha_decode_x_kernel(const float *__restri
   }
 }
 
+// Merge of the key-range states: one wavefront per (sample, head, query); lane = (range slice of 4, head channel);
+// out (B*Q, 128) float32.  (Inside the 13-workgroup token program this merge cost 39 us: 590 KB of states per
+// workgroup; as its own launch every CU takes a share.)
+__global__ __launch_bounds__(256) void combine_kernel(const float *__restrict__ part, float *__restrict__ out, int B,
+                                                      int Q, int nrange) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= B * HEADS * Q) return;
+  const int lane = threadIdx.x & 63, d = lane & 15, cs = lane >> 4;
+  const int qi = w % Q, h = (w / Q) % HEADS, b = w / (Q * HEADS);
+  const float *base = part + (((size_t)b * HEADS + h) * Q + qi) * nrange * (kHD + 2);
+  float M = -INFINITY;
+  for (int c = cs; c < nrange; c += 4) M = fmaxf(M, base[(size_t)c * (kHD + 2)]);
+  M = fmaxf(M, __shfl_xor(M, 16));
+  M = fmaxf(M, __shfl_xor(M, 32));
+  float L = 0.f, O = 0.f;
+  for (int c = cs; c < nrange; c += 4) {
+    const float *p = base + (size_t)c * (kHD + 2);
+    const float wgt = __builtin_amdgcn_exp2f(p[0] - M);
+    L += p[1] * wgt;
+    O += p[2 + d] * wgt;
+  }
+  L += __shfl_xor(L, 16);
+  L += __shfl_xor(L, 32);
+  O += __shfl_xor(O, 16);
+  O += __shfl_xor(O, 32);
+  if (cs == 0) out[((size_t)b * Q + qi) * HEADS * kHD + h * kHD + d] = O / L;
+}
+
 static void plan(int B, int Q, int S, int &qsplit, int &nrange, int &range_keys) {
   const int nqg = (Q + 15) / 16;
   qsplit = (nqg + MAXQG * WPH - 1) / (MAXQG * WPH);
@@ -291,7 +319,8 @@ int di_mha_decode_x_ranges(int B, int Q, int S) {
   return nrange;
 }
 
-int di_mha_decode_x_fwd(const float *q, const void *kx, float *scratch, int B, int Q, int S, float scale, void *stream) {
+int di_mha_decode_x_fwd(const float *q, const void *kx, float *scratch, float *out, int B, int Q, int S, float scale,
+                        void *stream) {
   using namespace di::xa;
   DI_REQUIRE(q && kx && scratch && B > 0 && Q > 0 && S > 0 && scale > 0.f, "bad attention shape (scale must be positive)");
   int qsplit, nrange, range_keys;
@@ -300,6 +329,8 @@ int di_mha_decode_x_fwd(const float *q, const void *kx, float *scratch, int B, i
   if (int rc = di::ensure_lds(raised, (const void *)mha_decode_x_kernel, 2 * STAGE_BYTES)) return rc;
   hipLaunchKernelGGL(mha_decode_x_kernel, dim3(nrange, qsplit, B), dim3(NTH), 2 * STAGE_BYTES, (hipStream_t)stream, q,
                      (const __half *)kx, scratch, B, Q, S, scale * 1.4426950408889634f, range_keys);
+  if (out != nullptr)
+    hipLaunchKernelGGL(combine_kernel, dim3((B * HEADS * Q + 3) / 4), dim3(256), 0, (hipStream_t)stream, scratch, out, B, Q, nrange);
   return di::check_launch("mha_decode_x_fwd");
 }
 

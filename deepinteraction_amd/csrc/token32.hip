@@ -81,7 +81,7 @@ constexpr int NW = 8;           // wavefronts per workgroup
 constexpr int NTH = NW * 64;
 constexpr int LDW = 516;        // floats per LDS row: 512 + 4 (float4 reads of 16 rows spread over the banks)
 constexpr int NBUF = 3;
-constexpr int LDS_BYTES = NBUF * TM * LDW * 4 + 256;
+constexpr int LDS_BYTES = NBUF * TM * LDW * 4 + 2 * TM * (512 + 8) * 2;   // row buffers + the hi / lo image of a linear step's input
 
 // ------------------------------------------------------------------------------------------------------------
 // The steps of a program.  `src` / `dst` / `aux` name LDS row buffers (0..2); widths are in floats.
@@ -190,12 +190,14 @@ __device__ __forceinline__ void step_load_parts(const Step &s, float *buf, long 
 
 // K_ATTN: self attention among the Q tokens of the sample for this workgroup's 16 queries (reference
 // decoder_utils.py:743-746 / :824-826 and :91-95): wave = head (8 heads x 16 dims), packed projection p0 = [q | k | v]
-// rows of ld0 floats.  Optional visibility (image RoI block: the attention runs among the queries of ONE view): key k
+// rows of ld0 floats [q | k] + the transposed values p3 = V^T (B, 128, Qp = b).  Optional visibility (image RoI block: the attention runs among the queries of ONE view): key k
 // is visible to query q when bit view[q] of member[k] is set, or when view[q] < 0.  f = scale * log2(e).
-// Key tiles go in chunks of 8: all loads of a chunk are issued first; the 8 score tiles are independent three-pass
-// products (16x16x16 fp16 MFMA on the hi / lo halves: the head dim is the 16 of k), ONE maximum exchange per chunk
-// (the first version did the online soft-max tile by tile: a dependent chain of MFMA -> 2 cross-lane exchanges ->
-// exp -> MFMA per tile, 28 000 cycles for 13 tiles), then the probabilities and O^T += V^T P^T, again three-pass.
+// Key tiles go in chunks of 8: all loads of a chunk are issued first; the 8 score tiles are independent products, ONE
+// maximum exchange per chunk (the first version did the online soft-max tile by tile: a dependent chain of MFMA -> 2
+// cross-lane exchanges -> exp -> MFMA per tile), then the probabilities and O^T += V^T P^T.  Both products use the
+// FLOAT32 MFMA (16x16x4: the head dim 16 = four of them per tile): the three-pass fp16 form measured 32 000 cycles per
+// step here - the split of K, V and P costs 5 VALU operations per element, a wave64 VALU operation takes 4 cycles and
+// two waves share a SIMD, so the step was bound by the conversions, not by the matrix cores.
 struct HL4 {
   h4 hi, lo;
 };
@@ -216,31 +218,35 @@ __device__ __forceinline__ void mfma3s(const HL4 &a, const HL4 &b, f4 &ch, f4 &c
   ch = __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.hi, ch, 0, 0, 0);
 }
 __device__ __forceinline__ void step_attn(const Step &s, float *buf, int b, int q0, int Q, int lane, int wave) {
-  const float *base = (const float *)s.p0 + (size_t)b * Q * s.ld0;
+  const float *base = (const float *)s.p0 + (size_t)b * Q * s.ld0;          // rows [q | k] of ld0 floats
   const unsigned char *member = (const unsigned char *)s.p1;
   const signed char *view = (const signed char *)s.p2;
-  const int ld = (int)s.ld0, h = wave, i = lane & 15, g = lane >> 4;
+  const int ld = (int)s.ld0, h = wave, i = lane & 15, g = lane >> 4, Qp = s.b;
+  const float *vt = (const float *)s.p3 + ((size_t)b * 128 + h * 16 + i) * Qp;   // V^T[dim i of head h][key]
   const int qc = min(q0 + i, Q - 1);
-  const HL4 qv = split4(ld4(base + (size_t)qc * ld + h * 16 + 4 * g));        // B[k = dim 4g + j][col = query i]
+  const f4 qv = ld4(base + (size_t)qc * ld + h * 16 + 4 * g);                 // B[k = dim 4g + j][col = query i]
   const int vq = member != nullptr ? (int)view[(size_t)b * Q + qc] : -1;
   const float sl2 = s.f;
   float m = -INFINITY, l = 0.f;
-  f4 oh = {0.f, 0.f, 0.f, 0.f}, ol = {0.f, 0.f, 0.f, 0.f};
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
   const int ntile = (Q + 15) >> 4;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  const bool mem4 = member != nullptr && (Q & 3) == 0;     // membership bytes of 4 keys as one aligned dword
   for (int t0 = 0; t0 < ntile; t0 += 8) {
-    // tile t: K row of key 16t + i (dims 4g..4g+3), V[key 16t + 4g + r][dim i], membership bytes of keys 16t + 4g + r;
-    // keys past the end clamp to the last one (masked below)
+    // tile t: K row of key 16t + i (dims 4g..4g+3), V^T[dim i][keys 16t + 4g .. + 3] (the transposed copy the producer
+    // stored: one 16-B load where the row-major layout needed four 4-B loads), membership bytes of keys 16t + 4g + r;
+    // keys past the end are masked below
     f4 kk[8], vv[8];
     unsigned mem[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int t = t0 + j, k4 = 16 * t + 4 * g;
+      const int t = min(t0 + j, ntile - 1), k4 = 16 * t + 4 * g;
       kk[j] = ld4(base + (size_t)min(16 * t + i, Q - 1) * ld + 128 + h * 16 + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) vv[j][r] = base[(size_t)min(k4 + r, Q - 1) * ld + 256 + h * 16 + i];
+      vv[j] = ld4(vt + k4);
       mem[j] = 0xFFFFFFFFu;
-      if (member != nullptr) {
+      if (mem4) {
+        mem[j] = k4 < Q ? *reinterpret_cast<const unsigned *>(member + (size_t)b * Q + k4) : 0u;
+      } else if (member != nullptr) {
         unsigned mm = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) mm |= (unsigned)member[(size_t)b * Q + min(k4 + r, Q - 1)] << (8 * r);
@@ -251,13 +257,12 @@ __device__ __forceinline__ void step_attn(const Step &s, float *buf, int b, int 
     float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      f4 ch = zero, cl = zero;
-      mfma3s(split4(kk[j]), qv, ch, cl);                     // S^T[key 4g + r][query i]
+      const f4 c = mfma4(kk[j], qv, zero);                   // S^T[key 4g + r][query i]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * (t0 + j) + 4 * g + r;
         const bool vis = key < Q && (vq < 0 || ((mem[j] >> (8 * r + vq)) & 1u));
-        const float x = vis ? fmaf(cl[r], kLoInv, ch[r]) * sl2 : -INFINITY;
+        const float x = vis ? c[r] * sl2 : -INFINITY;
         sc[j][r] = x;
         mx = fmaxf(mx, x);
       }
@@ -266,29 +271,25 @@ __device__ __forceinline__ void step_attn(const Step &s, float *buf, int b, int 
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mn = fmaxf(m, mx);
     const float ms = mn == -INFINITY ? 0.f : mn;             // nothing visible so far: keep everything at zero
-    const float a = exp2f(m - ms);
+    const float a = __builtin_amdgcn_exp2f(m - ms);
     l *= a;
-    oh *= a;
-    ol *= a;
+    acc *= a;
     m = mn;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       f4 p;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        p[r] = exp2f(sc[j][r] - ms);
+        p[r] = __builtin_amdgcn_exp2f(sc[j][r] - ms);
         l += p[r];
       }
-      mfma3s(split4(vv[j]), split4(p), oh, ol);              // O^T[dim 4g + r'][query i]: A = V^T[dim i][key 4g + r]
+      acc = mfma4(vv[j], p, acc);                            // O^T[dim 4g + r'][query i]: A = V^T[dim i][key 4g + r]
     }
   }
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
   const float inv = l > 0.f ? 1.f / l : 0.f;
-  f4 o;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = fmaf(ol[r], kLoInv, oh[r]) * inv;
-  *reinterpret_cast<f4 *>(buf + s.dst * TM * LDW + i * LDW + h * 16 + 4 * g) = o;
+  *reinterpret_cast<f4 *>(buf + s.dst * TM * LDW + i * LDW + h * 16 + 4 * g) = acc * inv;
 }
 
 // K_COMBINE: merge of the cross attention's partial softmax states (csrc/cross_attn.hip mha_decode_x_kernel: one state
@@ -330,7 +331,8 @@ __device__ __forceinline__ void step_combine(const Step &s, float *buf, int b, i
 // W = hi + lo / 2048 packed in fragment order (p0, see linear_issue).  Work items = (16-channel tile of this wave, 128-wide K
 // chunk), tile-major; the weight fragments of FOUR items (8 x 16 B per lane each) are issued before the first MFMA of
 // the group.  (Holding the next step's first group in registers across the barrier made the compiler spill 529
-// VGPRs; the kernel's prologue warms L2 with every weight line instead, see `touch_weights`.)
+// VGPRs; warming L2 with one 4-byte LDS-DMA request per weight line in a prologue cost as much texture-pipe time as
+// it saved.)
 struct WFrag {
   h8 w[8];              // k-step kk: w[2kk] = hi, w[2kk + 1] = lo
   f4 bias;
@@ -347,25 +349,38 @@ __device__ __forceinline__ void linear_issue(const Step &s, int it0, WFrag (&A)[
   const int total = mine * nch;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int it = min(it0 + j, total - 1);                  // past the end: the last item again (never used)
-    const int tt = it / nch, c = it - tt * nch, t = wave + NW * tt + rr * s.rt;
-    const __half *blk = wp + ((size_t)(t * nchw + c + rr * s.rc) * 8) * 512 + lane * 8;
+    const int it = it0 + j;
+    if (it < total) {                                        // wave-uniform (every load instruction costs the CU's one
+      const int tt = it / nch, c = it - tt * nch, t = wave + NW * tt + rr * s.rt;       // texture pipe 16 cycles)
+      const __half *blk = wp + ((size_t)(t * nchw + c + rr * s.rc) * 8) * 512 + lane * 8;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) A[j].w[q] = ld_h8(blk + q * 512);
-    A[j].bias = bias != nullptr ? ld4(bias + 16 * t + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < 8; ++q) A[j].w[q] = ld_h8(blk + q * 512);
+      A[j].bias = bias != nullptr ? ld4(bias + 16 * t + 4 * g) : f4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 }
-__device__ __forceinline__ void step_linear(const Step &s, float *buf, int lane, int wave, int rr) {
+// The B operands: the 16 token rows of `src`, split into hi / lo ONCE per step by the whole workgroup into an LDS image
+// (rows of KIMG halfs: hi then lo), not by every wave for itself (8 x the conversions: the step was VALU bound).
+constexpr int KIMG = 512 + 8;                           // halfs per image row and half (padding: 16-B reads of 16 rows spread over the banks)
+__device__ __forceinline__ void linear_image(const Step &s, const float *buf, __half *img, int tid) {
   const float *x = buf + s.src * TM * LDW;
+  const int k8 = s.K >> 3;
+  for (int e = tid; e < TM * k8; e += NTH) {
+    const int r = e / k8, c = (e - r * k8) * 8;
+    const HL v = split8(ld4(x + r * LDW + c), ld4(x + r * LDW + c + 4));
+    *reinterpret_cast<h8 *>(img + r * KIMG + c) = v.hi;
+    *reinterpret_cast<h8 *>(img + TM * KIMG + r * KIMG + c) = v.lo;
+  }
+}
+__device__ __forceinline__ void step_linear(const Step &s, float *buf, const __half *img, int lane, int wave, int rr) {
   float *d = buf + s.dst * TM * LDW;
   const int i = lane & 15, g = lane >> 4, nch = s.K >> 7;
   const int ntile = s.N >> 4;
   const int mine = wave < ntile ? (ntile - wave + NW - 1) / NW : 0;
   const int total = mine * nch;
   if (total == 0) return;
-  const float *xr = x + i * LDW + 8 * g;
+  const __half *xr = img + i * KIMG + 8 * g;
   f4 ah = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
-  HL bq[4];
   WFrag A[4];
   for (int it0 = 0; it0 < total; it0 += 4) {
     linear_issue(s, it0, A, lane, wave, rr);
@@ -378,12 +393,13 @@ __device__ __forceinline__ void step_linear(const Step &s, float *buf, int lane,
         ah = f4{0.f, 0.f, 0.f, 0.f};
         al = f4{0.f, 0.f, 0.f, 0.f};
       }
-      if (nch > 1 || it == 0) {                             // the B operands of chunk c: token rows from LDS, split
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) bq[kk] = split8(ld4(xr + 128 * c + 32 * kk), ld4(xr + 128 * c + 32 * kk + 4));
+      for (int kk = 0; kk < 4; ++kk) {
+        HL b;
+        b.hi = *reinterpret_cast<const h8 *>(xr + 128 * c + 32 * kk);
+        b.lo = *reinterpret_cast<const h8 *>(xr + TM * KIMG + 128 * c + 32 * kk);
+        mfma3(A[j].w[2 * kk], A[j].w[2 * kk + 1], b, ah, al);
       }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) mfma3(A[j].w[2 * kk], A[j].w[2 * kk + 1], bq[kk], ah, al);
       if (c == nch - 1) {
         const int n = 16 * (wave + NW * tt) + 4 * g;
         f4 v = A[j].bias;
@@ -447,10 +463,22 @@ __device__ __forceinline__ void step_rowop(const Step &s, float *buf, long long 
   st8(buf + s.dst * TM * LDW + r * LDW + c0, pack8f(v, 0.f));
 }
 
-// K_STORE: p0[m * ld0 + c] = src[r][a + c],  c < N
-__device__ __forceinline__ void step_store(const Step &s, const float *buf, long long m0, int rows, int tid, int rr) {
+// K_STORE: (p0 + role * roff)[m * ld0 + c] = src[r][a + c],  c < N.  With b == 1 the store is TRANSPOSED:
+// p0[(sample * N + c) * ld0 + q] = src[q - q0][a + c] - the layout the self attention reads its values in (ld0 = Qp).
+__device__ __forceinline__ void step_store(const Step &s, const float *buf, long long m0, int rows, int tid, int rr, int b,
+                                           int q0) {
   float *y = (float *)s.p0 + rr * s.roff;
   const float *x = buf + s.src * TM * LDW + s.a;
+  if (s.b == 1) {
+    for (int e = tid; e < s.N * 4; e += NTH) {
+      const int c = e >> 2, r4 = (e & 3) * 4;
+      f4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = x[(r4 + r) * LDW + c];
+      *reinterpret_cast<f4 *>(y + ((size_t)b * s.N + c) * s.ld0 + q0 + r4) = v;
+    }
+    return;
+  }
   const int n4 = s.N >> 2;
   for (int e = tid; e < rows * n4; e += NTH) {
     const int r = e / n4, c = (e - r * n4) * 4;
@@ -508,28 +536,8 @@ __device__ __forceinline__ void step_heads(const Step &s, const Heads &ho, const
   }
 }
 
-// Prologue: every weight line this wave will read in ANY linear step of the program is requested once, by LDS-DMA
-// into a junk area (no VGPRs, nothing waits for it): the steps' own loads then hit L2 instead of HBM - a program is a
-// chain of dependent round trips, and the weights (constants) are the part of it that can be started early.
-typedef __attribute__((address_space(1))) const void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
-__device__ __forceinline__ void touch_weights(const Program &prog, int nsteps, float *junk, int lane, int wave, int role) {
-  for (int si = 0; si < nsteps; ++si) {
-    if (__builtin_amdgcn_readfirstlane(prog.s[si].kind) != DI_TOK_LINEAR) continue;
-    const Step s = fetch_step(&prog.s[si]);
-    if (role < s.role_lo || role > s.role_hi) continue;
-    const int rr = role - s.role_lo;
-    const __half *wp = (const __half *)s.p0;
-    const int nch = s.K >> 7, ntile = s.N >> 4, nchw = s.nch > 0 ? s.nch : nch;
-    for (int t = wave; t < ntile; t += NW)
-      for (int c = 0; c < nch; ++c)     // an 8 KiB block = 64 lines of 128 B: one lane each
-        __builtin_amdgcn_global_load_lds((gptr_t)(wp + ((size_t)((t + rr * s.rt) * nchw + c + rr * s.rc) * 8) * 512 + lane * 64),
-                                         (lptr_t)junk, 4, 0, 0);
-  }
-}
-
 __global__ __launch_bounds__(NTH) void program_kernel(Program prog, Heads heads, int Q, int touch, unsigned long long *stamps) {
-  extern __shared__ __align__(16) float buf[];          // NBUF x TM x LDW, + 256 B of junk for the prologue's DMA
+  extern __shared__ __align__(16) float buf[];          // NBUF x TM x LDW floats, then the hi / lo image (2 x TM x KIMG halfs)
   __shared__ Program lp;
   __shared__ Heads lh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -549,7 +557,8 @@ __global__ __launch_bounds__(NTH) void program_kernel(Program prog, Heads heads,
   __syncthreads();
   const int nsteps = __builtin_amdgcn_readfirstlane(lp.n);
   const int role = blockIdx.z;
-  if (touch) touch_weights(lp, nsteps, buf + NBUF * TM * LDW, lane, wave, role);
+  __half *img = reinterpret_cast<__half *>(buf + NBUF * TM * LDW);
+  (void)touch;
   for (int si = 0; si < nsteps; ++si) {
     const Step s = fetch_step(&lp.s[si]);
     const bool mine = role >= s.role_lo && role <= s.role_hi;
@@ -564,9 +573,13 @@ __global__ __launch_bounds__(NTH) void program_kernel(Program prog, Heads heads,
         case DI_TOK_LOAD_PARTS: step_load_parts(s, buf, m0, rows, tid, rr); break;
         case DI_TOK_ATTN: step_attn(s, buf, b, q0, Q, lane, wave); break;
         case DI_TOK_COMBINE: step_combine(s, buf, b, q0, Q, lane, wave); break;
-        case DI_TOK_LINEAR: step_linear(s, buf, lane, wave, rr); break;
+        case DI_TOK_LINEAR:
+          linear_image(s, buf, img, tid);
+          __syncthreads();
+          step_linear(s, buf, img, lane, wave, rr);
+          break;
         case DI_TOK_ROWOP: step_rowop(s, buf, m0, rows, tid); break;
-        case DI_TOK_STORE: step_store(s, buf, m0, rows, tid, rr); break;
+        case DI_TOK_STORE: step_store(s, buf, m0, rows, tid, rr, b, q0); break;
         case DI_TOK_HEADS: step_heads(s, lh, buf, b, q0, Q, tid, rr); break;
         default: break;
       }
@@ -919,8 +932,9 @@ static int check_program(const di_tok_step *steps, int n, const di_tok_heads *he
         DI_REQUIRE(okbuf(s.dst) && s.p0 && s.a > 0 && s.b > 0, "step %d (load parts): bad arguments", i);
         break;
       case DI_TOK_ATTN:
-        DI_REQUIRE(okbuf(s.dst) && s.p0 && s.ld0 >= 384 && s.ld0 % 4 == 0 && (s.p1 == nullptr) == (s.p2 == nullptr),
-                   "step %d (attention): needs the packed [q|k|v] projection (8 heads x 16) and member + view together", i);
+        DI_REQUIRE(okbuf(s.dst) && s.p0 && s.p3 && s.ld0 >= 256 && s.ld0 % 4 == 0 && s.b >= 16 && s.b % 16 == 0 &&
+                       (s.p1 == nullptr) == (s.p2 == nullptr),
+                   "step %d (attention): needs rows [q|k] (8 heads x 16), V^T with a key stride multiple of 16, member + view together", i);
         break;
       case DI_TOK_COMBINE:
         DI_REQUIRE(okbuf(s.dst) && s.p0 && s.a > 0, "step %d (combine): bad arguments", i);

@@ -196,9 +196,10 @@ class FusedDecoder:
         hw1, hb1 = heads.pop('w1'), heads.pop('b1')
         p.linear(x_buf, hid_buf, hw1, hb1, act=1, roles=(0, nh - 1), n_per_role=64)
         p.heads(hid_buf, roles=(0, nh - 1), per_role=True, **heads)
-        if nxt is not None:
+        if nxt is not None:                                  # roles nh, nh + 1: q and k rows; role nh + 2: the values, transposed
             p.linear(x_buf, qkv_buf, nxt[0], nxt[1], roles=(nh, nh + 2), n_per_role=128)
-            p.store(qkv_buf, qkv_out, roles=(nh, nh + 2), n=128, role_offset=128)
+            p.store(qkv_buf, qkv_out[0], roles=(nh, nh + 1), n=128, role_offset=128)
+            p.store_t(qkv_buf, qkv_out[1], roles=(nh + 2, nh + 2))
 
     def _block(self, blk, sfx, x, qkv, roi, B, Q, heads, next_qkv_w, member=None, view=None, keep=None):
         """decoder_utils.py:743-756 / :824-837 on tokens x (B*Q,128) whose packed self-attention projection `qkv` the
@@ -210,7 +211,7 @@ class FusedDecoder:
         f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         y = f32e(M, 128)
         p = ops.TokenProgram()
-        p.attn(0, qkv, c['scale'], member, view)
+        p.attn(0, qkv[0], qkv[1], c['scale'], member, view)
         p.linear(0, 1, c['sa'][2], c['sa'][3])
         p.load(2, x)
         p.rowop(1, 1, aux=2, ln=c['n1'], eps=c['eps'][0])
@@ -234,7 +235,7 @@ class FusedDecoder:
         p.run(B, Q)
         nhd = len(heads['cls'])
         xn = f32e(M, 128)
-        qkv_n = f32e(M, 384) if next_qkv_w is not None else None
+        qkv_n = (f32e(M, 256), f32e(B, 128, (Q + 15) // 16 * 16)) if next_qkv_w is not None else None
         p = ops.TokenProgram(roles=nhd + (3 if next_qkv_w is not None else 0))
         p.load_parts(2, ws2, nh, M, c['b2'])
         p.load(0, z)
@@ -291,13 +292,15 @@ class FusedDecoder:
 
         # ---- decoder layer (decoder_utils.py:83-113: post-norm; positional embeddings added to q, k and v)
         c = self._layer_consts(layer)
-        qkv = f32e(M, 384)
+        Qp = (Q + 15) // 16 * 16
+        qk, vt = f32e(M, 256), f32e(B, 128, Qp)
         p = ops.TokenProgram(roles=3)                                                # a third of the packed projection each
-        p.load(0, x, pos=qpe).linear(0, 1, c['sa'][0], c['sa'][1], n_per_role=128).store(1, qkv, n=128, role_offset=128)
+        p.load(0, x, pos=qpe).linear(0, 1, c['sa'][0], c['sa'][1], n_per_role=128)
+        p.store(1, qk, roles=(0, 1), n=128, role_offset=128).store_t(1, vt, roles=(2, 2))
         p.run(B, Q)
         x1, qc = f32e(M, 128), f32e(M, 128)
         p = ops.TokenProgram()
-        p.attn(0, qkv, c['sa_scale'])
+        p.attn(0, qk, vt, c['sa_scale'])
         p.linear(0, 1, c['sa'][2], c['sa'][3])
         p.load(2, x).load(0, qpe)
         p.rowop(1, 1, aux=2, ln=c['n1'], eps=c['eps'][0])                            # x1
@@ -306,12 +309,11 @@ class FusedDecoder:
         p.linear(0, 2, c['wq'], c['bq'])
         p.store(2, qc)
         p.run(B, Q)
-        scratch, nrange = ops.mha_decode_x(qc.view(B, Q, 128), kx, c['ca_scale'])
+        o = ops.mha_decode_x(qc.view(B, Q, 128), kx, c['ca_scale'])
         x2 = f32e(M, 128)
         p = ops.TokenProgram()
-        p.combine(0, scratch, nrange)
+        p.load(0, o).load(2, x1)
         p.linear(0, 1, c['ca'][2], c['ca'][3])
-        p.load(2, x1)
         p.rowop(1, 1, aux=2, ln=c['n2'], eps=c['eps'][1])                            # x2
         p.store(1, x2)
         p.run(B, Q)
@@ -323,7 +325,7 @@ class FusedDecoder:
         p.linear(1, 2, c['w2'], None, k_per_role=128)
         p.store(2, wsf, n=128, role_offset=M * 128)
         p.run(B, Q)
-        x3, qkv_b = f32e(M, 128), f32e(M, 384)
+        x3, qkv_b = f32e(M, 128), (f32e(M, 256), f32e(B, 128, Qp))
         pos1 = f32e(B, Q, 2)
         p = ops.TokenProgram(roles=len(cls) + 3)
         p.load_parts(2, wsf, nh, M, c['b2'])

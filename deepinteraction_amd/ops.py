@@ -789,11 +789,16 @@ class TokenProgram:
         """buf[dst][:, :128] = sum of the partial sums workspace (nslices, total_rows, 128) (+ bias)."""
         return self._add(_lib.TOK_LOAD_PARTS, dst=dst, a=nslices, b=total_rows, p0=workspace, p1=bias, roles=roles)
 
-    def attn(self, dst, qkv, scale, member=None, view=None, roles=None):
-        """buf[dst][:, :128] = self attention (8 heads x 16) among the sample's tokens from qkv (M, 384) = [q|k|v]."""
-        assert _f32c(qkv).shape[1] == 384 and (member is None) == (view is None)
-        return self._add(_lib.TOK_ATTN, dst=dst, f=scale * 1.4426950408889634, p0=qkv, p1=member, p2=view,
-                         ld0=qkv.stride(0), roles=roles)
+    def attn(self, dst, qk, vt, scale, member=None, view=None, roles=None):
+        """buf[dst][:, :128] = self attention (8 heads x 16) among the sample's tokens from qk (M, 256) = [q|k] rows and
+        vt (B, 128, Qp) = the values transposed (`store_t`), Qp = Q rounded up to 16."""
+        assert _f32c(qk).shape[1] == 256 and (member is None) == (view is None)
+        assert _f32c(vt).dim() == 3 and vt.shape[1] == 128 and vt.shape[2] % 16 == 0 and vt.is_contiguous()
+        st = self._add(_lib.TOK_ATTN, dst=dst, f=scale * 1.4426950408889634, b=vt.shape[2], p0=qk, p1=member, p2=view,
+                       ld0=qk.stride(0), roles=roles)
+        self.steps[-1].p3 = vt.data_ptr()
+        self.refs.append(vt)
+        return st
 
     def combine(self, dst, scratch, nrange, roles=None):
         """buf[dst][:, :128] = merged key-range states of `mha_decode_x`."""
@@ -828,6 +833,11 @@ class TokenProgram:
         _f32c(y)
         return self._add(_lib.TOK_STORE, src=src, N=y.shape[-1] if n is None else n, a=col, p0=y, ld0=y.stride(-2),
                          roles=roles, roff=role_offset)
+
+    def store_t(self, src, vt, col=0, roles=None):
+        """vt (B, N, Qp)[sample, c, q] = buf[src][q - q0, col + c]: the transposed store (`attn` reads its values so)."""
+        assert _f32c(vt).dim() == 3 and vt.is_contiguous() and vt.shape[2] % 16 == 0
+        return self._add(_lib.TOK_STORE, src=src, N=vt.shape[1], a=col, b=1, p0=vt, ld0=vt.shape[2], roles=roles)
 
     def heads(self, src, w2, b2, qpos, outs, cls, center_head, ldo, col0, keep=None, first=None, pos_out=None, roles=None,
               per_role=False):
@@ -1003,14 +1013,16 @@ def kv_project(x_tokens, w_hi, w_lo, kbias, vbias):
     return out
 
 
-def mha_decode_x(q, kx, scale):
-    """q (B,Q,128) float32 (unscaled), kx (B,S,384) from `kv_project` -> (scratch, nrange): the partial soft-max states a
-    `TokenProgram.combine` step merges."""
+def mha_decode_x(q, kx, scale, merge=True):
+    """q (B,Q,128) float32 (unscaled), kx (B,S,384) from `kv_project` -> softmax(q k^T scale) v, (B*Q,128) float32; with
+    merge=False -> (scratch, nrange): the partial soft-max states a `TokenProgram.combine` step merges."""
     _dev(q, kx)
     B, Q, E = q.shape
     S = kx.shape[1]
     assert E == 128 and q.dtype == torch.float32 and q.is_contiguous() and kx.shape == (B, S, 384) and kx.is_contiguous()
     nrange = int(_lib.lib().di_mha_decode_x_ranges(B, Q, S))
     scratch = torch.empty(B * 8 * Q * nrange * 18, dtype=torch.float32, device=q.device)
-    _lib.call('di_mha_decode_x_fwd', q.data_ptr(), kx.data_ptr(), scratch.data_ptr(), B, Q, S, float(scale), _stream())
-    return scratch, nrange
+    out = torch.empty((B * Q, 128), dtype=torch.float32, device=q.device) if merge else None
+    _lib.call('di_mha_decode_x_fwd', q.data_ptr(), kx.data_ptr(), scratch.data_ptr(), 0 if out is None else out.data_ptr(),
+              B, Q, S, float(scale), _stream())
+    return out if merge else (scratch, nrange)

@@ -245,11 +245,13 @@ int di_mha_decode_fwd(const void *q, const void *kv, void *out, float *scratch, 
  *     out (B*S, 384) fp16 = [Khi | Klo | V] with K = Khi + Klo / 2048.
  *   di_mha_decode_x_fwd: q (B,Q,128) float32, UNSCALED; kx from di_kv_project_fwd; 8 heads x 16; writes one partial
  *     soft-max state [m (exp2 domain), l, O[16]] per (sample, head, query, key range) to scratch
- *     (B*8*Q*di_mha_decode_x_ranges(B,Q,S)*18 floats), merged by a DI_TOK_COMBINE step of di_token_program. */
+ *     (B*8*Q*di_mha_decode_x_ranges(B,Q,S)*18 floats); with `out` (B,Q,128) float32 a second launch merges them (one
+ *     wavefront per (sample, head, query)), with out == NULL a DI_TOK_COMBINE step of di_token_program does. */
 int di_kv_project_fwd(const void *x, const void *w_hi, const void *w_lo, const float *kbias, const float *vbias,
                       void *out, int B, int S, void *stream);
 int di_mha_decode_x_ranges(int B, int Q, int S);
-int di_mha_decode_x_fwd(const float *q, const void *kx, float *scratch, int B, int Q, int S, float scale, void *stream);
+int di_mha_decode_x_fwd(const float *q, const void *kx, float *scratch, float *out, int B, int Q, int S, float scale,
+                        void *stream);
 
 /* ---------------------------------------------------------------- DeepInteraction++ operators (row a20)
  * di_ms_deform_attn_fwd: the core of mmcv-full 1.3.18 `MultiScaleDeformableAttention` (CUDA op `ms_deform_attn`,
@@ -362,16 +364,17 @@ int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w_staged, co
  *   LOAD / STORE / LOAD_PARTS add r*roff to p0, HEADS with a = 1 evaluates head r only (hidden at columns 0..63).
  *     DI_TOK_LOAD        dst[:, a:a+K] = p0[m, :K] (+ p1[m, :K])                       rows of ld0 (ld1) floats
  *     DI_TOK_LOAD_PARTS  dst[:, :128]  = sum_{s<a} p0[(s*b + m)*128 : +128] + p1       split-K partial sums (b = B*Q)
- *     DI_TOK_ATTN        dst[:, :128]  = softmax(q k^T) v per head (8 heads x 16) among the Q tokens of the sample,
- *                        from the packed projection p0 = [q | k | v] (rows of ld0 floats), f = scale * log2(e);
- *                        optional visibility p1 = member (uint8), p2 = view (int8): key k is visible to query q when
- *                        bit view[q] of member[k] is set or view[q] < 0 (ImageRCNNBlock's per-view attention, :745)
+ *     DI_TOK_ATTN        dst[:, :128]  = softmax(q k^T) v per head (8 heads x 16) among the Q tokens of the sample, from
+ *                        rows p0 = [q | k] (ld0 floats) and the TRANSPOSED values p3 = V^T (B, 128, b) float32 (b = Q
+ *                        rounded up to 16), f = scale * log2(e); optional visibility p1 = member (uint8), p2 = view
+ *                        (int8): key k is visible to query q when bit view[q] of member[k] is set or view[q] < 0
+ *                        (ImageRCNNBlock's per-view attention, :745)
  *     DI_TOK_COMBINE     dst[:, :128]  = merge of the a key-range states of di_mha_decode_x_fwd (p0 = scratch)
  *     DI_TOK_LINEAR      dst[:, :N]    = act_a(src[:, :K] . W^T + p1), W (hi + lo / 2048) packed in MFMA fragment order
  *                        (blocks (N/16, K/128) of 8 x 1 KiB: `ops.pack_linear`); a: 0 none, 1 ReLU, 2 GELU(erf);
  *                        K multiple of 128, N of 16, both <= 512
  *     DI_TOK_ROWOP       dst[:, :128]  = mask_p2(relu_{b&1}(LayerNorm_{p0,p1,eps=f}(src + buf[aux])))   each part optional
- *     DI_TOK_STORE       p0[m, :N]     = src[:, a:a+N]
+ *     DI_TOK_STORE       p0[m, :N]     = src[:, a:a+N];  b = 1: transposed, p0[(sample*N + c)*ld0 + q] (the V^T above)
  *     DI_TOK_HEADS       second layers of the prediction heads on the hidden rows in src (first layers: a LINEAR step
  *                        with the BatchNorm-folded, stacked (nheads*64, K) weight), `center += query_pos`, the
  *                        on-the-image merge with the first stage (`keep`), written at column col0 of the

@@ -130,8 +130,13 @@ def test_program_attention(B, Q, masked):
         bits = (member.long()[:, None, :] >> view.long().clamp(min=0)[:, :, None]) & 1
         allowed = (bits == 1) | (view.long()[:, :, None] < 0)
     out = torch.empty((B * Q, E), dtype=torch.float32, device=DEV)
+    Qp = (Q + 15) // 16 * 16
+    qk, vt = torch.empty((B * Q, 256), dtype=torch.float32, device=DEV), torch.zeros((B, 128, Qp), dtype=torch.float32, device=DEV)
+    ops.TokenProgram().load(0, D(qkv)).store(0, qk).store_t(0, vt, col=256).run(B, Q)       # the producer's two stores
+    assert torch.equal(qk.cpu(), qkv[:, :256])
+    assert torch.equal(vt.cpu()[:, :, :Q], qkv[:, 256:].view(B, Q, 128).transpose(1, 2))
     p = ops.TokenProgram()
-    p.attn(0, D(qkv), 0.25, None if member is None else D(member.view(-1)), None if view is None else D(view.view(-1)))
+    p.attn(0, qk, vt, 0.25, None if member is None else D(member.view(-1)), None if view is None else D(view.view(-1)))
     p.store(0, out)
     p.run(B, Q)
     q, k, v = (t.double().view(B, Q, H, 16).transpose(1, 2) for t in qkv.split(E, dim=1))
@@ -257,9 +262,10 @@ def test_cross_attention_x(B, Q, S):
     got_k = kx[..., :E].double().cpu() + kx[..., E:2 * E].double().cpu() / 2048.0
     _close(got_k, K, 2e-6)
     _close(kx[..., 2 * E:], Vv, 1e-3)
-    scratch, nr = ops.mha_decode_x(D(q), kx, 0.25)
+    scratch, nr = ops.mha_decode_x(D(q), kx, 0.25, merge=False)
     out = torch.empty((B * Q, E), dtype=torch.float32, device=DEV)
     ops.TokenProgram().combine(0, scratch, nr).store(0, out).run(B, Q)
+    assert torch.allclose(ops.mha_decode_x(D(q), kx, 0.25), out, rtol=1e-5, atol=1e-6)      # the merge as its own launch
     qh = q.double().view(B, Q, H, 16).transpose(1, 2)
     kh = K.view(B, S, H, 16).transpose(1, 2)
     vh = kx[..., 2 * E:].double().cpu().view(B, S, H, 16).transpose(1, 2)          # the fp16 V the kernel read

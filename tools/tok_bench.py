@@ -37,6 +37,7 @@ def timeit(name, fn, reps=20, iters=40):
 
 x, y = r(M, 128), torch.empty(M, 128, device=DEV)
 qkv = r(M, 384)
+qk, vt = qkv[:, :256].contiguous(), r(B, 128, 208)
 ln = (r(128), r(128))
 W = {k: PK(r(n, kk) / math.sqrt(kk)) for k, (n, kk) in dict(a=(128, 128), q=(384, 128), f1=(512, 128), f2=(128, 512), h=(384, 256)).items()}
 bias = {k: r(n) for k, n in dict(a=128, q=384, f1=512, f2=128, h=384).items()}
@@ -47,7 +48,7 @@ timeit('load, linear 128->512 gelu, linear 512->128, store',
        lambda: ops.TokenProgram().load(0, x).linear(0, 1, W['f1'], bias['f1'], act=2).linear(1, 2, W['f2'], bias['f2']).store(2, y).run(B, Q))
 timeit('load, 4x linear 128->128, store', lambda: ops.TokenProgram().load(0, x).linear(0, 1, W['a'], bias['a']).linear(1, 0, W['a'], bias['a'])
        .linear(0, 1, W['a'], bias['a']).linear(1, 0, W['a'], bias['a']).store(0, y).run(B, Q))
-timeit('attn, store', lambda: ops.TokenProgram().attn(0, qkv, 0.25).store(0, y).run(B, Q))
+timeit('attn, store', lambda: ops.TokenProgram().attn(0, qk, vt, 0.25).store(0, y).run(B, Q))
 timeit('load, 4x rowop LN, store', lambda: ops.TokenProgram().load(0, x).rowop(0, 0, ln=ln).rowop(0, 0, ln=ln).rowop(0, 0, ln=ln).rowop(0, 0, ln=ln).store(0, y).run(B, Q))
 from deepinteraction_amd import decoder_fused
 xw = r(M, 128)
@@ -75,7 +76,7 @@ def stamped(name, prog):
 stamped('4x linear', lambda: ops.TokenProgram().load(0, x).linear(0, 1, W['a'], bias['a']).linear(1, 0, W['a'], bias['a'])
         .linear(0, 1, W['a'], bias['a']).linear(1, 0, W['a'], bias['a']).store(0, y))
 stamped('ffn', lambda: ops.TokenProgram().load(0, x).linear(0, 1, W['f1'], bias['f1'], act=2).linear(1, 2, W['f2'], bias['f2']).store(2, y))
-stamped('attn', lambda: ops.TokenProgram().attn(0, qkv, 0.25).store(0, y))
+stamped('attn', lambda: ops.TokenProgram().attn(0, qk, vt, 0.25).store(0, y))
 stamped('rowops', lambda: ops.TokenProgram().load(0, x).rowop(0, 0, ln=ln).rowop(0, 0, ln=ln).store(0, y))
 
 nol = lambda n: (lambda: [ops.TokenProgram().load(0, x)] and None)
