@@ -21,8 +21,10 @@ FLAGS = ['-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-cuda-compat', '-Wno-unus
          f'--offload-arch={ARCH}', '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 
 
-# per-file flags
+# per-file flags; DI_PACKED_FP32=1 (experiments only) compiles WITH the packed instructions
 EXTRA = {}
+if os.environ.get('DI_PACKED_FP32') == '1':
+    FLAGS = [f for f in FLAGS if f not in ('-Xclang', '-target-feature', '-packed-fp32-ops')]
 
 
 def sources():

@@ -397,8 +397,8 @@ int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out,
     }
     return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, variant - DI_LA_MFMA, (hipStream_t)stream);
   }
-  if (mfma_ok && variant == DI_LA_AUTO)   // fastest measured: 16x4 tiles, 2 workgroups per CU
-    return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, 2, (hipStream_t)stream);
+  if (mfma_ok && variant == DI_LA_AUTO)   // fastest measured (round 3, cold inputs): 8x8 tiles, 2 workgroups per CU: 39.6 us against
+    return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, 1, (hipStream_t)stream);   // 42.9 for 16x4 (image side)
   return di::run_la(di::OP_FUSED, dtype, kH, kW, A);
 }
 

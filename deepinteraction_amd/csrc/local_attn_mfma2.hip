@@ -430,13 +430,17 @@ static int launch(const void *q, const void *k, const void *v, void *out, int n,
 
 }  // namespace m2
 
-// cfg: 0 = 16x8 tile / 64-ch units / 1 workgroup per CU;   2 = 16x4 / 64-ch / 2 per CU (the default);
+// cfg: 0 = 16x8 tile / 64-ch units / 1 workgroup per CU;   2 = 16x4 / 64-ch / 2 per CU (the default of rounds 1-2);
+//      1 = 8x8 / 64-ch / 2 per CU (the default since round 3: halo 16x16 = 4.0 texels staged per query instead of 4.5,
+//      200 = 25 x 8 columns and 112 = 14 x 8 rows leave no ragged tile - 2100 tiles instead of 2184);  3 = 8x16 / 1 per CU;
 //      4 = measurement build of 0 (phase timestamps).  (32-channel units and 24x8 tiles spill at the
 //      VGPR caps their occupancy needs and were dropped.)
 int launch_local_attn_mfma2(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                             float scale, int cfg, hipStream_t stream) {
   switch (cfg) {
     case 0: return m2::launch<m2::Cfg<2, 4, 64, 2>>(q, k, v, out, n, H, W, scale, 1, stream);
+    case 1: return m2::launch<m2::Cfg<1, 4, 64, 2>>(q, k, v, out, n, H, W, scale, 2, stream);   // 8 x 8 tiles
+    case 3: return m2::launch<m2::Cfg<1, 8, 64, 2>>(q, k, v, out, n, H, W, scale, 1, stream);   // 8 x 16 tiles
     case 2: return m2::launch<m2::Cfg<2, 2, 64, 2>>(q, k, v, out, n, H, W, scale, 2, stream);
     case 4: return m2::launch<m2::Cfg<2, 4, 64, 2, 6>>(q, k, v, out, n, H, W, scale, 1, stream);
   }

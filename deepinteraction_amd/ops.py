@@ -90,7 +90,7 @@ def local_attention(q, k, v, kH, kW, scale, variant=LA_AUTO):
 
 def local_attention_kernel_name():
     """What LA_AUTO launches for fp16 / C=128 / 9x9 maps (bench.py's roofline line names it)."""
-    return 'local_attn_m2_kernel, 16x4 tiles, 2 persistent workgroups per CU'
+    return 'local_attn_m2_kernel, 8x8 tiles, 2 persistent workgroups per CU'
 
 
 def similar_forward(x_ori, x_loc, kH, kW):
