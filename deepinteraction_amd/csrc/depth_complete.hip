@@ -17,7 +17,7 @@ namespace di {
 
 __device__ __forceinline__ float inv_depth(float d) { return d > 0.1f ? 100.f - d : d; }  // :171-174
 
-// first valid row of a column, accumulated with atomicMin by the kernel that PRODUCES the map; H = "no valid pixel",
+// first valid row of a column (dc_col_first_kernel); H = "no valid pixel",
 // which np.argmax reports as row 0 (:209-213, :228)
 __device__ __forceinline__ int first_row(const int32_t *__restrict__ first, int idx, int H) {
   const int f = first[idx];
@@ -49,7 +49,6 @@ __global__ __launch_bounds__(256) void dc_multiscale_kernel(const float *__restr
                                                             float *__restrict__ out, int32_t *__restrict__ first_a,
                                                             int32_t *__restrict__ first_b, int V, int H, int W) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < V * W) first_a[i] = first_b[i] = H;          // accumulators of the later stages of this chain
   if (i >= V * H * W) return;
   const int v = i / (H * W), r = i - v * H * W, y = r / W, x = r - y * W;
   const float *d = in + (size_t)v * H * W;
@@ -115,6 +114,21 @@ __device__ __forceinline__ float median25(const float *__restrict__ d, int H, in
   return a[12];
 }
 
+// First valid row of every column of a map (H = none): one thread per column, plain stores.  (Round 2 accumulated these
+// with global atomicMin from the producing kernels after a plain-store initialisation by an earlier kernel of the chain -
+// the pattern that gave wrong results from the second hipGraph replay on in the top-k kernels; two 3-us launches on the
+// side stream cost nothing, the chain is hidden under the shared convolutions.)
+__global__ __launch_bounds__(256) void dc_col_first_kernel(const float *__restrict__ in, int32_t *__restrict__ first, int V,
+                                                           int H, int W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * W) return;
+  const int v = i / W, x = i - v * W;
+  const float *d = in + (size_t)v * H * W + x;
+  int f = H;
+  for (int y = H - 1; y >= 0; --y) f = d[(size_t)y * W] > 0.1f ? y : f;
+  first[i] = f;
+}
+
 // :203-206  s4 = s3 > 0.1 ? median(s3) : s3
 __global__ __launch_bounds__(256) void dc_median_valid_kernel(const float *__restrict__ in,
                                                               float *__restrict__ out, int32_t *__restrict__ first,
@@ -125,7 +139,6 @@ __global__ __launch_bounds__(256) void dc_median_valid_kernel(const float *__res
   const float c = in[i];
   const float o = c > 0.1f ? median25(in + (size_t)v * H * W, H, W, y, x) : c;
   out[i] = o;
-  if (o > 0.1f) atomicMin(&first[v * W + x], y);       // top of the valid region of s4, per column
 }
 
 // :216-222  empty = !(s4 > 0.1) & top_mask ; s5 = empty ? dilate9x9(s4) : s4
@@ -143,7 +156,6 @@ __global__ __launch_bounds__(256) void dc_fill_kernel(const float *__restrict__ 
   const bool empty = (STRICT_LT ? (c < 0.1f) : !(c > 0.1f)) && top;
   const float o = empty ? box_extreme<R, true>(in + (size_t)v * H * W, H, W, y, x) : c;
   out[i] = o;
-  if (first_out != nullptr && o > 0.1f) atomicMin(&first_out[v * W + x], y);   // top of the valid region of s5
 }
 
 // :248-250  valid = (s7 > 0.1) & top_mask ; s7 = valid ? median(s7) : s7   (valid kept for :260)
@@ -264,13 +276,16 @@ extern "C" int di_depth_complete(const float *sparse, float *dense, float *scrat
   float *A = scratch, *B = scratch + (size_t)n, *valid = scratch + 2 * (size_t)n;
   float *mm_part = scratch + 3 * (size_t)n;                  // per-block min / max partials: 2 * V * blocks-per-view
   int32_t *first_a = iscratch, *first_b = iscratch + (size_t)V * W;
-  // 13 launches: the per-column "first valid row" is accumulated with integer atomics, the per-view min / max as
-  // per-block partials, by the kernels that produce the maps they describe
-  hipLaunchKernelGGL(dc_multiscale_kernel, g, b, 0, s, sparse, A, first_a, first_b, V, H, W);   // s2 (+ accumulator init)
+  // 15 launches, no global atomics: the per-column "first valid row" by a column scan, the per-view min / max as
+  // per-block partials of the kernel that produces the map
+  hipLaunchKernelGGL(dc_multiscale_kernel, g, b, 0, s, sparse, A, first_a, first_b, V, H, W);   // s2
   hipLaunchKernelGGL((dc_box_kernel<2, true>), g, b, 0, s, A, B, V, H, W);               // close: dilate
   hipLaunchKernelGGL((dc_box_kernel<2, false>), g, b, 0, s, B, A, V, H, W);              //        erode -> s3
-  hipLaunchKernelGGL(dc_median_valid_kernel, g, b, 0, s, A, B, first_a, V, H, W);        // s4 (+ its top rows)
-  hipLaunchKernelGGL((dc_fill_kernel<4, false>), g, b, 0, s, B, first_a, A, first_b, V, H, W);      // s5 (+ its top rows)
+  const dim3 gc((V * W + 255) / 256);
+  hipLaunchKernelGGL(dc_median_valid_kernel, g, b, 0, s, A, B, first_a, V, H, W);        // s4
+  hipLaunchKernelGGL(dc_col_first_kernel, gc, b, 0, s, B, first_a, V, H, W);             // its top rows
+  hipLaunchKernelGGL((dc_fill_kernel<4, false>), g, b, 0, s, B, first_a, A, first_b, V, H, W);      // s5
+  hipLaunchKernelGGL(dc_col_first_kernel, gc, b, 0, s, A, first_b, V, H, W);             // its top rows
   float *src = A, *dst = B;
   for (int it = 0; it < 6; ++it) {                                                       // s7
     hipLaunchKernelGGL((dc_fill_kernel<2, true>), g, b, 0, s, src, first_b, dst, (int32_t *)nullptr, V, H, W);

@@ -19,12 +19,12 @@ def randomize_bn(mods, seed=5):
                 sub.running_var.copy_(torch.rand(sub.running_var.shape, generator=g) + 0.5)
 
 
-def build_models(shape, num_proposals, dtype, device, seed=1234, train_cfg=None):
+def build_models(shape, num_proposals, dtype, device, seed=1234, train_cfg=None, num_layers=2):
     """(DeepInteractionEncoder, DeepInteractionDecoder) of Fusion_0075_refactor.py:185-224 at `shape`, eval mode; dtype
     float16 = the benched mixed mode of `precision.half_maps_` (fp16 maps, float32 token path)."""
     from .mmdet3d_plugin import DeepInteractionDecoder, DeepInteractionEncoder
     torch.manual_seed(seed)
-    enc = DeepInteractionEncoder(num_layers=2, in_channels_img=shape['c_img'], in_channels_pts=shape['c_pts'],
+    enc = DeepInteractionEncoder(num_layers=num_layers, in_channels_img=shape['c_img'], in_channels_pts=shape['c_pts'],
                                  hidden_channel=128)
     cfg = decoder_cfg(bev=shape['bev_hw'][0], num_proposals=num_proposals)
     if train_cfg is not None:

@@ -151,22 +151,19 @@ def project(seq, x):
     return seq(x)
 
 
-_CHAIN_IMAGES = {}
-
-
 def _chain_consts(seq, dtype):
     """(LDS image, relu1, relu2, two links) of a one- or two-link projection (folded BatchNorm) for
-    ops.pointwise_multi; the image is rebuilt when a parameter of the projection changes."""
+    ops.pointwise_multi; the image lives ON the projection module and is rebuilt when one of its parameters changes."""
     mods = list(seq) if isinstance(seq, nn.Sequential) else [seq]
-    key = tuple(param_key(m) for m in mods)
-    hit = _CHAIN_IMAGES.get(id(seq))
+    key = (dtype,) + tuple(param_key(m) for m in mods)
+    hit = seq.__dict__.get('_di_chain_image')
     if hit is None or hit[0] != key:
         w1, _, b1 = mods[0].folded(dtype)
         w2, b2 = (None, None)
         if len(mods) == 2:
             w2, _, b2 = mods[1].folded(dtype)
         hit = (key, ops.chain_image(w1, b1, w2, b2))
-        _CHAIN_IMAGES[id(seq)] = hit
+        seq.__dict__['_di_chain_image'] = hit
     return (hit[1], mods[0].use_activation, mods[-1].use_activation if len(mods) == 2 else False, len(mods) == 2)
 
 
@@ -214,12 +211,15 @@ def mix2_folded(proj1, a, fold, mask, b, proj2, c, cache):
     """mix2 where the first input is `mask * (a @ w_f^T + b_f)` with fold = (w_f, b_f) - the output projection of the
     pillar attention on its valid cells (encoder_utils.py:314-319) - WITHOUT materialising it: w_f goes into the first
     half of proj1's weight and b_f becomes a bias on the marked pixels (ops.pointwise_chain mask / bm)."""
-    key = (param_key(proj1), tuple(t.data_ptr() for t in fold), tuple(t._version for t in fold))
-    if cache.get('key') != key:
+    # the fold tensors are derived (rebuilt whenever the attention's weights change: fresh tensors, version 0, perhaps at
+    # a recycled address), so the entry is keyed on proj1 AND the identity of the fold tensors, which it keeps alive
+    key = (param_key(proj1), tuple(id(t) for t in fold), tuple(t._version for t in fold))
+    held = cache.get('fold')
+    if cache.get('key') != key or held is None or any(x is not y for x, y in zip(held, fold)):
         w1, _, b1 = proj1.folded(torch.float32)
         w_f, b_f = fold[0].float(), fold[1].float()
         wa = w1[:, :128] @ w_f
-        cache.update(key=key, w=torch.cat([wa, w1[:, 128:]], 1).to(a.dtype).contiguous(), b=b1.float().contiguous(),
+        cache.update(key=key, fold=tuple(fold), w=torch.cat([wa, w1[:, 128:]], 1).to(a.dtype).contiguous(), b=b1.float().contiguous(),
                      bm=(w1[:, :128] @ b_f).contiguous())
     w2, _, b2 = proj2.folded(a.dtype)
     return ops.pointwise_chain(a, cache['w'], cache['b'], proj1.use_activation, x2=b, w2=w2, b2=b2,

@@ -146,6 +146,7 @@ class GradientReducer:
         self._seen = set()
         self._next = 0
         self._handles = []
+        self._dirty = False
 
     def _fill(self, p):
         b, o = self._where[id(p)]
@@ -166,7 +167,11 @@ class GradientReducer:
             self._next += 1
 
     def _on_grad(self, p):
-        if id(p) in self._seen:                # a second backward before finish(): re-copy at finish
+        if id(p) in self._seen:
+            # a second backward before finish() (gradient accumulation): the bucket slice - perhaps already on its way
+            # through an all-reduce - holds the first micro-batch only.  finish() then redoes the reduction from the
+            # accumulated p.grad of every parameter.
+            self._dirty = True
             return
         self._fill(p)
         self._launch_ready()
@@ -176,6 +181,16 @@ class GradientReducer:
         gradients in `p.grad` (views of the bucket buffers for float32 parameters)."""
         if self.world == 1:
             return
+        # Whether ANY rank accumulated decides for all of them (the ranks must issue the same collectives)
+        dirty = torch.tensor([1.0 if self._dirty else 0.0], device=self.params[0].device)
+        dist.all_reduce(dirty, op=dist.ReduceOp.MAX)
+        if dirty.item() > 0:
+            # the launched all-reduces carry stale first-micro-batch data; every rank launched the same prefix of buckets
+            # only if no rank skipped a parameter, so finish them pairwise by index: force the remaining ones out first
+            self._launch_ready(force=True)
+            for w in self._handles:
+                w.wait()
+            self._reset()
         for p in self.params:                  # no-hook mode, or gradients produced outside the hook path
             if p.grad is not None and id(p) not in self._seen:
                 self._fill(p)

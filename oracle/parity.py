@@ -32,13 +32,13 @@ def randomize_bn(mods, seed=5):
                 sub.running_var.copy_(torch.rand(sub.running_var.shape, generator=g) + 0.5)
 
 
-def build_oracle(shape, num_proposals, seed=1234, state=None, round_fp16=False):
+def build_oracle(shape, num_proposals, seed=1234, state=None, round_fp16=False, num_layers=2):
     """Oracle encoder + decoder (fp32, CPU, eval).  `state` = (encoder state_dict, decoder state_dict) to load
     (e.g. the product's); round_fp16: True rounds every floating parameter / buffer through fp16, 'maps' only those the
     product's fp16 mode holds in fp16 (`deepinteraction_amd.precision.half_maps_`: the encoder and the two heat-map
     heads) - the "identical parameters" comparison that isolates the arithmetic."""
     torch.manual_seed(seed)
-    E = oenc.DeepInteractionEncoder(2, shape['c_img'], shape['c_pts'], 128)
+    E = oenc.DeepInteractionEncoder(num_layers, shape['c_img'], shape['c_pts'], 128)
     D = odec.DeepInteractionDecoder(**configs.decoder_cfg(bev=shape['bev_hw'][0], num_proposals=num_proposals))
     if state is None:
         randomize_bn([E, D])

@@ -84,6 +84,26 @@ def _worker(rank, world, port, out):
                 want = sum(g if g is not None else torch.zeros_like(p) for g in gs) / world
                 assert torch.allclose(p.grad, want, atol=1e-6), n
         assert net['only0'].weight.grad is not None and net['never'].weight.grad is None
+    # (v) gradient accumulation: two backward calls per finish() - the hooks fire twice, the reduction must carry the SUM
+    for p in net.parameters():
+        p.grad = None
+    for micro in range(2):
+        x = torch.full((3, 6), float(rank + 1 + micro))
+        h = net['b'](torch.relu(net['a'](x)))
+        if rank == 0 and micro == 1:
+            h = h + net['only0'](h)
+        net['c'](h).sum().backward()
+    local = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+    red.finish()
+    allg = [None] * world
+    dist.all_gather_object(allg, local)
+    for n, p in net.named_parameters():
+        gs = [g[n] for g in allg]
+        if all(g is None for g in gs):
+            assert p.grad is None, n
+        else:
+            want = sum(g if g is not None else torch.zeros_like(p) for g in gs) / world
+            assert torch.allclose(p.grad, want, atol=1e-6), ('accumulation', n)
     out.put((rank, el))
     dist.destroy_process_group()
 
