@@ -60,6 +60,11 @@ def parse():
     ap.add_argument('--from-points', action='store_true',
                     help='start every step from the raw points: the pillars of pts_metas are rebuilt by the voxeliser inside '
                          'the captured forward (detector glue, detectors/deepinteraction.py:120-171) instead of being loaded')
+    ap.add_argument('--from-raw', action='store_true',
+                    help='the per-sample host work INSIDE the step: every step starts from NCHW device feature maps (the '
+                         'reference boundary: frozen backbones emit NCHW), raw points / pillars and the metas - the channels-last '
+                         'transposing copy, GraphedHotPath.prepare() (padding, host 4x4 inverses, H2D of the geometry constants) '
+                         'and load() all run inside the timed region.  A secondary line; the headline hands prepared records')
     ap.add_argument('--pool', type=int, default=4, help='distinct device-resident samples cycled through the steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true',
@@ -264,11 +269,20 @@ def bench_forward(args, rank, world, device):
             records = [g.prepare(d) for d in dev_pool]
             lanes = [torch.cuda.Stream() for _ in graphs] if len(graphs) > 1 else [None]
             it = [0]
+            raw_pool = None
+            if args.from_raw:          # NCHW-contiguous device maps, as a frozen backbone hands them over
+                raw_pool = [dict(d, img_feats=d['img_feats'].contiguous(), pts_feats=d['pts_feats'].contiguous()) for d in dev_pool]
 
             def step():
                 for gi, lane in zip(graphs, lanes):
                     with torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext():
-                        gi.load(records[it[0] % len(records)])      # per-sample: copies into the captured buffers ...
+                        if raw_pool is not None:
+                            raw = raw_pool[it[0] % len(raw_pool)]
+                            cl = dict(raw, img_feats=raw['img_feats'].contiguous(memory_format=torch.channels_last),
+                                      pts_feats=raw['pts_feats'].contiguous(memory_format=torch.channels_last))
+                            gi.load(gi.prepare(cl))
+                        else:
+                            gi.load(records[it[0] % len(records)])  # per-sample: copies into the captured buffers ...
                         it[0] += 1
                         gi()                                         # ... and one replay of the captured forward
         if not args.eager and len(graphs) > 1:
@@ -353,6 +367,8 @@ def bench_forward(args, rank, world, device):
                     frac=None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                     traffic=pmc.get('hbm_bytes_per_launch'), mfma_busy=pmc.get('mfma_busy'),
                     lds_busy=pmc.get('lds_busy'), pmc_source=pmc.get('source'),
+                    pmc_note='traffic / mfma_busy / lds_busy are read from the committed rocprofv3 --pmc session named in pmc_source '
+                             '(profiles/pmc_local_attn.json), not measured by this run; achieved / frac / avg_launch_us are live',
                     avg_launch_us=round(avg * 1e6, 2), launches=len(durs), algorithmic_bytes=alg_bytes,
                     in_step_avg_us=round(sum(shared) / max(len(shared), 1) * 1e6, 2),
                     timed_in=f'{args.roofline_steps} eager single-stream forwards right after the timed region, HIP '
@@ -363,7 +379,7 @@ def bench_forward(args, rank, world, device):
                 'Full MMRI encoder (2 layers) + MMPI decoder forward, '
                 f'Fusion_0075_refactor shapes (shape {args.shape}), random-init weights',
                 dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(dev_pool), inflight=max(1, args.inflight),
-                     from_points=bool(args.from_points),
+                     from_points=bool(args.from_points), from_raw=bool(args.from_raw),
                      launch='eager' if args.eager else 'per step and sample in flight: load() of the next pool sample into the '
                                                        'captured buffers + hipGraph replay of the captured forward',
                      graph_nodes=None if g is None else g.num_nodes()))
