@@ -31,42 +31,48 @@ __device__ __forceinline__ h8 ld_h8(const __half *p) { return __builtin_bit_cast
 __device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 
 // ------------------------------------------------------------------------------------------------------------
-// K / V projection of the BEV tokens.  X (B*S, 128) fp16 (the channels-last map); whi / wlo (256, 128) fp16 with
-// W = whi + wlo / 2048 (rows 0..127: K, 128..255: V); kbias, vbias (S, 128) float32; out (B*S, 384) fp16.
-// A wave owns 32 rows (two B-operand groups) and walks the 256 output channels in 8 steps of 32; the rows of a weight
-// tile pair map to MFMA rows so that a lane ends with 8 consecutive channels (16-B stores).
+// K / V projection of the BEV tokens.  X (B*S, 128) fp16 (the channels-last map); wp = the (256, 128) float32 weight
+// (rows 0..127: K, 128..255: V) as hi / lo fp16 in MFMA fragment order (`ops.pack_kv_weight`); kbias, vbias (S, 128)
+// float32; out (B*S, 384) fp16.  A workgroup owns 128 rows; WAVE w computes output channels [64w, 64w + 64) for all of
+// them, so its 32 KiB of weight fragments are read once (contiguous KiB loads) and stay in registers, and the rows
+// stream through as B operands (the first version had every wave walk all 256 channels of 32 rows: 128 KiB of
+// row-strided weight loads per wave, 512 KiB per CU through a 64 B/clk texture pipe).  The rows of a tile pair map to
+// MFMA rows so that a lane ends with 8 consecutive channels (16-B stores).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kv_project_kernel(const __half *__restrict__ X, const __half *__restrict__ whi,
-                                                         const __half *__restrict__ wlo, const float *__restrict__ kbias,
-                                                         const float *__restrict__ vbias, __half *__restrict__ out,
-                                                         long long rows, int S) {
+__global__ __launch_bounds__(256) void kv_project_kernel(const __half *__restrict__ X, const __half *__restrict__ wp,
+                                                         const float *__restrict__ kbias, const float *__restrict__ vbias,
+                                                         __half *__restrict__ out, long long rows, int S) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const long long row0 = ((long long)blockIdx.x * 4 + wave) * 32;
-  if (row0 >= rows) return;
-  h8 xb[2][4];
-  long long rr[2];
+  const long long row0 = (long long)blockIdx.x * 128;
+  h8 a[2][2][8];                                          // [pt][nb][2kk + h]
 #pragma unroll
-  for (int gi = 0; gi < 2; ++gi) {
-    rr[gi] = min(row0 + 16 * gi + i, rows - 1);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) xb[gi][kk] = ld_h8(X + rr[gi] * 128 + 32 * kk + 8 * g);
-  }
-#pragma unroll 1
-  for (int pt = 0; pt < 8; ++pt) {
-    const int c0 = 32 * pt;                                 // output channels c0 .. c0 + 31 (K: < 128, V: >= 128)
-    h8 ahi[2][4], alo[2][4];
+  for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      const int ch = c0 + 8 * (i >> 2) + 4 * nb + (i & 3);  // MFMA row i of tile nb
+      const __half *blk = wp + (size_t)(2 * (2 * wave + pl) + nb) * 4096 + lane * 8;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        ahi[nb][kk] = ld_h8(whi + (size_t)ch * 128 + 32 * kk + 8 * g);
-        alo[nb][kk] = ld_h8(wlo + (size_t)ch * 128 + 32 * kk + 8 * g);
-      }
+      for (int q = 0; q < 8; ++q) a[pl][nb][q] = ld_h8(blk + q * 512);
     }
+  const bool isk = wave < 2;
+  const float *bias = isk ? kbias : vbias;
+  const int cb = (isk ? 64 * wave : 64 * (wave - 2)) + 8 * g;         // first of the lane's 8 channels (pl = 0) inside K or V
+  h8 xb[4], xn[4];
+  f4 bb[4], bn[4];
+  auto fetch = [&](int gi, h8 (&x)[4], f4 (&bq)[4]) {
+    const long long r = min(row0 + 16 * gi + i, rows - 1);
 #pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
+    for (int kk = 0; kk < 4; ++kk) x[kk] = ld_h8(X + r * 128 + 32 * kk + 8 * g);
+    const float *bp = bias + (size_t)(r % S) * 128 + cb;
+    bq[0] = ld4(bp); bq[1] = ld4(bp + 4); bq[2] = ld4(bp + 32); bq[3] = ld4(bp + 36);
+  };
+  fetch(0, xb, bb);
+  for (int gi = 0; gi < 8; ++gi) {
+    if (row0 + 16 * gi >= rows) break;
+    if (gi + 1 < 8) fetch(gi + 1, xn, bn);
+    const long long row = row0 + 16 * gi + i;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
       f4 hi[2], lo[2];
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
@@ -74,36 +80,36 @@ __global__ __launch_bounds__(256) void kv_project_kernel(const __half *__restric
         lo[nb] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          lo[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[nb][kk], xb[gi][kk], lo[nb], 0, 0, 0);
-          hi[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[nb][kk], xb[gi][kk], hi[nb], 0, 0, 0);
+          lo[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[pl][nb][2 * kk + 1], xb[kk], lo[nb], 0, 0, 0);
+          hi[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[pl][nb][2 * kk], xb[kk], hi[nb], 0, 0, 0);
         }
       }
-      if (row0 + 16 * gi + i >= rows) continue;
-      const long long row = rr[gi];
-      const int s = (int)(row % S);
-      const bool isk = c0 < 128;
-      const int cc = (isk ? c0 : c0 - 128) + 8 * g;          // lane's 8 consecutive channels inside K or V
-      const float *bp = (isk ? kbias : vbias) + (size_t)s * 128 + cc;
-      const f4 b0 = ld4(bp), b1 = ld4(bp + 4);
-      float v[8];
+      if (row < rows) {
+        float v[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = fmaf(lo[0][r], kLoInv, hi[0][r]) + b0[r];
-        v[4 + r] = fmaf(lo[1][r], kLoInv, hi[1][r]) + b1[r];
-      }
-      h8 oh, ol;
+        for (int r = 0; r < 4; ++r) {
+          v[r] = fmaf(lo[0][r], kLoInv, hi[0][r]) + bb[2 * pl][r];
+          v[4 + r] = fmaf(lo[1][r], kLoInv, hi[1][r]) + bb[2 * pl + 1][r];
+        }
+        h8 oh, ol;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        oh[j] = (_Float16)v[j];
-        ol[j] = (_Float16)((v[j] - (float)oh[j]) * kLoScale);
+        for (int j = 0; j < 8; ++j) {
+          oh[j] = (_Float16)v[j];
+          ol[j] = (_Float16)((v[j] - (float)oh[j]) * kLoScale);
+        }
+        __half *o = out + row * 384 + cb + 32 * pl;
+        if (isk) {
+          *reinterpret_cast<h8 *>(o) = oh;
+          *reinterpret_cast<h8 *>(o + 128) = ol;
+        } else {
+          *reinterpret_cast<h8 *>(o + 256) = oh;
+        }
       }
-      __half *o = out + row * 384;
-      if (isk) {
-        *reinterpret_cast<h8 *>(o + cc) = oh;
-        *reinterpret_cast<h8 *>(o + 128 + cc) = ol;
-      } else {
-        *reinterpret_cast<h8 *>(o + 256 + cc) = oh;
-      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      xb[kk] = xn[kk];
+      bb[kk] = bn[kk];
     }
   }
 }
@@ -304,12 +310,12 @@ static void plan(int B, int Q, int S, int &qsplit, int &nrange, int &range_keys)
 
 extern "C" {
 
-int di_kv_project_fwd(const void *x, const void *w_hi, const void *w_lo, const float *kbias, const float *vbias,
-                      void *out, int B, int S, void *stream) {
-  DI_REQUIRE(x && w_hi && w_lo && kbias && vbias && out && B > 0 && S > 0, "bad kv_project call B=%d S=%d", B, S);
+int di_kv_project_fwd(const void *x, const void *w_packed, const float *kbias, const float *vbias, void *out, int B, int S,
+                      void *stream) {
+  DI_REQUIRE(x && w_packed && kbias && vbias && out && B > 0 && S > 0, "bad kv_project call B=%d S=%d", B, S);
   const long long rows = (long long)B * S;
   hipLaunchKernelGGL(di::xa::kv_project_kernel, dim3((unsigned)((rows + 127) / 128)), dim3(256), 0, (hipStream_t)stream,
-                     (const __half *)x, (const __half *)w_hi, (const __half *)w_lo, kbias, vbias, (__half *)out, rows, S);
+                     (const __half *)x, (const __half *)w_packed, kbias, vbias, (__half *)out, rows, S);
   return di::check_launch("kv_project_fwd");
 }
 

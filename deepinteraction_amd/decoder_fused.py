@@ -172,8 +172,7 @@ class FusedDecoder:
             w, b = _f32(ca.in_proj_weight)[E:], _f32(ca.in_proj_bias)[E:]
             kpe = layer.cross_posembed.tokens(bev_pos[:1], torch.float32)[0]            # (S,E) float32
             bias = torch.addmm(b, kpe, w.t())                                            # (S,2E)
-            hi, lo = ops.split_hi_lo(w)
-            return hi, lo, bias[:, :E].contiguous(), bias[:, E:].contiguous()
+            return ops.pack_kv_weight(w), bias[:, :E].contiguous(), bias[:, E:].contiguous()
         return self._c('kv', [p for p in layer.multihead_attn.parameters()] +
                        [t for t in list(layer.cross_posembed.parameters()) + list(layer.cross_posembed.buffers())] + [bev_pos],
                        build)

@@ -324,7 +324,7 @@ def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw,
         keys = i2p_key_table(pillars, coors, num_points, proj, aug_rev, ori_hw, (Hi, Wi), (Hb, Wb))
     T = keys.T
     assert keys.V == V and keys.bev_hw == (Hb, Wb), 'key table of another geometry'
-    ctx = torch.empty((1, C, Hb, Wb), dtype=img.dtype, device=img.device).contiguous(memory_format=torch.channels_last)
+    ctx = empty_cl(1, C, Hb, Wb, img)          # (allocating NCHW and converting was a 16 us transposing copy of garbage)
     valid = torch.empty((1, 1, Hb, Wb), dtype=img.dtype, device=img.device)
     order = bev_sector_order(Hb, Wb, img.device).data_ptr() if sector_order else None
     _lib.call('di_i2p_attn_fwd', img.data_ptr(), qfold.data_ptr(), keys.table.data_ptr(), order, ctx.data_ptr(),
@@ -341,10 +341,8 @@ def i2p_attention_bwd(img, qfold, grad_ctx, pillars, coors, num_points, proj, au
     V, C, Hi, Wi = img.shape
     _, _, Hb, Wb = qfold.shape
     P, T, D = pillars.shape
-    g_img = torch.zeros((V, C, Hi, Wi), dtype=torch.float32, device=img.device).contiguous(
-        memory_format=torch.channels_last)
-    g_q = torch.zeros((1, C, Hb, Wb), dtype=torch.float32, device=img.device).contiguous(
-        memory_format=torch.channels_last)
+    g_img = torch.empty((V, C, Hi, Wi), dtype=torch.float32, device=img.device, memory_format=torch.channels_last).zero_()
+    g_q = torch.empty((1, C, Hb, Wb), dtype=torch.float32, device=img.device, memory_format=torch.channels_last).zero_()
     _lib.call('di_i2p_attn_bwd', img.data_ptr(), qfold.data_ptr(), grad_ctx.data_ptr(), pillars.data_ptr(),
               coors.data_ptr(), num_points.data_ptr(), proj.data_ptr(), aug_rev.data_ptr(), g_img.data_ptr(),
               g_q.data_ptr(), P, T, D, V, Hi, Wi, Hb, Wb, C, float(ori_hw[0]), float(ori_hw[1]), float(dropout_p),
@@ -399,8 +397,7 @@ def bevwarp_gather_bwd(grad_out, depth, img2lidar, aug_fwd, xs, ys, pc_range, be
     grad_out = cl(grad_out)
     V, C, Hi, Wi = grad_out.shape
     Hb, Wb = bev_hw
-    g = torch.zeros((1, C, Hb, Wb), dtype=torch.float32, device=grad_out.device).contiguous(
-        memory_format=torch.channels_last)
+    g = torch.empty((1, C, Hb, Wb), dtype=torch.float32, device=grad_out.device, memory_format=torch.channels_last).zero_()
     _lib.call('di_bevwarp_gather_bwd', grad_out.data_ptr(), depth.data_ptr(), img2lidar.data_ptr(),
               aug_fwd.data_ptr(), xs.data_ptr(), ys.data_ptr(), pc_range.data_ptr(), g.data_ptr(), V, Hi, Wi, Hb,
               Wb, C, _code(grad_out), _stream())
@@ -481,8 +478,7 @@ def roi_align_bwd(grad_out, rois, feat_shape, spatial_scale):
     grad_out = grad_out.contiguous()
     N, C, H, W = feat_shape
     R = rois.shape[0]
-    g = torch.zeros((N, C, H, W), dtype=torch.float32, device=grad_out.device).contiguous(
-        memory_format=torch.channels_last)
+    g = torch.empty((N, C, H, W), dtype=torch.float32, device=grad_out.device, memory_format=torch.channels_last).zero_()
     _lib.call('di_roi_align_bwd', grad_out.data_ptr(), rois.contiguous().data_ptr(), g.data_ptr(), R, N, H, W, C,
               float(spatial_scale), _code(grad_out), _stream())
     return g
@@ -669,7 +665,7 @@ def grid_gather_bwd(grid, grad_out, feat_shape, grids_per_feat=1):
     Bf, C, H, W = feat_shape
     Bg, N = grid.shape[:2]
     grad_out = grad_out.contiguous()
-    gf = torch.zeros((Bf, C, H, W), dtype=torch.float32, device=grid.device).contiguous(memory_format=torch.channels_last)
+    gf = torch.empty((Bf, C, H, W), dtype=torch.float32, device=grid.device, memory_format=torch.channels_last).zero_()
     _lib.call('di_grid_gather_bwd', grid.data_ptr(), grad_out.data_ptr(), gf.data_ptr(), Bg, N, grids_per_feat, H, W, C,
               _code(grad_out), _stream())
     return gf
@@ -999,17 +995,25 @@ def split_hi_lo(w):
     return hi.contiguous(), lo.contiguous()
 
 
-def kv_project(x_tokens, w_hi, w_lo, kbias, vbias):
+def pack_kv_weight(w):
+    """(256,128) float32 K/V projection weight (rows [K ; V]) -> the packed operand of `kv_project`: rows permuted so
+    that MFMA row i' of tile (pt, nb) is channel 32pt + 8(i' >> 2) + 4nb + (i' & 3), then `pack_linear`."""
+    r = torch.arange(256, device=w.device)
+    pt, nb, ip = r // 32, (r % 32) // 16, r % 16
+    return pack_linear(w.detach().float()[32 * pt + 8 * (ip // 4) + 4 * nb + (ip % 4)])
+
+
+def kv_project(x_tokens, w_packed, kbias, vbias):
     """x_tokens (B,S,128) fp16 (a view of the channels-last BEV map) -> (B,S,384) fp16 = [Khi | Klo | V]
-    (K = Khi + Klo / 2048 = Wk x + kbias, V = Wv x + vbias; kbias / vbias (S,128) float32)."""
-    _dev(x_tokens, w_hi)
+    (K = Khi + Klo / 2048 = Wk x + kbias, V = Wv x + vbias; kbias / vbias (S,128) float32; w_packed = `pack_kv_weight`)."""
+    _dev(x_tokens, w_packed)
     B, S, C = x_tokens.shape
     assert C == 128 and x_tokens.dtype == torch.float16 and x_tokens.is_contiguous()
-    assert w_hi.shape == (256, 128) and w_lo.shape == (256, 128) and w_hi.dtype == torch.float16
+    assert w_packed.dtype == torch.float16 and w_packed.numel() == 256 * 128 * 2 and w_packed.is_contiguous()
     assert kbias.shape == (S, 128) and vbias.shape == (S, 128) and kbias.dtype == torch.float32 and kbias.is_contiguous()
     out = torch.empty((B, S, 384), dtype=torch.float16, device=x_tokens.device)
-    _lib.call('di_kv_project_fwd', x_tokens.data_ptr(), w_hi.data_ptr(), w_lo.data_ptr(), kbias.data_ptr(),
-              vbias.contiguous().data_ptr(), out.data_ptr(), B, S, _stream())
+    _lib.call('di_kv_project_fwd', x_tokens.data_ptr(), w_packed.data_ptr(), kbias.data_ptr(), vbias.contiguous().data_ptr(),
+              out.data_ptr(), B, S, _stream())
     return out
 
 

@@ -241,14 +241,15 @@ int di_mha_decode_fwd(const void *q, const void *kv, void *out, float *scratch, 
  *     so K and q in fp16 alone break the 1e-3 contract - DESIGN.md "Numerics"):
  *   di_kv_project_fwd: K = Wk x + kbias, V = Wv x + vbias for the B*S tokens x (fp16, 128 channels) of the BEV map
  *     (decoder_utils.py:98-100 with `key + key_pos` folded: kbias = Wk kpe + bk is constant, float32 (S,128));
- *     the float32 weight arrives split, W = w_hi + w_lo / 2048 (fp16 (256,128) each, rows [K ; V]);
+ *     the float32 weight (256,128) (rows [K ; V]) arrives as hi + lo / 2048 fp16 in MFMA fragment order, tile pairs'
+ *     rows permuted for 16-B stores (`ops.pack_kv_weight`);
  *     out (B*S, 384) fp16 = [Khi | Klo | V] with K = Khi + Klo / 2048.
  *   di_mha_decode_x_fwd: q (B,Q,128) float32, UNSCALED; kx from di_kv_project_fwd; 8 heads x 16; writes one partial
  *     soft-max state [m (exp2 domain), l, O[16]] per (sample, head, query, key range) to scratch
  *     (B*8*Q*di_mha_decode_x_ranges(B,Q,S)*18 floats); with `out` (B,Q,128) float32 a second launch merges them (one
  *     wavefront per (sample, head, query)), with out == NULL a DI_TOK_COMBINE step of di_token_program does. */
-int di_kv_project_fwd(const void *x, const void *w_hi, const void *w_lo, const float *kbias, const float *vbias,
-                      void *out, int B, int S, void *stream);
+int di_kv_project_fwd(const void *x, const void *w_packed, const float *kbias, const float *vbias, void *out, int B, int S,
+                      void *stream);
 int di_mha_decode_x_ranges(int B, int Q, int S);
 int di_mha_decode_x_fwd(const float *q, const void *kx, float *scratch, float *out, int B, int Q, int S, float scale,
                         void *stream);

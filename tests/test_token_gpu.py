@@ -255,8 +255,7 @@ def test_cross_attention_x(B, Q, S):
     w = r(2 * E, E) * 0.4
     kb, vb = r(S, E) * 8, r(S, E)
     q = r(B, Q, E) * 6
-    hi, lo = ops.split_hi_lo(D(w))
-    kx = ops.kv_project(D(x), hi, lo, D(kb), D(vb))
+    kx = ops.kv_project(D(x), ops.pack_kv_weight(D(w)), D(kb), D(vb))
     K = x.double() @ w[:E].double().t() + kb.double()
     Vv = x.double() @ w[E:].double().t() + vb.double()
     got_k = kx[..., :E].double().cpu() + kx[..., E:2 * E].double().cpu() / 2048.0
