@@ -120,13 +120,26 @@ __device__ __forceinline__ float median25(const float *__restrict__ d, int H, in
 // side stream cost nothing, the chain is hidden under the shared convolutions.)
 __global__ __launch_bounds__(256) void dc_col_first_kernel(const float *__restrict__ in, int32_t *__restrict__ first, int V,
                                                            int H, int W) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V * W) return;
-  const int v = i / W, x = i - v * W;
-  const float *d = in + (size_t)v * H * W + x;
+  // a block = 64 columns x 4 row quarters: coalesced row reads, every load independent (a serial scan of one column
+  // per thread was 112 dependent strided loads: 32 us)
+  __shared__ int part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), yq = threadIdx.x >> 6;
+  const int hq = (H + 3) >> 2, y0 = yq * hq, y1 = min(y0 + hq, H);
   int f = H;
-  for (int y = H - 1; y >= 0; --y) f = d[(size_t)y * W] > 0.1f ? y : f;
-  first[i] = f;
+  if (col < V * W) {
+    const int v = col / W, x = col - v * W;
+    const float *d = in + (size_t)v * H * W + x;
+    for (int yb = y0; yb < y1; yb += 8) {
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = d[(size_t)min(yb + j, y1 - 1) * W];
+#pragma unroll
+      for (int j = 7; j >= 0; --j) f = (yb + j < y1 && t[j] > 0.1f && yb + j < f) ? yb + j : f;
+    }
+  }
+  part[yq][threadIdx.x & 63] = f;
+  __syncthreads();
+  if (yq == 0 && col < V * W) first[col] = min(min(part[0][threadIdx.x], part[1][threadIdx.x]), min(part[2][threadIdx.x], part[3][threadIdx.x]));
 }
 
 // :203-206  s4 = s3 > 0.1 ? median(s3) : s3
@@ -281,7 +294,7 @@ extern "C" int di_depth_complete(const float *sparse, float *dense, float *scrat
   hipLaunchKernelGGL(dc_multiscale_kernel, g, b, 0, s, sparse, A, first_a, first_b, V, H, W);   // s2
   hipLaunchKernelGGL((dc_box_kernel<2, true>), g, b, 0, s, A, B, V, H, W);               // close: dilate
   hipLaunchKernelGGL((dc_box_kernel<2, false>), g, b, 0, s, B, A, V, H, W);              //        erode -> s3
-  const dim3 gc((V * W + 255) / 256);
+  const dim3 gc((V * W + 63) / 64);
   hipLaunchKernelGGL(dc_median_valid_kernel, g, b, 0, s, A, B, first_a, V, H, W);        // s4
   hipLaunchKernelGGL(dc_col_first_kernel, gc, b, 0, s, B, first_a, V, H, W);             // its top rows
   hipLaunchKernelGGL((dc_fill_kernel<4, false>), g, b, 0, s, B, first_a, A, first_b, V, H, W);      // s5
