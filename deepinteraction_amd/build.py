@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, 'libdeepinteraction_hip.so')
 ARCH = 'gfx950'
 # No packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): on the MI355X boxes of this project
 # they returned wrong results in lanes 48-63 - sporadically, only while a matrix-core kernel shared the CU (two streams /
-# two samples in flight) - see DESIGN.md section 6 and tools/keys_race3.py.  Scalar fp32 ops cost the hot kernels nothing
+# two samples in flight) - see DESIGN.md section 5, tools/hazard/ and tools/debug/keys_race3.py.  Scalar fp32 ops cost the hot kernels nothing
 # measurable (they are bound by MFMA, LDS or memory).
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-cuda-compat', '-Wno-unused-result',
          f'--offload-arch={ARCH}', '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']

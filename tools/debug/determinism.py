@@ -1,8 +1,8 @@
 """Run-to-run bitwise reproducibility of the hot-path ops and modules (GPU)."""
 import math, os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
 from deepinteraction_amd import ops, synth
 from test_graph_gpu import _to_device
 from deepinteraction_amd.mmdet3d_plugin import DeepInteractionEncoder

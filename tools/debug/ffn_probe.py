@@ -2,7 +2,7 @@
 rocprofv3 --kernel-trace --stats)."""
 import os, sys, torch
 import torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from deepinteraction_amd import ops
 M = 134400
 g = torch.Generator(device='cuda').manual_seed(0)

@@ -1,6 +1,6 @@
 """Which Python lines launch large device copies in one eager forward (torch.profiler with stacks)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from deepinteraction_amd import harness, synth
 from torch.profiler import profile, ProfilerActivity
 shape = synth.SHAPE_R

@@ -1,6 +1,6 @@
 """Debug: replayed hipGraph vs eager over a pool of samples (bench.py's per-step sequence)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from deepinteraction_amd import harness, parallel, synth
 from deepinteraction_amd.graphed import GraphedHotPath
 shape = synth.SHAPE_R

@@ -1,7 +1,7 @@
 """Does a plain torch kernel (no code of this repo) return different bits when it shares the chip with a matrix-core
 kernel inside a captured graph?"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from deepinteraction_amd import ops
 g = torch.Generator(device='cuda').manual_seed(0)
 Hi, Wi = 112, 200

@@ -1,6 +1,6 @@
 """Dump the key row of a cell whose count glitches under [key build || conv] graph replays."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from deepinteraction_amd import ops, synth
 from deepinteraction_amd.geometry import SampleGeometry
 shape = synth.SHAPE_R

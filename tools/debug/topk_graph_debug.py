@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from deepinteraction_amd import ops
 B, N, k = 1, 324000, 200
 g0 = torch.Generator(device='cuda').manual_seed(0)
