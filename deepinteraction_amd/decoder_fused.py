@@ -200,15 +200,11 @@ class FusedDecoder:
             p.store(qkv_buf, qkv_out[0], roles=(nh, nh + 1), n=128, role_offset=128)
             p.store_t(qkv_buf, qkv_out[1], roles=(nh + 2, nh + 2))
 
-    def _block(self, blk, sfx, x, qkv, roi, B, Q, heads, next_qkv_w, member=None, view=None, keep=None):
-        """decoder_utils.py:743-756 / :824-837 on tokens x (B*Q,128) whose packed self-attention projection `qkv` the
-        previous program wrote, then this stage's prediction heads (`heads` = the arguments of TokenProgram.heads, on
-        [x' ; x]) and the next block's packed projection.  Returns (x', qkv').  Three programs around the DynamicConv
-        kernels; the weights of a token group are spread over the roles (<= 128 KB per workgroup)."""
+    def _attend(self, blk, sfx, x, qkv, B, Q, member=None, view=None):
+        """decoder_utils.py:743-746 / :824-826: y = norm1(x + self_attention(x)) from the packed projection `qkv` = (rows
+        [q | k], V^T) the previous program wrote."""
         c = self._block_consts(blk, sfx)
-        M, dev = B * Q, x.device
-        f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        y = f32e(M, 128)
+        y = torch.empty((B * Q, 128), dtype=torch.float32, device=x.device)
         p = ops.TokenProgram()
         p.attn(0, qkv[0], qkv[1], c['scale'], member, view)
         p.linear(0, 1, c['sa'][2], c['sa'][3])
@@ -216,6 +212,16 @@ class FusedDecoder:
         p.rowop(1, 1, aux=2, ln=c['n1'], eps=c['eps'][0])
         p.store(1, y)
         p.run(B, Q)
+        return y
+
+    def _refine(self, blk, sfx, x, y, roi, B, Q, heads, next_qkv_w, keep=None):
+        """decoder_utils.py:747-756 / :827-837 on y (B*Q,128) and the RoI features, then this stage's prediction heads
+        (`heads` = the arguments of TokenProgram.heads, on [x' ; x]) and the next block's packed projection.  Returns
+        (x', qkv').  Two programs around the DynamicConv kernels; the weights of a token group are spread over the roles
+        (<= 128 KB per workgroup)."""
+        c = self._block_consts(blk, sfx)
+        M, dev = B * Q, x.device
+        f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         params = ops.token_wide(y, c['wd'], c['bd'])                                 # (M, 65536) hi / lo fragments
         f2p = ops.dynconv(roi, params, c['dn1'], c['dn2'], c['deps'][0])
         ws, ns = ops.token_splitk(f2p, c['wout'])
@@ -351,20 +357,29 @@ class FusedDecoder:
             nxt = (blk_consts[l + 1]['sa'][0], blk_consts[l + 1]['sa'][1]) if l + 1 < L else None
             heads = dict(w1=hc[0], b1=hc[1], w2=hc[2], b2=hc[3], qpos=pos, outs=final, cls=cls, center_head=ic, ldo=L * Q,
                          col0=l * Q, pos_out=pos_next)
+            # The RoI side (box geometry -> RoIs -> RoIAlign) and the token side (self attention among the queries) of a
+            # block are independent up to the DynamicConv core and CAN run as two branches (DI_OVERLAP bit 32; the image
+            # block's attention is masked by the per-view membership, so only its RoIAlign runs beside it).  Measured on
+            # one box, one sample at a time: 1.519-1.527 ms with the fork against 1.503-1.510 without (two in flight: 896
+            # against 902 samples/s) - the fork / join events cost more than the 6-18 us they hide.  Off by default.
+            par = (lambda a, b: fork_join(dev, a, b)) if utils.OVERLAP & 32 else (lambda a, b: [a(), b()])
             if l % 2 == 0:
                 on, rect, _ = ops.query_geometry(r32, geom.proj, geom.aug_rev, geom.per_sample,
                                                  cfg['out_size_factor'] * cfg['voxel_size'][0], cfg['pc_range'][:2],
                                                  1.0, 1.0, True, False, ld=ld)
                 rois, view, member, keep, on_img = ops.roi_select(rect, on)
-                roi = ops.roi_align(maps, rois, 1.0 / blk.out_size_factor_img, out_f32=True)     # (B*Q,49,C)
+                y, roi = par(lambda: self._attend(blk, '', x, qkv_b, B, Q, member, view),
+                             lambda: ops.roi_align(maps, rois, 1.0 / blk.out_size_factor_img, out_f32=True))   # (B*Q,49,C)
                 heads.update(keep=keep, first=first)
-                x, qkv_b = self._block(blk, '', x, qkv_b, roi, B, Q, heads, nxt, member, view, keep)
+                x, qkv_b = self._refine(blk, '', x, y, roi, B, Q, heads, nxt, keep)
                 dec.on_the_image_mask.append(keep.view(B, Q).bool())
             else:
-                _, _, rect = ops.query_geometry(r32, None, None, None, cell_bev, bc.pc_range[:2], cell_bev, 2.0,
-                                                False, True, ld=ld)
-                roi = ops.roi_align(new_lidar_feat, ops.roi_select(rect), 1.0, out_f32=True)
-                x, qkv_b = self._block(blk, '_pts', x, qkv_b, roi, B, Q, heads, nxt)
+                def rois_bev():
+                    _, _, rect = ops.query_geometry(r32, None, None, None, cell_bev, bc.pc_range[:2], cell_bev, 2.0,
+                                                    False, True, ld=ld)
+                    return ops.roi_align(new_lidar_feat, ops.roi_select(rect), 1.0, out_f32=True)
+                y, roi = par(lambda: self._attend(blk, '_pts', x, qkv_b, B, Q), rois_bev)
+                x, qkv_b = self._refine(blk, '_pts', x, y, roi, B, Q, heads, nxt)
             pos = pos_next
             res, ld, col = dict(zip(names, final)), L * Q, l * Q
 

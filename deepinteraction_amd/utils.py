@@ -13,7 +13,8 @@ def param_key(module_or_tensors):
 
 _SIDE_STREAMS = {}
 # which fork/join sites are active (bit 0: encoder layer sides, 1: the two shared convs, 2: depth chain, 3: decoder
-# first map, 4: the BEV -> image warp opens the side stream); DI_OVERLAP overrides for A/B measurements
+# first map, 4: the BEV -> image warp opens the side stream, 5: RoI side of a decoder block beside its self attention - measured
+# slower, off); DI_OVERLAP overrides for A/B measurements
 import os as _os
 OVERLAP = int(_os.environ.get('DI_OVERLAP', '29'))   # measured (tools/overlap_ab.sh), ms/step: 0: 1.848, 1: 1.800, 5: 1.750, 13: 1.726, 15 (three-way fork): 1.86; later build 13: 1.707, 29: 1.693
 
