@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdeepinteraction_hip.so')
 
-DI_F32, DI_F16 = 0, 1
+DI_F32, DI_F16, DI_F16_HL = 0, 1, 2
 ABI_VERSION = 1
 
 _c_p, _c_i, _c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float

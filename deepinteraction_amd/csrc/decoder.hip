@@ -159,10 +159,11 @@ __device__ __forceinline__ void roi_sample8(const T *__restrict__ map, int H, in
   for (int i = 0; i < 8; ++i) acc[i] = fmaf(w4, f[i], acc[i]);
 }
 
+struct HLOut {};      // output tag: split fp16 pair
 template <typename T, bool FULLC, typename TO = T>
 __global__ __launch_bounds__(256) void roi_align_kernel(const T *__restrict__ feat,
                                                         const float *__restrict__ rois,
-                                                        TO *__restrict__ out, int R, int N, int H, int W,
+                                                        typename std::conditional<std::is_same<TO, HLOut>::value, __half, TO>::type *__restrict__ out, int R, int N, int H, int W,
                                                         int C, float scale) {
   constexpr int PB = 7, G = 2;
   const int l16 = threadIdx.x & 15;
@@ -195,7 +196,21 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const T *__restrict__ fe
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] *= 1.f / (G * G);
-      st8(out + (size_t)g * C + ch0, pack8f(acc, TO()));
+      if constexpr (std::is_same<TO, HLOut>::value) {        // [hi C | lo C] fp16: x = hi + lo / 2048 (csrc/token32.hip)
+        __half *o = reinterpret_cast<__half *>(out) + (size_t)g * 2 * C + ch0;
+        Pack8<__half> ph, pl;
+        __half2 *hh = reinterpret_cast<__half2 *>(&ph.r), *hl = reinterpret_cast<__half2 *>(&pl.r);
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+          const __half a0 = __float2half(acc[2 * i2]), a1 = __float2half(acc[2 * i2 + 1]);
+          hh[i2] = __halves2half2(a0, a1);
+          hl[i2] = __floats2half2_rn((acc[2 * i2] - __half2float(a0)) * 2048.f, (acc[2 * i2 + 1] - __half2float(a1)) * 2048.f);
+        }
+        st8(o, ph);
+        st8(o + C, pl);
+      } else {
+        st8(out + (size_t)g * C + ch0, pack8f(acc, TO()));
+      }
     }
   }
 }
@@ -579,7 +594,8 @@ int di_roi_align_fwd(const void *feat, const float *rois, void *out, int R, int 
 int di_roi_align_x_fwd(const void *feat, const float *rois, void *out, int R, int N, int H, int W, int C,
                        float spatial_scale, int dtype, int out_dtype, void *stream) {
   DI_REQUIRE(R >= 0 && N > 0 && H > 0 && W > 0, "bad roi_align shape");
-  DI_REQUIRE(out_dtype == dtype || out_dtype == DI_F32, "roi_align writes the map's type or float32");
+  DI_REQUIRE(out_dtype == dtype || out_dtype == DI_F32 || (out_dtype == DI_F16_HL && dtype == DI_F16 && C == 128),
+             "roi_align writes the map's type, float32, or (fp16 map, C = 128) the split hi | lo pair");
   DI_REQUIRE(C > 0 && C % 8 == 0 && C <= 128, "C=%d must be a multiple of 8, <= 128", C);
   if (R == 0) return DI_OK;
   const int total = R * 49;
@@ -588,7 +604,10 @@ int di_roi_align_x_fwd(const void *feat, const float *rois, void *out, int R, in
 #define DI_ROI(TT, FULL)                                                                              \
   hipLaunchKernelGGL((di::roi_align_kernel<TT, FULL>), dim3(blocks), dim3(256), 0, s, (const TT *)feat, \
                      rois, (TT *)out, R, N, H, W, C, spatial_scale)
-  if (dtype == DI_F16 && out_dtype == DI_F32) {           // fp16 map, float32 RoI features (the decoder's token path)
+  if (out_dtype == DI_F16_HL) {                            // fp16 map -> RoI features with float32 accuracy as [hi | lo] fp16
+    hipLaunchKernelGGL((di::roi_align_kernel<__half, true, di::HLOut>), dim3(blocks), dim3(256), 0, s, (const __half *)feat,
+                       rois, (__half *)out, R, N, H, W, C, spatial_scale);
+  } else if (dtype == DI_F16 && out_dtype == DI_F32) {    // fp16 map, float32 RoI features
     if (C == 128)
       hipLaunchKernelGGL((di::roi_align_kernel<__half, true, float>), dim3(blocks), dim3(256), 0, s, (const __half *)feat,
                          rois, (float *)out, R, N, H, W, C, spatial_scale);

@@ -479,6 +479,17 @@ __device__ __forceinline__ void step_store(const Step &s, const float *buf, long
     }
     return;
   }
+  if (s.b == 2) {                                         // split store: p0 fp16 rows [hi N | lo N] (the B operand of wide_kernel)
+    __half *yh = (__half *)s.p0;
+    const int n8 = s.N >> 3;
+    for (int e = tid; e < rows * n8; e += NTH) {
+      const int r = e / n8, c = (e - r * n8) * 8;
+      const HL v = split8(ld4(x + r * LDW + c), ld4(x + r * LDW + c + 4));
+      *reinterpret_cast<h8 *>(yh + (m0 + r) * s.ld0 + c) = v.hi;
+      *reinterpret_cast<h8 *>(yh + (m0 + r) * s.ld0 + s.N + c) = v.lo;
+    }
+    return;
+  }
   const int n4 = s.N >> 2;
   for (int e = tid; e < rows * n4; e += NTH) {
     const int r = e / n4, c = (e - r * n4) * 4;
@@ -610,37 +621,40 @@ __global__ __launch_bounds__(NTH) void program_kernel(Program prog, Heads heads,
 //     operand of the split-K kernel, 16 rows x 128 B per (row tile, k-step);
 //   out_layer's weight in k-step order: [tile t][k-step ks][half h][lane][8] (ops.pack_ksteps).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wide_kernel(const float *__restrict__ X, int ldx, const __half *__restrict__ wp,
-                                                   const float *__restrict__ bias, __half *__restrict__ Y, int M) {
+__global__ __launch_bounds__(256, 2) void wide_kernel(const __half *__restrict__ X /*(M,256) = [hi | lo]*/, int ldx,
+                                                      const __half *__restrict__ wp, const float *__restrict__ bias,
+                                                      __half *__restrict__ Y, int M) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  // a workgroup = 2 groups of 64 values x 2 halves of the row tiles: 64 values per wave make 128-B stores, and the
-  // kernel is MFMA-issue bound (13 row tiles x 48 three-pass MFMAs per wave), so all four SIMDs of every CU work
-  const int wq = blockIdx.x * 2 + (wave & 1);             // this wave's 64 values V0 .. V0 + 63
-  const int half = wave >> 1;
-  const int ntile = (M + 15) >> 4, t_lo = half * ((ntile + 1) >> 1), t_hi = half ? ntile : (ntile + 1) >> 1;
-  const int V0 = wq * 64;
-  // packed weight: tile T = 4 wq + nb, row i' <-> value V0 + 16 (i' >> 2) + 4 nb + (i' & 3): a lane ends with the 16
+  // a wave = 64 values x a quarter of the row tiles: 2048 waves = two per SIMD (the kernel is a chain of MFMA and
+  // conversion latencies per row tile; one wave per SIMD left the CUs busy 3x longer than their MFMA + VALU work).
+  // The token rows arrive already split (the producing program stores hi | lo): every wave splitting the same 200 rows
+  // for itself cost more VALU time than the MFMAs.
+  const int wv = blockIdx.x, quarter = wave;              // the workgroup's 64 values V0 .. V0 + 63; a wave = a quarter of the rows
+  const int ntile = (M + 15) >> 4, per = (ntile + 3) >> 2, t_lo = quarter * per, t_hi = min(t_lo + per, ntile);
+  const int V0 = wv * 64;
+  // packed weight: tile T = 4 wv + nb, row i' <-> value V0 + 16 (i' >> 2) + 4 nb + (i' & 3): a lane ends with the 16
   // consecutive values V0 + 16 g + 4 nb + r
   h8 a[4][8];
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
-    const __half *blk = wp + (size_t)(4 * wq + nb) * 4096 + lane * 8;
+    const __half *blk = wp + (size_t)(4 * wv + nb) * 4096 + lane * 8;
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[nb][q] = ld_h8(blk + q * 512);
   }
   f4 bs[4];
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) bs[nb] = bias ? ld4(bias + V0 + 16 * g + 4 * nb) : f4{0.f, 0.f, 0.f, 0.f};
-  f4 xb[8], xn[8];
-  auto fetch = [&](int m0, f4 (&x)[8]) {
-    const float *p = X + (size_t)min(m0 + i, M - 1) * ldx + 8 * g;
+  HL xb[4], xn[4];
+  auto fetch = [&](int m0, HL (&x)[4]) {
+    const __half *p = X + (size_t)min(m0 + i, M - 1) * ldx + 8 * g;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      x[2 * kk] = ld4(p + 32 * kk);
-      x[2 * kk + 1] = ld4(p + 32 * kk + 4);
+      x[kk].hi = ld_h8(p + 32 * kk);
+      x[kk].lo = ld_h8(p + 128 + 32 * kk);
     }
   };
+  if (t_lo >= t_hi) return;
   fetch(16 * t_lo, xb);
   const size_t ooff = ((size_t)(V0 >> 9) * 2) * 512 + (V0 & 511) + 16 * g;
   for (int m0 = 16 * t_lo; m0 < 16 * t_hi; m0 += 16) {
@@ -652,11 +666,9 @@ __global__ __launch_bounds__(256) void wide_kernel(const float *__restrict__ X, 
       lo[nb] = f4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const HL b = split8(xb[2 * kk], xb[2 * kk + 1]);
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) mfma3(a[nb][2 * kk], a[nb][2 * kk + 1], b, hi[nb], lo[nb]);
-    }
+      for (int nb = 0; nb < 4; ++nb) mfma3(a[nb][2 * kk], a[nb][2 * kk + 1], xb[kk], hi[nb], lo[nb]);
     if (m0 + i < M) {
       const HL o0 = split8(hi[0] + lo[0] * kLoInv, hi[1] + lo[1] * kLoInv);
       const HL o1 = split8(hi[2] + lo[2] * kLoInv, hi[3] + lo[3] * kLoInv);
@@ -667,16 +679,19 @@ __global__ __launch_bounds__(256) void wide_kernel(const float *__restrict__ X, 
       *reinterpret_cast<h8 *>(y + 520) = o1.lo;
     }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) xb[c] = xn[c];
+    for (int kk = 0; kk < 4; ++kk) xb[kk] = xn[kk];
   }
 }
 
-constexpr int DC_LD = 132;      // floats per LDS row of the (64 positions x 128 channels) exchange buffer
-__global__ __launch_bounds__(256) void dynconv_kernel(const float *__restrict__ roi, const __half *__restrict__ params,
-                                                      const float *__restrict__ n1w, const float *__restrict__ n1b,
-                                                      const float *__restrict__ n2w, const float *__restrict__ n2b,
-                                                      __half *__restrict__ f2p, int M, float eps) {
-  __shared__ __align__(16) float xs[64 * DC_LD];          // RoI feature, then F1 (position-major)
+constexpr int DC_LD = 136;      // halfs per LDS row and half of the (64 positions x 128 channels) operand image
+__global__ __launch_bounds__(256) void dynconv_kernel(const __half *__restrict__ roi /*(R,49,256) = [hi | lo]*/,
+                                                      const __half *__restrict__ params, const float *__restrict__ n1w,
+                                                      const float *__restrict__ n1b, const float *__restrict__ n2w,
+                                                      const float *__restrict__ n2b, __half *__restrict__ f2p, int M, float eps) {
+  // the B operand of both products as an hi / lo image: the RoI feature (RoIAlign writes it split), then F1 (every wave
+  // writes its 32 channels split).  The first version kept float32 rows here and every wave split all of them for
+  // itself: 4x the conversions, the kernel was bound by them.
+  __shared__ __align__(16) __half img[2 * 64 * DC_LD];
   __shared__ float red[4][64];                            // per (wave, position) partial sums
   const int q = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -692,30 +707,32 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const float *__restrict__ 
   h8 a[2][8];
   frags(0, a);
   {                                                       // RoI feature -> LDS (rows >= 49 zero)
-    const float *rq = roi + (size_t)q * 49 * 128;
+    const __half *rq = roi + (size_t)q * 49 * 256;
+    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int e = tid; e < 64 * 32; e += 256) {
-      const int s = e >> 5, c = (e & 31) * 4;
-      *reinterpret_cast<f4 *>(&xs[s * DC_LD + c]) = s < 49 ? ld4(rq + s * 128 + c) : f4{0.f, 0.f, 0.f, 0.f};
+      const int s = e >> 5, h = (e >> 4) & 1, c = (e & 15) * 8;
+      *reinterpret_cast<h8 *>(&img[(h * 64 + s) * DC_LD + c]) = s < 49 ? ld_h8(rq + s * 256 + h * 128 + c) : zero;
     }
   }
   __syncthreads();
   f4 acc[2][4];                                           // [channel block][position group]: channel 32 wave + 16 nbl + 4g + r, position 16 pg + i
   auto product = [&]() {
-#pragma unroll
-    for (int nbl = 0; nbl < 2; ++nbl)
-#pragma unroll
-      for (int pg = 0; pg < 4; ++pg) acc[nbl][pg] = f4{0.f, 0.f, 0.f, 0.f};
     f4 lo[2][4];
 #pragma unroll
     for (int nbl = 0; nbl < 2; ++nbl)
 #pragma unroll
-      for (int pg = 0; pg < 4; ++pg) lo[nbl][pg] = f4{0.f, 0.f, 0.f, 0.f};
+      for (int pg = 0; pg < 4; ++pg) {
+        acc[nbl][pg] = f4{0.f, 0.f, 0.f, 0.f};
+        lo[nbl][pg] = f4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
     for (int pg = 0; pg < 4; ++pg) {
-      const float *xr = &xs[(16 * pg + i) * DC_LD + 8 * g];
+      const __half *xr = &img[(16 * pg + i) * DC_LD + 8 * g];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const HL b = split8(ld4(xr + 32 * kk), ld4(xr + 32 * kk + 4));
+        HL b;
+        b.hi = *reinterpret_cast<const h8 *>(xr + 32 * kk);
+        b.lo = *reinterpret_cast<const h8 *>(xr + 64 * DC_LD + 32 * kk);
 #pragma unroll
         for (int nbl = 0; nbl < 2; ++nbl) mfma3(a[nbl][2 * kk], a[nbl][2 * kk + 1], b, acc[nbl][pg], lo[nbl][pg]);
       }
@@ -766,11 +783,16 @@ __global__ __launch_bounds__(256) void dynconv_kernel(const float *__restrict__ 
   };
   product();                                              // F1^T
   frags(1, a);                                            // (in flight under the LayerNorm)
-  ln_relu(n1w, n1b);                                      // its last barrier: every wave is done reading the RoI rows
+  ln_relu(n1w, n1b);                                      // its last barrier: every wave is done reading the RoI image
 #pragma unroll
   for (int nbl = 0; nbl < 2; ++nbl)
 #pragma unroll
-    for (int pg = 0; pg < 4; ++pg) *reinterpret_cast<f4 *>(&xs[(16 * pg + i) * DC_LD + 32 * wave + 16 * nbl + 4 * g]) = acc[nbl][pg];
+    for (int pg = 0; pg < 4; ++pg) {
+      const HL4 v = split4(acc[nbl][pg]);
+      __half *o = &img[(16 * pg + i) * DC_LD + 32 * wave + 16 * nbl + 4 * g];
+      *reinterpret_cast<h4 *>(o) = v.hi;
+      *reinterpret_cast<h4 *>(o + 64 * DC_LD) = v.lo;
+    }
   __syncthreads();
   product();                                              // F2^T
   ln_relu(n2w, n2b);
@@ -1002,9 +1024,9 @@ int di_token_program_timed(const di_tok_step *steps, int nsteps, const di_tok_he
   return launch_program(steps, nsteps, heads, B, Q, stamps, stream);
 }
 
-int di_token_wide(const float *x, int ldx, const void *w_packed, const float *bias, void *params, int M, void *stream) {
-  DI_REQUIRE(x && w_packed && params && M > 0, "bad parameter generator call M=%d", M);
-  hipLaunchKernelGGL(di::t32::wide_kernel, dim3(32768 / 128), dim3(256), 0, (hipStream_t)stream, x, ldx,
+int di_token_wide(const void *x_hl, int ldx, const void *w_packed, const float *bias, void *params, int M, void *stream) {
+  DI_REQUIRE(x_hl && w_packed && params && M > 0 && ldx >= 256, "bad parameter generator call M=%d ldx=%d", M, ldx);
+  hipLaunchKernelGGL(di::t32::wide_kernel, dim3(32768 / 64), dim3(256), 0, (hipStream_t)stream, (const __half *)x_hl, ldx,
                      (const __half *)w_packed, bias, (__half *)params, M);
   return di::check_launch("token_wide");
 }
@@ -1021,11 +1043,11 @@ int di_token_splitk(const void *f2p, const void *w_packed, float *workspace, int
   return di::check_launch("token_splitk");
 }
 
-int di_dynconv_fwd(const float *roi, const void *params, const float *n1w, const float *n1b, const float *n2w,
+int di_dynconv_fwd(const void *roi_hl, const void *params, const float *n1w, const float *n1b, const float *n2w,
                    const float *n2b, void *f2p, int R, float eps, void *stream) {
-  DI_REQUIRE(R > 0 && roi && params && f2p && n1w && n1b && n2w && n2b, "bad DynamicConv call R=%d", R);
-  hipLaunchKernelGGL(di::t32::dynconv_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, roi, (const __half *)params, n1w,
-                     n1b, n2w, n2b, (__half *)f2p, R, eps);
+  DI_REQUIRE(R > 0 && roi_hl && params && f2p && n1w && n1b && n2w && n2b, "bad DynamicConv call R=%d", R);
+  hipLaunchKernelGGL(di::t32::dynconv_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const __half *)roi_hl,
+                     (const __half *)params, n1w, n1b, n2w, n2b, (__half *)f2p, R, eps);
   return di::check_launch("dynconv_fwd");
 }
 

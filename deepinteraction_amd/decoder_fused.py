@@ -205,14 +205,15 @@ class FusedDecoder:
         [q | k], V^T) the previous program wrote."""
         c = self._block_consts(blk, sfx)
         y = torch.empty((B * Q, 128), dtype=torch.float32, device=x.device)
+        y_hl = torch.empty((B * Q, 256), dtype=torch.float16, device=x.device)      # the same rows split: the generator's operand
         p = ops.TokenProgram()
         p.attn(0, qkv[0], qkv[1], c['scale'], member, view)
         p.linear(0, 1, c['sa'][2], c['sa'][3])
         p.load(2, x)
         p.rowop(1, 1, aux=2, ln=c['n1'], eps=c['eps'][0])
-        p.store(1, y)
+        p.store(1, y).store_hl(1, y_hl)
         p.run(B, Q)
-        return y
+        return y, y_hl
 
     def _refine(self, blk, sfx, x, y, roi, B, Q, heads, next_qkv_w, keep=None):
         """decoder_utils.py:747-756 / :827-837 on y (B*Q,128) and the RoI features, then this stage's prediction heads
@@ -222,7 +223,8 @@ class FusedDecoder:
         c = self._block_consts(blk, sfx)
         M, dev = B * Q, x.device
         f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        params = ops.token_wide(y, c['wd'], c['bd'])                                 # (M, 65536) hi / lo fragments
+        y, y_hl = y
+        params = ops.token_wide(y_hl, c['wd'], c['bd'])                              # (M, 65536) hi / lo fragments
         f2p = ops.dynconv(roi, params, c['dn1'], c['dn2'], c['deps'][0])
         ws, ns = ops.token_splitk(f2p, c['wout'])
         # FFN with the hidden dimension split over the roles: role r holds hidden channels [128r, 128r + 128)
@@ -369,7 +371,7 @@ class FusedDecoder:
                                                  1.0, 1.0, True, False, ld=ld)
                 rois, view, member, keep, on_img = ops.roi_select(rect, on)
                 y, roi = par(lambda: self._attend(blk, '', x, qkv_b, B, Q, member, view),
-                             lambda: ops.roi_align(maps, rois, 1.0 / blk.out_size_factor_img, out_f32=True))   # (B*Q,49,C)
+                             lambda: ops.roi_align(maps, rois, 1.0 / blk.out_size_factor_img, out_hl=True))   # (B*Q,49,2C) hi | lo
                 heads.update(keep=keep, first=first)
                 x, qkv_b = self._refine(blk, '', x, y, roi, B, Q, heads, nxt, keep)
                 dec.on_the_image_mask.append(keep.view(B, Q).bool())
@@ -377,7 +379,7 @@ class FusedDecoder:
                 def rois_bev():
                     _, _, rect = ops.query_geometry(r32, None, None, None, cell_bev, bc.pc_range[:2], cell_bev, 2.0,
                                                     False, True, ld=ld)
-                    return ops.roi_align(new_lidar_feat, ops.roi_select(rect), 1.0, out_f32=True)
+                    return ops.roi_align(new_lidar_feat, ops.roi_select(rect), 1.0, out_hl=True)
                 y, roi = par(lambda: self._attend(blk, '_pts', x, qkv_b, B, Q), rois_bev)
                 x, qkv_b = self._refine(blk, '_pts', x, y, roi, B, Q, heads, nxt)
             pos = pos_next

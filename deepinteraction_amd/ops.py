@@ -458,17 +458,24 @@ def query_geometry(res, proj, aug_rev, per_sample, cell, pc_xy, bev_cell, dim_sc
     return on, ri, rb
 
 
-def roi_align(feat, rois, spatial_scale, out_f32=False):
-    """feat (N,C,H,W) channels-last; rois (R,5) f32 [n,x0,y0,x1,y1] -> (R,49,C) (float32 with out_f32)."""
+def roi_align(feat, rois, spatial_scale, out_f32=False, out_hl=False):
+    """feat (N,C,H,W) channels-last; rois (R,5) f32 [n,x0,y0,x1,y1] -> (R,49,C) (float32 with out_f32; with out_hl - fp16
+    map, C = 128 - (R,49,2C) fp16 rows [hi | lo] of float32 accuracy, the matrix operand of `dynconv`)."""
     _dev(feat, rois)
     feat = cl(feat)
     N, C, H, W = feat.shape
     rois = rois.contiguous()
     assert rois.dtype == torch.float32 and rois.shape[1] == 5
     R = rois.shape[0]
-    out = torch.empty((R, 49, C), dtype=torch.float32 if out_f32 else feat.dtype, device=feat.device)
+    if out_hl:
+        assert feat.dtype == torch.float16 and C == 128
+        out = torch.empty((R, 49, 2 * C), dtype=torch.float16, device=feat.device)
+        code = _lib.DI_F16_HL
+    else:
+        out = torch.empty((R, 49, C), dtype=torch.float32 if out_f32 else feat.dtype, device=feat.device)
+        code = _lib.DI_F32 if out_f32 else _code(feat)
     _lib.call('di_roi_align_x_fwd', feat.data_ptr(), rois.data_ptr(), out.data_ptr(), R, N, H, W, C,
-              float(spatial_scale), _code(feat), _lib.DI_F32 if out_f32 else _code(feat), _stream())
+              float(spatial_scale), _code(feat), code, _stream())
     return out
 
 
@@ -835,6 +842,11 @@ class TokenProgram:
         assert _f32c(vt).dim() == 3 and vt.is_contiguous() and vt.shape[2] % 16 == 0
         return self._add(_lib.TOK_STORE, src=src, N=vt.shape[1], a=col, b=1, p0=vt, ld0=vt.shape[2], roles=roles)
 
+    def store_hl(self, src, y_hl, col=0, roles=None):
+        """y_hl (M, 2N) fp16 = [hi N | lo N] of buf[src][:, col:col+N]: the split store (`token_wide` reads tokens so)."""
+        assert y_hl.dtype == torch.float16 and y_hl.stride(-1) == 1 and y_hl.shape[-1] % 16 == 0
+        return self._add(_lib.TOK_STORE, src=src, N=y_hl.shape[-1] // 2, a=col, b=2, p0=y_hl, ld0=y_hl.stride(-2), roles=roles)
+
     def heads(self, src, w2, b2, qpos, outs, cls, center_head, ldo, col0, keep=None, first=None, pos_out=None, roles=None,
               per_role=False):
         """Second layers of the prediction heads on the hidden rows in buf[src] (see include/deepinteraction_hip.h);
@@ -866,17 +878,24 @@ class TokenProgram:
             _lib.call('di_token_program_timed', ctypes.addressof(arr), n, hp, B, Q, stamps.data_ptr(), _stream())
 
 
-def token_wide(x, w_packed, bias):
-    """DynamicConv's parameter generator (weight stationary): x (M,128) float32 -> params (M, 65536) fp16, the hi / lo
-    fragments `dynconv` reads; w_packed, bias from `decoder_fused._dyn_layout`."""
-    _dev(x, w_packed)
-    _f32c(x)
-    M = x.shape[0]
-    assert x.shape[1] == 128 and w_packed.dtype == torch.float16 and w_packed.numel() == 32768 * 128 * 2 and w_packed.is_contiguous()
+def token_wide(x_hl, w_packed, bias):
+    """DynamicConv's parameter generator (weight stationary): tokens x_hl (M,256) fp16 = [hi | lo] (`TokenProgram.store_hl`
+    / `split_rows`) -> params (M, 65536) fp16, the hi / lo fragments `dynconv` reads; w_packed, bias from
+    `decoder_fused._dyn_layout`."""
+    _dev(x_hl, w_packed)
+    M = x_hl.shape[0]
+    assert x_hl.shape[1] == 256 and x_hl.dtype == torch.float16 and x_hl.stride(1) == 1
+    assert w_packed.dtype == torch.float16 and w_packed.numel() == 32768 * 128 * 2 and w_packed.is_contiguous()
     assert bias.dtype == torch.float32 and bias.numel() == 32768
-    y = torch.empty((M, 65536), dtype=torch.float16, device=x.device)
-    _lib.call('di_token_wide', x.data_ptr(), x.stride(0), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), M, _stream())
+    y = torch.empty((M, 65536), dtype=torch.float16, device=x_hl.device)
+    _lib.call('di_token_wide', x_hl.data_ptr(), x_hl.stride(0), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), M, _stream())
     return y
+
+
+def split_rows(x):
+    """(M,N) float32 -> (M,2N) fp16 rows [hi | lo] (tests; the product's programs write this form with `store_hl`)."""
+    hi, lo = split_hi_lo(x)
+    return torch.cat([hi, lo], -1).contiguous()
 
 
 def token_splitk(f2p, w_packed):
@@ -894,11 +913,12 @@ def token_splitk(f2p, w_packed):
 
 
 def dynconv(roi, params, n1, n2, eps=1e-5):
-    """roi (R,49,128) float32, params (R, 65536) fp16 from `token_wide`, n1/n2 = (weight, bias) float32 of
-    DynamicConv.norm1/2 -> relu(LN2(relu(LN1(roi @ p1)) @ p2)) as f2p (196, R, 64) fp16 (k-step major, hi | lo)."""
+    """roi (R,49,256) fp16 = [hi | lo] (`roi_align(out_hl=True)`), params (R, 65536) fp16 from `token_wide`, n1/n2 =
+    (weight, bias) float32 of DynamicConv.norm1/2 -> relu(LN2(relu(LN1(roi @ p1)) @ p2)) as f2p (196, R, 64) fp16 (k-step
+    major, hi | lo)."""
     _dev(roi, params)
     R = roi.shape[0]
-    assert roi.shape == (R, 49, 128) and roi.is_contiguous() and roi.dtype == torch.float32
+    assert roi.shape == (R, 49, 256) and roi.is_contiguous() and roi.dtype == torch.float16
     assert params.shape == (R, 65536) and params.is_contiguous() and params.dtype == torch.float16
     assert n1[0].dtype == torch.float32
     f2p = torch.empty((196, R, 64), dtype=torch.float16, device=roi.device)

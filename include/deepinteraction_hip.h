@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-enum { DI_F32 = 0, DI_F16 = 1 };
+enum { DI_F32 = 0, DI_F16 = 1, DI_F16_HL = 2 /* outputs only: split pair [hi | lo] fp16, x = hi + lo / 2048 */ };
 enum {
   DI_OK = 0,
   DI_ERR_ARG = -1,      /* unsupported shape / window / dtype */
@@ -218,8 +218,8 @@ int di_query_geometry_ld(const float *center, const float *height, const float *
  *     DynamicConv without the reference's flatten/permute). */
 int di_roi_align_fwd(const void *feat, const float *rois, void *out, int R, int N, int H, int W, int C,
                      float spatial_scale, int dtype, void *stream);
-/* ... with the output type chosen separately (out_dtype = dtype, or DI_F32 RoI features from an fp16 map: the
- * decoder's float32 token path). */
+/* ... with the output type chosen separately: out_dtype = dtype, DI_F32, or DI_F16_HL = (R,49,2C) fp16 rows [hi C | lo C]
+ * with float32 accuracy (fp16 map, C = 128: the matrix operand of di_dynconv_fwd). */
 int di_roi_align_x_fwd(const void *feat, const float *rois, void *out, int R, int N, int H, int W, int C,
                        float spatial_scale, int dtype, int out_dtype, void *stream);
 
@@ -375,17 +375,20 @@ int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w_staged, co
  *                        (blocks (N/16, K/128) of 8 x 1 KiB: `ops.pack_linear`); a: 0 none, 1 ReLU, 2 GELU(erf);
  *                        K multiple of 128, N of 16, both <= 512
  *     DI_TOK_ROWOP       dst[:, :128]  = mask_p2(relu_{b&1}(LayerNorm_{p0,p1,eps=f}(src + buf[aux])))   each part optional
- *     DI_TOK_STORE       p0[m, :N]     = src[:, a:a+N];  b = 1: transposed, p0[(sample*N + c)*ld0 + q] (the V^T above)
+ *     DI_TOK_STORE       p0[m, :N]     = src[:, a:a+N];  b = 1: transposed, p0[(sample*N + c)*ld0 + q] (the V^T above);
+ *                        b = 2: split, p0 fp16 rows [hi N | lo N] (the token operand of di_token_wide)
  *     DI_TOK_HEADS       second layers of the prediction heads on the hidden rows in src (first layers: a LINEAR step
  *                        with the BatchNorm-folded, stacked (nheads*64, K) weight), `center += query_pos`, the
  *                        on-the-image merge with the first stage (`keep`), written at column col0 of the
  *                        (B, cls_h, ldo) float32 outputs; pos_out = the new centres (B,Q,2)   (:498-581, head :265-311)
  * DynamicConv (:608-624) as three kernels whose operands are laid out for one contiguous KiB per wave-level load
  * (layouts: csrc/token32.hip, host side `decoder_fused._dyn_layout` / `ops.pack_linear` / `ops.pack_ksteps`):
- * di_token_wide: params (M, 65536) fp16 = the generator Linear 128 -> 2*128*128 of x (M,128) float32, weight stationary,
+ * di_token_wide: params (M, 65536) fp16 = the generator Linear 128 -> 2*128*128 of the tokens x, given SPLIT as x_hl (M, 256)
+ *   fp16 = [hi 128 | lo 128] (a DI_TOK_STORE step with b = 2 writes that), weight stationary,
  *   written as hi / lo fragments in the order di_dynconv_fwd reads them; w_packed = the generator's weight, rows
  *   permuted to that order, in MFMA fragment order; bias (32768) in value order.
- * di_dynconv_fwd: F2 = relu(LN2(relu(LN1(roi . p1)) . p2)) per RoI (:617-622); roi (R,49,128) float32; F2 leaves as
+ * di_dynconv_fwd: F2 = relu(LN2(relu(LN1(roi . p1)) . p2)) per RoI (:617-622); roi_hl (R,49,256) fp16 = [hi | lo]
+ *   (di_roi_align_x_fwd with DI_F16_HL); F2 leaves as
  *   f2p (196, R, 64) fp16 = [k-step of the flattened (49*128) feature][RoI][hi 32 | lo 32].
  * di_token_splitk: partial sums of out_layer (:624) over 14 K slices into workspace (slices, M, 128) float32 from f2p
  *   and the weight in k-step order; a DI_TOK_LOAD_PARTS step of the next program sums them.
@@ -422,10 +425,10 @@ int di_token_program(const di_tok_step *steps_host, int nsteps, const di_tok_hea
  * barrier to stamps[0 .. nsteps] (device memory). */
 int di_token_program_timed(const di_tok_step *steps_host, int nsteps, const di_tok_heads *heads_host, int B, int Q,
                            unsigned long long *stamps, void *stream);
-int di_token_wide(const float *x, int ldx, const void *w_packed, const float *bias, void *params, int M, void *stream);
+int di_token_wide(const void *x_hl, int ldx, const void *w_packed, const float *bias, void *params, int M, void *stream);
 long long di_token_splitk_workspace_bytes(int M, int K);
 int di_token_splitk(const void *f2p, const void *w_packed, float *workspace, int M, int K, int *nslices_host, void *stream);
-int di_dynconv_fwd(const float *roi, const void *params, const float *n1w, const float *n1b, const float *n2w,
+int di_dynconv_fwd(const void *roi_hl, const void *params, const float *n1w, const float *n1b, const float *n2w,
                    const float *n2b, void *f2p, int R, float eps, void *stream);
 int di_roi_select(const int *on, const float *rect, float *rois, void *view, void *member, void *keep, float *on_img,
                   int B, int V, int Q, void *stream);

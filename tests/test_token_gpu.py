@@ -166,8 +166,13 @@ def test_wide_generator():
     g, r = _gen(5)
     x, w, b = r(200, 128), r(32768, 128) / 11, r(32768) * 0.1
     wp, bv = decoder_fused._dyn_layout(D(w), D(b))
-    _close(_join_params(ops.token_wide(D(x), wp, bv)), _ref_params(w, b, x), 1e-6)
-    _close(_join_params(ops.token_wide(D(x[:37]), wp, bv)), _ref_params(w, b, x[:37]), 1e-6)
+    xs = ops.split_rows(D(x))
+    _close(_join_params(ops.token_wide(xs, wp, bv)), _ref_params(w, b, x), 1e-6)
+    _close(_join_params(ops.token_wide(xs[:37], wp, bv)), _ref_params(w, b, x[:37]), 1e-6)
+    # the split store of a program writes the same rows
+    y_hl = torch.empty((200, 256), dtype=torch.float16, device=DEV)
+    ops.TokenProgram().load(0, D(x)).store_hl(0, y_hl).run(1, 200)
+    assert torch.equal(y_hl, xs)
 
 
 @pytest.mark.parametrize('M', [1, 37, 200, 400])
@@ -191,8 +196,8 @@ def test_dynconv_core():
     n = lambda: (1 + 0.2 * r(128), 0.1 * r(128))
     n1, n2 = n(), n()
     wp, bv = decoder_fused._dyn_layout(D(w), D(b))
-    params_dev = ops.token_wide(D(y), wp, bv)
-    got = ops.dynconv(D(roi), params_dev, tuple(D(t) for t in n1), tuple(D(t) for t in n2))
+    params_dev = ops.token_wide(ops.split_rows(D(y)), wp, bv)
+    got = ops.dynconv(ops.split_rows(D(roi).view(-1, 128)).view(R, 49, 256), params_dev, tuple(D(t) for t in n1), tuple(D(t) for t in n2))
     params = _join_params(params_dev)                                               # what the kernel multiplied by
     p1 = params[:, :16384].view(R, 128, 128)
     p2 = params[:, 16384:].view(R, 128, 128)
@@ -281,6 +286,8 @@ def test_roi_align_float32_out():
     a = ops.roi_align(feat, D(rois), 0.5)
     b = ops.roi_align(feat, D(rois), 0.5, out_f32=True)
     assert b.dtype == torch.float32 and torch.equal(b.half(), a)
+    c = ops.roi_align(feat, D(rois), 0.5, out_hl=True)                     # the split form carries the float32 values
+    assert c.shape == (3, 49, 256) and torch.equal(c, ops.split_rows(b.view(-1, 128)).view(3, 49, 256))
 
 
 def _decoder(Q, seed=7):

@@ -51,10 +51,10 @@ timeit('load, 4x linear 128->128, store', lambda: ops.TokenProgram().load(0, x).
 timeit('attn, store', lambda: ops.TokenProgram().attn(0, qk, vt, 0.25).store(0, y).run(B, Q))
 timeit('load, 4x rowop LN, store', lambda: ops.TokenProgram().load(0, x).rowop(0, 0, ln=ln).rowop(0, 0, ln=ln).rowop(0, 0, ln=ln).rowop(0, 0, ln=ln).store(0, y).run(B, Q))
 from deepinteraction_amd import decoder_fused
-xw = r(M, 128)
+xw = ops.split_rows(r(M, 128))
 wd, bd = decoder_fused._dyn_layout(r(32768, 128) / 11, r(32768))
 timeit('wide 128->32768', lambda: ops.token_wide(xw, wd, bd))
-roi = r(M, 49, 128)
+roi = ops.split_rows(r(M * 49, 128)).view(M, 49, 256)
 params = ops.token_wide(xw, wd, bd)
 n1, n2 = (r(128), r(128)), (r(128), r(128))
 timeit('dynconv', lambda: ops.dynconv(roi, params, n1, n2))
