@@ -397,6 +397,13 @@ int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out,
     }
     return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, variant - DI_LA_MFMA, (hipStream_t)stream);
   }
+  if (variant >= DI_LA_DMA && variant < DI_LA_DMA + 2) {
+    if (!mfma_ok) {
+      di::set_error("MFMA local attention needs fp16, C=128, 9x9, < 2^23 pixels (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
+      return DI_ERR_ARG;
+    }
+    return di::launch_local_attn_mfma3(q, k, v, out, n, H, W, scale, variant - DI_LA_DMA, (hipStream_t)stream);
+  }
   if (mfma_ok && variant == DI_LA_AUTO)   // fastest measured (round 3, cold inputs): 8x8 tiles, 2 workgroups per CU: 39.6 us against
     return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, 1, (hipStream_t)stream);   // 42.9 for 16x4 (image side)
   return di::run_la(di::OP_FUSED, dtype, kH, kW, A);

@@ -27,6 +27,7 @@
 //   * LDS texel slices are XOR-swizzled in 32-B segments by the key column so that the
 //     ds_read_b128 K fragments, the transposed V reads and the ds_write_b128 staging stores are
 //     all bank-conflict free for slices of 64, 128 or 256 bytes (SQ_LDS_BANK_CONFLICT = 0).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "di_common.h"
@@ -422,6 +423,8 @@ static int launch(const void *q, const void *k, const void *v, void *out, int n,
   // one workgroup per resident slot, a multiple of the 8 XCDs; never more than one per tile
   long long grid = (long long)n_cu * wg_per_cu;
   if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
+  static const int grid_env = getenv("DI_LA_GRID") ? atoi(getenv("DI_LA_GRID")) : 0;   // measurement: workgroups of the launch
+  if (grid_env > 0 && grid_env < grid) grid = grid_env / 8 * 8;
   hipLaunchKernelGGL(local_attn_m2_kernel<G>, dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, stream,
                      (const __half *)q, (const __half *)k, (const __half *)v, (__half *)out, n, H, W, scale,
                      tiles_x, tiles_y);
