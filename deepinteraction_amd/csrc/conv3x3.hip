@@ -312,14 +312,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(const __half *__res
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int TH>   // tile rows: 12, 16 or 20 (the host picks the one with the fewest rounds x rows for the map)
-__global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(const __half *__restrict__ x, const __half *__restrict__ wst,
+// TH: tile rows, 12, 16 or 20 (the host picks the one with the fewest rounds x rows for the map); NWV: 8 waves (4 x 2: a
+// wave owns TH / 4 rows x 64 output channels) or 16 (4 x 4: 32 output channels per wave, 4 waves per SIMD at <= 128 VGPRs)
+template <int TH, int NWV>
+__global__ __launch_bounds__(NWV * 64, 1) void conv3x3_dma_kernel(const __half *__restrict__ x, const __half *__restrict__ wst,
                                                              const float *__restrict__ bias, __half *__restrict__ y,
                                                              int H, int W, int Cin, int relu, int tiles_x, int tiles_y) {
-  constexpr int WN = 2, WM = 4, NTW = 4, RW = TH / WM;
+  constexpr int NT = NWV * 64, WM = 4, WN = NWV / WM, NTW = 8 / WN, RW = TH / WM;
+  static_assert(NWV == 8 || NWV == 16, "8 or 16 waves");
   static_assert(TH % WM == 0, "rows per wave");
   constexpr int HP = (TH + 2) * (TW + 2);                  // halo pixels
-  constexpr int NLD = (HP * 4 + 511) / 512;                // halo pieces per thread and chunk: 2, 3 or 4
+  constexpr int NLD = (HP * 4 + NT - 1) / NT;              // halo pieces per thread and chunk: 1 .. 4
   constexpr int ASZ = 3 * 128 * 64;                        // weight tile of a stage: 24 KB = 24 DMA chunks of 1 KB
   // the ring buffers are SEPARATE objects: stage 3 ch + k always uses buffer k, so every access names its buffer at
   // compile time and the compiler's wait-count insertion can tell a DMA into one buffer from reads of another (with
@@ -337,11 +340,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(const __half *__res
   const __half *xi = x + (size_t)img * H * W * Cin;
 
   uint4 b0, b1, b2, b3;                                    // named registers (see conv3x3_lds_kernel)
-  b2 = b3 = make_uint4(0, 0, 0, 0);
+  b1 = b2 = b3 = make_uint4(0, 0, 0, 0);
   int bsrc0, bsrc1, bsrc2, bsrc3, bdst0, bdst1, bdst2, bdst3;
   {
     auto piece = [&](int j, int &src, int &dst) {
-      const int e = tid + j * 512;
+      const int e = tid + j * NT;
       const int P = e >> 2, s4 = e & 3;
       const int hy = P / (TW + 2), hx = P - hy * (TW + 2);
       const int yy = y0 + hy - 1, xx = x0 + hx - 1;
@@ -354,28 +357,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(const __half *__res
     piece(2, bsrc2, bdst2);
     piece(3, bsrc3, bdst3);
   }
-  static_assert(NLD >= 2 && NLD <= 4, "two to four halo pieces per thread");
+  static_assert(NLD >= 1 && NLD <= 4, "one to four halo pieces per thread");
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
   const int nchunk = Cin / CK, nstage = nchunk * 3;
-  auto dma_a = [&](int st, unsigned char *buf) {           // 3 DMA instructions per wave: chunks wave*3 .. +2 of the tile
+  auto dma_a = [&](int st, unsigned char *buf) {           // the 24 chunks of 1 KB of the tile: 3 (8 waves) or 1-2 per wave
     const int sc = st < nstage ? st : nstage - 1;          // past the end: a re-read (keeps the vmcnt arithmetic uniform)
-    const unsigned char *src = reinterpret_cast<const unsigned char *>(wst) + (size_t)sc * ASZ + (wave * 3) * 1024 + lane * 16;
-    unsigned char *dst = buf + (wave * 3) * 1024;
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(wst) + (size_t)sc * ASZ + lane * 16;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + j * 1024), (lptr_t)(dst + j * 1024), 16, 0, 0);
+    for (int j = 0; j < (24 + NWV - 1) / NWV; ++j) {
+      const int c = NWV == 8 ? wave * 3 + j : wave + j * NWV;
+      if (NWV == 8 || c < 24) __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 1024), (lptr_t)(buf + c * 1024), 16, 0, 0);
+    }
   };
 #define DI_FETCH_B(c0)                                                                                                  \
   do {                                                                                                                  \
     b0 = bsrc0 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc0 + (c0)) : zero4;                                      \
-    b1 = bsrc1 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc1 + (c0)) : zero4;                                      \
+    if (NLD > 1) b1 = bsrc1 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc1 + (c0)) : zero4;                         \
     if (NLD > 2) b2 = bsrc2 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc2 + (c0)) : zero4;                         \
     if (NLD > 3) b3 = bsrc3 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc3 + (c0)) : zero4;                         \
   } while (0)
 #define DI_COMMIT_B(d_)                                                                                                 \
   do {                                                                                                                  \
     if (bdst0 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst0) = b0;                                                        \
-    if (bdst1 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst1) = b1;                                                        \
+    if (NLD > 1 && bdst1 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst1) = b1;                                             \
     if (NLD > 2 && bdst2 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst2) = b2;                                             \
     if (NLD > 3 && bdst3 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst3) = b3;                                             \
   } while (0)
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_dma_kernel(const __half *__res
       h8 a[NTW];
 #pragma unroll
       for (int n = 0; n < NTW; ++n)
-        a[n] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A + lds_off(kx * 128 + wn * 64 + n * 16 + i, g)));
+        a[n] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A + lds_off(kx * 128 + wn * NTW * 16 + n * 16 + i, g)));
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
         const int P = (wm * RW + r + ky) * (TW + 2) + i + kx;
@@ -508,11 +512,18 @@ extern "C" int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w
         if (best == 0 || cost < best_cost) best = th, best_cost = cost;
       }
       if (best == 0) best = 12;
-#define DI_DMA(TH_)                                                                                               \
-  hipLaunchKernelGGL(conv3x3_dma_kernel<TH_>, dim3(tiles_x * ((H + TH_ - 1) / TH_) * n), dim3(512), 0, s,          \
+      // 16-wave workgroups by default (measured against 8: 6x256x112x200 111.7 -> 109.0 us, 512x180x180 60.4 -> 53.8, 128x180x180
+      // 19.5 -> 18.1 on random maps); DI_CONV_W16=0 selects the 8-wave form for A/B runs
+      static const int w16 = getenv("DI_CONV_W16") ? atoi(getenv("DI_CONV_W16")) : 1;
+#define DI_DMA(TH_, NWV_)                                                                                         \
+  hipLaunchKernelGGL((conv3x3_dma_kernel<TH_, NWV_>), dim3(tiles_x * ((H + TH_ - 1) / TH_) * n), dim3(NWV_ * 64), 0, s, \
                      (const __half *)x, (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x,     \
                      (H + TH_ - 1) / TH_)
-      if (best == 12) DI_DMA(12); else if (best == 16) DI_DMA(16); else DI_DMA(20);
+      if (w16) {
+        if (best == 12) DI_DMA(12, 16); else if (best == 16) DI_DMA(16, 16); else DI_DMA(20, 16);
+      } else {
+        if (best == 12) DI_DMA(12, 8); else if (best == 16) DI_DMA(16, 8); else DI_DMA(20, 8);
+      }
 #undef DI_DMA
     } else if (H >= 8) {
       const int tiles_y = (H + 7) / 8;
