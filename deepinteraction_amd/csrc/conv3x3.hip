@@ -512,9 +512,11 @@ extern "C" int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w
         if (best == 0 || cost < best_cost) best = th, best_cost = cost;
       }
       if (best == 0) best = 12;
-      // 16-wave workgroups by default (measured against 8: 6x256x112x200 111.7 -> 109.0 us, 512x180x180 60.4 -> 53.8, 128x180x180
-      // 19.5 -> 18.1 on random maps); DI_CONV_W16=0 selects the 8-wave form for A/B runs
-      static const int w16 = getenv("DI_CONV_W16") ? atoi(getenv("DI_CONV_W16")) : 1;
+      // 16-wave workgroups for the 12- and 16-row tiles (measured against 8 waves: 512x180x180 60.4 -> 53.8 us, 128x180x180
+      // 19.5 -> 18.1 on random maps, 32.3 -> 31.3 inside the forward); the 20-row image tile stays at 8 waves (inside the
+      // forward 90.4 us against 102.4 with 16, although 111.7 -> 109.0 on random maps).  DI_CONV_W16=0 / 1 forces one form.
+      static const int w16_env = getenv("DI_CONV_W16") ? atoi(getenv("DI_CONV_W16")) : -1;
+      const int w16 = w16_env >= 0 ? w16_env : (best != 20);
 #define DI_DMA(TH_, NWV_)                                                                                         \
   hipLaunchKernelGGL((conv3x3_dma_kernel<TH_, NWV_>), dim3(tiles_x * ((H + TH_ - 1) / TH_) * n), dim3(NWV_ * 64), 0, s, \
                      (const __half *)x, (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x,     \
