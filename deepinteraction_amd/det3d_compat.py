@@ -162,8 +162,18 @@ class SamplingResult:
 def pseudo_sample(assign_result, bboxes, gt_bboxes):
     """mmdet PseudoSampler.sample: positives = gt_inds > 0, negatives = gt_inds == 0, no sub-sampling."""
     r = SamplingResult()
-    r.pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
-    r.neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+    rows = getattr(assign_result, 'host_rows', None)
+    if rows is not None:
+        # the assigner kept its matches on the host: the (sorted) index sets without a device round trip
+        pos = np.sort(rows)
+        mask = np.ones(assign_result.gt_inds.shape[0], dtype=bool)
+        mask[pos] = False
+        dev = assign_result.gt_inds.device
+        r.pos_inds = torch.from_numpy(pos).to(dev, non_blocking=True)
+        r.neg_inds = torch.from_numpy(np.nonzero(mask)[0]).to(dev, non_blocking=True)
+    else:
+        r.pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        r.neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
     r.pos_assigned_gt_inds = assign_result.gt_inds[r.pos_inds] - 1
     if gt_bboxes.numel() == 0:
         r.pos_gt_bboxes = gt_bboxes.view(-1, gt_bboxes.shape[-1] if gt_bboxes.dim() > 1 else 7)[:0]

@@ -4,6 +4,7 @@
 pieces they build on (FocalLossCost, BboxOverlaps3D, AssignResult) are the restatements of
 deepinteraction_amd/det3d_compat.py.  As in the reference the cost matrix is formed on the device and the
 Hungarian matching itself runs on the host (scipy `linear_sum_assignment`, one D2H copy per layer)."""
+import numpy as np
 import torch
 from scipy.optimize import linear_sum_assignment
 
@@ -120,6 +121,44 @@ class HungarianAssigner3D:
         max_overlaps = torch.zeros_like(iou.max(1).values)
         max_overlaps[rows] = iou[rows, cols]
         return AssignResult(num_gts, assigned_gt_inds, max_overlaps, labels=assigned_labels)
+
+
+    def assign_layers(self, bboxes, gt_bboxes, gt_labels, cls_pred, train_cfg, num_layers):
+        """`assign` for the `num_layers` groups of Q consecutive proposals of one sample at once (every decoder layer is
+        assigned separately, reference transfusion-style head :398-414): the three costs are row-wise / pair-wise, so ONE
+        evaluation over all num_layers * Q rows gives bit-for-bit the per-layer matrices; one device -> host copy, the
+        Hungarian solves on the host, and the ensemble result (the concatenation of the per-layer `AssignResult`s) is
+        written with three scatters.  The matched rows / columns stay available on the host (`host_rows`, `host_cols`)
+        so that the sampler needs no `nonzero` round trip."""
+        num_gts, n = gt_bboxes.size(0), bboxes.size(0)
+        Q = n // num_layers
+        gt_inds = bboxes.new_full((n,), -1, dtype=torch.long)
+        labels = bboxes.new_full((n,), -1, dtype=torch.long)
+        if num_gts == 0 or n == 0:
+            if num_gts == 0:
+                gt_inds[:] = 0
+            r = AssignResult(num_layers * num_gts, gt_inds, bboxes.new_zeros(n), labels=labels)
+            r.host_rows = r.host_cols = np.zeros(0, dtype=np.int64)
+            return r
+        iou = self.iou_calculator(bboxes, gt_bboxes)
+        cost = self.cls_cost(cls_pred[0].T, gt_labels) + self.reg_cost(bboxes, gt_bboxes, train_cfg) + self.iou_cost(iou)
+        cost = cost.detach().cpu()
+        rows, cols = [], []
+        for l in range(num_layers):
+            r_, c_ = linear_sum_assignment(cost[l * Q:(l + 1) * Q])
+            rows.append(np.asarray(r_, dtype=np.int64) + l * Q)
+            cols.append(np.asarray(c_, dtype=np.int64))
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        rows_d = torch.from_numpy(rows).to(bboxes.device, non_blocking=True)
+        cols_d = torch.from_numpy(cols).to(bboxes.device, non_blocking=True)
+        gt_inds[:] = 0
+        gt_inds[rows_d] = cols_d + 1
+        labels[rows_d] = gt_labels[cols_d]
+        max_overlaps = bboxes.new_zeros(n)
+        max_overlaps[rows_d] = iou[rows_d, cols_d]
+        r = AssignResult(num_layers * num_gts, gt_inds, max_overlaps, labels=labels)
+        r.host_rows, r.host_cols = rows, cols
+        return r
 
 
 def build_assigner(cfg):

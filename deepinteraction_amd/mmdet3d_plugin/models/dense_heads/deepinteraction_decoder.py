@@ -254,6 +254,7 @@ class DeepInteractionDecoder(nn.Module):
         """gt_bboxes_3d: list of LiDARInstance3DBoxes-like (`.tensor`, `.gravity_center`); preds_dict: the
         `[dict]` of one forward.  Returns (labels, label_weights, bbox_targets, bbox_weights, ious, num_pos,
         matched_ious, heatmap) as the reference."""
+        self._heatmap_peaks = {}
         res = [self.get_targets_single(gt_bboxes_3d[b], gt_labels_3d[b],
                                        {k: v[b:b + 1] for k, v in preds_dict[0].items()}, b)
                for b in range(len(gt_bboxes_3d))]
@@ -271,29 +272,35 @@ class DeepInteractionDecoder(nn.Module):
         bboxes_tensor = boxes_dict[0]['bboxes']
         score = preds_dict['heatmap'].detach()
         gt_bboxes_tensor = gt_bboxes_3d.tensor.to(dev)
+        gt_labels_host = gt_labels_3d.cpu()                      # (the labels arrive as host data)
         gt_labels_3d = gt_labels_3d.to(dev)
         num_layer = self.num_mmpi if self.auxiliary else 1
         Q = self.num_proposals
         tc = self.train_cfg
-        assign_result_list = []
-        for l in range(num_layer):                              # every layer is assigned separately
-            boxes_l = bboxes_tensor[Q * l:Q * (l + 1), :]
-            score_l = score[..., Q * l:Q * (l + 1)]
-            if tc['assigner']['type'] == 'HungarianAssigner3D':
-                r = self.bbox_assigner.assign(boxes_l, gt_bboxes_tensor, gt_labels_3d, score_l, tc)
-            elif tc['assigner']['type'] == 'HeuristicAssigner':
-                r = self.bbox_assigner.assign(boxes_l, gt_bboxes_tensor, None, gt_labels_3d,
-                                              self.query_labels[batch_idx])
-            else:
-                raise NotImplementedError
-            assign_result_list.append(r)
         zeros = lambda: bboxes_tensor.new_zeros(Q)
-        ens = AssignResult(
-            num_gts=sum(r.num_gts for r in assign_result_list),
-            gt_inds=torch.cat([r.gt_inds for r in assign_result_list]),
-            max_overlaps=torch.cat([zeros() if r.max_overlaps is None else r.max_overlaps
-                                    for r in assign_result_list]),
-            labels=torch.cat([r.labels for r in assign_result_list]))
+        if tc['assigner']['type'] == 'HungarianAssigner3D' and hasattr(self.bbox_assigner, 'assign_layers'):
+            # every layer is assigned separately; their costs are evaluated together (one device -> host copy per sample)
+            ens = self.bbox_assigner.assign_layers(bboxes_tensor[:Q * num_layer], gt_bboxes_tensor, gt_labels_3d,
+                                                   score[..., :Q * num_layer], tc, num_layer)
+        else:
+            assign_result_list = []
+            for l in range(num_layer):                          # every layer is assigned separately
+                boxes_l = bboxes_tensor[Q * l:Q * (l + 1), :]
+                score_l = score[..., Q * l:Q * (l + 1)]
+                if tc['assigner']['type'] == 'HungarianAssigner3D':
+                    r = self.bbox_assigner.assign(boxes_l, gt_bboxes_tensor, gt_labels_3d, score_l, tc)
+                elif tc['assigner']['type'] == 'HeuristicAssigner':
+                    r = self.bbox_assigner.assign(boxes_l, gt_bboxes_tensor, None, gt_labels_3d,
+                                                  self.query_labels[batch_idx])
+                else:
+                    raise NotImplementedError
+                assign_result_list.append(r)
+            ens = AssignResult(
+                num_gts=sum(r.num_gts for r in assign_result_list),
+                gt_inds=torch.cat([r.gt_inds for r in assign_result_list]),
+                max_overlaps=torch.cat([zeros() if r.max_overlaps is None else r.max_overlaps
+                                        for r in assign_result_list]),
+                labels=torch.cat([r.labels for r in assign_result_list]))
         sampling = pseudo_sample(ens, bboxes_tensor, gt_bboxes_tensor)
         pos_inds, neg_inds = sampling.pos_inds, sampling.neg_inds
         assert len(pos_inds) + len(neg_inds) == num_proposals
@@ -314,8 +321,10 @@ class DeepInteractionDecoder(nn.Module):
         if len(neg_inds) > 0:
             label_weights[neg_inds] = 1.0
 
-        # dense heat-map target: one Gaussian per GT box on the BEV grid (:450-475)
-        gt = torch.cat([gt_bboxes_3d.gravity_center, gt_bboxes_3d.tensor[:, 3:]], dim=1).to(dev)
+        # dense heat-map target: one Gaussian per GT box on the BEV grid (:450-475).  The boxes are host data: radius,
+        # centre and the element-wise max are evaluated on the host (the same float32 arithmetic, no device round trip
+        # per box) and the finished map is uploaded once
+        gt = torch.cat([gt_bboxes_3d.gravity_center, gt_bboxes_3d.tensor[:, 3:]], dim=1).float().cpu()
         grid_size = torch.tensor(tc['grid_size'])
         pc_range = torch.tensor(tc['point_cloud_range'])
         voxel_size = torch.tensor(tc['voxel_size'])
@@ -329,8 +338,10 @@ class DeepInteractionDecoder(nn.Module):
                 radius = max(tc['min_radius'], int(radius))
                 coor_x = (gt[idx][0] - pc_range[0]) / voxel_size[0] / tc['out_size_factor']
                 coor_y = (gt[idx][1] - pc_range[1]) / voxel_size[1] / tc['out_size_factor']
-                center_int = torch.tensor([coor_x, coor_y], dtype=torch.float32, device=dev).to(torch.int32)
-                draw_heatmap_gaussian(heatmap[gt_labels_3d[idx]], center_int, radius)
+                center_int = torch.tensor([coor_x, coor_y], dtype=torch.float32).to(torch.int32)
+                draw_heatmap_gaussian(heatmap[gt_labels_host[idx]], center_int, radius)
+        self._heatmap_peaks[batch_idx] = int(heatmap.eq(1).sum())       # `loss` normalises by it: known on the host
+        heatmap = heatmap.to(dev)
         mean_iou = ious[pos_inds].sum() / max(len(pos_inds), 1)
         return (labels[None], label_weights[None], bbox_targets[None], bbox_weights[None], ious[None],
                 int(pos_inds.shape[0]), float(mean_iou), heatmap[None])
@@ -347,23 +358,23 @@ class DeepInteractionDecoder(nn.Module):
             if m is not None:                                   # image layers: only queries some camera sees
                 label_weights[..., sl] = label_weights[..., sl] * m
                 bbox_weights[:, sl, :] = bbox_weights[:, sl, :] * m[:, :, None]
-            num_pos.append(bbox_weights.max(-1).values[..., sl].sum())
+            num_pos.append(bbox_weights.max(-1).values[..., sl].sum().clamp(min=1))      # = max(num_pos, 1), on the device
         preds_dict = preds_dicts[0][0]
         loss_dict = dict()
         loss_dict['loss_heatmap'] = self.loss_heatmap(clip_sigmoid(preds_dict['dense_heatmap'].float()), heatmap,
-                                                      avg_factor=max(heatmap.eq(1).float().sum().item(), 1))
+                                                      avg_factor=max(float(sum(self._heatmap_peaks.values())), 1))
         code_weights = self.train_cfg.get('code_weights', None)
         for l in range(self.num_mmpi):
             sl = slice(l * Q, (l + 1) * Q)
             layer_cls_score = preds_dict['heatmap'][..., sl].permute(0, 2, 1).reshape(-1, self.num_classes)
             layer_loss_cls = self.loss_cls(layer_cls_score.float(), labels[..., sl].reshape(-1),
-                                           label_weights[..., sl].reshape(-1), avg_factor=max(num_pos[l], 1))
+                                           label_weights[..., sl].reshape(-1), avg_factor=num_pos[l])
             parts = [preds_dict[k][..., sl] for k in ('center', 'height', 'dim', 'rot')]
             if 'vel' in preds_dict:
                 parts.append(preds_dict['vel'][..., sl])
             preds = torch.cat(parts, dim=1).permute(0, 2, 1).float()     # (B, Q, code_size)
             reg_w = bbox_weights[:, sl, :] * bbox_weights.new_tensor(code_weights)
-            layer_loss_bbox = self.loss_bbox(preds, bbox_targets[:, sl, :], reg_w, avg_factor=max(num_pos[l], 1))
+            layer_loss_bbox = self.loss_bbox(preds, bbox_targets[:, sl, :], reg_w, avg_factor=num_pos[l])
             loss_dict[f'layer_{l}_loss_cls'] = layer_loss_cls
             loss_dict[f'layer_{l}_loss_bbox'] = layer_loss_bbox
         loss_dict['matched_ious'] = layer_loss_cls.new_tensor(matched_ious)
