@@ -28,6 +28,8 @@ SIGNATURES = {
     'di_i2p_build_keys': [_c_p] * 6 + [_c_i] * 8 + [_c_f, _c_f, _c_p],
     'di_i2p_attn_fwd': [_c_p] * 6 + [_c_i] * 7 + [_c_f, ctypes.c_ulonglong, _c_i, _c_p],
     'di_i2p_attn_bwd': [_c_p] * 10 + [_c_i] * 9 + [_c_f, _c_f, _c_f, ctypes.c_ulonglong, _c_i, _c_p],
+    'di_i2p_attn_fwd_mass': [_c_p] * 7 + [_c_i] * 7 + [_c_f, ctypes.c_ulonglong, _c_i, _c_p],
+    'di_i2p_attn_bwd_mass': [_c_p] * 11 + [_c_i] * 9 + [_c_f, _c_f, _c_f, ctypes.c_ulonglong, _c_i, _c_p],
     'di_bevwarp_gather_bwd': [_c_p] * 8 + [_c_i] * 7 + [_c_p],
     'di_roi_align_bwd': [_c_p] * 3 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
     'di_depth_scatter': [_c_p, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_f, _c_f, _c_p],

@@ -80,23 +80,25 @@ class PixelLinear(torch.autograd.Function):
 
 
 class I2PAttention(torch.autograd.Function):
-    """ctx[cell] = sum_j softmax_j(<qfold[cell], s_j>) s_j over the pillar's valid image keys
-    (encoder_utils.py:257-320 with the single-head attention folded, see MMRI_I2P)."""
+    """ctx[cell] = sum_j d_j softmax_j(<qfold[cell], s_j>) s_j over the pillar's valid image keys
+    (encoder_utils.py:257-320 with the single-head attention folded, see MMRI_I2P), d_j the attention dropout factor.
+    Returns (ctx, valid, mass): mass = sum_j d_j p_j, the kept probability mass (= valid without dropout) - the folded
+    value bias enters the module's output scaled by it, and its gradient flows back into the scores."""
 
     @staticmethod
     def forward(ctx, img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p, seed, keys=None):
         ctx.save_for_backward(img, qfold, pillars, coors, num_points, proj, aug_rev)
         ctx.ori_hw, ctx.dropout_p, ctx.seed = ori_hw, float(dropout_p), int(seed)
-        out, valid = ops.i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p,
-                                       seed, keys)
+        out, valid, mass = ops.i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p,
+                                             seed, keys, with_mass=True)
         ctx.mark_non_differentiable(valid)
-        return out, valid
+        return out, valid, mass
 
     @staticmethod
-    def backward(ctx, grad_ctx, _grad_valid):
+    def backward(ctx, grad_ctx, _grad_valid, grad_mass):
         img, qfold, pillars, coors, num_points, proj, aug_rev = ctx.saved_tensors
         g_img, g_q = ops.i2p_attention_bwd(img, qfold, grad_ctx, pillars, coors, num_points, proj, aug_rev,
-                                           ctx.ori_hw, ctx.dropout_p, ctx.seed)
+                                           ctx.ori_hw, ctx.dropout_p, ctx.seed, grad_mass=grad_mass)
         return g_img.to(img.dtype), g_q.to(qfold.dtype), None, None, None, None, None, None, None, None, None
 
 

@@ -279,7 +279,7 @@ struct KeyEntB {
 
 template <typename T>
 __global__ __launch_bounds__(256) void i2p_attn_bwd_kernel(
-    const T *__restrict__ img, const T *__restrict__ qfold, const T *__restrict__ grad_ctx,
+    const T *__restrict__ img, const T *__restrict__ qfold, const T *__restrict__ grad_ctx, const T *__restrict__ grad_mass,
     const float *__restrict__ pillars, const int32_t *__restrict__ coors, const int32_t *__restrict__ num_points,
     const float *__restrict__ proj, const float *__restrict__ aug, float *__restrict__ grad_img,
     float *__restrict__ grad_qfold, int P, int Tp, int D, int V, int Hi, int Wi, int Hb, int Wb, int C,
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void i2p_attn_bwd_kernel(
       unpack8(ld8(grad_ctx + ((size_t)cy * Wb + cx) * C + ch0), g);
     }
     // ---- pass A: (m, l, ctx) exactly as the forward
-    float m = -INFINITY, l = 0.f, acc[8];
+    float m = -INFINITY, l = 0.f, ms = 0.f, acc[8];   // ms: the kept probability mass sum_j d_j p_j (before the 1 / l)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     for (int e = sub; e < count; e += 4) {
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void i2p_attn_bwd_kernel(
       const float a = __expf(m - mn), pe = __expf(sc - mn);
       l = l * a + pe;
       const float pv = drop_p > 0.f ? (di_keep(seed, p, k.cam, drop_p) ? pe / (1.f - drop_p) : 0.f) : pe;
+      ms = ms * a + pv;
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + pv * s8[i];
       m = mn;
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(256) void i2p_attn_bwd_kernel(
       const float a = (m == mn) ? 1.f : __expf(m - mn);
       const float b = (mo == mn) ? 1.f : __expf(mo - mn);
       l = l * a + lo * b;
+      ms = ms * a + __shfl_xor(ms, off) * b;
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] = acc[i] * a + __shfl_xor(acc[i], off) * b;
       m = mn;
@@ -368,6 +370,9 @@ __global__ __launch_bounds__(256) void i2p_attn_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) gc = fmaf(g[i], acc[i] * inv, gc);
     gc = row16_sum(gc);
+    // the output also carries mass * (folded value bias): d out / d p_j gains d_j * gm, <g, ctx> gains gm * mass
+    const float gm = grad_mass != nullptr ? (float)grad_mass[(size_t)cy * Wb + cx] : 0.f;
+    gc = fmaf(gm, ms * inv, gc);
     // ---- pass B
     float gq[8];
 #pragma unroll
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256) void i2p_attn_bwd_kernel(
       gs = row16_sum(gs);
       const float pj = __expf(sc - m) * inv;
       const float dj = drop_p > 0.f ? (di_keep(seed, p, k.cam, drop_p) ? 1.f / (1.f - drop_p) : 0.f) : 1.f;
-      const float ds = pj * (dj * gs - gc);             // ctx = sum_j d_j p_j s_j
+      const float ds = pj * (dj * (gs + gm) - gc);      // ctx = sum_j d_j p_j s_j, mass = sum_j d_j p_j
       float gsj[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -458,7 +463,7 @@ int di_roi_align_bwd(const void *grad_out, const float *rois, float *grad_feat, 
   return di::check_launch("roi_align_bwd");
 }
 
-int di_i2p_attn_bwd(const void *img, const void *qfold, const void *grad_ctx, const float *pillars,
+int di_i2p_attn_bwd_mass(const void *img, const void *qfold, const void *grad_ctx, const void *grad_mass, const float *pillars,
                     const int32_t *coors, const int32_t *num_points, const float *proj, const float *aug_rev,
                     float *grad_img, float *grad_qfold, int P, int T, int D, int n_views, int Hi, int Wi, int Hb,
                     int Wb, int C, float ori_H, float ori_W, float dropout_p, unsigned long long seed, int dtype,
@@ -471,17 +476,27 @@ int di_i2p_attn_bwd(const void *img, const void *qfold, const void *grad_ctx, co
   hipStream_t s = (hipStream_t)stream;
   if (dtype == DI_F16)
     hipLaunchKernelGGL(di::i2p_attn_bwd_kernel<__half>, dim3(blocks), dim3(256), 0, s, (const __half *)img,
-                       (const __half *)qfold, (const __half *)grad_ctx, pillars, coors, num_points, proj, aug_rev,
+                       (const __half *)qfold, (const __half *)grad_ctx, (const __half *)grad_mass, pillars, coors, num_points, proj, aug_rev,
                        grad_img, grad_qfold, P, T, D, n_views, Hi, Wi, Hb, Wb, C, ori_H, ori_W, dropout_p, seed);
   else if (dtype == DI_F32)
     hipLaunchKernelGGL(di::i2p_attn_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float *)img,
-                       (const float *)qfold, (const float *)grad_ctx, pillars, coors, num_points, proj, aug_rev,
+                       (const float *)qfold, (const float *)grad_ctx, (const float *)grad_mass, pillars, coors, num_points, proj, aug_rev,
                        grad_img, grad_qfold, P, T, D, n_views, Hi, Wi, Hb, Wb, C, ori_H, ori_W, dropout_p, seed);
   else {
     di::set_error("unsupported dtype %d", dtype);
     return DI_ERR_ARG;
   }
   return di::check_launch("i2p_attn_bwd");
+}
+
+
+int di_i2p_attn_bwd(const void *img, const void *qfold, const void *grad_ctx, const float *pillars,
+                    const int32_t *coors, const int32_t *num_points, const float *proj, const float *aug_rev,
+                    float *grad_img, float *grad_qfold, int P, int T, int D, int n_views, int Hi, int Wi, int Hb,
+                    int Wb, int C, float ori_H, float ori_W, float dropout_p, unsigned long long seed, int dtype,
+                    void *stream) {
+  return di_i2p_attn_bwd_mass(img, qfold, grad_ctx, nullptr, pillars, coors, num_points, proj, aug_rev, grad_img, grad_qfold, P,
+                              T, D, n_views, Hi, Wi, Hb, Wb, C, ori_H, ori_W, dropout_p, seed, dtype, stream);
 }
 
 }  // extern "C"

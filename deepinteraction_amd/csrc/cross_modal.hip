@@ -232,12 +232,14 @@ struct KeyRows {
   int slot;
 };
 
-template <typename T, bool FULLC>
+// MASS (training with attention dropout): also write the kept probability mass sum_j d_j p_j of every cell (1 without
+// dropout): the folded value bias enters the output scaled by it.
+template <typename T, bool FULLC, bool MASS = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 5 : 4) void i2p_attn_kernel(
     const T *__restrict__ img, const T *__restrict__ qfold, const int *__restrict__ cnt_tab,
     const int *__restrict__ pil_tab, const KeyEnt *__restrict__ keys, const int *__restrict__ order,
     T *__restrict__ ctx, T *__restrict__ valid_out, int ncell, int nslots, int Wi, int C_, float drop_p,
-    unsigned long long seed) {
+    unsigned long long seed, T *__restrict__ mass_out = nullptr) {
   typedef typename Vec8<T>::type V8;
   const int C = FULLC ? 128 : C_;                // 128 channels: the row offsets are shifts
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 5 : 4) void i2p_attn_kernel(
       *reinterpret_cast<V8 *>(ctx + (size_t)cell * C + ch0) = z;
     }
     if (lane == 0) valid_out[cell] = (T)0.f;
+    if (MASS && lane == 0) mass_out[cell] = (T)0.f;
   }
 
   // corner rows of one key: 32-bit BYTE offsets from the (uniform) map base (global_load with an SGPR base)
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 5 : 4) void i2p_attn_kernel(
   };
 
   // online-softmax state of the cell being reduced: ONE running maximum for the whole cell, partial sums per group
-  float m = -INFINITY, l = 0.f, acc[8];
+  float m = -INFINITY, l = 0.f, ms = 0.f, acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
   const float keep_scale = 1.f / (1.f - drop_p);
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 5 : 4) void i2p_attn_kernel(
     // stays in the softmax denominator, its value term vanishes, kept ones are scaled by 1 / (1 - p)
     float pv = pe;
     if (drop_p > 0.f) pv = di_keep(seed, pil_tab[cell], k.slot, drop_p) ? pe * keep_scale : 0.f;
+    if (MASS) ms = ms * a + pv;
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] *= a;
     axpy8(acc, pv * k.w00, k.f00);
@@ -322,6 +326,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 5 : 4) void i2p_attn_kernel(
       *reinterpret_cast<V8 *>(ctx + (size_t)cell * C + ch0) = o;
     }
     if (lane == 0) valid_out[cell] = (T)1.f;
+    if (MASS) {
+      ms = rows_sum(ms);
+      if (lane == 0) mass_out[cell] = (T)(ms / l);
+      ms = 0.f;
+    }
     m = -INFINITY;
     l = 0.f;
 #pragma unroll
@@ -516,9 +525,10 @@ int di_i2p_build_keys(const float *pillars, const int32_t *coors, const int32_t 
 }
 
 // Attention pass: writes EVERY cell of ctx (Hb*Wb, C) and valid (Hb*Wb) - zeros where the table has no key.
-int di_i2p_attn_fwd(const void *img, const void *qfold, const void *key_table, const int32_t *cell_order, void *ctx,
-                    void *valid, int T, int n_views, int Hi, int Wi, int Hb, int Wb, int C, float dropout_p,
-                    unsigned long long seed, int dtype, void *stream) {
+// `mass` (optional, Hb*Wb like valid): the kept probability mass of every cell under attention dropout.
+int di_i2p_attn_fwd_mass(const void *img, const void *qfold, const void *key_table, const int32_t *cell_order, void *ctx,
+                         void *valid, void *mass, int T, int n_views, int Hi, int Wi, int Hb, int Wb, int C, float dropout_p,
+                         unsigned long long seed, int dtype, void *stream) {
   DI_REQUIRE(T > 0 && n_views > 0 && T * n_views <= di::kMaxSlots, "T*n_views=%d exceeds %d key slots", T * n_views,
              di::kMaxSlots);
   DI_REQUIRE(C > 0 && C % 8 == 0 && C <= 128, "C=%d must be a multiple of 8, <= 128", C);
@@ -534,9 +544,16 @@ int di_i2p_attn_fwd(const void *img, const void *qfold, const void *key_table, c
   blocks = (blocks + 7) / 8 * 8;
   hipStream_t s = (hipStream_t)stream;
 #define DI_I2P_GO(TT, FULL)                                                                              \
-  hipLaunchKernelGGL((di::i2p_attn_kernel<TT, FULL>), dim3(blocks), dim3(256), 0, s, (const TT *)img,    \
-                     (const TT *)qfold, cnt, pil, keys, cell_order, (TT *)ctx, (TT *)valid, ncell, T * n_views, \
-                     Wi, C, dropout_p, seed)
+  do {                                                                                                   \
+    if (mass)                                                                                            \
+      hipLaunchKernelGGL((di::i2p_attn_kernel<TT, FULL, true>), dim3(blocks), dim3(256), 0, s, (const TT *)img, \
+                         (const TT *)qfold, cnt, pil, keys, cell_order, (TT *)ctx, (TT *)valid, ncell, T * n_views, \
+                         Wi, C, dropout_p, seed, (TT *)mass);                                            \
+    else                                                                                                 \
+      hipLaunchKernelGGL((di::i2p_attn_kernel<TT, FULL, false>), dim3(blocks), dim3(256), 0, s, (const TT *)img, \
+                         (const TT *)qfold, cnt, pil, keys, cell_order, (TT *)ctx, (TT *)valid, ncell, T * n_views, \
+                         Wi, C, dropout_p, seed, (TT *)nullptr);                                         \
+  } while (0)
   if (dtype == DI_F16) {
     if (C == 128) DI_I2P_GO(__half, true); else DI_I2P_GO(__half, false);
   } else if (dtype == DI_F32) {
@@ -547,6 +564,13 @@ int di_i2p_attn_fwd(const void *img, const void *qfold, const void *key_table, c
   }
 #undef DI_I2P_GO
   return di::check_launch("i2p_attn_fwd");
+}
+
+int di_i2p_attn_fwd(const void *img, const void *qfold, const void *key_table, const int32_t *cell_order, void *ctx,
+                    void *valid, int T, int n_views, int Hi, int Wi, int Hb, int Wb, int C, float dropout_p,
+                    unsigned long long seed, int dtype, void *stream) {
+  return di_i2p_attn_fwd_mass(img, qfold, key_table, cell_order, ctx, valid, nullptr, T, n_views, Hi, Wi, Hb, Wb, C, dropout_p,
+                              seed, dtype, stream);
 }
 
 int di_depth_scatter(const float *pts, int n_pts, int pt_stride, const float *proj,

@@ -486,9 +486,18 @@ class MMRI_I2P(nn.Module):
                     pts_metas['pillars_num_points'][s:e], geom.lidar2img, geom.aug_rev, geom.ori_hw, drop,
                     (seed + b * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF,   # per-sample stream: no mask reuse across b
                     self.pillar_keys(geom, pts_metas, s, e, (Hi, Wi), (Hb, Wb)))
-            ctx, valid = I2PAttention.apply(*args) if live else ops.i2p_attention(*args)
-            o = F.linear(ctx.permute(0, 2, 3, 1).reshape(-1, Ci), w_ov, b_ov)
-            o = o * valid.reshape(-1, 1)                                         # empty pillars / cells stay 0
+            if live:
+                # every key's value carries the bias bv, so under attention dropout Wo.bv is weighted by the kept
+                # probability mass of the cell (1 without dropout), as nn.MultiheadAttention does; bo by `valid`
+                ctx, valid, mass = I2PAttention.apply(*args)
+                la = self.learnedAlign
+                b_v = la.out_proj.weight @ la.in_proj_bias.chunk(3, 0)[2]
+                o = F.linear(ctx.permute(0, 2, 3, 1).reshape(-1, Ci), w_ov)
+                o = o + mass.reshape(-1, 1) * b_v.to(o.dtype) + valid.reshape(-1, 1) * la.out_proj.bias.to(o.dtype)
+            else:
+                ctx, valid = ops.i2p_attention(*args)
+                o = F.linear(ctx.permute(0, 2, 3, 1).reshape(-1, Ci), w_ov, b_ov)
+                o = o * valid.reshape(-1, 1)                                     # empty pillars / cells stay 0
             outs.append(o.view(1, Hb, Wb, C).permute(0, 3, 1, 2))
         return outs[0] if B == 1 else torch.cat(outs, 0)
 

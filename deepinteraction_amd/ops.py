@@ -313,10 +313,11 @@ def bev_sector_order(Hb, Wb, device):
 
 
 def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p=0.0, seed=0, keys=None,
-                  sector_order=True):
+                  sector_order=True, with_mass=False):
     """One sample.  img (V,C,Hi,Wi), qfold (1,C,Hb,Wb) channels-last; pillars (P,T,D) f32,
     coors (P,4) i32, num_points (P,) i32, proj (V,4,4) f32, aug_rev (12,) f32; `keys`: the sample's `i2p_key_table`
-    (built here when not given).  Returns ctx (1,C,Hb,Wb) and valid (1,1,Hb,Wb) (same dtype as img), every cell written."""
+    (built here when not given).  Returns ctx (1,C,Hb,Wb) and valid (1,1,Hb,Wb) (same dtype as img), every cell written;
+    with_mass: also the kept probability mass (1,1,Hb,Wb) of every cell under attention dropout."""
     _dev(img, qfold)
     img, qfold = cl(img), cl(qfold)
     V, C, Hi, Wi = img.shape
@@ -328,14 +329,21 @@ def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw,
     ctx = empty_cl(1, C, Hb, Wb, img)          # (allocating NCHW and converting was a 16 us transposing copy of garbage)
     valid = torch.empty((1, 1, Hb, Wb), dtype=img.dtype, device=img.device)
     order = bev_sector_order(Hb, Wb, img.device).data_ptr() if sector_order else None
+    if with_mass:
+        mass = torch.empty_like(valid)
+        _lib.call('di_i2p_attn_fwd_mass', img.data_ptr(), qfold.data_ptr(), keys.table.data_ptr(), order, ctx.data_ptr(),
+                  valid.data_ptr(), mass.data_ptr(), T, V, Hi, Wi, Hb, Wb, C, float(dropout_p), int(seed), _code(img),
+                  _stream())
+        return ctx, valid, mass
     _lib.call('di_i2p_attn_fwd', img.data_ptr(), qfold.data_ptr(), keys.table.data_ptr(), order, ctx.data_ptr(),
               valid.data_ptr(), T, V, Hi, Wi, Hb, Wb, C, float(dropout_p), int(seed), _code(img), _stream())
     return ctx, valid
 
 
 def i2p_attention_bwd(img, qfold, grad_ctx, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p=0.0,
-                      seed=0):
-    """Gradients of i2p_attention w.r.t. img (V,C,Hi,Wi) and qfold (1,C,Hb,Wb): float32, channels-last."""
+                      seed=0, grad_mass=None):
+    """Gradients of i2p_attention w.r.t. img (V,C,Hi,Wi) and qfold (1,C,Hb,Wb): float32, channels-last.  grad_mass
+    (1,1,Hb,Wb): the gradient of the kept mass (`with_mass` of the forward)."""
     _dev(img, qfold, grad_ctx)
     img, qfold = cl(img), cl(qfold)
     grad_ctx = cl(grad_ctx.to(img.dtype))
@@ -344,7 +352,9 @@ def i2p_attention_bwd(img, qfold, grad_ctx, pillars, coors, num_points, proj, au
     P, T, D = pillars.shape
     g_img = torch.empty((V, C, Hi, Wi), dtype=torch.float32, device=img.device, memory_format=torch.channels_last).zero_()
     g_q = torch.empty((1, C, Hb, Wb), dtype=torch.float32, device=img.device, memory_format=torch.channels_last).zero_()
-    _lib.call('di_i2p_attn_bwd', img.data_ptr(), qfold.data_ptr(), grad_ctx.data_ptr(), pillars.data_ptr(),
+    gm = None if grad_mass is None else grad_mass.to(img.dtype).contiguous()
+    _lib.call('di_i2p_attn_bwd_mass', img.data_ptr(), qfold.data_ptr(), grad_ctx.data_ptr(),
+              None if gm is None else gm.data_ptr(), pillars.data_ptr(),
               coors.data_ptr(), num_points.data_ptr(), proj.data_ptr(), aug_rev.data_ptr(), g_img.data_ptr(),
               g_q.data_ptr(), P, T, D, V, Hi, Wi, Hb, Wb, C, float(ori_hw[0]), float(ori_hw[1]), float(dropout_p),
               int(seed), _code(img), _stream())

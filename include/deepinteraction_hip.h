@@ -141,6 +141,13 @@ int di_i2p_build_keys(const float *pillars, const int32_t *coors, const int32_t 
 int di_i2p_attn_fwd(const void *img, const void *qfold, const void *key_table, const int32_t *cell_order, void *ctx,
                     void *valid, int T, int n_views, int Hi, int Wi, int Hb, int Wb, int C, float dropout_p,
                     unsigned long long seed, int dtype, void *stream);
+/* The same, also writing `mass` (Hb*Wb, the maps' element type; may be NULL = di_i2p_attn_fwd): the kept probability mass
+ * sum_j d_j p_j of every cell under attention dropout (1 for a non-empty cell without dropout, 0 for an empty one).
+ * nn.MultiheadAttention (encoder_utils.py:257-320 -> torch MHA dropout on the probabilities) adds the value bias to every
+ * key's value, so the folded bias Wo.bv enters the output scaled by this mass. */
+int di_i2p_attn_fwd_mass(const void *img, const void *qfold, const void *key_table, const int32_t *cell_order, void *ctx,
+                         void *valid, void *mass, int T, int n_views, int Hi, int Wi, int Hb, int Wb, int C, float dropout_p,
+                         unsigned long long seed, int dtype, void *stream);
 /* Backward of the above: grad_ctx (Hb,Wb,C) -> grad_img (n_views,Hi,Wi,C) and grad_qfold (Hb,Wb,C), both
  * float32, zero-filled by the caller (grad_img is accumulated with atomics).  The sampling coordinates carry
  * no gradient (points and metas are data). */
@@ -149,6 +156,12 @@ int di_i2p_attn_bwd(const void *img, const void *qfold, const void *grad_ctx, co
                     float *grad_img, float *grad_qfold, int P, int T, int D, int n_views, int Hi, int Wi, int Hb,
                     int Wb, int C, float ori_H, float ori_W, float dropout_p, unsigned long long seed, int dtype,
                     void *stream);
+/* The same with the gradient of the kept mass (Hb*Wb, the maps' element type; NULL = di_i2p_attn_bwd). */
+int di_i2p_attn_bwd_mass(const void *img, const void *qfold, const void *grad_ctx, const void *grad_mass, const float *pillars,
+                         const int32_t *coors, const int32_t *num_points, const float *proj, const float *aug_rev,
+                         float *grad_img, float *grad_qfold, int P, int T, int D, int n_views, int Hi, int Wi, int Hb,
+                         int Wb, int C, float ori_H, float ori_W, float dropout_p, unsigned long long seed, int dtype,
+                         void *stream);
 
 /* ---------------------------------------------------------------- BEV -> image gather
  * BEVWarp.forward (encoder_utils.py:142-199) in three steps per sample.

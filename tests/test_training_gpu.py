@@ -149,17 +149,29 @@ def test_i2p_attention_dropout_is_consistent():
     d, _ = ops.i2p_attention(ones, torch.zeros_like(qf), *args, dropout_p=0.5, seed=5)
     kept = (d[:, 0] * 0.5)[valid[:, 0] > 0]
     assert 0.45 <= kept.mean().item() <= 0.55, kept.mean().item()
-    # directional derivative
+    # the kept probability mass (what the folded value bias is scaled by): the same forward also returns it; without
+    # dropout it is `valid`, and it does not depend on the image (zero scores: softmax of the key count only)
+    d2, valid2, mass = ops.i2p_attention(img, torch.zeros_like(qf), *args, dropout_p=0.5, seed=5, with_mass=True)
+    assert torch.equal(valid2, valid) and (mass[valid == 0] == 0).all()
+    assert 0.9 <= (mass[valid > 0].mean() * 0.5 / kept.mean()).item() <= 1.1      # = kept mass / (1 - p), as measured above
+    _, _, mass0 = ops.i2p_attention(img, qf, *args, with_mass=True)
+    assert torch.allclose(mass0, valid, atol=1e-6)
+    # directional derivative of <ctx, w> + <mass, wm>
     w = torch.randn(a.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    wm = torch.randn(mass.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
     imr = img.clone().requires_grad_(True)
     qr = qf.clone().requires_grad_(True)
-    out, _ = I2PAttention.apply(imr, qr, *args, 0.5, 77)
-    (out * w).sum().backward()
+    out, _, ms = I2PAttention.apply(imr, qr, *args, 0.5, 77)
+    ((out * w).sum() + (ms * wm).sum()).backward()
     di = torch.randn(img.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
     dq = torch.randn(qf.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) * 0.05
     eps = 1e-2
-    fp = (ops.i2p_attention(_cl(img + eps * di), _cl(qf + eps * dq), *args, dropout_p=0.5, seed=77)[0] * w).sum()
-    fm = (ops.i2p_attention(_cl(img - eps * di), _cl(qf - eps * dq), *args, dropout_p=0.5, seed=77)[0] * w).sum()
+
+    def f(sign):
+        o, _, m_ = ops.i2p_attention(_cl(img + sign * eps * di), _cl(qf + sign * eps * dq), *args, dropout_p=0.5, seed=77,
+                                     with_mass=True)
+        return (o * w).sum() + (m_ * wm).sum()
+    fp, fm = f(1.0), f(-1.0)
     fd = ((fp - fm) / (2 * eps)).item()
     an = ((imr.grad * di).sum() + (qr.grad * dq).sum()).item()
     assert abs(fd - an) <= 2e-2 * max(abs(an), 1.0), (fd, an)
