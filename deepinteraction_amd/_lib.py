@@ -53,6 +53,7 @@ SIGNATURES = {
     'di_roi_align_fwd': [_c_p] * 3 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
     'di_mha_decode_fwd': [_c_p] * 4 + [_c_i] * 5 + [_c_f, _c_i, _c_p],
     'di_pointwise_multi_fwd': [_c_p, _c_i] + [_c_p] * 5 + [ctypes.c_longlong, _c_p],
+    'di_pointwise_multi_warp_fwd': [_c_p] * 7 + [_c_i] * 6 + [_c_p] * 6,
     'di_ffn_ln_fwd': [_c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, ctypes.c_longlong, _c_p],
     'di_conv3x3_fwd': [_c_p] * 5 + [_c_i] * 7 + [_c_p],
     'di_token_program': [_c_p, _c_i, _c_p, _c_i, _c_i, _c_p],

@@ -8,26 +8,9 @@
 // coordinates) is recomputed in registers in fp32 - it is a few dozen flops per key,
 // cheaper than caching it in HBM.
 #include "di_common.h"
+#include "warp_common.h"
 
 namespace di {
-
-struct Affine {  // p' = p @ A + t   (row-vector convention of mmdet3d's LiDARPoints.rotate)
-  float a[9], t[3];
-};
-__device__ __forceinline__ void apply_affine(const Affine &f, float &x, float &y, float &z) {
-  const float nx = x * f.a[0] + y * f.a[3] + z * f.a[6] + f.t[0];
-  const float ny = x * f.a[1] + y * f.a[4] + z * f.a[7] + f.t[1];
-  const float nz = x * f.a[2] + y * f.a[5] + z * f.a[8] + f.t[2];
-  x = nx; y = ny; z = nz;
-}
-__device__ __forceinline__ Affine load_affine(const float *p) {
-  Affine f;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) f.a[i] = p[i];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) f.t[i] = p[9 + i];
-  return f;
-}
 
 // lidar point -> camera; the mask and normalisation of encoder_utils.py:157-170 / :281-295.
 // Returns false when behind the camera or not strictly inside the image.
@@ -45,41 +28,6 @@ __device__ __forceinline__ bool project_point(const float *__restrict__ M /*4x4 
   nx = (u / ori_W - 0.5f) * 2.f;
   ny = (v / ori_H - 0.5f) * 2.f;
   return cz > eps && nx > -1.f && nx < 1.f && ny > -1.f && ny < 1.f;
-}
-
-// torch grid_sample(bilinear, zeros, align_corners=False) of one texel row slice (8 channels).
-template <typename T>
-__device__ __forceinline__ void bilinear8(const T *__restrict__ map, int Hm, int Wm, int C, float ix,
-                                          float iy, int ch0, float (&o)[8]) {
-  const float fx = floorf(ix), fy = floorf(iy);
-  const int x0 = (int)fx, y0 = (int)fy;
-  const float ax = ix - fx, ay = iy - fy;
-  const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = 0.f;
-  const bool xl = x0 >= 0 && x0 < Wm, xh = x0 + 1 >= 0 && x0 + 1 < Wm;
-  const bool yl = y0 >= 0 && y0 < Hm, yh = y0 + 1 >= 0 && y0 + 1 < Hm;
-  float f[8];
-  if (yl && xl) {
-    unpack8(ld8(map + ((size_t)y0 * Wm + x0) * C + ch0), f);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = fmaf(w00, f[i], o[i]);
-  }
-  if (yl && xh) {
-    unpack8(ld8(map + ((size_t)y0 * Wm + x0 + 1) * C + ch0), f);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = fmaf(w01, f[i], o[i]);
-  }
-  if (yh && xl) {
-    unpack8(ld8(map + ((size_t)(y0 + 1) * Wm + x0) * C + ch0), f);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = fmaf(w10, f[i], o[i]);
-  }
-  if (yh && xh) {
-    unpack8(ld8(map + ((size_t)(y0 + 1) * Wm + x0 + 1) * C + ch0), f);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = fmaf(w11, f[i], o[i]);
-  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -451,33 +399,16 @@ __global__ __launch_bounds__(256) void bevwarp_gather_kernel(
   const int l16 = threadIdx.x & 15;
   const bool ch_ok = FULLC || l16 * kChPerLane < C;
   const int ch0 = l16 * kChPerLane;
-  const Affine A = load_affine(aug);
-  const float r0 = pc_range[0], r1 = pc_range[1], r2 = pc_range[2];
-  const float r3 = pc_range[3], r4 = pc_range[4], r5 = pc_range[5];
+  const WarpGeom G = load_warp_geom(depth, img2lidar, aug, xs, ys, pc_range, Hi, Wi, Hb, Wb);
   const int total = V * Hi * Wi;
   const int ngrp = gridDim.x * (blockDim.x >> 4);
   for (int pix = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); pix < total; pix += ngrp) {
-    const int v = pix / (Hi * Wi);
-    const int rem = pix - v * Hi * Wi;
-    const int yy = rem / Wi, xx = rem - yy * Wi;
-    const float d = depth[pix];
-    const float X = xs[xx] * d, Y = ys[yy] * d;  // [x*d, y*d, d, 1] (:185-187)
-    const float *M = img2lidar + v * 16;
-    float x = M[0] * X + M[1] * Y + M[2] * d + M[3];
-    float y = M[4] * X + M[5] * Y + M[6] * d + M[7];
-    float z = M[8] * X + M[9] * Y + M[10] * d + M[11];
-    apply_affine(A, x, y, z);  // re-apply the augmentation (:189)
-    const bool lift = x > r0 && y > r1 && z > r2 && x < r3 && y < r4 && z < r5;  // strict (:191-192)
+    float ix, iy;
+    const bool lift = warp_position(G, pix, ix, iy);
     float o[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = 0.f;
-    if (lift && ch_ok) {
-      const float gx = ((x - r0) / (r3 - r0) - 0.5f) * 2.f;  // x -> BEV width (:193-194)
-      const float gy = ((y - r1) / (r4 - r1) - 0.5f) * 2.f;  // y -> BEV height
-      const float ix = ((gx + 1.f) * Wb - 1.f) * 0.5f;
-      const float iy = ((gy + 1.f) * Hb - 1.f) * 0.5f;
-      bilinear8(bev, Hb, Wb, C, ix, iy, ch0, o);
-    }
+    if (lift && ch_ok) bilinear8(bev, Hb, Wb, C, ix, iy, ch0, o);
     if (ch_ok) st8(out + (size_t)pix * C + ch0, pack8f(o, T()));  // masked texels are 0 (:196)
   }
 }

@@ -19,6 +19,7 @@
 // Weights live in LDS (XOR-swizzled 16-B chunks: conflict-free ds_read_b128 fragments), staged once per
 // persistent workgroup.  fp32 accumulation, bias add in fp32.
 #include "di_common.h"
+#include "warp_common.h"
 #include <type_traits>
 
 namespace di {
@@ -335,8 +336,19 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // The chain images are moved by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land as one contiguous KiB, no
 // VGPRs, asynchronous) into one of TWO LDS buffers: the next chain's weights arrive while the current chain is
 // multiplied.
-template <int NG>
-__global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__restrict__ x, MultiArgs A, long long M) {
+// WARP: the input map is not read but GATHERED - pixel p of the (V, Hi, Wi) image maps takes the BEV map's bilinear sample at
+// the position its completed depth un-projects to (BEVWarp, reference encoder_utils.py:185-196; the arithmetic of
+// bevwarp_gather_kernel, rounded to fp16 as that kernel stores it): the key / value projections of the P2I block read the
+// warped map straight from the BEV map and the 34 MB intermediate is never written.
+struct WarpArgs {
+  const __half *bev;
+  const float *depth, *img2lidar, *aug, *xs, *ys, *pc_range;
+  int Hi, Wi, Hb, Wb;
+};
+
+template <int NG, bool WARP = false>
+__global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__restrict__ x, MultiArgs A, long long M,
+                                                                WarpArgs Wp = WarpArgs{}) {
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -372,9 +384,23 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
     const int grp = wg + j * stride;
     pix[j] = grp < ngroups ? grp * 16 + i : Mi;                // M: "no pixel" (never stored)
     const int pc = pix[j] < Mi ? pix[j] : Mi - 1;
+    if constexpr (WARP) {
+      const WarpGeom G = load_warp_geom(Wp.depth, Wp.img2lidar, Wp.aug, Wp.xs, Wp.ys, Wp.pc_range, Wp.Hi, Wp.Wi, Wp.Hb, Wp.Wb);
+      float ix, iy;
+      const bool lift = warp_position(G, pc, ix, iy);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      xb[j][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(x + (size_t)pc * 128 + kk * 32 + g * 8));
+      for (int kk = 0; kk < 4; ++kk) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        if (lift) bilinear8(Wp.bev, Wp.Hb, Wp.Wb, 128, ix, iy, kk * 32 + g * 8, o);
+        xb[j][kk] = __builtin_bit_cast(h8, pack8f(o, __half()));
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        xb[j][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(x + (size_t)pc * 128 + kk * 32 + g * 8));
+    }
   }
 
   for (int c = 0; c < A.n; ++c) {
@@ -679,13 +705,42 @@ __global__ __launch_bounds__(NT, 2) void ffn_ln_kernel(const __half *__restrict_
   }
 }
 
-template <int NG>
-static int launch_multi(const void *x, const MultiArgs &A, long long M, long long grid, hipStream_t stream) {
+template <int NG, bool WARP>
+static int launch_multi(const void *x, const MultiArgs &A, long long M, long long grid, hipStream_t stream,
+                        const WarpArgs &Wp = WarpArgs{}) {
   constexpr int LDS = 2 * kChainImage;
   static LdsRaised lds_raised;
-  if (int rc = ensure_lds(lds_raised, (const void *)pointwise_multi_kernel<NG>, LDS)) return rc;
-  hipLaunchKernelGGL((pointwise_multi_kernel<NG>), dim3((unsigned)grid), dim3(NT), LDS, stream, (const __half *)x, A, M);
+  if (int rc = ensure_lds(lds_raised, (const void *)pointwise_multi_kernel<NG, WARP>, LDS)) return rc;
+  hipLaunchKernelGGL((pointwise_multi_kernel<NG, WARP>), dim3((unsigned)grid), dim3(NT), LDS, stream, (const __half *)x, A, M, Wp);
   return check_launch("pointwise_multi");
+}
+
+// chains of one launch + the split of the map over the workgroups (shared by the plain and the gathered form)
+static int multi_setup(MultiArgs &A, int n_chains, const void *const *image, void *const *y, const int *relu1, const int *relu2,
+                       const int *two_links, long long n_pixels, long long &grid, int &ng) {
+  DI_REQUIRE(n_chains >= 1 && n_chains <= kMaxChains, "1..%d chains, got %d", kMaxChains, n_chains);
+  A.n = n_chains;
+  for (int c = 0; c < kMaxChains; ++c) {
+    if (c < n_chains) {
+      DI_REQUIRE(image[c] && y[c], "chain %d: image and y are required", c);
+      A.c[c] = Chain{(const unsigned char *)image[c], (__half *)y[c], relu1[c], relu2[c], two_links[c]};
+    } else {
+      A.c[c] = Chain{nullptr, nullptr, 0, 0, 0};
+    }
+  }
+  const int n_cu = di::device_cus();
+  if (n_cu <= 0) return DI_ERR_LAUNCH;
+  // every wave keeps its pixel groups in registers: NG in {2, 4, 5} groups per wave, one workgroup per CU when the map
+  // allows it (more workgroups than CUs only beyond 5 groups per wave)
+  const long long ngroups = (n_pixels + 15) / 16;
+  grid = n_cu;
+  if (ngroups < (long long)grid * NW) grid = (ngroups + NW - 1) / NW;        // small map: one group per wave, every CU busy
+  ng = (int)((ngroups + grid * NW - 1) / (grid * NW));
+  if (ng > 5) {
+    grid = (ngroups + NW * 5 - 1) / (NW * 5);
+    ng = 5;
+  }
+  return DI_OK;
 }
 
 }  // namespace pw
@@ -721,33 +776,33 @@ extern "C" int di_pointwise_multi_fwd(const void *x, int n_chains, const void *c
                                       void *stream) {
   using namespace di::pw;
   DI_REQUIRE(n_pixels > 0 && n_pixels < (1ll << 24) && x, "bad map size (1 .. 2^24 - 1 pixels)");
-  DI_REQUIRE(n_chains >= 1 && n_chains <= kMaxChains, "1..%d chains, got %d", kMaxChains, n_chains);
   MultiArgs A;
-  A.n = n_chains;
-  for (int c = 0; c < kMaxChains; ++c) {
-    if (c < n_chains) {
-      DI_REQUIRE(image[c] && y[c], "chain %d: image and y are required", c);
-      A.c[c] = Chain{(const unsigned char *)image[c], (__half *)y[c], relu1[c], relu2[c], two_links[c]};
-    } else {
-      A.c[c] = Chain{nullptr, nullptr, 0, 0, 0};
-    }
-  }
-  const int n_cu = di::device_cus();
-  if (n_cu <= 0) return DI_ERR_LAUNCH;
-  // every wave keeps its pixel groups in registers: NG in {2, 4, 5} groups per wave, one workgroup per CU when the map
-  // allows it (more workgroups than CUs only beyond 5 groups per wave)
-  const long long ngroups = (n_pixels + 15) / 16;
-  long long grid = n_cu;
-  if (ngroups < (long long)grid * NW) grid = (ngroups + NW - 1) / NW;        // small map: one group per wave, every CU busy
-  int ng = (int)((ngroups + grid * NW - 1) / (grid * NW));
-  if (ng > 5) {
-    grid = (ngroups + NW * 5 - 1) / (NW * 5);
-    ng = 5;
-  }
+  long long grid;
+  int ng;
+  if (int rc = multi_setup(A, n_chains, image, y, relu1, relu2, two_links, n_pixels, grid, ng)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (ng <= 2) return launch_multi<2>(x, A, n_pixels, grid, s);
-  if (ng <= 4) return launch_multi<4>(x, A, n_pixels, grid, s);
-  return launch_multi<5>(x, A, n_pixels, grid, s);
+  if (ng <= 2) return launch_multi<2, false>(x, A, n_pixels, grid, s);
+  if (ng <= 4) return launch_multi<4, false>(x, A, n_pixels, grid, s);
+  return launch_multi<5, false>(x, A, n_pixels, grid, s);
+}
+
+extern "C" int di_pointwise_multi_warp_fwd(const void *bev, const float *depth, const float *img2lidar, const float *aug_fwd,
+                                           const float *xs, const float *ys, const float *pc_range, int n_views, int Hi,
+                                           int Wi, int Hb, int Wb, int n_chains, const void *const *image, void *const *y,
+                                           const int *relu1, const int *relu2, const int *two_links, void *stream) {
+  using namespace di::pw;
+  const long long n_pixels = (long long)n_views * Hi * Wi;
+  DI_REQUIRE(n_views > 0 && Hi > 0 && Wi > 0 && Hb > 0 && Wb > 0 && n_pixels < (1ll << 24), "bad gather shape");
+  DI_REQUIRE(bev && depth && img2lidar && aug_fwd && xs && ys && pc_range, "null geometry");
+  MultiArgs A;
+  long long grid;
+  int ng;
+  if (int rc = multi_setup(A, n_chains, image, y, relu1, relu2, two_links, n_pixels, grid, ng)) return rc;
+  const WarpArgs Wp{(const __half *)bev, depth, img2lidar, aug_fwd, xs, ys, pc_range, Hi, Wi, Hb, Wb};
+  hipStream_t s = (hipStream_t)stream;
+  if (ng <= 2) return launch_multi<2, true>(nullptr, A, n_pixels, grid, s, Wp);
+  if (ng <= 4) return launch_multi<4, true>(nullptr, A, n_pixels, grid, s, Wp);
+  return launch_multi<5, true>(nullptr, A, n_pixels, grid, s, Wp);
 }
 
 extern "C" int di_pointwise_chain_masked_fwd(const void *x1, const void *x2, const void *x3, const void *w1,

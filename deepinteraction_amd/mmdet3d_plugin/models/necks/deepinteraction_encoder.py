@@ -68,7 +68,7 @@ class DeepInteractionEncoderLayer(nn.Module):
         # P_integration(cat(P_out_proj(cat(I2P, P2P)), lidar)) (:26-27): one fused kernel at inference
         return mix2(self.P_out_proj, I2P_feat, P2P_feat, self.P_integration, lidar_feat)
 
-    def _image_side(self, img_feat, img5, lidar_feat, img_metas, pts_metas, warped=None, warped_ready=None):
+    def _image_side(self, img_feat, img5, lidar_feat, img_metas, pts_metas, warped=None, warped_ready=None, kv=None):
         BN, I_C, I_H, I_W = img_feat.shape
         # fp16 inference: the four projections of the image map (query / key / value of I_IML and the query of P2I)
         # are ONE launch that reads it once.
@@ -77,7 +77,7 @@ class DeepInteractionEncoderLayer(nn.Module):
             q_i, k_i, v_i, q_p = project_many([I.query_project, I.key_project, I.value_project, PL.query_project], img_feat)
             if warped_ready is not None:
                 torch.cuda.current_stream().wait_event(warped_ready)
-            P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas, query=q_p, warped=warped)
+            P2I_feat = self.P2I_block(lidar_feat, img5, img_metas, pts_metas, query=q_p, warped=warped, kv=kv)
             I2I_feat = ops.local_attention(q_i, k_i, v_i, I.kernel_size, I.kernel_size, 1.0 / math.sqrt(k_i.size(1)))
         else:
             if warped_ready is not None:
@@ -105,13 +105,20 @@ class DeepInteractionEncoderLayer(nn.Module):
             main, side = torch.cuda.current_stream(lidar_feat.device), utils.side_stream(lidar_feat.device, 0)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                warped = self.P2I_block.Warp(lidar_feat, img5, img_metas, pts_metas)
+                # fp16 inference: the warp is gathered inside the key / value projection launch (no warped map in memory)
+                warped = kv = None
+                if self.P2I_block.warp_kv_fusable(lidar_feat) and fusable_projections(
+                        img_feat, self.I_IML.query_project, self.I_IML.key_project, self.I_IML.value_project,
+                        self.P2I_block.Local.query_project):
+                    kv = self.P2I_block.warp_kv(lidar_feat, img5, img_metas, pts_metas)
+                else:
+                    warped = self.P2I_block.Warp(lidar_feat, img5, img_metas, pts_metas)
                 ready = torch.cuda.Event()
                 ready.record(side)
                 new_lidar_feat = self._bev_side(lidar_feat, img5, img_metas, pts_metas)
-            new_img_feat = self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas, warped, ready)
+            new_img_feat = self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas, warped, ready, kv)
             main.wait_stream(side)
-            del warped
+            del warped, kv
             return new_img_feat, new_lidar_feat
         new_lidar_feat = self._bev_side(lidar_feat, img5, img_metas, pts_metas)
         new_img_feat = self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas)

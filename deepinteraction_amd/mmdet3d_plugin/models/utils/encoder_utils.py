@@ -354,8 +354,38 @@ class MMRI_P2I(nn.Module):
         self.Warp = BEVWarp()
         self.Local = LocalContextAttentionBlock(in_channels, out_channels, kernel_size, last_affine=True)
 
-    def forward(self, lidar_feats, img_feats, img_metas, pts_metas, query=None, warped=None, **kwargs):
-        """`query` / `warped`: the projected query map / the warped BEV map when the caller already has them."""
+    def warp_kv_fusable(self, lidar_feats):
+        """fp16 inference on 128-channel maps: the key / value projections can gather the warped map themselves."""
+        L = self.Local
+        return (lidar_feats.is_cuda and lidar_feats.dtype == torch.float16 and lidar_feats.shape[1] == 128
+                and not torch.is_grad_enabled() and fusable_projections(lidar_feats, L.key_project, L.value_project))
+
+    def warp_kv(self, lidar_feats, img_feats, img_metas, pts_metas):
+        """key / value maps (B*N,C,H,W) of the local attention over the warped BEV map, WITHOUT the warped map in memory:
+        `ops.warp_project` gathers the BEV samples inside the projection launch (one launch per sample)."""
+        B, V, C, I_H, I_W = img_feats.shape
+        L = self.Local
+        chains = [_chain_consts(L.key_project, lidar_feats.dtype), _chain_consts(L.value_project, lidar_feats.dtype)]
+        ks, vs = [], []
+        for b in range(B):
+            geom = sample_geometry(img_metas, pts_metas, b, (I_H, I_W), lidar_feats.device)
+            depth = self.Warp.dense_depth(geom, pts_metas['pts'][b], I_H, I_W)
+            k, v = ops.warp_project(lidar_feats[b:b + 1], depth, geom.img2lidar, geom.aug_fwd, geom.xs, geom.ys,
+                                    geom.pc_range, chains)
+            ks.append(k)
+            vs.append(v)
+        return (ks[0], vs[0]) if B == 1 else (torch.cat(ks, 0), torch.cat(vs, 0))
+
+    def forward(self, lidar_feats, img_feats, img_metas, pts_metas, query=None, warped=None, kv=None, **kwargs):
+        """`query` / `warped` / `kv`: the projected query map / the warped BEV map / the key and value maps of the warped
+        map (`warp_kv`) when the caller already has them."""
+        B, N, C, H, W = img_feats.shape
+        if kv is None and warped is None and query is not None and self.warp_kv_fusable(lidar_feats):
+            kv = self.warp_kv(lidar_feats, img_feats, img_metas, pts_metas)
+        if kv is not None:
+            ks = self.Local.kernel_size
+            out = ops.local_attention(query, kv[0], kv[1], ks, ks, 1.0 / math.sqrt(kv[0].size(1)))
+            return out.view(B, N, -1, H, W)
         if warped is None:
             warped = self.Warp(lidar_feats, img_feats, img_metas, pts_metas)    # B, N, C, H, W
         B, N, C, H, W = warped.shape

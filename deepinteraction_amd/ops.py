@@ -402,6 +402,30 @@ def bevwarp_gather(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range):
     return out
 
 
+def warp_project(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range, chains):
+    """`pointwise_multi(bevwarp_gather(bev, depth, ...), chains)` in one launch: the warped map is gathered into the
+    projection kernel's registers and never written (bit-identical outputs).  bev (1,128,Hb,Wb) fp16 channels-last."""
+    _dev(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range)
+    bev = cl(bev)
+    _, C, Hb, Wb = bev.shape
+    V, Hi, Wi = depth.shape
+    assert C == 128 and bev.dtype == torch.float16 and depth.dtype == torch.float32 and depth.is_contiguous()
+    nc = len(chains)
+    assert 1 <= nc <= 4
+    ys_ = [empty_cl(V, 128, Hi, Wi, bev) for _ in chains]
+    P, I = ctypes.c_void_p * nc, ctypes.c_int * nc
+    for (im, r1, r2, two) in chains:
+        assert im.dtype == torch.uint8 and im.numel() == 2 * 128 * 128 * 2 + 1024 and im.is_cuda
+    a_im, a_y = P(*[c[0].data_ptr() for c in chains]), P(*[y.data_ptr() for y in ys_])
+    a_r1, a_r2 = I(*[int(bool(c[1])) for c in chains]), I(*[int(bool(c[2])) for c in chains])
+    a_two = I(*[int(bool(c[3])) for c in chains])
+    _profiled('pointwise_multi_warp', V, lambda: _lib.call(
+        'di_pointwise_multi_warp_fwd', bev.data_ptr(), depth.data_ptr(), img2lidar.data_ptr(), aug_fwd.data_ptr(),
+        xs.data_ptr(), ys.data_ptr(), pc_range.data_ptr(), V, Hi, Wi, Hb, Wb, nc, ctypes.addressof(a_im),
+        ctypes.addressof(a_y), ctypes.addressof(a_r1), ctypes.addressof(a_r2), ctypes.addressof(a_two), _stream()))
+    return ys_
+
+
 def bevwarp_gather_bwd(grad_out, depth, img2lidar, aug_fwd, xs, ys, pc_range, bev_hw):
     """Gradient of bevwarp_gather w.r.t. the BEV map: (1,C,Hb,Wb) float32, channels-last."""
     _dev(grad_out, depth)

@@ -333,6 +333,15 @@ int di_polar_bev_sample_bwd(const void *grad_out, const float *proj, const float
 int di_pointwise_multi_fwd(const void *x, int n_chains, const void *const *image_host, void *const *y_host,
                            const int *relu1_host, const int *relu2_host, const int *two_links_host, long long n_pixels,
                            void *stream);
+/* The same chains over the BEV map WARPED onto the image maps (MMRI_P2I: BEVWarp, encoder_utils.py:185-196, then the key /
+ * value projections of its LocalContextAttentionBlock, :127-131) without the warped map in memory: input pixel p of the
+ * (n_views, Hi, Wi) maps is the bilinear sample of bev (Hb, Wb, 128) fp16 where the pixel's completed depth un-projects to -
+ * the arithmetic and fp16 rounding of di_bevwarp_gather_fwd (whose arguments these are), so the outputs equal
+ * di_pointwise_multi_fwd on that kernel's output bit for bit. */
+int di_pointwise_multi_warp_fwd(const void *bev, const float *depth, const float *img2lidar, const float *aug_fwd,
+                                const float *xs, const float *ys, const float *pc_range, int n_views, int Hi, int Wi, int Hb,
+                                int Wb, int n_chains, const void *const *image_host, void *const *y_host,
+                                const int *relu1_host, const int *relu2_host, const int *two_links_host, void *stream);
 
 /* Transformer FFN + post-norm of the DeepInteraction++ layers (mmcv FFN followed by LayerNorm: necks/fusion_transformerv4.py
  * operation_order (..., 'ffn', 'norm')) in one pass over the tokens:

@@ -416,3 +416,32 @@ def test_pointwise_multi_equals_single_chains(npix):
         for (w1, b1, r1, w2, b2, r2), y in zip(chains[:k], got):
             ref = ops.pointwise_chain(x, w1, b1, r1, w2=w2, b2=b2, relu2=r2)
             assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize('shape_name', ['tiny', 'R'])
+def test_warp_project_equals_gather_then_project(shape_name):
+    """ops.warp_project (the BEV -> image warp gathered INSIDE the key / value projection launch of the P2I block, no warped
+    map in memory) against bevwarp_gather followed by pointwise_multi: bit-identical maps.  Depth with holes (zeros
+    un-project to the camera centre) and values beyond the point-cloud range (masked pixels)."""
+    _require_gpu()
+    from deepinteraction_amd import harness
+    shape = synth.SHAPE_TINY if shape_name == 'tiny' else harness.SHAPES['R']
+    inp = synth.make_inputs(1, shape, seed=4, aug=synth.example_aug(0))
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    geom = SampleGeometry(inp['img_metas'][0], (Hi, Wi), DEV)
+    g = torch.Generator().manual_seed(5)
+    bev = torch.randn(1, 128, Hb, Wb, generator=g).half().to(DEV).contiguous(memory_format=torch.channels_last)
+    depth = (torch.rand(6, Hi, Wi, generator=g) * 90 + 0.5)
+    depth[:, :2] = 0
+    depth = depth.to(DEV)
+    mk = lambda: ((torch.randn(128, 128, generator=g) / math.sqrt(128)).half().to(DEV), (torch.randn(128, generator=g) * 0.1).to(DEV))
+    (w1, b1), (w2, b2), (wv, bv) = mk(), mk(), mk()
+    packed = [(ops.chain_image(w1, b1, w2, b2), True, True, True), (ops.chain_image(wv, bv), False, False, False)]
+    args = (depth, geom.img2lidar, geom.aug_fwd, geom.xs, geom.ys, geom.pc_range)
+    warped = ops.bevwarp_gather(bev, *args)
+    assert (warped != 0).any() and (warped.flatten(1).abs().amax(1) == 0).sum() == 0
+    ref = ops.pointwise_multi(warped, packed)
+    got = ops.warp_project(bev, *args, packed)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and torch.equal(a, b)
