@@ -223,6 +223,22 @@ def draw_heatmap_gaussian(heatmap, center, radius, k=1):
     return heatmap
 
 
+def draw_heatmap_gaussian_host(heatmap, center, radius, k=1):
+    """`draw_heatmap_gaussian` on a float32 numpy map (the host-side target builder: single-threaded, no OpenMP team to
+    wake per box); the same float64 Gaussian rounded to float32 and the same element-wise max."""
+    diameter = 2 * radius + 1
+    g = _gaussian_2d((diameter, diameter), sigma=diameter / 6)
+    x, y = int(center[0]), int(center[1])
+    height, width = heatmap.shape[0:2]
+    left, right = min(x, radius), min(width - x, radius + 1)
+    top, bottom = min(y, radius), min(height - y, radius + 1)
+    masked_heatmap = heatmap[y - top:y + bottom, x - left:x + right]
+    masked_gaussian = g[radius - top:radius + bottom, radius - left:radius + right].astype(np.float32)
+    if min(masked_gaussian.shape) > 0 and min(masked_heatmap.shape) > 0:
+        np.maximum(masked_heatmap, masked_gaussian * np.float32(k), out=masked_heatmap)
+    return heatmap
+
+
 def clip_sigmoid(x, eps=1e-4):
     return torch.clamp(x.sigmoid(), min=eps, max=1 - eps)
 

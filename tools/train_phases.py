@@ -1,4 +1,5 @@
-"""Wall time (host clock, device synchronised at every boundary) of the phases of the training step of `bench.py --mode train`."""
+"""Wall time (host clock, device synchronised at every boundary) of the phases of the training step of `bench.py --mode train`:
+median / mean / max over STEPS (default 20) steps - single steps on the GPU boxes show 2x outliers."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepinteraction_amd import harness, train_step
@@ -8,7 +9,7 @@ tr = train_step.Trainer(harness.SHAPES['R'], 200, dev, 1)
 if os.environ.get('FUSED'):
     tr.opt = torch.optim.AdamW(tr.params, lr=1e-4, weight_decay=0.01, fused=True)
 names = ['encoder fwd', 'decoder fwd', 'loss (targets + Hungarian)', 'zero_grad', 'backward', 'reduce + clip + AdamW']
-acc = [0.0] * len(names)
+acc = [[] for _ in names]
 
 
 def tick():
@@ -41,14 +42,16 @@ def step(record):
     t.append(tick())
     if record:
         for i in range(len(names)):
-            acc[i] += t[i + 1] - t[i]
+            acc[i].append(t[i + 1] - t[i])
 
 
 for _ in range(3):
     step(False)
-N = 5
+N = int(os.environ.get('STEPS', '20'))
 for _ in range(N):
     step(True)
+med = lambda v: sorted(v)[len(v) // 2]
+tot = [sum(a[k] for a in acc) for k in range(N)]
 for n, a in zip(names, acc):
-    print(f'{n:32s} {a / N * 1e3:8.2f} ms')
-print(f'{"sum":32s} {sum(acc) / N * 1e3:8.2f} ms')
+    print(f'{n:32s} median {med(a) * 1e3:8.2f} ms   mean {sum(a) / N * 1e3:8.2f} ms   max {max(a) * 1e3:8.2f} ms')
+print(f'{"step":32s} median {med(tot) * 1e3:8.2f} ms   mean {sum(tot) / N * 1e3:8.2f} ms   max {max(tot) * 1e3:8.2f} ms   ({N} steps)')
