@@ -101,28 +101,33 @@ __device__ __forceinline__ void bilin_gather8(const T *__restrict__ map, int Wm,
     for (int i = 0; i < 8; ++i) o[i] = fmaf(b.w11, f[i], o[i]);
   }
 }
-__device__ __forceinline__ void scatter8(float *__restrict__ gmap, int Wm, int C, const Bilin &b, int ch0,
-                                         const float (&g)[8]) {
-  if (b.v00) {
-    float *p = gmap + ((size_t)b.y0 * Wm + b.x0) * C + ch0;
+// Float32 atomics want 64 CONSECUTIVE bytes per 16-lane instruction: with the forward's layout (lane l = channels 8 l ..
+// 8 l + 7, the lanes of one instruction 32 B apart) the L2 atomic units retire 37 G adds / s, with lane l = channels l,
+// l + 16, ... (each instruction covers one contiguous 64-B piece) 329 G / s (tools/micro/atomic_pattern.hip).  The gradient
+// rows are therefore transposed inside their 16-lane group through a 512-B LDS slot before they are scattered:
+// in g[e] = channel 8 l16 + e, out t[k] = channel l16 + 16 k.  (DS operations of one wave are served in issue order, so the
+// reads see every lane's writes; the wave barrier only keeps the compiler from reordering them.)
+constexpr int kSlotFloats = 128;
+__device__ __forceinline__ void to_lane_major(const float (&g)[8], float (&t)[8], float *slot, int l16) {
+  *reinterpret_cast<float4 *>(slot + 8 * l16) = make_float4(g[0], g[1], g[2], g[3]);
+  *reinterpret_cast<float4 *>(slot + 8 * l16 + 4) = make_float4(g[4], g[5], g[6], g[7]);
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(p + i, b.w00 * g[i]);
-  }
-  if (b.v01) {
-    float *p = gmap + ((size_t)b.y0 * Wm + b.x0 + 1) * C + ch0;
+  for (int k = 0; k < 8; ++k) t[k] = slot[l16 + 16 * k];
+  __builtin_amdgcn_wave_barrier();
+}
+// row += w * t for the channels l16 + 16 k < C of one texel row
+__device__ __forceinline__ void add_row(float *__restrict__ row, int C, int l16, float w, const float (&t)[8]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(p + i, b.w01 * g[i]);
-  }
-  if (b.v10) {
-    float *p = gmap + ((size_t)(b.y0 + 1) * Wm + b.x0) * C + ch0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(p + i, b.w10 * g[i]);
-  }
-  if (b.v11) {
-    float *p = gmap + ((size_t)(b.y0 + 1) * Wm + b.x0 + 1) * C + ch0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(p + i, b.w11 * g[i]);
-  }
+  for (int k = 0; k < 8; ++k)
+    if (l16 + 16 * k < C) atomicAdd(row + l16 + 16 * k, w * t[k]);
+}
+__device__ __forceinline__ void scatter_rows(float *__restrict__ gmap, int Wm, int C, const Bilin &b, int l16,
+                                             const float (&t)[8]) {
+  if (b.v00) add_row(gmap + ((size_t)b.y0 * Wm + b.x0) * C, C, l16, b.w00, t);
+  if (b.v01) add_row(gmap + ((size_t)b.y0 * Wm + b.x0 + 1) * C, C, l16, b.w01, t);
+  if (b.v10) add_row(gmap + ((size_t)(b.y0 + 1) * Wm + b.x0) * C, C, l16, b.w10, t);
+  if (b.v11) add_row(gmap + ((size_t)(b.y0 + 1) * Wm + b.x0 + 1) * C, C, l16, b.w11, t);
 }
 
 // ---------------------------------------------------------------- BEV -> image gather, backward
@@ -139,7 +144,9 @@ __global__ __launch_bounds__(256) void bevwarp_gather_bwd_kernel(
     const float *__restrict__ aug, const float *__restrict__ xs, const float *__restrict__ ys,
     const float *__restrict__ pc_range, float *__restrict__ grad_bev, int V, int Hi, int Wi, int Hb, int Wb,
     int C) {
+  __shared__ float slots[16 * kSlotFloats];            // one transposition slot per 16-lane group
   const int l16 = threadIdx.x & 15;
+  float *slot = slots + (threadIdx.x >> 4) * kSlotFloats;
   const bool ch_ok = l16 * kChPerLane < C;
   const int ch0 = l16 * kChPerLane;
   const AffineB A = load_affine_b(aug);
@@ -157,17 +164,19 @@ __global__ __launch_bounds__(256) void bevwarp_gather_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) a00[i] = a01[i] = a10[i] = a11[i] = 0.f;
     auto flush = [&]() {
-      if (cx0 == INT_MIN || !ch_ok) return;
+      if (cx0 == INT_MIN) return;                       // (uniform over the 16-lane group)
       const bool xl = cx0 >= 0 && cx0 < Wb, xh = cx0 + 1 >= 0 && cx0 + 1 < Wb;
       const bool yl = cy0 >= 0 && cy0 < Hb, yh = cy0 + 1 >= 0 && cy0 + 1 < Hb;
-      float *p = grad_bev + ((long long)cy0 * Wb + cx0) * C + ch0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (yl && xl) atomicAdd(p + i, a00[i]);
-        if (yl && xh) atomicAdd(p + C + i, a01[i]);
-        if (yh && xl) atomicAdd(p + (long long)Wb * C + i, a10[i]);
-        if (yh && xh) atomicAdd(p + (long long)Wb * C + C + i, a11[i]);
-      }
+      float *p = grad_bev + ((long long)cy0 * Wb + cx0) * C;
+      float t[8];
+      to_lane_major(a00, t, slot, l16);
+      if (yl && xl) add_row(p, C, l16, 1.f, t);
+      to_lane_major(a01, t, slot, l16);
+      if (yl && xh) add_row(p + C, C, l16, 1.f, t);
+      to_lane_major(a10, t, slot, l16);
+      if (yh && xl) add_row(p + (long long)Wb * C, C, l16, 1.f, t);
+      to_lane_major(a11, t, slot, l16);
+      if (yh && xh) add_row(p + (long long)Wb * C + C, C, l16, 1.f, t);
 #pragma unroll
       for (int i = 0; i < 8; ++i) a00[i] = a01[i] = a10[i] = a11[i] = 0.f;
     };
@@ -208,8 +217,8 @@ __global__ __launch_bounds__(256) void bevwarp_gather_bwd_kernel(
 }
 
 // ---------------------------------------------------------------- RoIAlign, backward
-__device__ __forceinline__ void roi_scatter8(float *__restrict__ gmap, int H, int W, int C, float y, float x,
-                                             int ch0, const float (&g)[8], float wgt) {
+__device__ __forceinline__ void roi_scatter_rows(float *__restrict__ gmap, int H, int W, int C, float y, float x,
+                                                 int l16, const float (&t)[8], float wgt) {
   if (y < -1.f || y > (float)H || x < -1.f || x > (float)W) return;
   y = fmaxf(y, 0.f);
   x = fmaxf(x, 0.f);
@@ -217,16 +226,10 @@ __device__ __forceinline__ void roi_scatter8(float *__restrict__ gmap, int H, in
   if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
   if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
   const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
-  const float w1 = hy * hx * wgt, w2 = hy * lx * wgt, w3 = ly * hx * wgt, w4 = ly * lx * wgt;
-  float *p1 = gmap + ((size_t)yl * W + xl) * C + ch0, *p2 = gmap + ((size_t)yl * W + xh) * C + ch0;
-  float *p3 = gmap + ((size_t)yh * W + xl) * C + ch0, *p4 = gmap + ((size_t)yh * W + xh) * C + ch0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    atomicAdd(p1 + i, w1 * g[i]);
-    atomicAdd(p2 + i, w2 * g[i]);
-    atomicAdd(p3 + i, w3 * g[i]);
-    atomicAdd(p4 + i, w4 * g[i]);
-  }
+  add_row(gmap + ((size_t)yl * W + xl) * C, C, l16, hy * hx * wgt, t);
+  add_row(gmap + ((size_t)yl * W + xh) * C, C, l16, hy * lx * wgt, t);
+  add_row(gmap + ((size_t)yh * W + xl) * C, C, l16, ly * hx * wgt, t);
+  add_row(gmap + ((size_t)yh * W + xh) * C, C, l16, ly * lx * wgt, t);
 }
 
 template <typename T>
@@ -235,13 +238,14 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const T *__restrict_
                                                             float *__restrict__ grad_feat, int R, int N, int H,
                                                             int W, int C, float scale) {
   constexpr int PB = 7, G = 2;
+  __shared__ float slots[16 * kSlotFloats];            // one transposition slot per 16-lane group
   const int l16 = threadIdx.x & 15;
+  float *slot = slots + (threadIdx.x >> 4) * kSlotFloats;
   const bool ch_ok = l16 * kChPerLane < C;
   const int ch0 = l16 * kChPerLane;
   const int total = R * PB * PB;
   const int ngrp = gridDim.x * (blockDim.x >> 4);
   for (int g = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); g < total; g += ngrp) {
-    if (!ch_ok) continue;
     const int r = g / (PB * PB), bin = g - r * PB * PB;
     const int ph = bin / PB, pw = bin - ph * PB;
     const float *roi = rois + (size_t)r * 5;
@@ -250,8 +254,11 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const T *__restrict_
     const float sw = roi[1] * scale - 0.5f, sh = roi[2] * scale - 0.5f;
     const float ew = roi[3] * scale - 0.5f, eh = roi[4] * scale - 0.5f;
     const float bw = (ew - sw) / PB, bh = (eh - sh) / PB;
-    float go[8];
-    unpack8(ld8(grad_out + (size_t)g * C + ch0), go);
+    float go[8], gt[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) go[i] = 0.f;
+    if (ch_ok) unpack8(ld8(grad_out + (size_t)g * C + ch0), go);
+    to_lane_major(go, gt, slot, l16);
     float *gmap = grad_feat + (size_t)n * H * W * C;
 #pragma unroll
     for (int iy = 0; iy < G; ++iy) {
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const T *__restrict_
 #pragma unroll
       for (int ix = 0; ix < G; ++ix) {
         const float x = sw + pw * bw + (ix + 0.5f) * bw / G;
-        roi_scatter8(gmap, H, W, C, y, x, ch0, go, 1.f / (G * G));
+        roi_scatter_rows(gmap, H, W, C, y, x, l16, gt, 1.f / (G * G));
       }
     }
   }
@@ -285,8 +292,10 @@ __global__ __launch_bounds__(256) void i2p_attn_bwd_kernel(
     float *__restrict__ grad_qfold, int P, int Tp, int D, int V, int Hi, int Wi, int Hb, int Wb, int C,
     float ori_H, float ori_W, float drop_p, unsigned long long seed) {
   __shared__ KeyEntB s_list[4][kMaxSlotsB];
+  __shared__ float slots[16 * kSlotFloats];            // one transposition slot per 16-lane group
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
   const int l16 = lane & 15, sub = lane >> 4;
+  float *slot = slots + (tid >> 4) * kSlotFloats;
   const bool ch_ok = l16 * kChPerLane < C;
   const int ch0 = l16 * kChPerLane;
   KeyEntB *list = s_list[wib];
@@ -401,7 +410,9 @@ __global__ __launch_bounds__(256) void i2p_attn_bwd_kernel(
         gsj[i] = dj * pj * g[i] + ds * qf[i];
         gq[i] = fmaf(ds, s8[i], gq[i]);
       }
-      if (ch_ok) scatter8(grad_img + (size_t)(k.cam % V) * Hi * Wi * C, Wi, C, b, ch0, gsj);
+      float gst[8];
+      to_lane_major(gsj, gst, slot, l16);
+      scatter_rows(grad_img + (size_t)(k.cam % V) * Hi * Wi * C, Wi, C, b, l16, gst);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
