@@ -148,6 +148,44 @@ def test_assigners_known_answers():
     assert h.gt_inds.tolist() == [2, 0, 1, 0]
 
 
+def test_assign_layers_equals_per_layer_assignment():
+    """`HungarianAssigner3D.assign_layers` (all decoder layers' costs in one evaluation, one device -> host copy) against
+    `assign` called per layer: the concatenated result bit for bit, the matched rows on the host, the sync-free sampler."""
+    g = torch.Generator().manual_seed(3)
+    L, Q, G = 5, 40, 9
+    gt = torch.cat([(torch.rand(G, 2, generator=g) - 0.5) * 80, torch.rand(G, 1, generator=g) * 2 - 2,
+                    torch.rand(G, 3, generator=g) * 3 + 0.5, (torch.rand(G, 1, generator=g) - 0.5) * 6, torch.randn(G, 2, generator=g)], 1)
+    lab = torch.randint(0, 10, (G,), generator=g)
+    boxes = torch.cat([(torch.rand(L * Q, 2, generator=g) - 0.5) * 80, torch.rand(L * Q, 1, generator=g) * 2 - 2,
+                       torch.rand(L * Q, 3, generator=g) * 3 + 0.5, (torch.rand(L * Q, 1, generator=g) - 0.5) * 6,
+                       torch.randn(L * Q, 2, generator=g)], 1)
+    boxes[::7, :7] = gt[torch.arange(boxes[::7].shape[0]) % G, :7]                   # some proposals sit on a ground truth
+    cls = torch.randn(1, 10, L * Q, generator=g)
+    asg = HungarianAssigner3D(**{k: v for k, v in TRAIN_CFG['assigner'].items() if k != 'type'})
+    per = [asg.assign(boxes[l * Q:(l + 1) * Q], gt, lab, cls[..., l * Q:(l + 1) * Q], TRAIN_CFG) for l in range(L)]
+    ens = asg.assign_layers(boxes, gt, lab, cls, TRAIN_CFG, L)
+    assert ens.num_gts == sum(r.num_gts for r in per)
+    assert torch.equal(ens.gt_inds, torch.cat([r.gt_inds for r in per]))
+    assert torch.equal(ens.labels, torch.cat([r.labels for r in per]))
+    assert torch.equal(ens.max_overlaps, torch.cat([r.max_overlaps for r in per]))
+    assert sorted(ens.host_rows.tolist()) == torch.nonzero(ens.gt_inds > 0).flatten().tolist()
+    fast = dc.pseudo_sample(ens, boxes, gt)
+    slow = dc.pseudo_sample(dc.AssignResult(ens.num_gts, ens.gt_inds, ens.max_overlaps, ens.labels), boxes, gt)
+    for k in ('pos_inds', 'neg_inds', 'pos_assigned_gt_inds', 'pos_gt_bboxes'):
+        assert torch.equal(getattr(fast, k), getattr(slow, k)), k
+    empty = asg.assign_layers(boxes, gt[:0], lab[:0], cls, TRAIN_CFG, L)
+    assert empty.gt_inds.eq(0).all() and empty.host_rows.size == 0
+
+
+def test_host_heatmap_drawing_equals_tensor_drawing():
+    """The numpy Gaussian drawing of the host-side target builder against the tensor form (same float64 Gaussian, float32 max)."""
+    hm_t, hm_n = torch.zeros(40, 50), np.zeros((40, 50), dtype=np.float32)
+    for (x, y, r) in ((10, 12, 3), (11, 13, 5), (0, 0, 4), (49, 39, 6), (25, 2, 2)):
+        dc.draw_heatmap_gaussian(hm_t, torch.tensor([x, y]), r)
+        dc.draw_heatmap_gaussian_host(hm_n, (x, y), r)
+    assert np.array_equal(hm_t.numpy(), hm_n) and (hm_n == 1).sum() == 5
+
+
 # ------------------------------------------------------------------ against the reference's own Python
 @pytest.fixture(scope='module')
 def ref():
