@@ -277,10 +277,7 @@ def bench_forward(args, rank, world, device):
                 for gi, lane in zip(graphs, lanes):
                     with torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext():
                         if raw_pool is not None:
-                            raw = raw_pool[it[0] % len(raw_pool)]
-                            cl = dict(raw, img_feats=raw['img_feats'].contiguous(memory_format=torch.channels_last),
-                                      pts_feats=raw['pts_feats'].contiguous(memory_format=torch.channels_last))
-                            gi.load(gi.prepare(cl))
+                            gi.load_raw(raw_pool[it[0] % len(raw_pool)])    # NCHW -> channels-last inside the one copy
                         else:
                             gi.load(records[it[0] % len(records)])  # per-sample: copies into the captured buffers ...
                         it[0] += 1

@@ -248,6 +248,49 @@ class GraphedHotPath:
                 r.extra.append((mod, [mod.static_geometry_record(g, m) for g, m in zip(self.sample_geom, r.img_metas)]))
         return r
 
+    def load_raw(self, inputs):
+        """`load(prepare(inputs))` without the intermediate record: every input of a raw batch (dict as produced by
+        `harness.to_device`; the maps in ANY dense memory format, e.g. the NCHW a backbone hands over) goes straight into
+        its captured buffer - one strided copy per tensor, which also does the channels-last conversion - and the
+        geometry constants are packed on the host and uploaded.  Batch size 1 per capture (the benched form); other
+        batches go through `prepare()`."""
+        if self.batch != 1 or self.batch != len(inputs['img_metas']):
+            return self.load(self.prepare(inputs))
+        pm = inputs['pts_metas']
+
+        def put(dst, src, fill=None):
+            if isinstance(dst, (list, tuple)):
+                for d, s_ in zip(dst, src):
+                    put(d, s_, fill)
+                return
+            if fill is None:
+                if tuple(dst.shape) != tuple(src.shape):
+                    raise ValueError(f'input of shape {tuple(src.shape)} where the captured forward has {tuple(dst.shape)}')
+                dst.copy_(src, non_blocking=True)
+                return
+            n = src.shape[0]
+            if n > dst.shape[0]:
+                raise ValueError(f'sample of {n} rows exceeds the captured capacity {dst.shape[0]}')
+            dst[:n].copy_(src, non_blocking=True)
+            dst[n:].fill_(fill)
+
+        put(self.img_feats, inputs['img_feats'])
+        put(self.pts_feats, inputs['pts_feats'])
+        put(self.pts, pm['pts'], float('nan'))
+        if self.glue is None:
+            put(self.pillars, pm['pillars'], 0.0)
+            put(self.pillar_coors, pm['pillar_coors'], 0)
+            put(self.pillars_num_points, pm['pillars_num_points'], 0)
+        self.img_metas = [dict(m) for m in inputs['img_metas']]
+        for g, m in zip(self.sample_geom, self.img_metas):
+            g._buf.copy_(SampleGeometry._pack(m, g.img_hw), non_blocking=True)
+            g.forget()
+        self.query_geom._buf.copy_(QueryGeometry._pack(self.img_metas)[0], non_blocking=True)
+        for mod in self.enc.modules():
+            if hasattr(mod, 'static_geometry_record'):
+                for g, m in zip(self.sample_geom, self.img_metas):
+                    mod.load_static_geometry(g, mod.static_geometry_record(g, m))
+
     def load(self, inputs):
         """Make a new batch the current one: copy it into the static buffers and refresh the geometry constants in
         place.  `inputs`: a `Record` from `prepare()` (device-to-device copies only) or a raw input dict."""

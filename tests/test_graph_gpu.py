@@ -59,6 +59,13 @@ def test_graph_replay_matches_eager_and_load_switches_sample():
     _same(g()[0][0], ref_b)
     g.load(a)
     _same(g()[0][0], ref_a)
+    # load_raw: straight from a raw batch with NCHW-contiguous maps (what a backbone hands over) into the captured buffers
+    raw_b = dict(b, img_feats=b['img_feats'].contiguous(), pts_feats=b['pts_feats'].contiguous())
+    assert not raw_b['img_feats'].is_contiguous(memory_format=torch.channels_last)
+    g.load_raw(raw_b)
+    _same(g()[0][0], ref_b)
+    g.load_raw(a)
+    _same(g()[0][0], ref_a)
 
 
 def _to_device_pp(inp, dtype):
