@@ -13,6 +13,7 @@
 // written to the other LDS buffer: one barrier per chunk.  Weights (A operand, pre-packed (Cout, 9, Cin)) come straight
 // from L2, one tap ahead of the MFMAs that use them.  fp32 accumulate, bias / ReLU on the accumulators.
 #include "di_common.h"
+#include <type_traits>
 
 namespace di {
 namespace cv {
@@ -314,7 +315,16 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 
 // TH: tile rows, 12, 16 or 20 (the host picks the one with the fewest rounds x rows for the map); NWV: 8 waves (4 x 2: a
 // wave owns TH / 4 rows x 64 output channels) or 16 (4 x 4: 32 output channels per wave, 4 waves per SIMD at <= 128 VGPRs)
-template <int TH, int NWV>
+template <int B_, int E_, class F_>
+__device__ __forceinline__ void static_for_cv(F_ &&f) {
+  if constexpr (B_ < E_) {
+    f(std::integral_constant<int, B_>{});
+    static_for_cv<B_ + 1, E_>(f);
+  }
+}
+
+// PIPE: the fragment reads of a stage are issued by hand, a fixed distance ahead of the MFMAs that use them (see `multiply`)
+template <int TH, int NWV, bool PIPE, bool TS = false>   // TS: measurement build, phase timestamps of workgroup 0 into y
 __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_dma_kernel(const __half *__restrict__ x, const __half *__restrict__ wst,
                                                              const float *__restrict__ bias, __half *__restrict__ y,
                                                              int H, int W, int Cin, int relu, int tiles_x, int tiles_y) {
@@ -384,13 +394,75 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_dma_kernel(const __half *
     if (NLD > 3 && bdst3 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst3) = b3;                                             \
   } while (0)
 
+  // the same requests one at a time, for the hand-scheduled stages: piece j of a weight tile, halo register k
+  constexpr int NPIECE = (24 + NWV - 1) / NWV;
+  auto dma_piece = [&](int st, unsigned char *buf, int j) {
+    const int sc = st < nstage ? st : nstage - 1;
+    const int c = NWV == 8 ? wave * 3 + j : wave + j * NWV;
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(wst) + (size_t)sc * ASZ + lane * 16;
+    if (NWV == 8 || c < 24) __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 1024), (lptr_t)(buf + c * 1024), 16, 0, 0);
+  };
+  auto fetch_one = [&](int k, int c0) {
+    if (k == 0) b0 = bsrc0 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc0 + c0) : zero4;
+    if (k == 1 && NLD > 1) b1 = bsrc1 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc1 + c0) : zero4;
+    if (k == 2 && NLD > 2) b2 = bsrc2 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc2 + c0) : zero4;
+    if (k == 3 && NLD > 3) b3 = bsrc3 >= 0 ? *reinterpret_cast<const uint4 *>(xi + bsrc3 + c0) : zero4;
+  };
+  auto commit_one = [&](int k, unsigned char *d_) {
+    if (k == 0 && bdst0 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst0) = b0;
+    if (k == 1 && NLD > 1 && bdst1 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst1) = b1;
+    if (k == 2 && NLD > 2 && bdst2 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst2) = b2;
+    if (k == 3 && NLD > 3 && bdst3 >= 0) *reinterpret_cast<uint4 *>(d_ + bdst3) = b3;
+  };
+
   f4 acc[RW][NTW];
 #pragma unroll
   for (int r = 0; r < RW; ++r)
 #pragma unroll
     for (int n = 0; n < NTW; ++n) acc[r][n] = f4{0.f, 0.f, 0.f, 0.f};
 
+  // One stage = 3 RW steps (kx, r); step s multiplies weight set kx (NTW fragments) with the shifted pixel row B(kx, r).
+  // Left to the compiler the stage came out as bursts - read 8, wait, 8 MFMAs, read 2, wait, ... (a dozen exposed LDS
+  // latencies per stage, both waves of a SIMD in the same phase after the barrier: the matrix pipe idled half the time).
+  // Here every read is issued D steps (>= 8 MFMAs = 128 clk) before its use: B fragments through a ring of D + 1
+  // registers, the next weight set spread over the current set's steps; sched_barriers pin the order.
+  auto multiply_pipe = [&](const unsigned char *A, int ky, const unsigned char *B, auto &&hook) {
+    constexpr int NS = 3 * RW, D = NTW >= 4 ? 2 : 4;
+    h8 a[2][NTW], b[D + 1];
+    auto rd_a = [&](int kx, int n) {
+      return __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A + lds_off(kx * 128 + wn * NTW * 16 + n * 16 + i, g)));
+    };
+    auto rd_b = [&](int st) {
+      const int kx = st / RW, r = st - kx * RW;
+      return __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(B + lds_off((wm * RW + r + ky) * (TW + 2) + i + kx, g)));
+    };
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) a[0][n] = rd_a(0, n);
+#pragma unroll
+    for (int d = 0; d < D; ++d) b[d] = rd_b(d);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for_cv<0, NS>([&](auto sc) {
+      constexpr int st = decltype(sc)::value, kx = st / RW, r = st % RW;
+      if constexpr (st + D < NS) b[(st + D) % (D + 1)] = rd_b(st + D);
+      if constexpr (kx + 1 < 3) {                          // fragment n of the next weight set leaves at row n * RW / NTW
+        static_for_cv<0, NTW>([&](auto nc) {
+          constexpr int n = decltype(nc)::value;
+          if constexpr (n * RW / NTW == r) a[(kx + 1) & 1][n] = rd_a(kx + 1, n);
+        });
+      }
+      hook(sc);                                            // this step's share of the stage's memory requests
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n = 0; n < NTW; ++n)
+        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kx & 1][n], b[st % (D + 1)], acc[r][n], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
   auto multiply = [&](const unsigned char *A, int ky, const unsigned char *B) {
+    if constexpr (PIPE) {
+      multiply_pipe(A, ky, B, [](auto) {});
+      return;
+    }
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       h8 a[NTW];
@@ -412,6 +484,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_dma_kernel(const __half *
   // A counted wait (vmcnt(3): all but the youngest tile) measured the same, so the plain one stays.  s_barrier, not
   // __syncthreads(): its release fence would be placed by the compiler where it also stalls the fragment reads.
 #define DI_STAGE_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  __shared__ unsigned long long ts_lds[TS ? NWV * 16 : 1];
+  int tsi = 0;
+  bool ts_on = false;
+#define DI_TS()                                                                                                          \
+  do {                                                                                                                   \
+    if (TS && ts_on && lane == 0 && tsi < 16) ts_lds[wave * 16 + tsi++] = __builtin_readcyclecounter();                  \
+  } while (0)
   // prologue: halo chunk 0 and weight tiles 0, 1
   DI_FETCH_B(0);
   dma_a(0, lA0);
@@ -421,24 +500,72 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_dma_kernel(const __half *
   // one chunk = stages 3 ch .. 3 ch + 2 = weight buffers 0, 1, 2; halo buffers alternate per chunk (loop unrolled by 2)
   auto chunk = [&](int ch, unsigned char *Bcur, unsigned char *Bnext) {
     const int st = ch * 3;
+    ts_on = TS && blockIdx.x == 0 && ch == 3;
+    DI_TS();                                               // 0: start of the chunk
+    if constexpr (PIPE) {
+      // Measured with the phase timestamps of the TS build: issued in a burst at the start of a stage, the 4 halo loads + 3
+      // DMA pieces of every wave blocked the waves for 1 500 (waves 0-3) to 3 900 ticks (waves 4-7: the texture path takes
+      // the 56 KB of requests of the eight waves in order) before the first MFMA, and the early waves then waited as long at
+      // the barrier: a chunk of three stages took 11 800 ticks for 3 x 1 450 ticks of products.  Here every request is
+      // one step's hook: the eight waves send 8 KB at a time, under the MFMAs of the other steps.
+      constexpr int NS = 3 * RW;
+      const int c_next = (ch + 1 < nchunk ? ch + 1 : ch) * CK;
+      multiply_pipe(lA0, 0, Bcur, [&](auto sc) {           // ky = 0: next halo chunk (registers), weight tile st + 2
+        constexpr int q = decltype(sc)::value;
+        if constexpr (q < 2 * NLD && q % 2 == 0) fetch_one(q / 2, c_next);
+        if constexpr (q % 3 == 1 && q / 3 < NPIECE) dma_piece(st + 2, lA2, q / 3);
+      });
+      DI_TS();
+      DI_STAGE_BARRIER();
+      DI_TS();
+      multiply_pipe(lA1, 1, Bcur, [&](auto sc) {           // ky = 1: weight tile st + 3
+        constexpr int q = decltype(sc)::value;
+        if constexpr (q % 3 == 1 && q / 3 < NPIECE) dma_piece(st + 3, lA0, q / 3);
+      });
+      DI_TS();
+      DI_STAGE_BARRIER();
+      DI_TS();
+      multiply_pipe(lA2, 2, Bcur, [&](auto sc) {           // ky = 2: the halo registers go to the other buffer, weight tile st + 4
+        constexpr int q = decltype(sc)::value;
+        if constexpr (q < 2 * NLD && q % 2 == 0) commit_one(q / 2, Bnext);
+        if constexpr (q % 3 == 1 && q / 3 < NPIECE) dma_piece(st + 4, lA1, q / 3);
+      });
+      DI_TS();
+      DI_STAGE_BARRIER();
+      DI_TS();
+      static_assert(NS >= 9, "nine steps hold the requests of a stage");
+      return;
+    }
     // ky = 0: the next halo chunk starts its trip, then the weight tile two stages ahead
     DI_FETCH_B((ch + 1 < nchunk ? ch + 1 : ch) * CK);
     dma_a(st + 2, lA2);
     __builtin_amdgcn_sched_barrier(0);                     // the requests leave at the START of the stage
+    DI_TS();                                               // 1: requests issued
     multiply(lA0, 0, Bcur);
+    DI_TS();                                               // 2: products of ky = 0 issued
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DI_TS();                                               // 3: LDS idle
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DI_TS();                                               // 4: DMA / loads landed
     DI_STAGE_BARRIER();
+    DI_TS();                                               // 5: past the barrier
     // ky = 1
     dma_a(st + 3, lA0);
     __builtin_amdgcn_sched_barrier(0);
     multiply(lA1, 1, Bcur);
+    DI_TS();                                               // 6
     DI_STAGE_BARRIER();
+    DI_TS();                                               // 7
     // ky = 2: the halo of the next chunk goes to the other buffer (its last readers passed a barrier a chunk ago)
     DI_COMMIT_B(Bnext);                                    // first: the wait for the halo registers (loaded two stages
     __builtin_amdgcn_sched_barrier(0);                     // ago) must not cover the DMA issued next
+    DI_TS();                                               // 8: halo committed
     dma_a(st + 4, lA1);
     __builtin_amdgcn_sched_barrier(0);
     multiply(lA2, 2, Bcur);
+    DI_TS();                                               // 9
     DI_STAGE_BARRIER();
+    DI_TS();                                               // 10
   };
   for (int ch = 0; ch < nchunk; ch += 2) {
     chunk(ch, lB0, lB1);
@@ -448,6 +575,242 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv3x3_dma_kernel(const __half *
 #undef DI_COMMIT_B
 #undef DI_STAGE_BARRIER
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no DMA may outlive the workgroup's LDS
+  if (TS && blockIdx.x == 0) {
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long *dump = reinterpret_cast<unsigned long long *>(y);
+      for (int e = 0; e < NWV * 16; ++e) dump[e] = ts_lds[e];
+    }
+    return;
+  }
+
+  // epilogue (row permutation of the staged weights: a lane's fragment pair = 8 consecutive channels = one 16-B store)
+  const int xx = x0 + i;
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int yy = y0 + wm * RW + r;
+    if (yy >= H || xx >= W) continue;
+#pragma unroll
+    for (int p2 = 0; p2 < NTW / 2; ++p2) {
+      const int c0 = 32 * ((wn * NTW) / 2 + p2) + 8 * g;
+      h8 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v0 = acc[r][2 * p2][q] + bias[c0 + q], v1 = acc[r][2 * p2 + 1][q] + bias[c0 + 4 + q];
+        if (relu) {
+          v0 = fmaxf(v0, 0.f);
+          v1 = fmaxf(v1, 0.f);
+        }
+        o[q] = (_Float16)v0;
+        o[4 + q] = (_Float16)v1;
+      }
+      *reinterpret_cast<h8 *>(y + (((size_t)img * H + yy) * W + xx) * 128 + c0) = o;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Fourth kernel: PRODUCER / CONSUMER wavefronts.  What the phase timestamps of the kernel above showed
+// (tools/debug/conv_ts.py): a stage's 60 MFMAs per wave take 1 450 ticks, but every wave also issues the stage's memory
+// requests, and a wave is BLOCKED while the texture path accepts them - 600 ticks for its 3 weight DMA pieces (L2 hits,
+// ~40 B/clk per CU), 1 500 - 3 900 ticks in the stage that also loads the next halo chunk (first-touch lines from HBM /
+// Infinity Cache: ~10-15 B/clk per CU, the eight waves served in order) - and the early waves then wait as long at the
+// barrier: 11 800 ticks per chunk of three stages for 4 350 ticks of products.  Spreading the requests over the steps of the
+// stage did not help (the blocking moves, the total stays).
+// Here the eight MFMA wavefronts (consumers) never touch the vector-memory path: four more wavefronts (producers, one
+// per SIMD; 12 waves = 3 per SIMD at <= 168 VGPRs) issue everything as LDS-DMA - the weight tiles as before and ALSO the
+// input halo (1 KB pieces of 16 pixels x 64 B, the slot rotation of `lds_off` applied to the address each lane fetches,
+// pixels outside the map read a zero line) - and only they block.  One s_barrier per stage for all twelve waves.
+// Lessons of the bring-up (timestamps of the TS build, tools/debug/conv_ts.py): (i) a SPILLED consumer is a consumer on
+// the vector-memory path - four spilled registers reloaded in a stage's first steps queued behind the producers' requests
+// and made that stage 2.5x slower: the consumers keep ONE set of weight fragments (re-read right after their last MFMA of
+// a set) and compute the pixel-row addresses inside the loop (hoisted they cost 45 registers); (ii) staging the halo
+// through the producers' registers instead of LDS-DMA is slower (their LDS writes and the wait in front of them sit in
+// front of the chunk's last barrier: 128x180x180 16.7 -> 27.4 us); (iii) what is left: the two consumers of a SIMD
+// need ~1 900 ticks for a 12-row stage whose 72 MFMAs take 1 152 (address arithmetic and LDS waits between the MFMAs),
+// plus ~250 ticks of barrier per stage.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(64))) unsigned int cv_zero_line[16];
+
+template <int TH, bool TS = false>   // TS: measurement build, phase timestamps of workgroup 0 into y
+__global__ __launch_bounds__(768, 1) void conv3x3_pc_kernel(const __half *__restrict__ x, const __half *__restrict__ wst,
+                                                            const float *__restrict__ bias, __half *__restrict__ y, int H, int W,
+                                                            int Cin, int relu, int tiles_x, int tiles_y) {
+  constexpr int WM = 4, WN = 2, NTW = 4, RW = TH / WM, NPROD = 4;
+  static_assert(TH % WM == 0, "rows per wave");
+  constexpr int HP = (TH + 2) * (TW + 2);                  // halo pixels
+  constexpr int NPH = (HP + 15) / 16;                      // halo pieces of 1 KB (16 pixels x 64 B) per chunk
+  constexpr int KH = (NPH + NPROD - 1) / NPROD;            // ... per producer
+  constexpr int KH0 = (KH + 1) / 2;                        // issued in the ky = 0 stage (the rest in ky = 1)
+  constexpr int ASZ = 3 * 128 * 64;                        // weight tile of a stage: 24 KB = 24 DMA pieces
+  constexpr int WPP = 24 / NPROD;                          // weight pieces per producer and stage
+  __shared__ __align__(16) unsigned char lA0[ASZ], lA1[ASZ], lA2[ASZ];
+  __shared__ __align__(16) unsigned char lB0[NPH * 1024], lB1[NPH * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, img = t / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int nchunk = Cin / CK, nstage = nchunk * 3;
+  __shared__ unsigned long long ts_lds[TS ? 12 * 16 : 1];
+  int tsi = 0;
+  bool ts_on = false;
+#define DI_TS()                                                                                                          \
+  do {                                                                                                                   \
+    if (TS && ts_on && lane == 0 && tsi < 16) ts_lds[wave * 16 + tsi++] = __builtin_readcyclecounter();                  \
+  } while (0)
+  auto ts_dump = [&]() {
+    if (TS && blockIdx.x == 0) {
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long *dump = reinterpret_cast<unsigned long long *>(y);
+        for (int e = 0; e < 12 * 16; ++e) dump[e] = ts_lds[e];
+      }
+    }
+  };
+
+  if (wave >= 8) {
+    // ------------------------------------------------------------------ producer
+    const int pw = wave - 8;
+    const unsigned char *xi = reinterpret_cast<const unsigned char *>(x + (size_t)img * H * W * Cin);
+    const int pos = lane & 3;
+    const unsigned char *zsrc = reinterpret_cast<const unsigned char *>(cv_zero_line) + pos * 16;
+    // piece q = min(pw + 4 k, NPH - 1) (the clamp repeats the last piece: same data to the same place, uniform counts);
+    // lane l of a piece = pixel 16 q + l / 4, slot position l % 4 <- channel slot s4 with lds_off's rotation
+    long long hsrc[KH];                                    // byte offset of the lane's 16 B inside the image's map, -1 = zeros
+    int hq[KH];
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      const int q = min(pw + NPROD * k, NPH - 1);
+      const int P = q * 16 + (lane >> 2);
+      const int s4 = (pos - 2 * (P >> 2)) & 3;
+      const int hy = P / (TW + 2), hx = P - hy * (TW + 2);
+      const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+      const bool ok = P < HP && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      hsrc[k] = ok ? ((long long)(yy * W + xx) * Cin + s4 * 8) * 2 : -1;
+      hq[k] = q;
+    }
+    auto dma_w = [&](int st, unsigned char *buf) {
+      const int sc = st < nstage ? st : nstage - 1;        // past the end: a re-read (uniform counts)
+      const unsigned char *src = reinterpret_cast<const unsigned char *>(wst) + (size_t)sc * ASZ + lane * 16;
+#pragma unroll
+      for (int j = 0; j < WPP; ++j) {
+        const int c = pw * WPP + j;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + c * 1024), (lptr_t)(buf + c * 1024), 16, 0, 0);
+      }
+    };
+    auto dma_h = [&](int chunk, unsigned char *buf, int k_lo, int k_hi) {
+      const int c0 = (chunk < nchunk ? chunk : nchunk - 1) * CK * 2;
+#pragma unroll
+      for (int k = 0; k < KH; ++k)
+        if (k >= k_lo && k < k_hi) {
+          const unsigned char *p = hsrc[k] >= 0 ? xi + hsrc[k] + c0 : zsrc;
+          __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(buf + hq[k] * 1024), 16, 0, 0);
+        }
+    };
+#define DI_PROD_BARRIER(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory")
+    dma_h(0, lB0, 0, KH);
+    dma_w(0, lA0);
+    dma_w(1, lA1);
+    DI_PROD_BARRIER(0);
+    for (int ch = 0; ch < nchunk; ++ch) {
+      unsigned char *Bnext = (ch & 1) ? lB0 : lB1;
+      const int st = ch * 3;
+      // whatever a stage issues may still be in flight at its end; everything older has landed
+      ts_on = TS && blockIdx.x == 0 && ch == 3;
+      DI_TS();                                             // 0
+      dma_w(st + 2, lA2);
+      dma_h(ch + 1, Bnext, 0, KH0);
+      DI_TS();                                             // 1: ky0 requests issued
+      DI_PROD_BARRIER(WPP + KH0);
+      DI_TS();                                             // 3: barrier
+      dma_w(st + 3, lA0);
+      dma_h(ch + 1, Bnext, KH0, KH);
+      DI_TS();                                             // 4
+      DI_PROD_BARRIER(WPP + KH - KH0);
+      DI_TS();                                             // 5
+      dma_w(st + 4, lA1);
+      DI_TS();                                             // 6
+      DI_PROD_BARRIER(WPP);
+      DI_TS();                                             // 7
+    }
+#undef DI_PROD_BARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no DMA may outlive the workgroup's LDS
+    ts_dump();
+    return;
+  }
+
+  // ------------------------------------------------------------------ consumer
+  const int i = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  f4 acc[RW][NTW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[r][n] = f4{0.f, 0.f, 0.f, 0.f};
+  // one stage: every fragment read D steps ahead of its MFMAs (see conv3x3_dma_kernel's multiply_pipe)
+  auto multiply = [&](const unsigned char *A, int ky, const unsigned char *B) {
+    constexpr int NS = 3 * RW, D = 2;
+    h8 a[NTW], b[D + 1];
+    // (the 3 x 15 pixel-row addresses are loop invariant; hoisted out of the chunk loop they cost 45 registers and spill -
+    // scratch traffic in the waves that must stay off the vector-memory path.  An opaque zero keeps them inside.)
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    auto rd_a = [&](int kx, int n) {
+      return __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A + lds_off(kx * 128 + wn * NTW * 16 + n * 16 + i, g)));
+    };
+    auto rd_b = [&](int st) {
+      const int kx = st / RW, r = st - kx * RW;
+      return __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(B + lds_off((wm * RW + r + ky) * (TW + 2) + i + kx + z, g)));
+    };
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) a[n] = rd_a(0, n);
+#pragma unroll
+    for (int d = 0; d < D; ++d) b[d] = rd_b(d);
+    __builtin_amdgcn_sched_barrier(0);
+    // ONE set of weight fragments (a second set does not fit 168 registers without spilling): in the last row of a weight
+    // set every fragment is re-read for the next set right after its last MFMA has issued
+    static_for_cv<0, NS>([&](auto sc) {
+      constexpr int st = decltype(sc)::value, kx = st / RW, r = st % RW;
+      if constexpr (st + D < NS) b[(st + D) % (D + 1)] = rd_b(st + D);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for_cv<0, NTW>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[n], b[st % (D + 1)], acc[r][n], 0, 0, 0);
+        if constexpr (r == RW - 1 && kx + 1 < 3) {
+          a[n] = rd_a(kx + 1, n);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+#define DI_CONS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  DI_CONS_BARRIER();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const unsigned char *Bcur = (ch & 1) ? lB1 : lB0;
+    ts_on = TS && blockIdx.x == 0 && ch == 3;
+    DI_TS();                                               // 0
+    multiply(lA0, 0, Bcur);
+    DI_TS();                                               // 1: ky0 products issued
+    DI_CONS_BARRIER();
+    DI_TS();                                               // 3: barrier
+    multiply(lA1, 1, Bcur);
+    DI_TS();                                               // 4
+    DI_CONS_BARRIER();
+    DI_TS();                                               // 5
+    multiply(lA2, 2, Bcur);
+    DI_TS();                                               // 6
+    DI_CONS_BARRIER();
+    DI_TS();                                               // 7
+  }
+#undef DI_CONS_BARRIER
+  if (TS) {
+    ts_dump();
+    if (blockIdx.x == 0) return;
+  }
 
   // epilogue (row permutation of the staged weights: a lane's fragment pair = 8 consecutive channels = one 16-B store)
   const int xx = x0 + i;
@@ -517,15 +880,44 @@ extern "C" int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w
       // forward 90.4 us against 102.4 with 16, although 111.7 -> 109.0 on random maps).  DI_CONV_W16=0 / 1 forces one form.
       static const int w16_env = getenv("DI_CONV_W16") ? atoi(getenv("DI_CONV_W16")) : -1;
       const int w16 = w16_env >= 0 ? w16_env : (best != 20);
-#define DI_DMA(TH_, NWV_)                                                                                         \
-  hipLaunchKernelGGL((conv3x3_dma_kernel<TH_, NWV_>), dim3(tiles_x * ((H + TH_ - 1) / TH_) * n), dim3(NWV_ * 64), 0, s, \
+      // the producer / consumer kernel for the 12- and 20-row tiles (measured against conv3x3_dma_kernel on random maps: 6x256x112x200
+      // 111.4 -> 90.7 us, 512x180x180 51.4 -> 47.8, 128x180x180 18.4 -> 16.7; the benched forward 885 -> 905 samples/s);
+      // DI_CONV_PC=0 selects the older kernel for A/B runs
+      static const int pc = getenv("DI_CONV_PC") ? atoi(getenv("DI_CONV_PC")) : 1;
+      if (pc && (best == 12 || best == 20)) {
+#define DI_PC(TH_)                                                                                                  \
+  hipLaunchKernelGGL((conv3x3_pc_kernel<TH_>), dim3(tiles_x * ((H + TH_ - 1) / TH_) * n), dim3(768), 0, s,             \
+                     (const __half *)x, (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x,       \
+                     (H + TH_ - 1) / TH_)
+        static const int pcts = getenv("DI_CONV_TS") ? atoi(getenv("DI_CONV_TS")) : 0;
+        if (pcts && best == 12)
+          hipLaunchKernelGGL((conv3x3_pc_kernel<12, true>), dim3(tiles_x * ((H + 11) / 12) * n), dim3(768), 0, s, (const __half *)x,
+                             (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x, (H + 11) / 12);
+        else if (pcts && best == 20)
+          hipLaunchKernelGGL((conv3x3_pc_kernel<20, true>), dim3(tiles_x * ((H + 19) / 20) * n), dim3(768), 0, s, (const __half *)x,
+                             (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x, (H + 19) / 20);
+        else if (best == 12) DI_PC(12); else DI_PC(20);
+#undef DI_PC
+        return di::check_launch("conv3x3_fwd");
+      }
+      static const int ts = getenv("DI_CONV_TS") ? atoi(getenv("DI_CONV_TS")) : 0;   // measurement build (20-row tiles, 8 waves)
+      if (ts) {
+        hipLaunchKernelGGL((conv3x3_dma_kernel<20, 8, true, true>), dim3(tiles_x * ((H + 19) / 20) * n), dim3(512), 0, s,
+                           (const __half *)x, (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x, (H + 19) / 20);
+        return di::check_launch("conv3x3_fwd");
+      }
+      static const int pipe = getenv("DI_CONV_PIPE") ? atoi(getenv("DI_CONV_PIPE")) : 1;   // 0: compiler-scheduled stages (A/B)
+#define DI_DMA2(TH_, NWV_, P_)                                                                                    \
+  hipLaunchKernelGGL((conv3x3_dma_kernel<TH_, NWV_, P_>), dim3(tiles_x * ((H + TH_ - 1) / TH_) * n), dim3(NWV_ * 64), 0, s, \
                      (const __half *)x, (const __half *)w_staged, bias, (__half *)y, H, W, Cin, relu, tiles_x,     \
                      (H + TH_ - 1) / TH_)
+#define DI_DMA(TH_, NWV_) do { if (pipe) DI_DMA2(TH_, NWV_, true); else DI_DMA2(TH_, NWV_, false); } while (0)
       if (w16) {
         if (best == 12) DI_DMA(12, 16); else if (best == 16) DI_DMA(16, 16); else DI_DMA(20, 16);
       } else {
         if (best == 12) DI_DMA(12, 8); else if (best == 16) DI_DMA(16, 8); else DI_DMA(20, 8);
       }
+#undef DI_DMA2
 #undef DI_DMA
     } else if (H >= 8) {
       const int tiles_y = (H + 7) / 8;
