@@ -750,20 +750,27 @@ __global__ __launch_bounds__(768, 1) void conv3x3_pc_kernel(const __half *__rest
   for (int r = 0; r < RW; ++r)
 #pragma unroll
     for (int n = 0; n < NTW; ++n) acc[r][n] = f4{0.f, 0.f, 0.f, 0.f};
+  int brow[8];
+  {
+    const int q = wm * RW * (TW + 2) + i;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) brow[c] = q * 64 + (((g + 2 * ((((q & 7) + c) >> 2) & 1)) & 3) << 4);
+  }
   // one stage: every fragment read D steps ahead of its MFMAs (see conv3x3_dma_kernel's multiply_pipe)
   auto multiply = [&](const unsigned char *A, int ky, const unsigned char *B) {
     constexpr int NS = 3 * RW, D = 2;
     h8 a[NTW], b[D + 1];
-    // (the 3 x 15 pixel-row addresses are loop invariant; hoisted out of the chunk loop they cost 45 registers and spill -
-    // scratch traffic in the waves that must stay off the vector-memory path.  An opaque zero keeps them inside.)
-    int z = 0;
-    asm volatile("" : "+v"(z));
     auto rd_a = [&](int kx, int n) {
       return __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A + lds_off(kx * 128 + wn * NTW * 16 + n * 16 + i, g)));
     };
+    // pixel row of step (kx, r): pixel P = q + ct with q = wm RW 18 + i (this lane) and ct = (r + ky) 18 + kx (compile time);
+    // lds_off(P, g) = 64 q + rot + 64 ct, and the slot rotation only needs bit 2 of P = bit 2 of (q & 7) + (ct & 7): one of
+    // EIGHT per-lane addresses (brow[ct & 7], set up once) plus an immediate - no address arithmetic between the MFMAs
+    // (computed per read it was ~7 VALU instructions x 15 reads per stage; hoisted by the compiler, 45 registers and spills)
     auto rd_b = [&](int st) {
       const int kx = st / RW, r = st - kx * RW;
-      return __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(B + lds_off((wm * RW + r + ky) * (TW + 2) + i + kx + z, g)));
+      const int ct = (r + ky) * (TW + 2) + kx;
+      return __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(B + brow[ct & 7] + ct * 64));
     };
 #pragma unroll
     for (int n = 0; n < NTW; ++n) a[n] = rd_a(0, n);
