@@ -295,6 +295,247 @@ __global__ __launch_bounds__(NT, WPS) void local_attn_m3_kernel(
 }
 #undef DI_UNIT_BARRIER
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Fourth generation: PRODUCER / CONSUMER wavefronts (the lesson of the 3x3 convolution, conv3x3.hip: a wave that runs
+// MFMAs must not issue vector-memory requests - it is blocked while the texture path accepts them - and must not spill).
+// A workgroup = 4 consumer waves (the 8 x 8 tile: LDS reads, MFMAs, soft-max; their only memory instructions are the
+// output stores) + 2 producer waves that issue every LDS-DMA piece (8 of the 16 pieces of a unit each), three units ahead
+// through a ring of FOUR 16 KB buffers (the ring position is a run-time counter: 9 units per tile).  One s_barrier per unit
+// for the six waves: the producers arrive after a counted wait (unit U has landed, two younger units may be in flight), the
+// consumers after their LDS reads of unit U - 1, whose buffer the producers then refill with unit U + 3.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int NBUF4 = 4, NPROD4 = 2, NT4 = (WY + NPROD4) * 64;
+
+__global__ __launch_bounds__(NT4, 2) void local_attn_m4_kernel(
+    const __half *__restrict__ q, const __half *__restrict__ k, const __half *__restrict__ v,
+    __half *__restrict__ out, int n, int H, int W, float scale, int tiles_x, int tiles_y) {
+  __shared__ __align__(1024) unsigned char bufs[NBUF4 * UNITB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned lds0 = lds_addr_of(bufs);
+
+  // ---- tiles: XCD x owns the contiguous range [T*x/8, T*(x+1)/8) and walks it `gxw` tiles per round
+  const int per_img = tiles_x * tiles_y, ntiles = n * per_img;
+  const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+  const int gxw = ((int)gridDim.x - xcd + 7) >> 3;
+  const int t_end = (int)(((long long)ntiles * (xcd + 1)) >> 3);
+  int tile = (int)(((long long)ntiles * xcd) >> 3) + wl;
+  if (tile >= t_end) return;
+  TileCoord cur = decode_tile(tile, tiles_x, per_img);
+
+  if (wave >= WY) {
+    // ------------------------------------------------------------------ producer
+    const int pw = wave - WY;
+    const int d_hc = lane >> 2, d_pos = lane & 3;
+    const int d_c16 = (((d_pos >> 1) ^ ((d_hc >> 2) & 1)) << 1) | (d_pos & 1);
+    const int d_off = d_hc * 256 + d_c16 * 16;
+    const unsigned char *const zsrc = reinterpret_cast<const unsigned char *>(zero_line) + d_pos * 16;
+    // halo rows 8 pw .. 8 pw + 7 of a K / V unit (operand `src`, channels cu0 .. cu0 + 31) of tile t -> LDS byte `dst`
+    auto dma_halo = [&](const __half *__restrict__ src, const TileCoord &t, int cu0, unsigned dst) {
+      const long long tile_off = ((long long)(t.img * H + t.y0 - 4) * W + (t.x0 - 4)) * 256 + cu0 * 2;
+      const unsigned char *base = reinterpret_cast<const unsigned char *>(src) + tile_off;
+      const int gx = t.x0 - 4 + d_hc;
+      const bool x_ok = gx >= 0 && gx < W;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int hr = pw * 8 + r, gy = t.y0 - 4 + hr;
+        const bool ok = x_ok && gy >= 0 && gy < H;
+        const unsigned char *p = ok ? base + (long long)hr * W * 256 + d_off : zsrc;
+        dma16(p, __builtin_amdgcn_readfirstlane(dst + hr * ROWB));
+      }
+    };
+    // pieces 8 pw .. 8 pw + 7 of the Q unit: piece e = queries (row e / 2, columns 4 (e % 2) .. + 3)
+    auto dma_q = [&](const TileCoord &t, unsigned dst) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int e = pw * 8 + r;
+        const int tq = (e >> 1) * 8 + 4 * (e & 1) + (lane >> 4);
+        const int gy = min(t.y0 + (tq >> 3), H - 1), gx = min(t.x0 + (tq & 7), W - 1);
+        const unsigned char *p = reinterpret_cast<const unsigned char *>(q) + ((long long)((t.img * H + gy) * W + gx) << 8) +
+                                 (((lane & 15) ^ (tq & 15)) << 4);
+        dma16(p, __builtin_amdgcn_readfirstlane(dst + e * 1024));
+      }
+    };
+    auto dma_unit = [&](auto xc, const TileCoord &t, unsigned dst) {
+      constexpr int x = decltype(xc)::value;
+      if constexpr (x == 0) dma_q(t, dst);
+      else if constexpr (x <= NU) dma_halo(k, t, (x - 1) * CU, dst);
+      else dma_halo(v, t, (x - 1 - NU) * CU, dst);
+    };
+    // unit U has landed (the 16 pieces of the two younger units may be in flight), then the barrier of unit U
+#define DI_PROD_BARRIER() asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory")
+    int ring = 0;                                            // buffer of the unit whose barrier comes next
+    dma_unit(std::integral_constant<int, 0>{}, cur, lds0);
+    dma_unit(std::integral_constant<int, 1>{}, cur, lds0 + UNITB);
+    dma_unit(std::integral_constant<int, 2>{}, cur, lds0 + 2 * UNITB);
+    for (;;) {
+      // past the last tile the pipeline re-reads this tile's first units into free buffers (nobody reads them)
+      const bool has_next = tile + gxw < t_end;
+      TileCoord nxt = cur;
+      if (has_next) nxt = decode_tile(tile + gxw, tiles_x, per_img);
+      static_for<0, NUNIT>([&](auto xc) {
+        constexpr int x = decltype(xc)::value;
+        DI_PROD_BARRIER();                                   // unit x of this tile; buffer (ring - 1) & 3 is free now
+        const unsigned dst = lds0 + ((ring + NBUF4 - 1) & (NBUF4 - 1)) * UNITB;
+        if constexpr (x + NBUF4 - 1 < NUNIT) dma_unit(std::integral_constant<int, x + NBUF4 - 1>{}, cur, dst);
+        else dma_unit(std::integral_constant<int, x + NBUF4 - 1 - NUNIT>{}, nxt, dst);
+        ring = (ring + 1) & (NBUF4 - 1);
+      });
+      if (!has_next) break;
+      cur = nxt;
+      tile += gxw;
+    }
+#undef DI_PROD_BARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no DMA may outlive the workgroup's LDS
+    return;
+  }
+
+  // ------------------------------------------------------------------ consumer
+  const int wy = wave;
+  const int i = lane & 15, g = lane >> 4;
+  const int j = i & 7, qrow = i >> 3;
+  const int koff = wy * 2 * ROWB + i * S + swz(i, g);
+  const int kcv = 4 * g + (i >> 2);
+  const int vsw = (kcv >> 2) & 1;
+  const int vbase = wy * 2 * ROWB + kcv * S + (i & 3) * 8;
+  const float cs = scale * 1.44269504088896f;
+  f4 nm_mid, nm_first, nm_last;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool in_band = 4 * g + r >= j && 4 * g + r <= j + 8;
+    nm_mid[r] = in_band ? 0.f : -INFINITY;
+    nm_first[r] = (in_band && qrow == 0) ? 0.f : -INFINITY;
+    nm_last[r] = (in_band && qrow == 1) ? 0.f : -INFINITY;
+  }
+  h4 pend[2];
+  __half *pend_dst = nullptr;
+  bool pend_ok = false;
+  auto st_pend = [&]() {
+    if (pend_ok) {
+      *reinterpret_cast<h4 *>(pend_dst) = pend[0];
+      *reinterpret_cast<h4 *>(pend_dst + 16) = pend[1];
+    }
+  };
+#define DI_CONS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  int ring = 0;
+  for (;;) {
+    const bool has_next = tile + gxw < t_end;
+    // ---------------- unit 0: the Q^T fragments (query i, channels kk*32 + 8g .. +7)
+    h8 qf[4];
+    {
+      DI_CONS_BARRIER();
+      st_pend();                                             // the last V unit of the previous tile
+      const unsigned char *buf = bufs + ring * UNITB + ((2 * wy + qrow) * 8 + j) * 256;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        qf[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(buf + (((kk * 4 + g) ^ i) << 4)));
+      ring = (ring + 1) & (NBUF4 - 1);
+    }
+    // ---------------- S^T = K . Q^T over the K units
+    f4 s[10];
+#pragma unroll
+    for (int rr = 0; rr < 10; ++rr) s[rr] = f4{0.f, 0.f, 0.f, 0.f};
+    static_for<0, NU>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      DI_CONS_BARRIER();
+      const unsigned char *buf = bufs + ring * UNITB + koff;
+#pragma unroll
+      for (int rr = 0; rr < 10; ++rr) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(buf + rr * ROWB);
+        s[rr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, raw), qf[u], s[rr], 0, 0, 0);
+      }
+      ring = (ring + 1) & (NBUF4 - 1);
+    });
+    // ---------------- softmax over the 81 window slots of query i, in log2 units: y = s*cs + mask
+    h8 pf[5];
+    float sum;
+    {
+      float m = -INFINITY;
+#pragma unroll
+      for (int rr = 0; rr < 10; ++rr) {
+        const f4 nm = rr == 0 ? nm_first : (rr == 9 ? nm_last : nm_mid);
+        s[rr] = s[rr] * cs + nm;
+        m = fmaxf(m, fmaxf(fmaxf(s[rr][0], s[rr][1]), fmaxf(s[rr][2], s[rr][3])));
+      }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      f2 sum2 = {0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < 5; ++pr) {
+        h8 pk;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f4 d = s[2 * pr + t] - m;
+          f4 e;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(d[r]);   // masked slots: exp2(-inf) = 0
+          sum2 += f2{e[0], e[1]} + f2{e[2], e[3]};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[4 * t + r] = (_Float16)e[r];
+        }
+        pf[pr] = pk;
+      }
+      sum = sum2[0] + sum2[1];
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+    }
+    // ---------------- O^T = V^T . P^T over the V units, each unit finishes CU output channels
+    const float inv = 1.f / sum;
+    const int gy = cur.y0 + 2 * wy + qrow, gx = cur.x0 + j;
+    const bool pix_ok = gy < H && gx < W;
+    __half *dst = out + ((long long)(cur.img * H + gy) * W + gx) * 128 + 4 * g;
+    static_for<0, NU>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      DI_CONS_BARRIER();
+      if constexpr (u > 0) st_pend();                        // the previous V unit
+      const unsigned char *buf = bufs + ring * UNITB + vbase;
+      f4 acc[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int pr = 0; pr < 5; ++pr) {
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) {
+          const unsigned char *p0 = buf + ((nl ^ vsw) << 5) + 2 * pr * ROWB;
+          const hv4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(p0));
+          const hv4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(p0 + ROWB));
+          h8 a;
+          a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3];
+          a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+          acc[nl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[pr], acc[nl], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nl = 0; nl < 2; ++nl) {
+        const f4 o = acc[nl] * inv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pend[nl][r] = (_Float16)o[r];
+      }
+      pend_dst = dst + u * CU;
+      pend_ok = pix_ok;
+      ring = (ring + 1) & (NBUF4 - 1);
+    });
+    if (!has_next) break;
+    tile += gxw;
+    cur = decode_tile(tile, tiles_x, per_img);
+  }
+#undef DI_CONS_BARRIER
+  st_pend();                                                 // the last V unit of the last tile
+}
+
+static int launch_m4(const void *q, const void *k, const void *v, void *out, int n, int H, int W, float scale, hipStream_t stream) {
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const long long ntiles = (long long)n * tiles_x * tiles_y;
+  DI_REQUIRE((long long)n * H * W * 256 < (1ll << 31), "map of %d x %d x %d texels exceeds the 2 GiB offset range", n, H, W);
+  const int n_cu = device_cus();
+  if (n_cu <= 0) return DI_ERR_LAUNCH;
+  long long grid = (long long)n_cu * 2;
+  if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
+  static const int grid_env = getenv("DI_LA_GRID") ? atoi(getenv("DI_LA_GRID")) : 0;
+  if (grid_env > 0 && grid_env < grid) grid = grid_env / 8 * 8;
+  hipLaunchKernelGGL(local_attn_m4_kernel, dim3((unsigned)grid), dim3(NT4), 0, stream, (const __half *)q, (const __half *)k,
+                     (const __half *)v, (__half *)out, n, H, W, scale, tiles_x, tiles_y);
+  return check_launch("local_attn_m4");
+}
+
 template <int WPS>
 static int launch(const void *q, const void *k, const void *v, void *out, int n, int H, int W, float scale, hipStream_t stream) {
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
@@ -314,12 +555,14 @@ static int launch(const void *q, const void *k, const void *v, void *out, int n,
 
 }  // namespace m3
 
-// cfg 0: three workgroups per CU; 1: two (the second generation's occupancy, for A/B measurements)
+// cfg 0: three workgroups per CU; 1: two (the second generation's occupancy, for A/B measurements); 2: the producer /
+// consumer form (fourth generation)
 int launch_local_attn_mfma3(const void *q, const void *k, const void *v, void *out, int n, int H, int W, float scale,
                             int cfg, hipStream_t stream) {
   switch (cfg) {
     case 0: return m3::launch<3>(q, k, v, out, n, H, W, scale, stream);
     case 1: return m3::launch<2>(q, k, v, out, n, H, W, scale, stream);
+    case 2: return m3::launch_m4(q, k, v, out, n, H, W, scale, stream);      // producer / consumer waves
   }
   set_error("unknown local_attn_mfma3 configuration %d", cfg);
   return DI_ERR_ARG;

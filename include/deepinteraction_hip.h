@@ -69,7 +69,7 @@ int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, in
 enum { DI_LA_AUTO = 0, DI_LA_VALU = 1,
        DI_LA_MFMA = 3 /* + configuration: 3 = 16x8 tiles, 4 = 8x8 tiles, 5 = 16x4 tiles, 6 = 8x16 tiles, 7 = timestamps */,
        DI_LA_DMA = 16 /* local_attn_mfma3.hip (halo and queries by LDS-DMA, 16 KB units): + 0 / 1 = three / two
-                         workgroups per CU */ };
+                         workgroups per CU, + 2 = producer / consumer wavefronts */ };
 int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                          int C, int kH, int kW, float scale, int dtype, int variant, void *stream);
 

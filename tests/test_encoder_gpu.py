@@ -49,7 +49,7 @@ _VARIANT_CASES = {}
 
 
 @pytest.mark.parametrize('variant', [ops.LA_AUTO, ops.LA_VALU, ops.LA_MFMA, ops.LA_MFMA + 1, ops.LA_MFMA + 2, ops.LA_MFMA + 3,
-                                     ops.LA_DMA, ops.LA_DMA + 1])
+                                     ops.LA_DMA, ops.LA_DMA + 1, ops.LA_DMA + 2])
 @pytest.mark.parametrize('shape', [(2, 13, 37), (1, 4, 16), (3, 9, 200), (1, 180, 180), (1, 1, 5), (6, 112, 200)])
 def test_local_attention_fp16_kernel_variants(variant, shape):
     """Both fp16 kernels of the fused op (LDS-tiled VALU; banded 16x16x32 MFMA) against the

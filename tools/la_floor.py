@@ -32,5 +32,5 @@ timed('addcmul (3 reads + 1 write, element-wise)', lambda i: torch.addcmul(sets[
 timed('copy_ (1 read + 1 write)', lambda i: outs[i].copy_(sets[i][0]), byt // 2)
 timed('add (2 reads + 1 write)', lambda i: torch.add(sets[i][0], sets[i][1], out=outs[i]), byt * 3 // 4)
 for var, name in ((4, 'window attention, 2nd generation, 8x8 tiles, 2 workgroups per CU'), (16, 'LDS-DMA generation, 3 workgroups per CU'),
-                  (17, 'LDS-DMA generation, 2 workgroups per CU')):
+                  (17, 'LDS-DMA generation, 2 workgroups per CU'), (18, 'producer / consumer generation, 2 workgroups per CU')):
     timed(name, lambda i, var=var: ops.local_attention(*sets[i], 9, 9, 1 / math.sqrt(C), variant=var))
