@@ -387,36 +387,50 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
   for (int j = 0; j < NG; ++j) {
     const int grp = wg + j * stride;
     pix[j] = grp < ngroups ? grp * 16 + i : Mi;                // M: "no pixel" (never stored)
-    const int pc = pix[j] < Mi ? pix[j] : Mi - 1;
-    if constexpr (WARP) {
-      const WarpGeom G = load_warp_geom(Wp.depth, Wp.img2lidar, Wp.aug, Wp.xs, Wp.ys, Wp.pc_range, Wp.Hi, Wp.Wi, Wp.Hb, Wp.Wb);
-      float ix, iy;
-      const bool lift = warp_position(G, pc, ix, iy);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = 0.f;
-        if (lift) bilinear8(Wp.bev, Wp.Hb, Wp.Wb, 128, ix, iy, kk * 32 + g * 8, o);
-        xb[j][kk] = __builtin_bit_cast(h8, pack8f(o, __half()));
-      }
-    } else {
+    if constexpr (!WARP) {
+      const int pc = pix[j] < Mi ? pix[j] : Mi - 1;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
         xb[j][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(x + (size_t)pc * 128 + kk * 32 + g * 8));
     }
   }
+  // WARP (at most two chains: the host checks): BOTH weight images are resident in the two LDS buffers, so the groups go
+  // through the chains one PAIR at a time and a pair is gathered right before its products - only 2 x 16 operand registers
+  // are live beside the 64 of a group's 16 corner rows, which therefore leave together, without a branch between them
+  // (bilinear8_nb).  Gathered up front for all five groups (80 operand registers) the rows were fetched one load -> blend
+  // round trip at a time: 17 us of the launch with the matrix pipe idle.
+  auto gather = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int pc = pix[j] < Mi ? pix[j] : Mi - 1;
+    const WarpGeom G = load_warp_geom(Wp.depth, Wp.img2lidar, Wp.aug, Wp.xs, Wp.ys, Wp.pc_range, Wp.Hi, Wp.Wi, Wp.Hb, Wp.Wb);
+    float ix, iy;
+    const bool lift = warp_position(G, pc, ix, iy);
+    const Bilin4 bl = bilinear_setup(Wp.Hb, Wp.Wb, ix, iy, lift);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      float o[8];
+      bilinear8_nb(Wp.bev, 128, bl, kk * 32 + g * 8, o);
+      xb[j][kk] = __builtin_bit_cast(h8, pack8f(o, __half()));
+    }
+  };
+  if constexpr (WARP) {
+    if (A.n > 1) dma_chain(A.c[1], lds + kChainImage);
+  }
 
-  for (int c = 0; c < A.n; ++c) {
+  // chain c on the pair(s) of groups `only` (-1: all of them)
+  auto run_chain = [&](int c, auto onlyc) {
+    constexpr int only = decltype(onlyc)::value;
     const Chain ch = A.c[c];
     const bool two = ch.two != 0;
     unsigned char *buf = lds + (c & 1) * kChainImage;
     const unsigned char *lw1 = buf, *lw2 = buf + 128 * 128 * 2;
     const float *lb = reinterpret_cast<const float *>(buf + 2 * 128 * 128 * 2);
-    // chain c's image has landed (issued a whole chain ago), and everybody is done with the other buffer
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (c + 1 < A.n) dma_chain(A.c[c + 1], lds + ((c + 1) & 1) * kChainImage);
+    if constexpr (!WARP) {
+      // chain c's image has landed (issued a whole chain ago), and everybody is done with the other buffer
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (c + 1 < A.n) dma_chain(A.c[c + 1], lds + ((c + 1) & 1) * kChainImage);
+    }
 
     // one step = the chain on NP (2, or 1 for the odd last one) pixel groups of this wave, sharing every weight fragment
     // ReLU as a floor (0 or -inf): no branch inside the MFMA loops
@@ -531,15 +545,31 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
     // conditions are wave-uniform and there is no barrier inside a step.
     static_for<0, (NG + 1) / 2>([&](auto S) {
       constexpr int j0 = 2 * decltype(S)::value;
-      if (wg + j0 * stride < ngroups) {
-        if constexpr (j0 + 1 < NG) {
-          if (wg + (j0 + 1) * stride < ngroups) step(std::integral_constant<int, j0>{}, std::integral_constant<int, 2>{});
-          else step(std::integral_constant<int, j0>{}, std::integral_constant<int, 1>{});
-        } else {
-          step(std::integral_constant<int, j0>{}, std::integral_constant<int, 1>{});
+      if constexpr (only < 0 || only == decltype(S)::value) {
+        if (wg + j0 * stride < ngroups) {
+          if constexpr (j0 + 1 < NG) {
+            if (wg + (j0 + 1) * stride < ngroups) step(std::integral_constant<int, j0>{}, std::integral_constant<int, 2>{});
+            else step(std::integral_constant<int, j0>{}, std::integral_constant<int, 1>{});
+          } else {
+            step(std::integral_constant<int, j0>{}, std::integral_constant<int, 1>{});
+          }
         }
       }
     });
+  };
+  if constexpr (WARP) {
+    static_for<0, (NG + 1) / 2>([&](auto S) {
+      constexpr int j0 = 2 * decltype(S)::value;
+      gather(std::integral_constant<int, j0>{});
+      if constexpr (j0 + 1 < NG) gather(std::integral_constant<int, j0 + 1>{});
+      if constexpr (j0 == 0) {                               // both images have landed (every wave's pieces)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      for (int c = 0; c < A.n; ++c) run_chain(c, S);
+    });
+  } else {
+    for (int c = 0; c < A.n; ++c) run_chain(c, std::integral_constant<int, -1>{});
   }
 }
 
@@ -796,6 +826,7 @@ extern "C" int di_pointwise_multi_warp_fwd(const void *bev, const float *depth, 
   const long long n_pixels = (long long)n_views * Hi * Wi;
   DI_REQUIRE(n_views > 0 && Hi > 0 && Wi > 0 && Hb > 0 && Wb > 0 && n_pixels < (1ll << 24), "bad gather shape");
   DI_REQUIRE(bev && depth && img2lidar && aug_fwd && xs && ys && pc_range, "null geometry");
+  DI_REQUIRE(n_chains <= 2, "the gathered form keeps both weight images resident: at most 2 chains, got %d", n_chains);
   MultiArgs A;
   long long grid;
   int ng;

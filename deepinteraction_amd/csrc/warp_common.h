@@ -59,6 +59,52 @@ __device__ __forceinline__ void bilinear8(const T *__restrict__ map, int Hm, int
   }
 }
 
+// The same sample with every load UNCONDITIONAL (corner addresses clamped into the map, the weights of corners outside it -
+// and of a masked pixel, `live` false - set to zero): no branch between the loads, so the 4 x 4 corner rows of a pixel group
+// fly together.  Adding w * f with w = +0 leaves the running sum bit for bit, and the order of the four terms is bilinear8's:
+// identical results.
+struct Bilin4 {
+  int o00, o01, o10, o11;        // texel indices (y * Wm + x) of the four corners, clamped
+  float w00, w01, w10, w11;
+};
+__device__ __forceinline__ Bilin4 bilinear_setup(int Hm, int Wm, float ix, float iy, bool live) {
+  const float fx = floorf(ix), fy = floorf(iy);
+  const float ax = ix - fx, ay = iy - fy;
+  // a masked pixel may carry any coordinates (inf / nan): keep the integer conversions defined
+  const int x0 = live ? (int)fminf(fmaxf(fx, -2.f), (float)Wm + 1.f) : 0, y0 = live ? (int)fminf(fmaxf(fy, -2.f), (float)Hm + 1.f) : 0;
+  const bool xl = live && x0 >= 0 && x0 < Wm, xh = live && x0 + 1 >= 0 && x0 + 1 < Wm;
+  const bool yl = y0 >= 0 && y0 < Hm, yh = y0 + 1 >= 0 && y0 + 1 < Hm;
+  const int cx0 = min(max(x0, 0), Wm - 1), cx1 = min(max(x0 + 1, 0), Wm - 1);
+  const int cy0 = min(max(y0, 0), Hm - 1), cy1 = min(max(y0 + 1, 0), Hm - 1);
+  Bilin4 b;
+  b.o00 = cy0 * Wm + cx0; b.o01 = cy0 * Wm + cx1; b.o10 = cy1 * Wm + cx0; b.o11 = cy1 * Wm + cx1;
+  b.w00 = (yl && xl) ? (1.f - ax) * (1.f - ay) : 0.f;
+  b.w01 = (yl && xh) ? ax * (1.f - ay) : 0.f;
+  b.w10 = (yh && xl) ? (1.f - ax) * ay : 0.f;
+  b.w11 = (yh && xh) ? ax * ay : 0.f;
+  return b;
+}
+template <typename T>
+__device__ __forceinline__ void bilinear8_nb(const T *__restrict__ map, int C, const Bilin4 &b, int ch0, float (&o)[8]) {
+  const Pack8<T> p00 = ld8(map + (size_t)b.o00 * C + ch0), p01 = ld8(map + (size_t)b.o01 * C + ch0);
+  const Pack8<T> p10 = ld8(map + (size_t)b.o10 * C + ch0), p11 = ld8(map + (size_t)b.o11 * C + ch0);
+  float f[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = 0.f;
+  unpack8(p00, f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = fmaf(b.w00, f[i], o[i]);
+  unpack8(p01, f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = fmaf(b.w01, f[i], o[i]);
+  unpack8(p10, f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = fmaf(b.w10, f[i], o[i]);
+  unpack8(p11, f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = fmaf(b.w11, f[i], o[i]);
+}
+
 // Where feature pixel `pix` = (view v, row yy, column xx) of the (V, Hi, Wi) image maps samples the BEV map: un-project through
 // the completed depth, re-apply the augmentation, strict range test, normalised grid -> texel coordinates
 // (encoder_utils.py:185-196).  False: the pixel lifts outside the point-cloud range and reads zeros.
