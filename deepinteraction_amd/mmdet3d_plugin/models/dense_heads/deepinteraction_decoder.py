@@ -344,6 +344,8 @@ class DeepInteractionDecoder(nn.Module):
                 coor_y = (gt[idx][1] - pc_range[1]) / voxel_size[1] / tc['out_size_factor']
                 center_int = torch.tensor([coor_x, coor_y], dtype=torch.float32).to(torch.int32)
                 draw_heatmap_gaussian_host(heatmap[int(gt_labels_host[idx])], center_int, radius)
+        if getattr(self, '_heatmap_peaks', None) is None:                # (get_targets_single called on its own)
+            self._heatmap_peaks = {}
         self._heatmap_peaks[batch_idx] = int((heatmap == 1).sum())       # `loss` normalises by it: known on the host
         heatmap = torch.from_numpy(heatmap).to(dev)
         mean_iou = ious[pos_inds].sum() / max(len(pos_inds), 1)
