@@ -404,14 +404,15 @@ def bevwarp_gather(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range):
 
 def warp_project(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range, chains):
     """`pointwise_multi(bevwarp_gather(bev, depth, ...), chains)` in one launch: the warped map is gathered into the
-    projection kernel's registers and never written (bit-identical outputs).  bev (1,128,Hb,Wb) fp16 channels-last."""
+    projection kernel's registers and never written (bit-identical outputs).  At most two chains (the P2I block's key / value
+    projections): both weight images stay resident in LDS.  bev (1,128,Hb,Wb) fp16 channels-last."""
     _dev(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range)
     bev = cl(bev)
     _, C, Hb, Wb = bev.shape
     V, Hi, Wi = depth.shape
     assert C == 128 and bev.dtype == torch.float16 and depth.dtype == torch.float32 and depth.is_contiguous()
     nc = len(chains)
-    assert 1 <= nc <= 4
+    assert 1 <= nc <= 2, 'both weight images stay resident in LDS: at most two chains'
     ys_ = [empty_cl(V, 128, Hi, Wi, bev) for _ in chains]
     P, I = ctypes.c_void_p * nc, ctypes.c_int * nc
     for (im, r1, r2, two) in chains:

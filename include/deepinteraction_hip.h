@@ -337,7 +337,8 @@ int di_pointwise_multi_fwd(const void *x, int n_chains, const void *const *image
  * value projections of its LocalContextAttentionBlock, :127-131) without the warped map in memory: input pixel p of the
  * (n_views, Hi, Wi) maps is the bilinear sample of bev (Hb, Wb, 128) fp16 where the pixel's completed depth un-projects to -
  * the arithmetic and fp16 rounding of di_bevwarp_gather_fwd (whose arguments these are), so the outputs equal
- * di_pointwise_multi_fwd on that kernel's output bit for bit. */
+ * di_pointwise_multi_fwd on that kernel's output bit for bit.  n_chains <= 2: both weight images stay resident in LDS and
+ * the pixel groups go through the chains a pair at a time. */
 int di_pointwise_multi_warp_fwd(const void *bev, const float *depth, const float *img2lidar, const float *aug_fwd,
                                 const float *xs, const float *ys, const float *pc_range, int n_views, int Hi, int Wi, int Hb,
                                 int Wb, int n_chains, const void *const *image_host, void *const *y_host,
