@@ -7,8 +7,8 @@ the data, a `torch.cat` over the batch).  A captured hipGraph wants fixed shapes
 sample (rows beyond a sample's pillar count are zero with `num_points = 0`, which every consumer skips), so the batch
 split is known on the host (`pillar_batch_bounds`) and nothing depends on a device-side count.
 
-Out of scope here: the frozen backbones (`pts_voxel_layer` / `pts_middle_encoder` / `pts_backbone`, the image
-backbone + FPN) - their outputs `img_feats` / `pts_feats` are inputs of the hot path."""
+Out of scope here: the frozen LiDAR backbone (`pts_voxel_layer` / `pts_middle_encoder` / `pts_backbone`) - its
+output `pts_feats` is an input of the hot path.  The image side (`extract_img_feat`) is `image_glue.py`."""
 import torch
 from torch import nn
 

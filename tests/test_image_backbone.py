@@ -1,0 +1,128 @@
+"""The frozen image feature extractor in front of the hot path (`FrozenResNetFPN` / `ImageGlue`) against the oracle's
+unfused restatement of mmdet's ResNet-50 + FPN (`oracle/image_backbone.py`; parity unpinned - mmdet is not importable
+here, the anchor is the checkpoint key layout)."""
+import pytest
+import torch
+
+from deepinteraction_amd.mmdet3d_plugin import FrozenResNetFPN, ImageGlue
+from oracle import image_backbone as ob
+
+
+@pytest.fixture(scope='module')
+def nets():
+    torch.manual_seed(0)
+    return ob.randomize(ob.ResNet(50), 1).eval(), ob.randomize(ob.FPN(), 2).eval()
+
+
+def test_checkpoint_key_layout(nets):
+    backbone, neck = nets
+    sd = backbone.state_dict()
+    assert len(sd) == 318                       # torchvision resnet50: 320 entries, minus fc.weight / fc.bias
+    for k in ('conv1.weight', 'bn1.running_var', 'layer1.0.downsample.0.weight', 'layer1.0.downsample.1.running_mean',
+              'layer3.5.conv3.weight', 'layer4.2.bn3.num_batches_tracked'):
+        assert k in sd, k
+    assert 'layer1.1.downsample.0.weight' not in sd
+    assert sd['layer2.0.conv2.weight'].shape == (128, 128, 3, 3)
+    assert sd['layer4.0.downsample.0.weight'].shape == (2048, 1024, 1, 1)
+    nd = neck.state_dict()
+    assert sorted(nd) == sorted(f'{kind}.{i}.conv.{p}' for kind in ('lateral_convs', 'fpn_convs') for i in range(4)
+                                for p in ('weight', 'bias'))
+
+
+@pytest.mark.parametrize('levels', [None, (0,), (0, 1), (2, 4)])
+def test_folded_network_equals_unfused_oracle(nets, levels):
+    backbone, neck = nets
+    net = FrozenResNetFPN(levels=levels, dtype=torch.float32).load_mmdet_state(backbone.state_dict(), neck.state_dict())
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(2, 3, 96, 160, generator=g)
+    with torch.no_grad():
+        want = neck(backbone(img))
+    got = net(img)
+    idx = range(5) if levels is None else levels
+    assert len(got) == len(idx)
+    for o, l in zip(got, idx):
+        w = want[l]
+        assert o.shape == w.shape
+        assert o.is_contiguous(memory_format=torch.channels_last) or o.shape[-1] == 1 or o.shape[-2] == 1
+        scale = float(w.abs().max())
+        assert float((o - w).abs().max()) <= 2e-5 * max(scale, 1.0), (l, float((o - w).abs().max()), scale)
+
+
+def test_pruned_levels_skip_unused_convolutions(nets, monkeypatch):
+    backbone, neck = nets
+    net = FrozenResNetFPN(levels=(0,), dtype=torch.float32).load_mmdet_state(backbone.state_dict(), neck.state_dict())
+    seen = []
+    orig = net._conv
+    monkeypatch.setattr(net, '_conv', lambda x, name, *a, **k: (seen.append(name), orig(x, name, *a, **k))[1])
+    net(torch.zeros(1, 3, 64, 64))
+    assert [n for n in seen if n.startswith('fpn_convs')] == ['fpn_convs.0']
+    assert [n for n in seen if n.startswith('lateral')] == [f'lateral_convs.{i}' for i in range(4)]
+    assert len([n for n in seen if n.startswith(('conv1', 'layer'))]) == 53
+
+
+def test_fp16_channels_last_form(nets):
+    backbone, neck = nets
+    net = FrozenResNetFPN(levels=(0,)).load_mmdet_state(backbone.state_dict(), neck.state_dict())
+    w, b = net._get('layer2.0.conv2')
+    assert w.dtype == torch.float16 and w.is_contiguous(memory_format=torch.channels_last) and b.dtype == torch.float16
+    assert not net.state_dict()                 # derived buffers: the checkpoint stays the mmdet one
+
+
+def test_loading_fails_loudly(nets):
+    backbone, neck = nets
+    sd = dict(backbone.state_dict())
+    del sd['layer3.2.bn2.running_var']
+    with pytest.raises(KeyError, match='layer3.2.bn2.running_var'):
+        FrozenResNetFPN().load_mmdet_state(sd, neck.state_dict())
+    nd = dict(neck.state_dict())
+    nd['fpn_convs.1.conv.weight'] = nd['fpn_convs.1.conv.weight'][:, :128]
+    with pytest.raises(ValueError, match='fpn_convs.1.conv.weight'):
+        FrozenResNetFPN().load_mmdet_state(backbone.state_dict(), nd)
+    with pytest.raises(RuntimeError, match='no weights'):
+        FrozenResNetFPN()(torch.zeros(1, 3, 32, 32))
+
+
+def test_image_glue_mirrors_extract_img_feat(nets):
+    backbone, neck = nets
+    net = FrozenResNetFPN(levels=(0,), dtype=torch.float32).load_mmdet_state(backbone.state_dict(), neck.state_dict())
+    glue = ImageGlue(net)
+    metas = [dict(), dict()]
+    img = torch.randn(2, 3, 3, 64, 96, generator=torch.Generator().manual_seed(5))
+    (lvl0,) = glue(img, metas)
+    assert lvl0.shape == (6, 256, 16, 24)
+    assert all(m['input_shape'] == (64, 96) for m in metas)
+    (flat,) = glue(img.view(6, 3, 64, 96), [dict()])
+    assert torch.equal(flat, lvl0)
+    assert glue(None, metas) is None
+
+
+def test_synthetic_state_has_the_checkpoint_layout(nets):
+    backbone, neck = nets
+    net = FrozenResNetFPN(levels=(0,), dtype=torch.float32)
+    bb, nk = net.synthetic_state(seed=4)
+    ref = {k: v for k, v in backbone.state_dict().items() if not k.endswith('num_batches_tracked')}
+    assert sorted(bb) == sorted(ref) and all(bb[k].shape == ref[k].shape for k in bb)
+    assert sorted(nk) == sorted(neck.state_dict())
+    (out,) = net.load_mmdet_state(bb, nk)(torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(6)))
+    assert torch.isfinite(out).all() and 1e-3 < float(out.abs().max()) < 1e3       # fp16-safe magnitudes
+
+
+@pytest.mark.gpu
+def test_fp16_channels_last_on_the_device_against_the_oracle():
+    """fp16 storage and MIOpen's fp16 convolutions against the fp32 oracle on the host; 53 folded layers deep, so the
+    bound is a fraction of the map's magnitude rather than the 1e-3 of the hot path's own contract."""
+    net = FrozenResNetFPN(levels=(0, 1))
+    bb, nk = net.synthetic_state(seed=8)            # activations of O(1): the `nets` fixture's grow past fp16's range
+    backbone, neck = ob.ResNet(50), ob.FPN()
+    assert not backbone.load_state_dict(bb, strict=False).unexpected_keys and not neck.load_state_dict(nk).missing_keys
+    net.load_mmdet_state(bb, nk).cuda()
+    img = torch.randn(2, 3, 128, 160, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        want = neck(backbone(img))
+    got = net(img.cuda())
+    torch.cuda.synchronize()
+    for o, l in zip(got, (0, 1)):
+        assert o.dtype == torch.float16 and o.is_contiguous(memory_format=torch.channels_last)
+        assert torch.isfinite(o).all()
+        err = float((o.float().cpu() - want[l]).abs().max())
+        assert err <= 3e-2 * float(want[l].abs().max()), (l, err)
