@@ -57,6 +57,9 @@ def parse():
                          'on its own stream (a step = N x batch samples; 2 = the reference\'s samples_per_gpu, '
                          'Fusion_0075_refactor.py:94); 1 = one sample at a time (the latency figure, also reported as '
                          '`single_sample` in the default line)')
+    ap.add_argument('--from-images', action='store_true',
+                    help='forward mode: the captured forward starts from the six camera images - the frozen ResNet-50 + FPN '
+                         'stand-in (FrozenResNetFPN, torch / MIOpen, random init) runs inside every replay')
     ap.add_argument('--from-points', action='store_true',
                     help='start every step from the raw points: the pillars of pts_metas are rebuilt by the voxeliser inside '
                          'the captured forward (detector glue, detectors/deepinteraction.py:120-171) instead of being loaded')
@@ -245,6 +248,19 @@ def bench_forward(args, rank, world, device):
     dev_pool = [harness.to_device(inp, device, dtype) for inp in host_pool]
     n_pillars = [int(d['pts_metas']['pillars'].shape[0]) for d in dev_pool]
 
+    image_net = None
+    if args.from_images:
+        assert not args.eager and not args.from_raw, '--from-images is a graph mode of its own'
+        from deepinteraction_amd.mmdet3d_plugin import FrozenResNetFPN
+        image_net = FrozenResNetFPN(out_channels=shape['c_img'], levels=(0,), dtype=dtype)
+        image_net.load_mmdet_state(*image_net.synthetic_state(0)).to(device)
+        H, W = shape['input_shape']
+        for i, (h, d) in enumerate(zip(host_pool, dev_pool)):   # the maps every other leg of this run sees are the net's own
+            cams = torch.randn(6 * args.batch, 3, H, W, generator=torch.Generator().manual_seed(1000 + i))
+            d['images'] = cams.to(device, dtype).contiguous(memory_format=torch.channels_last)
+            d['img_feats'] = image_net(d['images'])[0]
+            h['img_feats'] = d['img_feats'].float().cpu()
+
     with torch.no_grad():
         if args.eager:
             it = [0]
@@ -264,7 +280,7 @@ def bench_forward(args, rank, world, device):
                 rng = list(synth.PC_RANGE)
                 glue = PointGlue(dict(max_num_points=20, max_voxels=(30000, 60000), point_cloud_range=rng,
                                       voxel_size=[(rng[3] - rng[0]) / Wb, (rng[4] - rng[1]) / Hb, rng[5] - rng[2]])).eval()
-            graphs = [GraphedHotPath(enc, dec, dev_pool[cap], glue=glue) for _ in range(max(1, args.inflight))]
+            graphs = [GraphedHotPath(enc, dec, dev_pool[cap], glue=glue, image_net=image_net) for _ in range(max(1, args.inflight))]
             g = graphs[-1]                                  # (the modules' output attributes point at the last capture)
             records = [g.prepare(d) for d in dev_pool]
             lanes = [torch.cuda.Stream() for _ in graphs] if len(graphs) > 1 else [None]
@@ -373,10 +389,11 @@ def bench_forward(args, rank, world, device):
     out = _line(args, 'samples/sec forward (Fusion_0075 synthetic)',
                 parallel.throughput(args.batch * max(1, args.inflight), args.steps, elapsed, world), elapsed,
                 'f16' if dtype == torch.float16 else 'f32',
+                ('frozen ResNet-50 + FPN image network (torch / MIOpen) + ' if args.from_images else '') +
                 'Full MMRI encoder (2 layers) + MMPI decoder forward, '
                 f'Fusion_0075_refactor shapes (shape {args.shape}), random-init weights',
                 dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(dev_pool), inflight=max(1, args.inflight),
-                     from_points=bool(args.from_points), from_raw=bool(args.from_raw),
+                     from_points=bool(args.from_points), from_raw=bool(args.from_raw), from_images=bool(args.from_images),
                      launch='eager' if args.eager else 'per step and sample in flight: load() of the next pool sample into the '
                                                        'captured buffers + hipGraph replay of the captured forward',
                      graph_nodes=None if g is None else g.num_nodes()))

@@ -31,17 +31,27 @@ from .mmdet3d_plugin.models.utils.encoder_utils import GEOM_KEY
 
 
 class GraphedHotPath:
-    def __init__(self, encoder, decoder, inputs, warmup=3, glue=None):
-        """glue: a `PointGlue` (mmdet3d_plugin/models/detectors) - the captured forward then STARTS FROM THE POINTS:
+    def __init__(self, encoder, decoder, inputs, warmup=3, glue=None, image_net=None):
+        """image_net: a `FrozenResNetFPN` (mmdet3d_plugin/models/detectors/image_glue.py) - the captured forward then STARTS
+        FROM THE CAMERA IMAGES: `inputs['images']` ((B*N, 3, H, W), the network's dtype) takes the place of
+        `inputs['img_feats']` as the static input of the image slot (`self.img_feats` holds the images), and the feature
+        levels the neck reads are produced inside every replay.
+        glue: a `PointGlue` (mmdet3d_plugin/models/detectors) - the captured forward then STARTS FROM THE POINTS:
         the pillars / coordinates / counts of `pts_metas` are rebuilt by the voxeliser inside every replay (capacity-sized
         buffers, no host synchronisation) instead of being copied in by `load()`."""
         assert not encoder.training and not decoder.training, 'graph capture is for the inference form'
         self.enc, self.dec = encoder, decoder
         self.glue = glue
-        # one map per modality (v1 neck) or a list of levels (DeepInteraction++ neck)
-        self.img_feats = self._clone(inputs['img_feats'])
+        self.image_net = image_net
+        self._img_key = 'images' if image_net is not None else 'img_feats'
+        # one map per modality (v1 neck) or a list of levels (DeepInteraction++ neck); the camera images with `image_net`
+        self.img_feats = self._clone(inputs[self._img_key])
         self.pts_feats = self._clone(inputs['pts_feats'])
-        first_img = self.img_feats[0] if isinstance(self.img_feats, list) else self.img_feats
+        if image_net is not None:
+            with torch.no_grad():
+                first_img = image_net(self.img_feats)[0]
+        else:
+            first_img = self.img_feats[0] if isinstance(self.img_feats, list) else self.img_feats
         dev = first_img.device
         pm = inputs['pts_metas']
         self.batch = len(inputs['img_metas'])
@@ -129,7 +139,11 @@ class GraphedHotPath:
             g.forget()
         self.dec.static_geometry = self.query_geom
         try:
-            img, pts = self.enc(self.img_feats, self.pts_feats, self.img_metas, self._pts_metas())
+            img_in = self.img_feats
+            if self.image_net is not None:      # frozen image network inside the (captured) forward
+                levels = self.image_net(img_in)
+                img_in = levels[0] if len(levels) == 1 else list(levels)
+            img, pts = self.enc(img_in, self.pts_feats, self.img_metas, self._pts_metas())
             self.enc_out = (img, pts)           # static buffers too: valid after every replay
             return self.dec(pts, img, self.img_metas)
         finally:
@@ -195,7 +209,7 @@ class GraphedHotPath:
         if self.batch != len(inputs['img_metas']):
             raise ValueError('batch size differs from the captured one')
         r = GraphedHotPath.Record()
-        r.img_feats, r.pts_feats = inputs['img_feats'], inputs['pts_feats']
+        r.img_feats, r.pts_feats = inputs[self._img_key], inputs['pts_feats']
         pm = inputs['pts_metas']
         r.pts = [self._padded(src, dst, float('nan')) for dst, src in zip(self.pts, pm['pts'])]
         if self.glue is not None:
@@ -274,7 +288,7 @@ class GraphedHotPath:
             dst[:n].copy_(src, non_blocking=True)
             dst[n:].fill_(fill)
 
-        put(self.img_feats, inputs['img_feats'])
+        put(self.img_feats, inputs[self._img_key])
         put(self.pts_feats, inputs['pts_feats'])
         put(self.pts, pm['pts'], float('nan'))
         if self.glue is None:

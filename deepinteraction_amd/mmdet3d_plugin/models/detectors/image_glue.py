@@ -136,8 +136,10 @@ class FrozenResNetFPN(nn.Module):
         C = self.out_channels
         for i, cin in enumerate(self.stage_channels):
             for kind, ci, k in (('lateral_convs', cin, 1), ('fpn_convs', C, 3)):
-                nk[f'{kind}.{i}.conv.weight'] = torch.randn(C, ci, k, k, generator=g) * (1.0 / (ci * k * k)) ** 0.5
-                nk[f'{kind}.{i}.conv.bias'] = 0.05 * torch.randn(C, generator=g)
+                # the output convolutions bring the maps to the magnitude of `synth.make_inputs`' feature maps (std ~0.3)
+                gain = 0.05 if kind == 'fpn_convs' else 1.0
+                nk[f'{kind}.{i}.conv.weight'] = gain * torch.randn(C, ci, k, k, generator=g) * (1.0 / (ci * k * k)) ** 0.5
+                nk[f'{kind}.{i}.conv.bias'] = gain * 0.05 * torch.randn(C, generator=g)
         return bb, nk
 
     # ------------------------------------------------------------------ forward

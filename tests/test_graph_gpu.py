@@ -236,3 +236,47 @@ def test_point_glue_rebuilds_pts_metas_and_the_graph_can_start_from_points():
             out = g()[0][0]
             torch.cuda.synchronize()
             _same(out, eager[it % 2])
+
+
+def test_the_graph_can_start_from_the_camera_images():
+    """`GraphedHotPath(image_net=...)`: the frozen ResNet-50 + FPN stand-in (`FrozenResNetFPN`, torch / MIOpen) runs inside
+    every replay on the static image buffer; the result equals the forward on the maps the same network produces
+    eagerly, and `load()` switches the images with the rest of the sample."""
+    from deepinteraction_amd.mmdet3d_plugin import FrozenResNetFPN
+    shape = synth.SHAPE_TINY
+    torch.backends.cudnn.deterministic = True
+    torch.manual_seed(4)
+    enc = DeepInteractionEncoder(2, shape['c_img'], shape['c_pts'], 128).cuda().half().eval()
+    dec = DeepInteractionDecoder(**decoder_cfg(bev=shape['bev_hw'][0], num_proposals=50)).cuda().half().eval()
+    net = FrozenResNetFPN(out_channels=shape['c_img'], levels=(0,))
+    net.load_mmdet_state(*net.synthetic_state(1)).cuda()
+    H, W = shape['input_shape']
+    pool, want = [], []
+    for i in range(2):
+        d = _to_device(synth.make_inputs(1, shape, seed=5 + i), torch.float16)
+        cams = torch.randn(6, 3, H, W, generator=torch.Generator().manual_seed(20 + i))
+        d['images'] = cams.cuda().half().contiguous(memory_format=torch.channels_last)
+        for _ in range(2):
+            d['img_feats'] = net(d['images'])[0]
+        assert d['img_feats'].shape == (6, shape['c_img'], *shape['img_hw'])
+        pool.append(d)
+    with torch.no_grad():
+        for d in pool:
+            for _ in range(2):
+                img, pts = enc(d['img_feats'], d['pts_feats'], d['img_metas'], dict(d['pts_metas']))
+            want.append((img.clone(), [p.clone() for p in pts], {k: v.clone() for k, v in dec(pts, img, d['img_metas'])[0][0].items()}))
+    cap = max(range(2), key=lambda i: int(pool[i]['pts_metas']['pillars'].shape[0]))
+    g = GraphedHotPath(enc, dec, pool[cap], image_net=net)
+    recs = [g.prepare(d) for d in pool]
+    for it in range(4):
+        g.load(recs[it % 2])
+        out = g()[0][0]
+        torch.cuda.synchronize()
+        img, pts = g.enc_out
+        wimg, wpts, wout = want[it % 2]
+        scale = float(wimg.float().abs().max())
+        assert float((img.float() - wimg.float()).abs().max()) <= 2e-3 * scale
+        for p, wp in zip(pts, wpts):
+            assert float((p.float() - wp.float()).abs().max()) <= 2e-3 * float(wp.float().abs().max())
+        if torch.equal(img, wimg) and all(torch.equal(p, wp) for p, wp in zip(pts, wpts)):
+            _same(out, wout)            # same kernels on the same maps: the head's outputs are then identical too
