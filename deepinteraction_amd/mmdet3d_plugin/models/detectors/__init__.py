@@ -1,3 +1,3 @@
 from .deepinteraction import PointGlue  # noqa: F401
-from .image_glue import FrozenResNetFPN, ImageGlue  # noqa: F401
+from .image_glue import FrozenResNetFPN, FrozenSwinFPN, ImageGlue  # noqa: F401
 from .inference import DeepInteractionInference, bbox3d2result  # noqa: F401

@@ -105,6 +105,33 @@ def _patch_pp(ns):
     du.PointRCNNBlockV2.forward = with_return
 
 
+def load_reference_swin():
+    """The reference's own image backbone of the ++ configuration (`models/backbones/swin.py`, `swin_utils.py`), imported
+    unmodified on the stand-ins of `stubs.install()` + `stubs.install_swin_extras()`.  Returns the `swin` module."""
+    if not reference_available():
+        raise FileNotFoundError(f'{REF_ROOT} not present')
+    from . import stubs
+    roots = stubs.STUB_ROOTS
+    saved = {k: v for k, v in sys.modules.items()
+             if k == 'projects' or k.startswith('projects.') or k.split('.')[0] in roots}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        stubs.install('reference')
+        stubs.install_swin_extras()
+        for name in ('projects', 'projects.mmdet3d_plugin', 'projects.mmdet3d_plugin.models',
+                     'projects.mmdet3d_plugin.models.backbones'):
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(REF_ROOT, *name.split('.'))]
+            m.__package__ = name
+            sys.modules[name] = m
+        return importlib.import_module('projects.mmdet3d_plugin.models.backbones.swin')
+    finally:
+        for k in [k for k in sys.modules if k == 'projects' or k.startswith('projects.') or k.split('.')[0] in roots]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
 def reference_available():
     return os.path.isdir(os.path.join(REF_ROOT, 'projects', 'mmdet3d_plugin'))
 

@@ -227,6 +227,62 @@ def make_locatt_module(kind):
     return m
 
 
+def install_swin_extras():
+    """The further third-party names `models/backbones/swin.py` and `swin_utils.py` import (mmcv 1.3.18 / mmdet 2.14.0
+    surfaces, restated; call after `install()`)."""
+    import logging
+    mm = sys.modules
+
+    def build_norm_layer(cfg, num_features, postfix=''):
+        assert cfg['type'] == 'LN'
+        return 'ln' + str(postfix), nn.LayerNorm(num_features)
+
+    def constant_init(module, val, bias=0):
+        nn.init.constant_(module.weight, val)
+        if getattr(module, 'bias', None) is not None:
+            nn.init.constant_(module.bias, bias)
+
+    def trunc_normal_init(module, mean=0., std=1., a=-2., b=2., bias=0.):
+        nn.init.trunc_normal_(module.weight, mean, std, a, b)
+        if getattr(module, 'bias', None) is not None:
+            nn.init.constant_(module.bias, bias)
+
+    def _na(*a, **k):
+        raise NotImplementedError('outside the pinned path')
+
+    class ModuleList(BaseModule, nn.ModuleList):
+        def __init__(self, modules=None, init_cfg=None):
+            BaseModule.__init__(self, init_cfg)
+            nn.ModuleList.__init__(self, modules)
+
+    for k, v in dict(build_norm_layer=build_norm_layer, constant_init=constant_init, trunc_normal_init=trunc_normal_init,
+                     build_activation_layer=_na, xavier_init=_na).items():
+        setattr(mm['mmcv.cnn'], k, v)
+    reg = mm['mmcv.cnn.bricks.registry']
+    reg.TRANSFORMER_LAYER_SEQUENCE = Registry('transformer-layers sequence')
+    tr = mm['mmcv.cnn.bricks.transformer']
+    tr.build_dropout = tp.build_dropout
+    tr.TransformerLayerSequence = BaseModule
+    tr.build_transformer_layer_sequence = reg.TRANSFORMER_LAYER_SEQUENCE.build
+    _mod('mmcv.cnn.utils')
+    _mod('mmcv.cnn.utils.weight_init', trunc_normal_=nn.init.trunc_normal_)
+    mm['mmcv.runner'].ModuleList = ModuleList
+    mm['mmcv.runner']._load_checkpoint = _na
+    _mod('mmcv.runner.base_module', BaseModule=BaseModule)
+    import collections.abc
+    # mmcv `_ntuple(2)`: ANY iterable (a str too: AdaptivePadding's 'corner') is returned as it is
+    to_2tuple = lambda x: x if isinstance(x, collections.abc.Iterable) else (x, x)
+    if 'mmcv.utils' in mm:
+        mm['mmcv.utils'].to_2tuple = to_2tuple
+    else:
+        _mod('mmcv.utils', to_2tuple=to_2tuple)
+    _mod('mmdet.utils', get_root_logger=lambda *a, **k: logging.getLogger('refpin'))
+    _mod('mmdet.models')
+    _mod('mmdet.models.builder', BACKBONES=Registry('backbone'))
+    _mod('mmdet.models.utils')
+    _mod('mmdet.models.utils.builder', TRANSFORMER=Registry('Transformer'))
+
+
 def install(locatt_kind='reference'):
     BBOX_CODERS, NECKS, HEADS = Registry('bbox_coder'), Registry('neck'), Registry('head')
 

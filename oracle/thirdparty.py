@@ -334,18 +334,46 @@ class TransFFN(torch.nn.Module):
                  ffn_drop=0., dropout_layer=None, add_identity=True, init_cfg=None, **kwargs):
         super().__init__()
         nn = torch.nn
-        assert num_fcs >= 2 and act_cfg['type'] == 'ReLU' and dropout_layer is None
+        assert num_fcs >= 2 and act_cfg['type'] in ('ReLU', 'GELU')
         self.embed_dims = embed_dims
+        act = (lambda: nn.ReLU(inplace=True)) if act_cfg['type'] == 'ReLU' else nn.GELU
         layers, cin = [], embed_dims
         for _ in range(num_fcs - 1):
-            layers.append(nn.Sequential(nn.Linear(cin, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(ffn_drop)))
+            layers.append(nn.Sequential(nn.Linear(cin, feedforward_channels), act(), nn.Dropout(ffn_drop)))
             cin = feedforward_channels
         layers += [nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop)]
         self.layers = nn.Sequential(*layers)
+        # `dropout_layer` (DropPath in the Swin blocks) sits on the branch before the identity is added
+        self.dropout_layer = build_dropout(dropout_layer) if dropout_layer else nn.Identity()
         self.add_identity = add_identity
 
     def forward(self, x, identity=None):
         out = self.layers(x)
         if not self.add_identity:
-            return out
-        return (x if identity is None else identity) + out
+            return self.dropout_layer(out)
+        return (x if identity is None else identity) + self.dropout_layer(out)
+
+
+class DropPath(torch.nn.Module):
+    """mmcv `DropPath` (stochastic depth): drops whole samples of the branch in training, identity in evaluation."""
+
+    def __init__(self, drop_prob=0.1):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0. or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        mask = (keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device)).floor()
+        return x.div(keep) * mask
+
+
+def build_dropout(cfg):
+    """mmcv `build_dropout`: {'type': 'DropPath' | 'Dropout', ...}."""
+    cfg = dict(cfg)
+    typ = cfg.pop('type')
+    if typ == 'DropPath':
+        return DropPath(**cfg)
+    assert typ == 'Dropout'
+    return torch.nn.Dropout(p=cfg.pop('drop_prob', 0.5), **cfg)

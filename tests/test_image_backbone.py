@@ -126,3 +126,105 @@ def test_fp16_channels_last_on_the_device_against_the_oracle():
         assert torch.isfinite(o).all()
         err = float((o.float().cpu() - want[l]).abs().max())
         assert err <= 3e-2 * float(want[l].abs().max()), (l, err)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DeepInteraction++ image side: the plugin's Swin-T (reference models/backbones/swin.py) + FPN
+# ---------------------------------------------------------------------------------------------------------------------
+import os
+
+import numpy as np
+
+from deepinteraction_amd.mmdet3d_plugin import FrozenSwinFPN
+from oracle import refpin
+from oracle.refpin import make_golden_swin as mgs
+
+GOLDEN_SWIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'swin_t.npz')
+
+
+def test_swin_stage_maps_against_the_golden_vectors_of_the_reference():
+    """tests/golden/swin_t.npz was written by the REFERENCE'S OWN SwinTransformer (oracle/refpin/make_golden_swin.py): an
+    image whose token map needs padding in the patch embedding, in every stage's windows and in a PatchMerging."""
+    state, img = mgs.case()
+    net = FrozenSwinFPN(dtype=torch.float32)
+    net.load_mmdet_state(state, net.synthetic_state(0)[1])
+    got = mgs.subsample([f.float() for f in net.stage_maps(img)])
+    gold = np.load(GOLDEN_SWIN)
+    assert sorted(gold.files) == sorted(got)
+    for k in gold.files:
+        assert got[k].shape == gold[k].shape, k
+        err = float(np.abs(got[k] - gold[k]).max())
+        assert err <= 2e-5 * max(1.0, float(np.abs(gold[k]).max())), (k, err)
+
+
+@pytest.mark.skipif(not refpin.reference_available(), reason='/root/reference not present (e.g. on the GPU box)')
+@pytest.mark.parametrize('hw', [(70, 101), (64, 112)])
+def test_swin_fpn_against_the_reference_module(hw):
+    """Direct comparison with the reference's SwinTransformer imported unmodified (all levels; the FPN behind it is the
+    oracle's restatement of mmdet's - parity unpinned there)."""
+    swin = refpin.load_reference_swin()
+    net = FrozenSwinFPN(levels=None, dtype=torch.float32)
+    bb, nk = net.synthetic_state(3)
+    ref = swin.SwinTransformer(**mgs.CFG)
+    ref.eval()
+    ref.load_state_dict(bb, strict=True)                    # the product's synthetic state IS a reference checkpoint
+    neck = ob.FPN(in_channels=(96, 192, 384, 768)).eval()
+    neck.load_state_dict(nk)
+    net.load_mmdet_state(bb, nk)
+    img = torch.randn(2, 3, *hw, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        want = neck(ref(img))
+    got = net(img)
+    assert len(got) == 5
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        assert float((g - w).abs().max()) <= 2e-5 * max(1.0, float(w.abs().max()))
+
+
+def test_swin_pruned_levels_and_loading_errors():
+    net = FrozenSwinFPN(dtype=torch.float32)                # the ++ neck reads levels 0 and 1
+    bb, nk = net.synthetic_state(5)
+    net.load_mmdet_state(bb, nk)
+    full = FrozenSwinFPN(levels=None, dtype=torch.float32).load_mmdet_state(bb, nk)
+    img = torch.randn(1, 3, 56, 84, generator=torch.Generator().manual_seed(1))
+    a, b = net(img), full(img)
+    assert len(a) == 2 and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[0].is_contiguous(memory_format=torch.channels_last) and a[0].shape == (1, 256, 14, 21)
+    assert not net.state_dict()
+    bad = dict(bb)
+    del bad['stages.2.blocks.4.attn.w_msa.qkv.bias']
+    with pytest.raises(KeyError, match='stages.2.blocks.4.attn.w_msa.qkv.bias'):
+        FrozenSwinFPN().load_mmdet_state(bad, nk)
+    with pytest.raises(RuntimeError, match='no weights'):
+        FrozenSwinFPN()(img)
+
+
+def test_swin_fp16_form_on_the_host_stays_close():
+    """fp16 weights and activations (the device form) against the float32 form of the same network: the error budget of
+    12 blocks in half precision, checked on the host so that the device test only has to confirm the kernels."""
+    bb, nk = FrozenSwinFPN().synthetic_state(7)
+    f32 = FrozenSwinFPN(dtype=torch.float32).load_mmdet_state(bb, nk)
+    f16 = FrozenSwinFPN(dtype=torch.float16).load_mmdet_state(bb, nk)
+    img = torch.randn(1, 3, 56, 84, generator=torch.Generator().manual_seed(2))
+    want = f32(img)
+    try:
+        got = f16(img)
+    except RuntimeError as e:                               # a CPU build without half kernels for some op
+        pytest.skip(f'half precision not runnable on this host: {e}')
+    for g, w in zip(got, want):
+        assert float((g.float() - w).abs().max()) <= 3e-2 * float(w.abs().max())
+
+
+@pytest.mark.gpu
+def test_swin_fp16_on_the_device():
+    bb, nk = FrozenSwinFPN().synthetic_state(7)
+    f32 = FrozenSwinFPN(dtype=torch.float32).load_mmdet_state(bb, nk)
+    dev = FrozenSwinFPN().load_mmdet_state(bb, nk).cuda()
+    img = torch.randn(2, 3, 70, 101, generator=torch.Generator().manual_seed(2))
+    want = f32(img)
+    got = dev(img.cuda())
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        assert g.dtype == torch.float16 and g.is_contiguous(memory_format=torch.channels_last)
+        assert torch.isfinite(g).all()
+        assert float((g.float().cpu() - w).abs().max()) <= 3e-2 * float(w.abs().max())
