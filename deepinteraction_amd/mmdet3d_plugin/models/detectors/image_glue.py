@@ -14,6 +14,9 @@ What is MI355X-specific here is the form the frozen network is kept in:
     the max-pool level are skipped.  `levels=None` computes all `num_outs` levels as the reference does;
   * no host synchronisation and only static shapes: the module can be captured into the same hipGraph as the hot path.
 
+`FrozenSwinFPN` is the same for the DeepInteraction++ configuration (`Fusion_0075_plusplus.py:147-170`: the plugin's own
+Swin-T, reference `models/backbones/swin.py`, in front of the same FPN) - see its docstring.
+
 `load_mmdet_state` takes the two state dicts in mmdet's own key layout (the reference's checkpoints: `img_backbone.*`,
 `img_neck.*` with the prefix stripped), checks every expected key and shape, and fails loudly on a mismatch.
 """
