@@ -59,7 +59,8 @@ def parse():
                          '`single_sample` in the default line)')
     ap.add_argument('--from-images', action='store_true',
                     help='forward mode: the captured forward starts from the six camera images - the frozen ResNet-50 + FPN '
-                         'stand-in (FrozenResNetFPN, torch / MIOpen, random init) runs inside every replay')
+                         'stand-in (FrozenResNetFPN, torch / MIOpen, random init) runs inside every replay; with --model pp '
+                         'the Swin-T + FPN stand-in (FrozenSwinFPN; that combination was not yet run on the device)')
     ap.add_argument('--from-points', action='store_true',
                     help='start every step from the raw points: the pillars of pts_metas are rebuilt by the voxeliser inside '
                          'the captured forward (detector glue, detectors/deepinteraction.py:120-171) instead of being loaded')
@@ -444,6 +445,17 @@ def bench_forward_pp(args, rank, world, device):
     pool = [dev(synth.make_inputs_pp(args.batch, shape, seed=parallel.sample_seed(
         parallel.sample_ids(i, args.batch, rank, world)[0]))) for i in range(max(1, args.pool))]
     n_pillars = [int(d['pts_metas']['pillars'].shape[0]) for d in pool]
+    image_net = None
+    if args.from_images:        # the ++ image side (the plugin's Swin-T + FPN, levels 0-1) inside the captured forward
+        assert not args.eager, '--from-images is a graph mode'
+        from deepinteraction_amd.mmdet3d_plugin import FrozenSwinFPN
+        image_net = FrozenSwinFPN(out_channels=shape['c_img'], levels=(0, 1), dtype=dtype)
+        image_net.load_mmdet_state(*image_net.synthetic_state(0)).to(device)
+        H, W = shape['input_shape']
+        for i, d in enumerate(pool):
+            cams = torch.randn(6 * args.batch, 3, H, W, generator=torch.Generator().manual_seed(1000 + i))
+            d['images'] = cams.to(device, dtype).contiguous(memory_format=torch.channels_last)
+            d['img_feats'] = list(image_net(d['images']))
 
     def eager(d):
         im, p = enc(d['img_feats'], d['pts_feats'], d['img_metas'], dict(d['pts_metas']))
@@ -457,7 +469,7 @@ def bench_forward_pp(args, rank, world, device):
                 eager(pool[it[0] % len(pool)])
                 it[0] += 1
         else:
-            g = GraphedHotPath(enc, dec, pool[max(range(len(pool)), key=lambda i: n_pillars[i])])
+            g = GraphedHotPath(enc, dec, pool[max(range(len(pool)), key=lambda i: n_pillars[i])], image_net=image_net)
             records = [g.prepare(d) for d in pool]
 
             def step():
@@ -489,7 +501,7 @@ def bench_forward_pp(args, rank, world, device):
                 'f16' if dtype == torch.float16 else 'f32',
                 'DeepInteraction++ forward: FusionTransformerv4 neck (2 layers) + DeepInteractionPlusPlusDecoder, '
                 'Fusion_0075_plusplus shapes (2 image levels 112x200 / 56x100, BEV 180x180), random-init weights',
-                dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(pool),
+                dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(pool), from_images=bool(args.from_images),
                      launch='eager' if args.eager else 'per step: load() + hipGraph replay',
                      graph_nodes=None if g is None else g.num_nodes()))
     out['roofline'] = dict(bound='hbm', kernel='pp::ms_deform_attn_kernel, image self-attention (2 levels)',
