@@ -169,8 +169,8 @@ def pseudo_sample(assign_result, bboxes, gt_bboxes):
         mask = np.ones(assign_result.gt_inds.shape[0], dtype=bool)
         mask[pos] = False
         dev = assign_result.gt_inds.device
-        r.pos_inds = torch.from_numpy(pos).to(dev, non_blocking=True)
-        r.neg_inds = torch.from_numpy(np.nonzero(mask)[0]).to(dev, non_blocking=True)
+        r.pos_inds = torch.from_numpy(pos).to(dev)
+        r.neg_inds = torch.from_numpy(np.nonzero(mask)[0]).to(dev)
     else:
         r.pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
         r.neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()

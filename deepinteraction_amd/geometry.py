@@ -56,7 +56,7 @@ class SampleGeometry:
         host = self._pack(img_meta, img_hw)
         V = int(np.asarray(img_meta['lidar2img']).shape[0])
         ori_H, ori_W = img_meta['input_shape'][:2]
-        buf = host.to(device, non_blocking=True)
+        buf = host.to(device)                  # pageable source: a blocking copy (the temporary dies right after)
         self._buf = buf
         o = 0
 
@@ -103,5 +103,5 @@ class SampleGeometry:
         assert (float(ori_H), float(ori_W)) == self.ori_hw, 'input_shape changed: rebuild the geometry'
         host = self._pack(img_meta, self.img_hw)
         assert host.numel() == self._buf.numel(), 'view count changed: rebuild the geometry'
-        self._buf.copy_(host, non_blocking=True)
+        self._buf.copy_(host)
         self.forget()

@@ -297,9 +297,9 @@ class GraphedHotPath:
             put(self.pillars_num_points, pm['pillars_num_points'], 0)
         self.img_metas = [dict(m) for m in inputs['img_metas']]
         for g, m in zip(self.sample_geom, self.img_metas):
-            g._buf.copy_(SampleGeometry._pack(m, g.img_hw), non_blocking=True)
+            g._buf.copy_(SampleGeometry._pack(m, g.img_hw))      # pageable host temporaries: blocking copies
             g.forget()
-        self.query_geom._buf.copy_(QueryGeometry._pack(self.img_metas)[0], non_blocking=True)
+        self.query_geom._buf.copy_(QueryGeometry._pack(self.img_metas)[0])
         for mod in self.enc.modules():
             if hasattr(mod, 'static_geometry_record'):
                 for g, m in zip(self.sample_geom, self.img_metas):

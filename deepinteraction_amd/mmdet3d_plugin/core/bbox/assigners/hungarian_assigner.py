@@ -149,8 +149,8 @@ class HungarianAssigner3D:
             rows.append(np.asarray(r_, dtype=np.int64) + l * Q)
             cols.append(np.asarray(c_, dtype=np.int64))
         rows, cols = np.concatenate(rows), np.concatenate(cols)
-        rows_d = torch.from_numpy(rows).to(bboxes.device, non_blocking=True)
-        cols_d = torch.from_numpy(cols).to(bboxes.device, non_blocking=True)
+        rows_d = torch.from_numpy(rows).to(bboxes.device)
+        cols_d = torch.from_numpy(cols).to(bboxes.device)
         gt_inds[:] = 0
         gt_inds[rows_d] = cols_d + 1
         labels[rows_d] = gt_labels[cols_d]

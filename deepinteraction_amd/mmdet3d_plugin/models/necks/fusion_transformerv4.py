@@ -233,7 +233,7 @@ class MMRI_I2P_Polar(nn.Module):
         key = (H, W, self.radius, tuple(self.radius_range))
         if getattr(geom, 'polar_key', None) != key:
             grid, cam_xy = self.ray_grid(img_metas[b], H, W)
-            geom.polar = (grid.to(device, non_blocking=True), cam_xy.to(device, non_blocking=True))
+            geom.polar = (grid.to(device), cam_xy.to(device))
             geom.polar_key = key
         return geom
 

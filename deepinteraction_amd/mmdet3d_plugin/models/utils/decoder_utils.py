@@ -321,7 +321,7 @@ class QueryGeometry:
 
     def __init__(self, img_metas, device):
         host, B, V = self._pack(img_metas)
-        buf = host.to(device, non_blocking=True)
+        buf = host.to(device)
         self._buf = buf
         self.B, self.V = B, V
         self.proj = buf[:B * V * 16].view(B, V, 4, 4)
@@ -349,7 +349,7 @@ class QueryGeometry:
         captured hipGraph."""
         host, B, V = self._pack(img_metas)
         assert (B, V) == (self.B, self.V), 'batch or view count changed: rebuild the geometry'
-        self._buf.copy_(host, non_blocking=True)
+        self._buf.copy_(host)
 
 
 def _roi_align(feat, rois, scale):

@@ -101,8 +101,10 @@ class GradientReducer:
       touch some parameter (that bucket then waits for `finish()` on this rank only);
     * `find_unused_parameters` semantics: a parameter no rank produced a gradient for keeps `grad = None` (AdamW
       then leaves it alone - no weight decay on a frozen-by-construction branch such as the detached heat-map
-      head); a parameter unused on THIS rank but used elsewhere contributes zeros.  The used-bitmap is reduced
-      (MAX) after the last bucket.
+      head); a parameter unused on THIS rank but used elsewhere contributes zeros.  The used-bitmap (and the
+      "a rank accumulated two micro-batches" flag) is reduced (MAX) in ONE collective issued after the last bucket,
+      never between buckets: ranks launch different bucket prefixes during backward when a parameter is unused on
+      one of them, and any collective slipped in there would pair with a bucket all-reduce on the peer.
 
         red = GradientReducer(model.parameters(), world)
         loss.backward(); red.finish(); optimizer.step()
@@ -176,47 +178,57 @@ class GradientReducer:
         self._fill(p)
         self._launch_ready()
 
-    def finish(self):
-        """Call after backward: completes the outstanding buckets, resolves unused parameters, leaves the averaged
-        gradients in `p.grad` (views of the bucket buffers for float32 parameters)."""
-        if self.world == 1:
-            return
-        # Whether ANY rank accumulated decides for all of them (the ranks must issue the same collectives)
-        dirty = torch.tensor([1.0 if self._dirty else 0.0], device=self.params[0].device)
-        dist.all_reduce(dirty, op=dist.ReduceOp.MAX)
-        if dirty.item() > 0:
-            # the launched all-reduces carry stale first-micro-batch data; every rank launched the same prefix of buckets
-            # only if no rank skipped a parameter, so finish them pairwise by index: force the remaining ones out first
-            self._launch_ready(force=True)
-            for w in self._handles:
-                w.wait()
-            self._reset()
-        for p in self.params:                  # no-hook mode, or gradients produced outside the hook path
-            if p.grad is not None and id(p) not in self._seen:
-                self._fill(p)
+    def _drain(self, extra):
+        """Force the remaining buckets out, then reduce `extra` (MAX) and wait for everything.  Ranks may have launched
+        DIFFERENT bucket prefixes during backward (a parameter unused on one rank holds its bucket back there), so a
+        collective other than a bucket all-reduce may only be issued once a rank has all of its buckets out: after
+        `_launch_ready(force=True)` every rank has issued exactly buckets 0..n-1, in index order."""
         self._launch_ready(force=True)
-        used = torch.tensor([1.0 if id(p) in self._seen else 0.0 for p in self.params],
-                            dtype=torch.float32, device=self.params[0].device)
-        h = dist.all_reduce(used, op=dist.ReduceOp.MAX, async_op=True)
+        h = dist.all_reduce(extra, op=dist.ReduceOp.MAX, async_op=True)
         for w in self._handles:
             w.wait()
         h.wait()
-        used = used.tolist()
+        return extra.tolist()
+
+    def finish(self):
+        """Call after backward: completes the outstanding buckets, resolves unused parameters, leaves the averaged
+        gradients in `p.grad`.  `p.grad` never aliases a bucket buffer (an in-place all-reduce launched from a hook
+        would otherwise rewrite a gradient that a second micro-batch is still accumulating into)."""
+        if self.world == 1:
+            return
+        dev = self.params[0].device
+        for p in self.params:                  # no-hook mode, or gradients produced outside the hook path
+            if p.grad is not None and id(p) not in self._seen:
+                self._fill(p)
+        # one vector: the used-parameter bitmap + "some rank accumulated" (decides for all ranks together)
+        flags = torch.tensor([1.0 if id(p) in self._seen else 0.0 for p in self.params] +
+                             [1.0 if self._dirty else 0.0], dtype=torch.float32, device=dev)
+        flags = self._drain(flags)
+        used, dirty = flags[:-1], flags[-1]
+        if dirty > 0:
+            # the reductions above carried first-micro-batch data: redo them from the accumulated p.grad.  Every rank
+            # takes this branch (MAX) and issues all buckets again, nothing else in between.
+            self._reset()
+            for p in self.params:
+                if p.grad is not None:
+                    self._fill(p)
+            self._drain(torch.zeros(1, dtype=torch.float32, device=dev))
         inv = 1.0 / self.world
-        for flat, _ in self.buckets:
-            flat.mul_(inv)
+        torch._foreach_mul_([flat for flat, _ in self.buckets], inv)
+        dst, src = [], []
         for p, u in zip(self.params, used):
             if u == 0.0:
                 p.grad = None                  # unused on every rank: stays frozen, as under DDP
                 continue
             b, o = self._where[id(p)]
             g = self.buckets[b][0][o:o + p.numel()].view_as(p)
-            if p.dtype == torch.float32:
-                p.grad = g
-            elif p.grad is None:
-                p.grad = g.to(p.dtype)
+            if p.grad is None:                 # unused on this rank only: the other ranks' average
+                p.grad = g.to(p.dtype, copy=True)
             else:
-                p.grad.copy_(g)
+                dst.append(p.grad)
+                src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)
         self._reset()
 
     def remove(self):

@@ -104,6 +104,51 @@ def _worker(rank, world, port, out):
         else:
             want = sum(g if g is not None else torch.zeros_like(p) for g in gs) / world
             assert torch.allclose(p.grad, want, atol=1e-6), ('accumulation', n)
+    # (vi) ranks launch DIFFERENT bucket prefixes during backward: the rank-0-only branch is registered last, so it
+    # sits in bucket 0 - rank 0 launches every bucket from its hooks, rank 1 none before finish().  No collective may
+    # be issued between them (a flag all-reduce in front of the forced buckets paired with a bucket
+    # all-reduce on the peer).  With and without accumulation, and with gradients zeroed IN PLACE between steps
+    # (p.grad must not alias the bucket an in-flight all-reduce rewrites).
+    torch.manual_seed(2)
+    net2 = torch.nn.ModuleDict(dict(a=torch.nn.Linear(6, 8), b=torch.nn.Linear(8, 8), c=torch.nn.Linear(8, 1),
+                                    only0=torch.nn.Linear(8, 8)))
+    red2 = parallel.GradientReducer(net2.parameters(), world, bucket_bytes=32)
+    assert len(red2.buckets) >= 6
+    assert red2._where[id(net2['only0'].bias)][0] == 0
+    launched = []
+    for case, (micros, in_place_zero) in enumerate([(1, False), (2, False), (1, True), (2, True), (1, False)]):
+        for p in net2.parameters():
+            if in_place_zero and p.grad is not None:
+                p.grad.zero_()
+            else:
+                p.grad = None
+        local = {n: None for n, _ in net2.named_parameters()}
+        for micro in range(micros):
+            x = torch.full((3, 6), float(rank + 1 + micro + case))
+            h = net2['b'](torch.relu(net2['a'](x)))
+            if rank == 0:
+                h = h + net2['only0'](h)
+            before = {n: (None if p.grad is None else p.grad.clone()) for n, p in net2.named_parameters()}
+            net2['c'](h).sum().backward()
+            if micro == 0:
+                launched.append(red2._next)
+            for n, p in net2.named_parameters():       # this rank's own contribution, independent of the reducer
+                if p.grad is None:
+                    continue
+                d = p.grad.clone() if before[n] is None else p.grad - before[n]
+                local[n] = d if local[n] is None else local[n] + d
+        red2.finish()
+        allg = [None] * world
+        dist.all_gather_object(allg, local)
+        for n, p in net2.named_parameters():
+            gs = [g[n] for g in allg]
+            want = sum(g if g is not None else torch.zeros_like(p) for g in gs) / world
+            assert torch.allclose(p.grad, want, atol=1e-5), ('prefix', case, n, p.grad, want)
+            assert not any(p.grad.data_ptr() == flat.data_ptr() or
+                           flat.data_ptr() < p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4
+                           for flat, _ in red2.buckets), n
+    # the scenario really happened: rank 0 had buckets out during backward, rank 1 none
+    assert (launched[0] > 0) == (rank == 0), launched
     out.put((rank, el))
     dist.destroy_process_group()
 
