@@ -96,7 +96,7 @@ def self_launch(args):
 
 
 # ------------------------------------------------------------------------------------------------ CPU side
-def cpu_baseline(shape, num_proposals, state, sample, product_out, budget_s=60.0, state_same=None):
+def cpu_baseline(shape, num_proposals, state, sample, product_out, budget_s=60.0, state_same=None, conditioned=None):
     """The CPU oracle (kind "port": PyTorch fp32 restatement of the reference path, its per-sample and per-view
     Python loops and scipy depth completion included) on this box's host cores, BOUNDED: a 1/16-area probe of the
     workload is timed first; when the predicted full-size time fits `budget_s` the oracle runs the full-size
@@ -147,6 +147,19 @@ def cpu_baseline(shape, num_proposals, state, sample, product_out, budget_s=60.0
                 same['vs'] = ('the same with the oracle holding the product\'s parameter VALUES (encoder and heat-map '
                               'heads rounded through fp16, token path float32 on both sides): arithmetic only')
                 par['identical_parameters'] = same
+            if conditioned is not None:       # (head state_dict, product outputs): the same encoder under a conditioned head
+                dec_state_c, (_, out_c, labels_c, masks_c, top_c) = conditioned
+                _, Dc = parity.build_oracle(shape, num_proposals, state=(state[0], dec_state_c))
+                free_c = parity.oracle_decoder(Dc, ref_enc, sample['img_metas'])
+                forced_c = parity.oracle_decoder(Dc, ref_enc, sample['img_metas'], top_override=top_c.cpu())
+                dc = parity.compare_decoder(out_c, labels_c, masks_c, top_c, free_c, forced_c)
+                r3 = lambda x: float(f'{x:.3g}')
+                par['conditioned_head'] = dict(
+                    {f'dec.{k}': dict(max=r3(v['max']), median=r3(v['median']), p999=r3(v['p999']), frac_gt_1e3=r3(v['frac_gt_1e3']))
+                     for k, v in dc['keys'].items()},
+                    vs='the same encoder, kernels and float32-parameter oracle, but the head\'s four RoI blocks conditioned '
+                       '(harness.condition_head: residual branches x 0.5 - as initialised every block multiplies its input '
+                       'error by 2-3, which is what sets the tail of dec.* above)')
     else:
         div = 2 if t16 * 4.0 * 1.3 <= budget_s else 4
         dt, sh = probe(div) if div != 4 else (t16, sh)
@@ -155,6 +168,36 @@ def cpu_baseline(shape, num_proposals, state, sample, product_out, budget_s=60.0
                 sample=(f'oracle MMRI+MMPI forward, fp32, {cores} threads, on a 1/{div * div}-area sample '
                         f'(image feats 6x{sh["c_img"]}x{sh["img_hw"][0]}x{sh["img_hw"][1]}, BEV {sh["bev_hw"][0]}^2, '
                         f'{sh["n_points"]} points) in {dt:.1f} s; value = area fraction / time'))
+    return base, par
+
+
+def cpu_baseline_pp(shape, num_proposals, state, sample, product_out):
+    """DeepInteraction++ (configs[4]): the CPU oracle (`oracle/plusplus.py`, kind "port") runs ONE full-size sample with
+    the model's float32 parameters - ~40 s on 8-16 host threads (the per-camera Python loops of the polar attention, the
+    deformable gathers as grid_sample) - which is both the baseline and the reference of the `parity` block."""
+    import torch
+    from oracle import parity
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    E, D = parity.build_oracle_pp(shape, num_proposals, state)
+    t0 = time.time()
+    ref_enc = parity.oracle_encoder_pp(E, sample)
+    free = parity.oracle_decoder(D, ref_enc, sample['img_metas'])
+    dt = time.time() - t0
+    par = None
+    if product_out is not None:
+        got_enc, out, labels, masks, top = product_out
+        forced = parity.oracle_decoder(D, ref_enc, sample['img_metas'], top_override=top.cpu())
+        par = parity.summarize(parity.compare_encoder(got_enc, ref_enc),
+                               parity.compare_decoder(out, labels, masks, top, free, forced))
+        par['vs'] = ('CPU oracle full ++ forward (neck + head) on the same sample with the FLOAT32 parameters of the model, '
+                     'no depth injection; continuous outputs as |got-ref|/max(1,max|ref|); decoder outputs against the '
+                     'oracle head run on the product\'s proposals')
+    Hi, Wi = shape['img_hw']
+    base = dict(value=round(1.0 / dt, 5), unit='samples/s', cores=cores, kind='port',
+                sample=(f'oracle FusionTransformerv4 + DeepInteractionPlusPlusDecoder forward, fp32, {cores} threads, ONE full-size '
+                        f'sample (image levels 6x{shape["c_img"]}x{Hi}x{Wi} / {Hi // 2}x{Wi // 2}, BEV {shape["bev_hw"][0]}^2, '
+                        f'{shape["n_points"]} points) in {dt:.1f} s'))
     return base, par
 
 
@@ -407,8 +450,19 @@ def bench_forward(args, rank, world, device):
         # the model as built, before precision.half_maps_ rounded its map side: same seed, same init, float32 on the host
         e32, d32 = harness.build_models(shape, args.proposals, torch.float32, 'cpu')
         state = (e32.state_dict(), d32.state_dict())
+        conditioned = None
+        if dtype == torch.float16 and product_out is not None:
+            import copy
+            from deepinteraction_amd import precision
+            dec_c = harness.condition_head(copy.deepcopy(d32))
+            _, dec_cd = precision.to_inference(enc, copy.deepcopy(dec_c).to(device), dtype)
+            with torch.no_grad():
+                (ic, pc), rc = harness.forward(enc, dec_cd.eval(), dev_pool[0])
+            torch.cuda.synchronize()
+            conditioned = (dec_c.state_dict(), (None, {k: v.float().cpu() for k, v in rc[0][0].items()}, dec_cd.query_labels.cpu(),
+                                                [m.cpu() for m in dec_cd.on_the_image_mask], dec_cd.top_proposals.cpu()))
         base, par = cpu_baseline(shape, args.proposals, state, host_pool[0], product_out,
-                                 state_same=same if dtype == torch.float16 else None)
+                                 state_same=same if dtype == torch.float16 else None, conditioned=conditioned)
         out['cpu_baseline'] = base
         if par is not None and g is not None:
             par['graph_vs_eager'] = graph_vs_eager
@@ -422,28 +476,20 @@ def bench_forward_pp(args, rank, world, device):
     from deepinteraction_amd import configs, ops, parallel, synth
     from deepinteraction_amd.graphed import GraphedHotPath
     from deepinteraction_amd.mmdet3d_plugin import DeepInteractionPlusPlusDecoder, FusionTransformerv4
+    from deepinteraction_amd import harness
     shape = synth.SHAPE_PP if args.shape != 'TINY' else synth.SHAPE_PP_TINY
     bev = shape['bev_hw'][0]
     dtype = dict(f16=torch.float16, f32=torch.float32)[args.dtype]
-    torch.manual_seed(0)
-    enc = FusionTransformerv4(**configs.encoder_pp_cfg(shape['c_img'], shape['c_pts'])).to(device, dtype).eval()
-    dec = DeepInteractionPlusPlusDecoder(**configs.decoder_cfg(bev=bev, num_proposals=args.proposals if bev >= 100 else 24)
-                                         ).to(device, dtype).eval()
-    gen = torch.Generator().manual_seed(1)
-    with torch.no_grad():                      # off the mmcv zero-init so that the sampling offsets are spread
-        for m in enc.modules():
-            if hasattr(m, 'sampling_offsets'):
-                for lin in (m.sampling_offsets, m.attention_weights):
-                    lin.weight.add_(torch.randn(lin.weight.shape, generator=gen).to(device, dtype) * 0.05)
-    cl = lambda t: t.to(device, dtype).contiguous(memory_format=torch.channels_last)
-
-    def dev(inp):
-        pm = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
-        pm['pts'] = [p.to(device) for p in inp['pts_metas']['pts']]
-        return dict(img_feats=[cl(f) for f in inp['img_feats']], pts_feats=[cl(f) for f in inp['pts_feats']],
-                    img_metas=inp['img_metas'], pts_metas=pm)
-    pool = [dev(synth.make_inputs_pp(args.batch, shape, seed=parallel.sample_seed(
-        parallel.sample_ids(i, args.batch, rank, world)[0]))) for i in range(max(1, args.pool))]
+    nprop = args.proposals if bev >= 100 else 24
+    # fp16 = the mixed mode of precision.half_maps_ (fp16 neck + heat-map heads, float32 token path in the head), as v1
+    enc, dec = harness.build_models_pp(shape, nprop, dtype, device)
+    host_pool = []
+    for i in range(max(1, args.pool)):
+        inp = synth.make_inputs_pp(args.batch, shape, seed=parallel.sample_seed(parallel.sample_ids(i, args.batch, rank, world)[0]))
+        inp['img_feats'] = [f.to(dtype).float() for f in inp['img_feats']]
+        inp['pts_feats'] = [f.to(dtype).float() for f in inp['pts_feats']]
+        host_pool.append(inp)
+    pool = [harness.to_device_pp(inp, device, dtype) for inp in host_pool]
     n_pillars = [int(d['pts_metas']['pillars'].shape[0]) for d in pool]
     image_net = None
     if args.from_images:        # the ++ image side (the plugin's Swin-T + FPN, levels 0-1) inside the captured forward
@@ -480,6 +526,25 @@ def bench_forward_pp(args, rank, world, device):
         for _ in range(args.warmup):
             step()
         elapsed = parallel.timed_region(step, args.steps, device)
+        product_out = graph_vs_eager = None
+        want_cpu = rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and not args.from_images
+        if want_cpu:               # the product's outputs on pool[0], in the benched launch mode
+            def outputs(res):
+                return ({k: v.float().cpu() for k, v in res[0][0].items()}, dec.query_labels.cpu(),
+                        [m.cpu() for m in dec.on_the_image_mask], dec.top_proposals.cpu())
+            if g is not None:
+                g.load(records[0])
+                res = g()
+                img, pts = g.enc_out
+            else:
+                img, pts = enc(pool[0]['img_feats'], pool[0]['pts_feats'], pool[0]['img_metas'], dict(pool[0]['pts_metas']))
+                res = dec(pts, img, pool[0]['img_metas'])
+            torch.cuda.synchronize()
+            product_out = ((img.float().cpu(), [t.float().cpu() for t in pts]),) + outputs(res)
+            if g is not None:
+                eg = outputs(eager(pool[0]))
+                graph_vs_eager = dict(max_abs=max(float((eg[0][k] - product_out[1][k]).abs().max()) for k in eg[0]),
+                                      proposals_identical=bool(torch.equal(eg[3], product_out[4])))
         eager(pool[0])
         torch.cuda.synchronize()
         ops.PROFILE = []
@@ -509,6 +574,12 @@ def bench_forward_pp(args, rank, world, device):
                            frac=round(alg / avg / 1e9 / HBM_PEAK_GBS, 4) if durs else None,
                            traffic=pmc_file('pmc_ms_deform_attn.json').get('hbm_bytes_per_launch'),
                            avg_launch_us=round(avg * 1e6, 2), launches=len(durs), algorithmic_bytes=alg)
+    if want_cpu:
+        e32, d32 = harness.build_models_pp(shape, nprop, torch.float32, 'cpu')      # same seed / init, before half_maps_
+        base, par = cpu_baseline_pp(shape, nprop, (e32.state_dict(), d32.state_dict()), host_pool[0], product_out)
+        if par is not None and graph_vs_eager is not None:
+            par['graph_vs_eager'] = graph_vs_eager
+        out['cpu_baseline'], out['parity'] = base, par
     return out
 
 

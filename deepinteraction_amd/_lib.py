@@ -70,7 +70,7 @@ SIGNATURES = {
 # helpers that return a value instead of an error code
 VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_i2p_key_table_bytes': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 3,
                'di_token_splitk_workspace_bytes': [_c_i] * 2, 'di_mha_decode_x_ranges': [_c_i] * 3,
-               'di_graph_node_count': [_c_p]}
+               'di_graph_node_count': [_c_p], 'di_local_attn_ring_timeouts': [_c_p]}
 _LONGLONG = {'di_topk_workspace_bytes', 'di_i2p_key_table_bytes', 'di_graph_node_count', 'di_token_splitk_workspace_bytes'}
 
 # ---- the step program of di_token_program (structs of include/deepinteraction_hip.h)

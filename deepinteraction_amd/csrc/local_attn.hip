@@ -369,6 +369,9 @@ int launch_local_attn_mfma2(const void *q, const void *k, const void *v, void *o
                             float scale, int cfg, hipStream_t stream);   // local_attn_mfma2.hip
 int launch_local_attn_mfma3(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                             float scale, int cfg, hipStream_t stream);   // local_attn_mfma3.hip
+int launch_local_attn_ring(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
+                           float scale, int cfg, hipStream_t stream);    // local_attn_ring.hip
+int ring_timeouts(unsigned *host_out, hipStream_t stream);
 
 static int run_la(LaOp op, int dtype, int kH, int kW, const LaArgs &A) {
   DI_REQUIRE(A.n > 0 && A.H > 0 && A.W > 0, "empty feature map n=%d H=%d W=%d", A.n, A.H, A.W);
@@ -404,9 +407,22 @@ int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out,
     }
     return di::launch_local_attn_mfma3(q, k, v, out, n, H, W, scale, variant - DI_LA_DMA, (hipStream_t)stream);
   }
+  if (variant >= DI_LA_RING && variant < DI_LA_RING + 4) {
+    if (!mfma_ok) {
+      di::set_error("MFMA local attention needs fp16, C=128, 9x9, < 2^23 pixels (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
+      return DI_ERR_ARG;
+    }
+    return di::launch_local_attn_ring(q, k, v, out, n, H, W, scale, variant - DI_LA_RING, (hipStream_t)stream);
+  }
   if (mfma_ok && variant == DI_LA_AUTO)   // fastest measured (round 3, cold inputs): 8x8 tiles, 2 workgroups per CU: 39.6 us against
     return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, 1, (hipStream_t)stream);   // 42.9 for 16x4 (image side)
   return di::run_la(di::OP_FUSED, dtype, kH, kW, A);
+}
+
+int di_local_attn_ring_timeouts(void *stream) {
+  unsigned n = 0;
+  if (di::ring_timeouts(&n, (hipStream_t)stream) != DI_OK) return -1;
+  return (int)n;
 }
 
 int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, int n, int H, int W,

@@ -1,0 +1,431 @@
+// Fused 9x9 local-window attention on the gfx950 matrix cores, fifth generation (fp16 maps, C = 128):
+// ONE fat workgroup per CU, a 144 KB ring of halo ROWS filled by LDS-DMA, and NO workgroup barrier in the steady state.
+//
+// What the earlier generations measured: a launch takes (rounds of tiles) x (tile latency), and the
+// tile latency (8.5-9 us) is a chain of dependent phases - stage a unit, barrier, 20 MFMAs per wave, barrier, ... - in which
+// a wave is idle 70 % of the time; no unit of the CU is saturated.  The second generation (local_attn_mfma2.hip) holds two
+// units in registers + two in LDS per workgroup and pays a commit pass and a barrier per unit; the DMA generations
+// (local_attn_mfma3.hip) moved 64-byte pieces, had at most 48 KB in flight and kept one barrier per 10-20 MFMAs.  Here:
+//
+//   * the halo of a 16 x 8 (or 8 x 16) query tile is staged as ROWS of 64 channels: one ring slot = (TW + 8) texels x 128 B
+//     (128-B pieces: whole L2 lines; tools/micro/halo_read.hip: 64-B pieces do not scale with the bytes in flight, 128-B
+//     pieces do).  A tile is four BLOCKS of HR rows - K channels 0-63, K 64-127, V 0-63, V 64-127 - and the ring holds three
+//     blocks (144 KB): one block is being multiplied while up to two (96 KB per CU) are in flight;
+//   * two PRODUCER wavefronts issue every LDS-DMA instruction (global_load_lds_dwordx4, 1 KB each; rows of even / odd
+//     sequence number), texels outside the map read a zero line, the LDS swizzle of the second generation is applied to
+//     the address each lane fetches.  A producer publishes `landed[p]` (all its rows below that sequence number are in
+//     LDS) after a COUNTED s_waitcnt vmcnt - the oldest row, not the youngest - and refills a slot as soon as the eight
+//     consumers' `done[w]` counters say nobody reads it any more (row granularity: the top waves free their rows first);
+//   * eight CONSUMER wavefronts (8 x 2 queries each, the row-pair MFMA tiles and the soft-max of the second generation,
+//     bit-identical results) never touch the vector-memory path except for their 4 query loads and 8 output stores per
+//     tile; they wait on `landed` with an LDS poll only when the producers are not ahead, and never on each other.
+//     Flags are plain LDS words (one writer each, monotonic): no atomics, no s_barrier after the prologue.
+//   * 10 waves at <= 168 VGPRs; every spin is bounded (a stuck pipeline gives wrong results and sets `di_ring_timeouts`,
+//     it does not hang the device).
+#include <stdlib.h>
+#include <type_traits>
+
+#include "di_common.h"
+
+namespace di {
+namespace ring {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __attribute__((aligned(128))) unsigned int zero_line[32];   // what a texel outside the map reads (128 B)
+__device__ unsigned int timeouts;                                       // bounded spins that gave up (0 on a healthy run)
+
+template <int WX_, int WY_, int SCHED_ = 0>
+struct Cfg {
+  static constexpr int WX = WX_, WY = WY_;
+  static constexpr int SCHED = SCHED_;                 // 1: LDS fragment reads interleaved with the MFMAs by sched_group_barrier
+  static constexpr int NCW = WX * WY, NPW = 2, NT = (NCW + NPW) * 64;
+  static constexpr int TW = 8 * WX, TH = 2 * WY, HC = TW + 8, HR = TH + 8;
+  static constexpr int S = 128;                        // bytes of a texel slice (64 channels)
+  static constexpr int ROWB = HC * S, IPR = ROWB / 1024;   // one DMA instruction = 8 texels
+  static constexpr int BLKB = HR * ROWB, NBLK = 3, NSLOT = NBLK * HR;
+  static constexpr int BPT = 4;                        // blocks per tile: K lo, K hi, V lo, V hi
+  static constexpr int RING = NBLK * BLKB;
+  static constexpr int LDS_BYTES = RING + 64;          // + landed[2] at RING, done[8] at RING + 32
+  static constexpr int DEPTH = 60 / IPR;               // rows a producer may have unpublished (vmcnt is 6 bits)
+  static_assert(NCW == 8 && HR % 2 == 0 && HC % 8 == 0 && LDS_BYTES <= 160 * 1024, "ring geometry");
+};
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+struct TileCoord {
+  int img, y0, x0;
+};
+__device__ __forceinline__ TileCoord decode_tile(int tile, int tiles_x, int per_img, int TH, int TW) {
+  TileCoord t;
+  t.img = tile / per_img;
+  const int r = tile - t.img * per_img;
+  const int ty = r / tiles_x;
+  t.y0 = ty * TH;
+  t.x0 = (r - ty * tiles_x) * TW;
+  return t;
+}
+
+// ---- LDS flag words and the DMA instruction.  All inline assembly on purpose: the compiler must neither reorder its own
+// LDS accesses across them ("memory") nor learn about the DMA (it would put vmcnt(0) in front of every LDS read).
+__device__ __forceinline__ unsigned long long lds_ld64(unsigned addr) {
+  unsigned long long v;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint4 lds_ld128(unsigned addr) {
+  uint4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_st32(unsigned addr, unsigned val) {
+  asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(val) : "memory");
+}
+__device__ __forceinline__ void dma16(const void *gp, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gp), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void *p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+// at most 3 n / 2 n DMA instructions of this wave still in flight
+template <int IPR>
+__device__ __forceinline__ void wait_rows(int n) {
+#define DI_W(N) case N: asm volatile("s_waitcnt vmcnt(%0)" : : "n"((N) * IPR > 63 ? 63 : (N) * IPR) : "memory"); break;
+  switch (n) {
+    DI_W(0) DI_W(1) DI_W(2) DI_W(3) DI_W(4) DI_W(5) DI_W(6) DI_W(7) DI_W(8) DI_W(9) DI_W(10) DI_W(11) DI_W(12) DI_W(13) DI_W(14)
+    DI_W(15) DI_W(16) DI_W(17) DI_W(18) DI_W(19) DI_W(20) DI_W(21) DI_W(22) DI_W(23) DI_W(24) DI_W(25) DI_W(26) DI_W(27)
+    DI_W(28) DI_W(29) DI_W(30)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef DI_W
+}
+
+constexpr int SPIN_LIMIT = 1 << 20;
+
+template <class G>
+__global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
+    const __half *__restrict__ q, const __half *__restrict__ k, const __half *__restrict__ v,
+    __half *__restrict__ out, int n, int H, int W, float scale, int tiles_x, int tiles_y) {
+  extern __shared__ __align__(1024) unsigned char lds[];
+  constexpr int ROWB = G::ROWB, S = G::S, HR = G::HR;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = lds_addr_of(lds);
+  const unsigned f_landed = lds0 + G::RING, f_done = lds0 + G::RING + 32;
+
+  // ---- tiles: XCD x (workgroups with blockIdx % 8 == x share an L2) owns the contiguous range [T*x/8, T*(x+1)/8) and
+  // walks it `gxw` tiles per round
+  const int per_img = tiles_x * tiles_y, ntiles = n * per_img;
+  const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+  const int gxw = ((int)gridDim.x - xcd + 7) >> 3;
+  const int t_end = (int)(((long long)ntiles * (xcd + 1)) >> 3);
+  const int tile0 = (int)(((long long)ntiles * xcd) >> 3) + wl;
+  if (tile0 >= t_end) return;
+  const int ntl = (t_end - tile0 + gxw - 1) / gxw;            // tiles of this workgroup
+
+  if (tid < 16) lds_st32(f_landed + 4 * tid, 0);             // landed[0..1] (+ padding), done[0..7]
+  __syncthreads();                                           // the only barrier of the kernel
+
+  if (wave >= G::NCW) {
+    // ------------------------------------------------------------------------------------------------ producer
+    const int p = wave - G::NCW;
+    // lane -> texel lane / 8 of the instruction's 8, LDS chunk position lane % 8 <- the global chunk that belongs there
+    const int d_t = lane >> 3, d_pos = lane & 7;
+    const int d_f = (d_t >> 1) & 3;                           // (texel / 2) % 4: 8 j + d_t has the same value for every j
+    const int d_c16 = (((d_pos >> 1) ^ d_f) << 1) | (d_pos & 1);
+    const int d_off = d_t * 256 + d_c16 * 16;
+    const unsigned char *const zsrc = reinterpret_cast<const unsigned char *>(zero_line) + d_pos * 16;
+    const int total = ntl * G::BPT * (HR / 2);                // rows of this producer
+    int min_done = 0;                                         // cached min over done[w]
+    int issued = 0, published = 0;
+    int cur_it = -1;
+    TileCoord t = {0, 0, 0};
+    auto publish = [&]() { lds_st32(f_landed + 4 * p, (unsigned)(p + 2 * published)); };
+    auto reload_done = [&]() {
+      const uint4 a = lds_ld128(f_done), b = lds_ld128(f_done + 16);
+      const unsigned m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
+      min_done = __builtin_amdgcn_readfirstlane((int)m);
+    };
+    for (int kk = 0; kk < total; ++kk) {
+      const int seq = p + 2 * kk;
+      const int B = seq / HR, r = seq - B * HR;
+      const int it = B >> 2, b = B & 3;
+      if (it != cur_it) {
+        cur_it = it;
+        t = decode_tile(tile0 + it * gxw, tiles_x, per_img, G::TH, G::TW);
+      }
+      // the slot of row seq held row seq - NSLOT: free once every consumer is past it
+      int spins = 0;
+      while (seq - G::NSLOT >= min_done) {
+        if (published < issued) {                             // let the consumers have what has landed meanwhile
+          wait_rows<G::IPR>(issued - published - 1);
+          ++published;
+          publish();
+        } else {
+          __builtin_amdgcn_s_sleep(2);
+        }
+        reload_done();
+        if (++spins > SPIN_LIMIT) {
+          if (lane == 0) atomicAdd(&timeouts, 1u);
+          break;
+        }
+      }
+      const __half *src = b < 2 ? k : v;
+      const int gy = t.y0 - 4 + r;
+      const bool y_ok = gy >= 0 && gy < H;
+      const unsigned char *base = reinterpret_cast<const unsigned char *>(src) +
+                                  ((long long)(t.img * H + gy) * W + (t.x0 - 4)) * 256 + (b & 1) * 128 + d_off;
+      const unsigned dst = lds0 + (B % G::NBLK) * G::BLKB + r * ROWB;
+#pragma unroll
+      for (int j = 0; j < G::IPR; ++j) {
+        const int gx = t.x0 - 4 + 8 * j + d_t;
+        const bool ok = y_ok && gx >= 0 && gx < W;
+        const unsigned char *gp = ok ? base + j * 2048 : zsrc;
+        dma16(gp, __builtin_amdgcn_readfirstlane(dst + j * 1024));
+      }
+      ++issued;
+      if (issued - published > G::DEPTH) {
+        wait_rows<G::IPR>(G::DEPTH);
+        published = issued - G::DEPTH;
+        publish();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no DMA may outlive the workgroup's LDS
+    published = issued;
+    publish();
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- consumer
+  const int wx = wave % G::WX, wy = wave / G::WX;
+  const int i = lane & 15, g = lane >> 4;
+  const int j = i & 7, qrow = i >> 3;
+  // ---- fragment constants (the LDS image of local_attn_mfma2.hip with 128-byte slices: 32-B segments XOR-swizzled by
+  // (texel / 2) % 4)
+  const int hcq = wx * 8 + i;                                // K fragment: key column i of the wave's 16
+  const int fq = (hcq >> 1) & 3;
+  int koff[2];
+#pragma unroll
+  for (int kl = 0; kl < 2; ++kl) koff[kl] = wy * 2 * ROWB + hcq * S + ((((kl * 4 + g) >> 1) ^ fq) << 5) + (((kl * 4 + g) & 1) << 4);
+  const int kcv = wx * 8 + 4 * g + (i >> 2);                 // V^T fragment: key column addressed by this lane
+  const int vsw = (kcv >> 1) & 3;
+  const int vbase = wy * 2 * ROWB + kcv * S + (i & 3) * 8;
+  // additive softmax masks: 0 where key c = 4g + r lies in the band of query column j (j <= c <= j + 8) and the key row
+  // belongs to the window of the query's row, -inf elsewhere
+  const float cs = scale * 1.44269504088896f;                // scores in log2 units
+  f4 nm_mid, nm_first, nm_last;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool in_band = 4 * g + r >= j && 4 * g + r <= j + 8;
+    nm_mid[r] = in_band ? 0.f : -INFINITY;
+    nm_first[r] = (in_band && qrow == 0) ? 0.f : -INFINITY;  // key row 0: only the upper query row
+    nm_last[r] = (in_band && qrow == 1) ? 0.f : -INFINITY;   // key row 9: only the lower query row
+  }
+
+  int landed0 = 0, landed1 = 0;                              // last values seen of landed[0], landed[1]
+  // rows [.., last] of the sequence are in LDS: the row `last` and the row before it belong to different producers
+  auto wait_landed = [&](int last) {
+    const int need0 = (last & 1) ? last - 1 : last, need1 = (last & 1) ? last : last - 1;
+    int spins = 0;
+    while (landed0 <= need0 || landed1 <= need1) {
+      const unsigned long long l = lds_ld64(f_landed);
+      landed0 = __builtin_amdgcn_readfirstlane((int)(unsigned)l);
+      landed1 = __builtin_amdgcn_readfirstlane((int)(unsigned)(l >> 32));
+      if (landed0 > need0 && landed1 > need1) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > SPIN_LIMIT) {
+        if (lane == 0) atomicAdd(&timeouts, 1u);
+        break;
+      }
+    }
+  };
+  auto release = [&](int seq) { lds_st32(f_done + 4 * wave, (unsigned)seq); };   // rows below `seq`: not needed by this wave
+
+  // Q^T fragments (query i, channels kk*32 + 8g .. +7) straight from global; queries beyond the map edge (ragged tiles)
+  // read a clamped texel, their results are never stored
+  h8 qf[4];
+  auto load_q = [&](const TileCoord &t) {
+    const int gy = min(t.y0 + 2 * wy + qrow, H - 1), gx = min(t.x0 + 8 * wx + j, W - 1);
+    const unsigned char *qb = reinterpret_cast<const unsigned char *>(q) + ((unsigned)((t.img * H + gy) * W + gx) << 8) + g * 16;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(qb + kk * 64));
+  };
+
+  TileCoord cur = decode_tile(tile0, tiles_x, per_img, G::TH, G::TW);
+  load_q(cur);
+  for (int it = 0; it < ntl; ++it) {
+    const bool has_next = it + 1 < ntl;
+    TileCoord nxt = cur;
+    if (has_next) nxt = decode_tile(tile0 + (it + 1) * gxw, tiles_x, per_img, G::TH, G::TW);
+    const int B0 = it * G::BPT;
+
+    // ---------------- S^T = K . Q^T over the two K blocks
+    f4 s[10];
+#pragma unroll
+    for (int rr = 0; rr < 10; ++rr) s[rr] = f4{0.f, 0.f, 0.f, 0.f};
+    static_for<0, 2>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int B = B0 + u;
+      wait_landed(B * HR + 2 * wy + 9);
+      const unsigned char *buf = lds + (B % G::NBLK) * G::BLKB;
+#pragma unroll
+      for (int kl = 0; kl < 2; ++kl) {                       // k-step outer: an accumulator's two MFMAs are 10 apart
+#pragma unroll
+        for (int rr = 0; rr < 10; ++rr) {
+          const uint4 raw = *reinterpret_cast<const uint4 *>(buf + koff[kl] + rr * ROWB);
+          s[rr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, raw), qf[u * 2 + kl], s[rr], 0, 0, 0);
+        }
+      }
+      if constexpr (G::SCHED == 1) {                         // 6 reads ahead, then one read per MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int e = 0; e < 14; ++e) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      }
+      release((B + 1) * HR + 2 * wy);
+    });
+
+    // ---------------- softmax over the 81 window slots of query i, in log2 units: y = s*cs + mask
+    h8 pf[5];
+    float sum;
+    {
+      float m = -INFINITY;
+#pragma unroll
+      for (int rr = 0; rr < 10; ++rr) {
+        const f4 nm = rr == 0 ? nm_first : (rr == 9 ? nm_last : nm_mid);
+        s[rr] = s[rr] * cs + nm;
+        m = fmaxf(m, fmaxf(fmaxf(s[rr][0], s[rr][1]), fmaxf(s[rr][2], s[rr][3])));
+      }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      f2 sum2 = {0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < 5; ++pr) {
+        h8 pk;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f4 d = s[2 * pr + t] - m;
+          f4 e;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(d[r]);   // masked slots: exp2(-inf) = 0
+          sum2 += f2{e[0], e[1]} + f2{e[2], e[3]};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[4 * t + r] = (_Float16)e[r];
+        }
+        pf[pr] = pk;
+      }
+      sum = sum2[0] + sum2[1];
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+    }
+    if (has_next) load_q(nxt);                               // qf is dead until the next tile's first block
+
+    // ---------------- O^T = V^T . P^T over the two V blocks, each block finishes 64 output channels
+    const float inv = 1.f / sum;
+    const int gy = cur.y0 + 2 * wy + qrow, gx = cur.x0 + 8 * wx + j;
+    const bool pix_ok = gy < H && gx < W;
+    __half *dst = out + ((long long)(cur.img * H + gy) * W + gx) * 128 + 4 * g;
+    static_for<0, 2>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int B = B0 + 2 + u;
+      wait_landed(B * HR + 2 * wy + 9);
+      const unsigned char *buf = lds + (B % G::NBLK) * G::BLKB;
+      f4 acc[4];
+#pragma unroll
+      for (int nl = 0; nl < 4; ++nl) acc[nl] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pr = 0; pr < 5; ++pr) {
+#pragma unroll
+        for (int nl = 0; nl < 4; ++nl) {
+          const unsigned char *p0 = buf + vbase + ((nl ^ vsw) << 5) + 2 * pr * ROWB;
+          const hv4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(p0));
+          const hv4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(p0 + ROWB));
+          h8 a;
+          a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3];
+          a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+          acc[nl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[pr], acc[nl], 0, 0, 0);
+        }
+      }
+      if constexpr (G::SCHED == 1) {                         // 8 transposed reads ahead, then two per MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      }
+      release((B + 1) * HR + 2 * wy);
+      if (pix_ok) {
+#pragma unroll
+        for (int nl = 0; nl < 4; ++nl) {
+          const f4 o = acc[nl] * inv;
+          h4 ov;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = (_Float16)o[r];
+          *reinterpret_cast<h4 *>(dst + u * 64 + 16 * nl) = ov;
+        }
+      }
+    });
+    cur = nxt;
+  }
+}
+
+template <class G>
+static int launch(const void *q, const void *k, const void *v, void *out, int n, int H, int W, float scale,
+                  hipStream_t stream) {
+  const int tiles_x = (W + G::TW - 1) / G::TW, tiles_y = (H + G::TH - 1) / G::TH;
+  const long long ntiles = (long long)n * tiles_x * tiles_y;
+  DI_REQUIRE((long long)n * H * W * 256 < (1ll << 31), "map of %d x %d x %d texels exceeds the 2 GiB offset range", n, H, W);
+  static LdsRaised lds_raised;
+  if (int rc = ensure_lds(lds_raised, (const void *)local_attn_ring_kernel<G>, G::LDS_BYTES)) return rc;
+  const int n_cu = device_cus();
+  if (n_cu <= 0) return DI_ERR_LAUNCH;
+  long long grid = n_cu;                                     // one workgroup per CU, a multiple of the 8 XCDs
+  if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
+  static const int grid_env = getenv("DI_LA_GRID") ? atoi(getenv("DI_LA_GRID")) : 0;
+  if (grid_env > 0 && grid_env < grid) grid = grid_env / 8 * 8;
+  hipLaunchKernelGGL(local_attn_ring_kernel<G>, dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, stream,
+                     (const __half *)q, (const __half *)k, (const __half *)v, (__half *)out, n, H, W, scale, tiles_x,
+                     tiles_y);
+  return check_launch("local_attn_ring");
+}
+
+}  // namespace ring
+
+// cfg 0: 16 x 8 query tiles (halo 24 x 16);  cfg 1: 8 x 16 tiles (halo 16 x 24: 112 x 200 maps leave no ragged tile);
+// + 2: the same with the LDS fragment reads interleaved with the MFMAs by sched_group_barrier
+int launch_local_attn_ring(const void *q, const void *k, const void *v, void *out, int n, int H, int W, float scale,
+                           int cfg, hipStream_t stream) {
+  switch (cfg) {
+    case 0: return ring::launch<ring::Cfg<2, 4>>(q, k, v, out, n, H, W, scale, stream);
+    case 1: return ring::launch<ring::Cfg<1, 8>>(q, k, v, out, n, H, W, scale, stream);
+    case 2: return ring::launch<ring::Cfg<2, 4, 1>>(q, k, v, out, n, H, W, scale, stream);
+    case 3: return ring::launch<ring::Cfg<1, 8, 1>>(q, k, v, out, n, H, W, scale, stream);
+  }
+  set_error("unknown local_attn_ring configuration %d", cfg);
+  return DI_ERR_ARG;
+}
+
+// bounded spins that gave up since the library was loaded (tests: must stay 0)
+int ring_timeouts(unsigned *host_out, hipStream_t stream) {
+  unsigned *dev = nullptr;
+  if (hipGetSymbolAddress((void **)&dev, HIP_SYMBOL(ring::timeouts)) != hipSuccess) return DI_ERR_LAUNCH;
+  if (hipMemcpyAsync(host_out, dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess) return DI_ERR_LAUNCH;
+  return hipStreamSynchronize(stream) == hipSuccess ? DI_OK : DI_ERR_LAUNCH;
+}
+
+}  // namespace di

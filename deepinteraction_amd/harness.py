@@ -8,6 +8,7 @@ from . import synth
 from .configs import decoder_cfg
 
 SHAPES = dict(R=synth.SHAPE_R, A=synth.SHAPE_A, TINY=synth.SHAPE_TINY)
+SHAPES_PP = dict(R=synth.SHAPE_PP, A=synth.SHAPE_PP, TINY=synth.SHAPE_PP_TINY)
 
 
 def randomize_bn(mods, seed=5):
@@ -36,6 +37,34 @@ def build_models(shape, num_proposals, dtype, device, seed=1234, train_cfg=None,
     return enc.eval(), dec.eval()
 
 
+def condition_head(dec, branch=0.5, cross=None):
+    """In place: make the random-init head a CONDITIONED one, for the parity tests that separate the kernels' error from
+    the head's amplification of its input error.
+
+    With random-init weights every RoI block of the MMPI chain (box -> RoI -> DynamicConv -> box, 4 blocks) multiplies a
+    perturbation of its inputs by 2-3 (oracle, tests/tools/conditioned_head.py: an exact float32 encoder whose three maps
+    are rounded ONCE to fp16 - the least any fp16-map implementation can do - already moves the last block's `dim` by
+    3.7e-3 of its scale; per block the p99.9 goes 1e-4 -> 2e-4 -> 9e-4 -> 2.8e-3).  `branch` scales the three residual
+    branches of every RoI block (self-attention out_proj, DynamicConv's final LayerNorm, the FFN's second Linear): with
+    0.5 the refinement is a perturbation of the residual stream, as in a trained head, and the same input error stays
+    below 1e-3.  `cross` (optional) scales the q / k projections of the decoder layer's cross attention (logits |s| ~ 500 as
+    initialised); it turned out NOT to be what sets the tail."""
+    with torch.no_grad():
+        for l, blk in enumerate(dec.decode_head):
+            sfx = '' if l % 2 == 0 else '_pts'
+            g = lambda n: getattr(blk, n + sfx)
+            for t in (g('dyconv').norm3.weight, g('dyconv').norm3.bias, g('linear2').weight, g('linear2').bias,
+                      g('dyconv_pre_self_attn').out_proj.weight, g('dyconv_pre_self_attn').out_proj.bias):
+                t.mul_(branch)
+        if cross is not None:
+            for layer in dec.decoder:
+                mha = layer.multihead_attn
+                E = mha.embed_dim
+                mha.in_proj_weight[:2 * E].mul_(cross)
+                mha.in_proj_bias[:2 * E].mul_(cross)
+    return dec
+
+
 def to_device(inp, device, dtype):
     """A `synth.make_inputs` batch on `device`: channels-last feature maps in `dtype`, points / pillars as they are."""
     pm = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
@@ -49,3 +78,34 @@ def forward(enc, dec, d):
     """One eager forward of the hot path; returns (encoder outputs, decoder output)."""
     img, pts = enc(d['img_feats'], d['pts_feats'], d['img_metas'], dict(d['pts_metas']))
     return (img, pts), dec(pts, img, d['img_metas'])
+
+
+def build_models_pp(shape, num_proposals, dtype, device, seed=0, num_layers=2):
+    """(FusionTransformerv4, DeepInteractionPlusPlusDecoder) of Fusion_0075_plusplus.py:210-303 (BASELINE.json configs[4])
+    at `shape`, eval mode, random init - with the sampling-offset / attention-weight Linears moved off mmcv's zero init so
+    that the deformable samples are spread.  dtype float16 = the mixed mode of `precision.half_maps_`: fp16 neck and
+    heat-map heads, float32 token path in the head."""
+    from .configs import encoder_pp_cfg
+    from .mmdet3d_plugin import DeepInteractionPlusPlusDecoder, FusionTransformerv4
+    torch.manual_seed(seed)
+    enc = FusionTransformerv4(**encoder_pp_cfg(shape['c_img'], shape['c_pts'], num_layers))
+    dec = DeepInteractionPlusPlusDecoder(**decoder_cfg(bev=shape['bev_hw'][0], num_proposals=num_proposals))
+    randomize_bn([enc, dec])
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in enc.modules():
+            if hasattr(m, 'sampling_offsets'):
+                for lin in (m.sampling_offsets, m.attention_weights):
+                    lin.weight.add_(torch.randn(lin.weight.shape, generator=gen) * 0.05)
+    from .precision import to_inference
+    enc, dec = to_inference(enc.to(device), dec.to(device), dtype)
+    return enc.eval(), dec.eval()
+
+
+def to_device_pp(inp, device, dtype):
+    """A `synth.make_inputs_pp` batch on `device`: channels-last lists of levels in `dtype`."""
+    cl = lambda t: t.to(device, dtype).contiguous(memory_format=torch.channels_last)
+    pm = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
+    pm['pts'] = [p.to(device) for p in inp['pts_metas']['pts']]
+    return dict(img_feats=[cl(f) for f in inp['img_feats']], pts_feats=[cl(f) for f in inp['pts_feats']],
+                img_metas=inp['img_metas'], pts_metas=pm)

@@ -75,6 +75,7 @@ def _f32(t):
 LA_AUTO, LA_VALU = 0, 1
 LA_MFMA = 3           # + configuration 0..4 of the persistent pipelined row-pair kernel (1 = 8x8 tiles)
 LA_DMA = 16           # + 0 / 1: the LDS-DMA generation at three / two workgroups per CU; + 2: producer / consumer waves
+LA_RING = 24          # + 0 / 1: the ring generation (one workgroup per CU, flag-synchronised), 16x8 / 8x16 tiles; + 2 / 3: hand-interleaved reads
 
 
 def local_attention(q, k, v, kH, kW, scale, variant=LA_AUTO):

@@ -69,9 +69,16 @@ int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, in
 enum { DI_LA_AUTO = 0, DI_LA_VALU = 1,
        DI_LA_MFMA = 3 /* + configuration: 3 = 16x8 tiles, 4 = 8x8 tiles, 5 = 16x4 tiles, 6 = 8x16 tiles, 7 = timestamps */,
        DI_LA_DMA = 16 /* local_attn_mfma3.hip (halo and queries by LDS-DMA, 16 KB units): + 0 / 1 = three / two
-                         workgroups per CU, + 2 = producer / consumer wavefronts */ };
+                         workgroups per CU, + 2 = producer / consumer wavefronts */,
+       DI_LA_RING = 24 /* local_attn_ring.hip (one workgroup per CU, 144 KB ring of 128-byte halo rows filled by two producer
+                          wavefronts, eight consumer wavefronts synchronised by LDS flag words, no workgroup barrier):
+                          + 0 = 16x8 query tiles, + 1 = 8x16, + 2 / + 3 = the same with hand-interleaved fragment reads */ };
 int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                          int C, int kH, int kW, float scale, int dtype, int variant, void *stream);
+/* The DI_LA_RING kernel bounds every flag spin; a pipeline that gave up produced wrong results instead of hanging the
+ * device.  Returns the number of spins that gave up since the library was loaded (0 on a healthy run; synchronises
+ * `stream`), -1 on a HIP error. */
+int di_local_attn_ring_timeouts(void *stream);
 
 /* The five entry points of locatt_ops (localAttention.h:11-40), channels-last features,
  * float32 window tensors of shape (n,H,W,kH*kW):

@@ -63,6 +63,34 @@ def oracle_encoder(E, inputs, fp16_inputs=False):
     return dict(img=img, pts_conv=p0, pts=p1, seconds=time.time() - t0)
 
 
+def build_oracle_pp(shape, num_proposals, state, round_fp16=False, num_layers=2):
+    """Oracle DeepInteraction++ neck + head (fp32, CPU, eval) holding `state` = (neck state_dict, head state_dict) of the
+    product (reference `necks/fusion_transformerv4.py:26-127`, `dense_heads/deepinteractionplusplus_decoder.py:20-320`,
+    kwargs of `Fusion_0075_plusplus.py:210-303`).  round_fp16='maps': the parameters the product's fp16 mode holds in fp16
+    (the whole neck and the two heat-map heads) are rounded through fp16 - the comparison that isolates the arithmetic."""
+    from . import plusplus as opp
+    E = opp.FusionTransformerv4(**configs.encoder_pp_cfg(shape['c_img'], shape['c_pts'], num_layers))
+    D = opp.DeepInteractionPlusPlusDecoder(**configs.decoder_cfg(bev=shape['bev_hw'][0], num_proposals=num_proposals))
+    E.load_state_dict({k: v.detach().float().cpu() for k, v in state[0].items()})
+    D.load_state_dict({k: v.detach().float().cpu() for k, v in state[1].items()})
+    if round_fp16:
+        mods = (E, D) if round_fp16 is True else (E, D.heatmap_head, D.heatmap_head_img)
+        for m in mods:
+            for t in list(m.parameters()) + list(m.buffers()):
+                if t.is_floating_point():
+                    t.data = t.data.half().float()
+    return E.eval(), D.eval()
+
+
+def oracle_encoder_pp(E, inputs):
+    """The ++ neck on a `synth.make_inputs_pp` batch (lists of levels)."""
+    t0 = time.time()
+    with torch.no_grad():
+        img, (p0, p1) = E([f.float().cpu() for f in inputs['img_feats']], [f.float().cpu() for f in inputs['pts_feats']],
+                          inputs['img_metas'], inputs['pts_metas'])
+    return dict(img=img, pts_conv=p0, pts=p1, seconds=time.time() - t0)
+
+
 def oracle_decoder(D, enc, img_metas, top_override=None):
     t0 = time.time()
     with torch.no_grad():

@@ -49,7 +49,8 @@ _VARIANT_CASES = {}
 
 
 @pytest.mark.parametrize('variant', [ops.LA_AUTO, ops.LA_VALU, ops.LA_MFMA, ops.LA_MFMA + 1, ops.LA_MFMA + 2, ops.LA_MFMA + 3,
-                                     ops.LA_DMA, ops.LA_DMA + 1, ops.LA_DMA + 2])
+                                     ops.LA_DMA, ops.LA_DMA + 1, ops.LA_DMA + 2,
+                                     ops.LA_RING, ops.LA_RING + 1, ops.LA_RING + 2, ops.LA_RING + 3])
 @pytest.mark.parametrize('shape', [(2, 13, 37), (1, 4, 16), (3, 9, 200), (1, 180, 180), (1, 1, 5), (6, 112, 200)])
 def test_local_attention_fp16_kernel_variants(variant, shape):
     """Both fp16 kernels of the fused op (LDS-tiled VALU; banded 16x16x32 MFMA) against the
@@ -72,6 +73,27 @@ def test_local_attention_fp16_kernel_variants(variant, shape):
     out = ops.local_attention(qd, kd, vd, 9, 9, 1.0 / math.sqrt(C), variant=variant).float().cpu()
     err = (out - ref).abs().max().item()
     assert err <= 1e-3 * max(ref.abs().max().item(), 1.0), err
+
+
+@pytest.mark.parametrize('shape', [(2, 13, 37), (1, 4, 16), (3, 9, 200), (1, 180, 180), (1, 1, 5), (6, 112, 200), (2, 61, 95)])
+def test_local_attention_ring_is_bit_identical_to_the_register_staged_kernel(shape):
+    """The ring generation (LDS-DMA rows, flag-synchronised producer / consumer wavefronts) computes the second
+    generation's arithmetic in the same order: identical bits, on ragged / tiny / full-size maps, launched several times
+    back to back (the flag protocol has no state across launches), and no bounded spin ever gave up."""
+    _require_gpu()
+    from deepinteraction_amd import _lib
+    n, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(n, 128, H, W, generator=g).relu().half().to(DEV).contiguous(memory_format=torch.channels_last)
+               for _ in range(3))
+    sc = 1.0 / math.sqrt(128)
+    ref = ops.local_attention(q, k, v, 9, 9, sc, variant=ops.LA_MFMA + 1)
+    for var in range(ops.LA_RING, ops.LA_RING + 4):
+        for rep in range(3):
+            out = ops.local_attention(q, k, v, 9, 9, sc, variant=var)
+            assert torch.equal(out, ref), (var, rep, (out.float() - ref.float()).abs().max().item())
+    torch.cuda.synchronize()
+    assert _lib.lib().di_local_attn_ring_timeouts(None) == 0
 
 
 def test_local_attention_mfma_rejects_unsupported():
