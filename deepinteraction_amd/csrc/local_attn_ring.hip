@@ -39,20 +39,20 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __attribute__((aligned(128))) unsigned int zero_line[32];   // what a texel outside the map reads (128 B)
 __device__ unsigned int timeouts;                                       // bounded spins that gave up (0 on a healthy run)
 
-template <int WX_, int WY_, int SCHED_ = 0>
+template <int WX_, int WY_, int SCHED_ = 0, int NPW_ = 2>
 struct Cfg {
   static constexpr int WX = WX_, WY = WY_;
   static constexpr int SCHED = SCHED_;                 // 1: LDS fragment reads interleaved with the MFMAs by sched_group_barrier
-  static constexpr int NCW = WX * WY, NPW = 2, NT = (NCW + NPW) * 64;
+  static constexpr int NCW = WX * WY, NPW = NPW_, NT = (NCW + NPW) * 64;   // consumer / producer wavefronts
   static constexpr int TW = 8 * WX, TH = 2 * WY, HC = TW + 8, HR = TH + 8;
   static constexpr int S = 128;                        // bytes of a texel slice (64 channels)
   static constexpr int ROWB = HC * S, IPR = ROWB / 1024;   // one DMA instruction = 8 texels
   static constexpr int BLKB = HR * ROWB, NBLK = 3, NSLOT = NBLK * HR;
   static constexpr int BPT = 4;                        // blocks per tile: K lo, K hi, V lo, V hi
   static constexpr int RING = NBLK * BLKB;
-  static constexpr int LDS_BYTES = RING + 64;          // + landed[2] at RING, done[8] at RING + 32
+  static constexpr int LDS_BYTES = RING + 64;          // + landed[NPW <= 8] at RING, done[8] at RING + 32
   static constexpr int DEPTH = 60 / IPR;               // rows a producer may have unpublished (vmcnt is 6 bits)
-  static_assert(NCW == 8 && HR % 2 == 0 && HC % 8 == 0 && LDS_BYTES <= 160 * 1024, "ring geometry");
+  static_assert(NCW == 8 && HR % NPW == 0 && NPW <= 8 && HC % 8 == 0 && LDS_BYTES <= 160 * 1024, "ring geometry");
 };
 
 template <int B, int E, class F>
@@ -145,19 +145,19 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     const int d_c16 = (((d_pos >> 1) ^ d_f) << 1) | (d_pos & 1);
     const int d_off = d_t * 256 + d_c16 * 16;
     const unsigned char *const zsrc = reinterpret_cast<const unsigned char *>(zero_line) + d_pos * 16;
-    const int total = ntl * G::BPT * (HR / 2);                // rows of this producer
+    const int total = ntl * G::BPT * (HR / G::NPW);           // rows of this producer: sequence numbers p, p + NPW, ...
     int min_done = 0;                                         // cached min over done[w]
     int issued = 0, published = 0;
     int cur_it = -1;
     TileCoord t = {0, 0, 0};
-    auto publish = [&]() { lds_st32(f_landed + 4 * p, (unsigned)(p + 2 * published)); };
+    auto publish = [&]() { lds_st32(f_landed + 4 * p, (unsigned)(p + G::NPW * published)); };
     auto reload_done = [&]() {
       const uint4 a = lds_ld128(f_done), b = lds_ld128(f_done + 16);
       const unsigned m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
       min_done = __builtin_amdgcn_readfirstlane((int)m);
     };
     for (int kk = 0; kk < total; ++kk) {
-      const int seq = p + 2 * kk;
+      const int seq = p + G::NPW * kk;
       const int B = seq / HR, r = seq - B * HR;
       const int it = B >> 2, b = B & 3;
       if (it != cur_it) {
@@ -232,16 +232,29 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     nm_last[r] = (in_band && qrow == 1) ? 0.f : -INFINITY;   // key row 9: only the lower query row
   }
 
-  int landed0 = 0, landed1 = 0;                              // last values seen of landed[0], landed[1]
-  // rows [.., last] of the sequence are in LDS: the row `last` and the row before it belong to different producers
+  // rows [.., last] of the sequence are in LDS: producer p has published a count above the last of ITS rows <= last
+  int seen = 0;                                              // rows [.., seen) are known to have landed
   auto wait_landed = [&](int last) {
-    const int need0 = (last & 1) ? last - 1 : last, need1 = (last & 1) ? last : last - 1;
     int spins = 0;
-    while (landed0 <= need0 || landed1 <= need1) {
-      const unsigned long long l = lds_ld64(f_landed);
-      landed0 = __builtin_amdgcn_readfirstlane((int)(unsigned)l);
-      landed1 = __builtin_amdgcn_readfirstlane((int)(unsigned)(l >> 32));
-      if (landed0 > need0 && landed1 > need1) break;
+    while (seen <= last) {
+      unsigned l[8];
+      if constexpr (G::NPW == 2) {
+        const unsigned long long v2 = lds_ld64(f_landed);
+        l[0] = (unsigned)v2, l[1] = (unsigned)(v2 >> 32);
+      } else {
+        const uint4 a = lds_ld128(f_landed);
+        l[0] = a.x, l[1] = a.y, l[2] = a.z, l[3] = a.w;
+        if constexpr (G::NPW == 8) {
+          const uint4 b = lds_ld128(f_landed + 16);
+          l[4] = b.x, l[5] = b.y, l[6] = b.z, l[7] = b.w;
+        }
+      }
+      // producer p: all its rows below l[p] are in; the first row of p NOT known to be in is l[p] (= p mod NPW)
+      unsigned m = l[0];
+#pragma unroll
+      for (int pp = 1; pp < G::NPW; ++pp) m = min(m, l[pp]);
+      seen = __builtin_amdgcn_readfirstlane((int)m);
+      if (seen > last) break;
       __builtin_amdgcn_s_sleep(1);
       if (++spins > SPIN_LIMIT) {
         if (lane == 0) atomicAdd(&timeouts, 1u);
@@ -415,6 +428,9 @@ int launch_local_attn_ring(const void *q, const void *k, const void *v, void *ou
     case 1: return ring::launch<ring::Cfg<1, 8>>(q, k, v, out, n, H, W, scale, stream);
     case 2: return ring::launch<ring::Cfg<2, 4, 1>>(q, k, v, out, n, H, W, scale, stream);
     case 3: return ring::launch<ring::Cfg<1, 8, 1>>(q, k, v, out, n, H, W, scale, stream);
+    case 4: return ring::launch<ring::Cfg<2, 4, 1, 4>>(q, k, v, out, n, H, W, scale, stream);   // four producer wavefronts
+    case 5: return ring::launch<ring::Cfg<2, 4, 1, 8>>(q, k, v, out, n, H, W, scale, stream);   // eight
+    case 6: return ring::launch<ring::Cfg<1, 8, 1, 8>>(q, k, v, out, n, H, W, scale, stream);
   }
   set_error("unknown local_attn_ring configuration %d", cfg);
   return DI_ERR_ARG;

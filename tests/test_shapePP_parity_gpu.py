@@ -84,23 +84,26 @@ def _check_fp32(name, es, ds):
         assert s['max'] <= 2e-3, (name, k, s)
 
 
-# fp16 bounds: filled in from the measured report (profiles/r04_parity_shapePP.json), see DESIGN.md section 10
-FP16_ENC = dict(median=2e-3, p999=2e-2, frac_gt_1e2=5e-3)
-FP16_DEC = dict(median=1e-3, p999=2e-2, frac_gt_1e2=1e-2)
+# fp16 bounds = the measured floor (profiles/r04_parity_shapePP.json) with 2x head-room.  Measured:
+# neck maps median 7-9e-5, p99.9 5.9-6.3e-4, max 1.2-1.5e-3 of the map's range (fp16 storage of ~30 stacked maps; the
+# LayerNorm-ed token maps are O(1) so 2^-11 per store is 5e-4 of the range), nothing beyond 1e-2; head (float32 token
+# path on the fp16 maps) median 0.5-1.1e-4, p99.9 4-11e-4, max 1.2e-3.  Round 3 asserted 3e-2 with 0.2 % outliers at TINY.
+FP16_ENC = dict(median=2e-4, p999=1.5e-3, frac_gt_1e2=0.0)
+FP16_DEC = dict(median=2.5e-4, p999=2.5e-3, frac_gt_1e2=0.0)
 
 
 def _check_fp16(name, es, ds):
     for k, s in es.items():
-        assert s['median'] <= FP16_ENC['median'] and s['p999'] <= FP16_ENC['p999'] and \
+        assert s['median'] <= FP16_ENC['median'] and s['p999'] <= FP16_ENC['p999'] and s['max'] <= 5e-3 and \
             s['frac_gt_1e2'] <= FP16_ENC['frac_gt_1e2'], (name, k, s)
-    assert ds['proposal_set_overlap'] >= 0.98, (name, ds['proposal_set_overlap'])
+    assert ds['proposal_set_overlap'] >= 0.99, (name, ds['proposal_set_overlap'])
     assert ds['labels_equal_on_same_proposals']
-    assert all(m >= 0.99 for m in ds['mask_agreement']), (name, ds['mask_agreement'])
+    assert all(m >= 0.995 for m in ds['mask_agreement']), (name, ds['mask_agreement'])
     for k, s in ds['keys'].items():
         if k == 'query_heatmap_score':           # a score is 0 or the heat value: an NMS near-tie flips it whole
             assert s['frac_gt_1e3'] <= 2e-2, (name, k, s)
             continue
-        assert s['median'] <= FP16_DEC['median'] and s['p999'] <= FP16_DEC['p999'] and \
+        assert s['median'] <= FP16_DEC['median'] and s['p999'] <= FP16_DEC['p999'] and s['max'] <= 5e-3 and \
             s['frac_gt_1e2'] <= FP16_DEC['frac_gt_1e2'], (name, k, s)
 
 
@@ -121,7 +124,8 @@ def test_fp16_eager(ctx):
     ds = parity.compare_decoder(out, labels, masks, top, ctx['free'], forced)
     # the head alone: the oracle head on the PRODUCT's fp16 neck outputs and proposals (what the fp16 neck costs the
     # head is the difference between this and the row above)
-    own = dict(img=got_enc[0].float().cpu(), pts_conv=got_enc[1][0].float().cpu(), pts=got_enc[1][1].float().cpu())
+    nchw = lambda t: t.float().cpu().contiguous()            # (the product's maps are channels-last)
+    own = dict(img=nchw(got_enc[0]), pts_conv=nchw(got_enc[1][0]), pts=nchw(got_enc[1][1]))
     forced_own = parity.oracle_decoder(ctx['D'], own, ctx['inp']['img_metas'], top_override=top.cpu())
     hs = parity.compare_decoder(out, labels, masks, top, forced_own, forced_own)
     _report('fp16_eager_B1_Q200', dict(encoder=es, decoder=ds, head_on_product_maps=hs))

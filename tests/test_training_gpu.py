@@ -301,6 +301,62 @@ def test_training_step_gradients_match_oracle(inject_depth):
             assert p.grad is None or torch.isfinite(p.grad).all(), name
 
 
+def test_encoder_gradients_at_shape_R_match_reference_golden():
+    """Gradient parity at the BENCHED shape (BASELINE.json configs[2]: Fusion_0075_refactor shape R, 2 interaction
+    layers): the product's backward - fused-window-attention entry points, pillar-attention / BEV-gather scatter kernels,
+    every 1x1 and 3x3 weight gradient - against gradients the REFERENCE'S OWN Python produced for the same seeded inputs,
+    weights and linear functional (tests/golden/grad_shapeR.npz, oracle/refpin/make_golden_grad_shapeR.py; eval-mode
+    BatchNorm).  Compared on the stored strided samples: the bulk within 5e-4 of each tensor's gradient scale, <= 1 % of
+    the entries beyond it (a projected point within float round-off of a texel boundary moves its bilinear corner),
+    none beyond 5 %, absolute sums within 1e-3."""
+    import os
+
+    import numpy as np
+    from deepinteraction_amd.mmdet3d_plugin import DeepInteractionEncoder
+    from oracle.refpin import make_golden_grad_shapeR as gg
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+    torch.backends.cudnn.deterministic = True
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'grad_shapeR.npz'))
+    inp = gg.case()
+    M = DeepInteractionEncoder(num_layers=2, in_channels_img=gg.SHAPE['c_img'], in_channels_pts=gg.SHAPE['c_pts'],
+                               hidden_channel=128)
+    mg.randomize(M, gg.SEED_WEIGHTS)
+    M = M.to(DEV).eval()
+    pm = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
+    pm['pts'] = [p.to(DEV) for p in inp['pts_metas']['pts']]
+    img = inp['img_feats'].to(DEV).requires_grad_(True)
+    pts = inp['pts_feats'].to(DEV).requires_grad_(True)
+    im, (p0, p1) = M(img, pts, inp['img_metas'], pm)
+    # forward first: the three outputs against the reference's (samples)
+    for name, t in (('out_img', im), ('out_pts_conv', p0), ('out_pts', p1)):
+        s, a, m = gg.sample(t)
+        d = np.abs(s - gold[name + '.sample'])
+        assert d.max() <= 2e-4 * max(1.0, float(gold[name + '.absmax'])), (name, d.max())
+    gg.functional((im, p0, p1), DEV).backward()
+    torch.cuda.synchronize()
+    got = dict([('d_img_feats', img.grad), ('d_pts_feats', pts.grad)] +
+               [('p.' + n, p.grad) for n, p in M.named_parameters() if p.grad is not None])
+    names = sorted(k[:-len('.sample')] for k in gold.files if k.endswith('.sample') and not k.startswith('out_'))
+    assert len(names) > 60 and set(names) <= set(got), set(names) - set(got)
+    worst = {}
+    for name in names:
+        s, a, m = gg.sample(got[name])
+        ref, scale = gold[name + '.sample'], float(gold[name + '.absmax'])
+        if scale < 1e-7:
+            continue
+        d = np.abs(s - ref)
+        bad = float((d > 5e-4 * scale + 2e-4).mean())
+        worst[name] = (bad, float(d.max() / scale))
+        assert bad <= 1e-2, (name, bad, d.max(), scale)
+        assert d.max() <= 5e-2 * scale + 2e-4, (name, d.max(), scale)
+        assert abs(float(a) - float(gold[name + '.abssum'])) <= 1e-3 * float(gold[name + '.abssum']) + 1e-3, name
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    import json
+    with open(os.path.join(out, 'grad_parity_shapeR.json'), 'w') as f:
+        json.dump({k: dict(frac_beyond_5e4=v[0], max_rel=v[1]) for k, v in worst.items()}, f, indent=1)
+
+
 def test_full_training_step_with_loss():
     """Forward (train mode, dropout on) -> head.loss against ground truth -> backward -> one SGD step, all on
     the HIP path: every trainable parameter gets a finite gradient and the loss goes down."""
