@@ -18,6 +18,8 @@
 //     so the (n,H,W,81) weight tensor of the reference never touches HBM.
 //   * fp32 accumulation for both element types (v_dot2_f32_f16 for fp16).
 //   * block->tile map is XCD-aware (neighbouring tiles share halos in one L2).
+#include <stdlib.h>
+
 #include "di_common.h"
 
 namespace di {
@@ -367,11 +369,10 @@ int launch_local_attn_mfma(const void *q, const void *k, const void *v, void *ou
                            float scale, hipStream_t stream);   // local_attn_mfma.hip
 int launch_local_attn_mfma2(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                             float scale, int cfg, hipStream_t stream);   // local_attn_mfma2.hip
-int launch_local_attn_mfma3(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
-                            float scale, int cfg, hipStream_t stream);   // local_attn_mfma3.hip
 int launch_local_attn_ring(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                            float scale, int cfg, hipStream_t stream);    // local_attn_ring.hip
 int ring_timeouts(unsigned *host_out, hipStream_t stream);
+int ring_stamps(unsigned long long *host_out, hipStream_t stream);
 
 static int run_la(LaOp op, int dtype, int kH, int kW, const LaArgs &A) {
   DI_REQUIRE(A.n > 0 && A.H > 0 && A.W > 0, "empty feature map n=%d H=%d W=%d", A.n, A.H, A.W);
@@ -393,6 +394,10 @@ int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out,
   di::LaArgs A{q, k, v, out, n, H, W, C, scale, (hipStream_t)stream};
   const bool mfma_ok = dtype == DI_F16 && C == 128 && kH == 9 && kW == 9 && n > 0 && H > 0 && W > 0 &&
                        (long long)n * H * W * 256 < (1ll << 31);   // 32-bit byte offsets inside the kernel
+  if (mfma_ok && variant == DI_LA_AUTO) {
+    static const int auto_env = getenv("DI_LA_AUTO") ? atoi(getenv("DI_LA_AUTO")) : 0;   // measurement: what AUTO launches
+    if (auto_env > 0) variant = auto_env;
+  }
   if (variant >= DI_LA_MFMA && variant < DI_LA_MFMA + 5) {
     if (!mfma_ok) {
       di::set_error("MFMA local attention needs fp16, C=128, 9x9, < 2^23 pixels (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
@@ -400,23 +405,27 @@ int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out,
     }
     return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, variant - DI_LA_MFMA, (hipStream_t)stream);
   }
-  if (variant >= DI_LA_DMA && variant < DI_LA_DMA + 3) {
-    if (!mfma_ok) {
-      di::set_error("MFMA local attention needs fp16, C=128, 9x9, < 2^23 pixels (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
-      return DI_ERR_ARG;
-    }
-    return di::launch_local_attn_mfma3(q, k, v, out, n, H, W, scale, variant - DI_LA_DMA, (hipStream_t)stream);
-  }
-  if (variant >= DI_LA_RING && variant < DI_LA_RING + 7) {
+  if (variant >= DI_LA_RING && variant < DI_LA_RING + 5) {
     if (!mfma_ok) {
       di::set_error("MFMA local attention needs fp16, C=128, 9x9, < 2^23 pixels (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
       return DI_ERR_ARG;
     }
     return di::launch_local_attn_ring(q, k, v, out, n, H, W, scale, variant - DI_LA_RING, (hipStream_t)stream);
   }
-  if (mfma_ok && variant == DI_LA_AUTO)   // fastest measured (round 3, cold inputs): 8x8 tiles, 2 workgroups per CU: 39.6 us against
-    return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, 1, (hipStream_t)stream);   // 42.9 for 16x4 (image side)
+  if (mfma_ok && variant == DI_LA_AUTO) {
+    // Round 4, cold inputs, 6 x 112 x 200: the ring generation 37.1-38.8 us against 40.0-40.5 for the register-staged second
+    // generation (8 x 8 tiles, 2 workgroups per CU); inside the forward both take ~40 us per image-side launch, the ring form
+    // gives the better step (953.6 against 947.9 samples/s, one sample at a time 1.415 against 1.452 ms).  Maps with fewer
+    // than two 16 x 8 tiles per CU (the 180 x 180 BEV map: 276 tiles) stay on the second generation (16.0 against 16.3 us).
+    const long long ring_tiles = (long long)n * ((W + 15) / 16) * ((H + 7) / 8);
+    if (ring_tiles >= 2 * 256) return di::launch_local_attn_ring(q, k, v, out, n, H, W, scale, 0, (hipStream_t)stream);
+    return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, 1, (hipStream_t)stream);
+  }
   return di::run_la(di::OP_FUSED, dtype, kH, kW, A);
+}
+
+int di_local_attn_ring_stamps(void *host_out, void *stream) {
+  return di::ring_stamps((unsigned long long *)host_out, (hipStream_t)stream);
 }
 
 int di_local_attn_ring_timeouts(void *stream) {

@@ -5,17 +5,18 @@
 // tile latency (8.5-9 us) is a chain of dependent phases - stage a unit, barrier, 20 MFMAs per wave, barrier, ... - in which
 // a wave is idle 70 % of the time; no unit of the CU is saturated.  The second generation (local_attn_mfma2.hip) holds two
 // units in registers + two in LDS per workgroup and pays a commit pass and a barrier per unit; the DMA generations
-// (local_attn_mfma3.hip) moved 64-byte pieces, had at most 48 KB in flight and kept one barrier per 10-20 MFMAs.  Here:
+// (round 3, deleted in round 4) moved 64-byte pieces, had at most 48 KB in flight and kept one barrier per 10-20 MFMAs.  Here:
 //
 //   * the halo of a 16 x 8 (or 8 x 16) query tile is staged as ROWS of 64 channels: one ring slot = (TW + 8) texels x 128 B
 //     (128-B pieces: whole L2 lines; tools/micro/halo_read.hip: 64-B pieces do not scale with the bytes in flight, 128-B
 //     pieces do).  A tile is four BLOCKS of HR rows - K channels 0-63, K 64-127, V 0-63, V 64-127 - and the ring holds three
 //     blocks (144 KB): one block is being multiplied while up to two (96 KB per CU) are in flight;
-//   * two PRODUCER wavefronts issue every LDS-DMA instruction (global_load_lds_dwordx4, 1 KB each; rows of even / odd
-//     sequence number), texels outside the map read a zero line, the LDS swizzle of the second generation is applied to
-//     the address each lane fetches.  A producer publishes `landed[p]` (all its rows below that sequence number are in
-//     LDS) after a COUNTED s_waitcnt vmcnt - the oldest row, not the youngest - and refills a slot as soon as the eight
-//     consumers' `done[w]` counters say nobody reads it any more (row granularity: the top waves free their rows first);
+//   * NPW PRODUCER wavefronts issue every LDS-DMA instruction (global_load_lds_dwordx4, 1 KB each; producer p owns the rows
+//     r = p mod NPW of every block), texels outside the map read a zero line, the LDS swizzle of the second generation is
+//     applied to the address each lane fetches.  A producer publishes `landed[p]` = the number of blocks whose rows it has
+//     in LDS after a COUNTED s_waitcnt vmcnt - the oldest block, not the youngest - and refills a block's buffer as soon as
+//     the eight consumers' `done[w]` counters say all of them are past it.  (A first version synchronised per ROW: two
+//     LDS round trips of flag traffic per row made the producers the bottleneck - 122 us with 2 producers, 46 us with 8.)
 //   * eight CONSUMER wavefronts (8 x 2 queries each, the row-pair MFMA tiles and the soft-max of the second generation,
 //     bit-identical results) never touch the vector-memory path except for their 4 query loads and 8 output stores per
 //     tile; they wait on `landed` with an LDS poll only when the producers are not ahead, and never on each other.
@@ -43,16 +44,19 @@ template <int WX_, int WY_, int SCHED_ = 0, int NPW_ = 2>
 struct Cfg {
   static constexpr int WX = WX_, WY = WY_;
   static constexpr int SCHED = SCHED_;                 // 1: LDS fragment reads interleaved with the MFMAs by sched_group_barrier
-  static constexpr int NCW = WX * WY, NPW = NPW_, NT = (NCW + NPW) * 64;   // consumer / producer wavefronts
+  static constexpr int NCW = WX * WY, NPW = NPW_;        // consumer / producer wavefronts
+  static constexpr int NT = (NCW + NPW) * 64;
   static constexpr int TW = 8 * WX, TH = 2 * WY, HC = TW + 8, HR = TH + 8;
   static constexpr int S = 128;                        // bytes of a texel slice (64 channels)
   static constexpr int ROWB = HC * S, IPR = ROWB / 1024;   // one DMA instruction = 8 texels
   static constexpr int BLKB = HR * ROWB, NBLK = 3, NSLOT = NBLK * HR;
   static constexpr int BPT = 4;                        // blocks per tile: K lo, K hi, V lo, V hi
   static constexpr int RING = NBLK * BLKB;
-  static constexpr int LDS_BYTES = RING + 64;          // + landed[NPW <= 8] at RING, done[8] at RING + 32
-  static constexpr int DEPTH = 60 / IPR;               // rows a producer may have unpublished (vmcnt is 6 bits)
-  static_assert(NCW == 8 && HR % NPW == 0 && NPW <= 8 && HC % 8 == 0 && LDS_BYTES <= 160 * 1024, "ring geometry");
+  static constexpr int TSB = 768;                      // measurement (dbg & 16): 96 time stamps per wavefront of workgroup 0
+  static constexpr int LDS_BYTES = RING + 64 + (NCW + NPW_) * TSB;   // + landed[NPW <= 8] at RING, done[8] at RING + 32, the time stamps
+  static constexpr int RPB = HR / NPW_, IPB = RPB * IPR;  // rows / DMA instructions of one producer per block
+  static_assert(NCW == 8 && HR % NPW == 0 && (NPW == 2 || NPW == 4 || NPW == 8) && HC % 8 == 0 && LDS_BYTES <= 160 * 1024,
+                "ring geometry");
 };
 
 template <int B, int E, class F>
@@ -97,17 +101,13 @@ __device__ __forceinline__ void dma16(const void *gp, unsigned lds_addr) {
 __device__ __forceinline__ unsigned lds_addr_of(const void *p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
-// at most 3 n / 2 n DMA instructions of this wave still in flight
-template <int IPR>
-__device__ __forceinline__ void wait_rows(int n) {
-#define DI_W(N) case N: asm volatile("s_waitcnt vmcnt(%0)" : : "n"((N) * IPR > 63 ? 63 : (N) * IPR) : "memory"); break;
-  switch (n) {
-    DI_W(0) DI_W(1) DI_W(2) DI_W(3) DI_W(4) DI_W(5) DI_W(6) DI_W(7) DI_W(8) DI_W(9) DI_W(10) DI_W(11) DI_W(12) DI_W(13) DI_W(14)
-    DI_W(15) DI_W(16) DI_W(17) DI_W(18) DI_W(19) DI_W(20) DI_W(21) DI_W(22) DI_W(23) DI_W(24) DI_W(25) DI_W(26) DI_W(27)
-    DI_W(28) DI_W(29) DI_W(30)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef DI_W
+// at most n blocks' worth (IPB instructions each) of this wave's DMA still in flight
+template <int IPB>
+__device__ __forceinline__ void wait_blocks(int n) {
+  static_assert(2 * IPB <= 63, "vmcnt is 6 bits");
+  if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(IPB) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * IPB) : "memory");
 }
 
 constexpr int SPIN_LIMIT = 1 << 20;
@@ -115,13 +115,37 @@ constexpr int SPIN_LIMIT = 1 << 20;
 template <class G>
 __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     const __half *__restrict__ q, const __half *__restrict__ k, const __half *__restrict__ v,
-    __half *__restrict__ out, int n, int H, int W, float scale, int tiles_x, int tiles_y) {
+    __half *__restrict__ out, int n, int H, int W, float scale, int tiles_x, int tiles_y, int dbg,
+    unsigned long long *__restrict__ ts_out) {
+  // dbg (measurement only, DI_RING_DBG): 1 = no output stores, 2 = no query loads, 4 = no DMA (blocks announced at once),
+  // 8 = consumers skip the LDS reads and MFMAs, 16 = phase time stamps of workgroup 0 (tools/ring_timeline.py)
   extern __shared__ __align__(1024) unsigned char lds[];
   constexpr int ROWB = G::ROWB, S = G::S, HR = G::HR;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds0 = lds_addr_of(lds);
   const unsigned f_landed = lds0 + G::RING, f_done = lds0 + G::RING + 32;
+  // measurement: lane 0 of every wave of workgroup 0 stamps the shader clock into its own KB of LDS (no vector-memory traffic:
+  // the producers count theirs); copied out at the end
+  const bool ts_on = (dbg & 16) && blockIdx.x == 0;
+  int tsi = 0;
+  const unsigned ts_base = lds0 + G::RING + 64 + wave * G::TSB;
+  auto stamp = [&](unsigned tag) {
+    if (ts_on && tsi < G::TSB / 8 - 1) {
+      const unsigned long long c = __builtin_readcyclecounter();
+      asm volatile("ds_write_b64 %0, %1" : : "v"(ts_base + 8 * tsi), "v"((c & 0x00FFFFFFFFFFFFFFull) | ((unsigned long long)tag << 56)) : "memory");
+      ++tsi;
+    }
+  };
+  auto dump_ts = [&]() {
+    if (ts_on && ts_out != nullptr) {
+      asm volatile("ds_write_b64 %0, %1" : : "v"(ts_base + G::TSB - 8), "v"((unsigned long long)tsi) : "memory");
+      if (lane < G::TSB / 16) {
+        const uint4 v4 = lds_ld128(ts_base + lane * 16);
+        reinterpret_cast<uint4 *>(ts_out)[wave * 64 + lane] = v4;
+      }
+    }
+  };
 
   // ---- tiles: XCD x (workgroups with blockIdx % 8 == x share an L2) owns the contiguous range [T*x/8, T*(x+1)/8) and
   // walks it `gxw` tiles per round
@@ -145,64 +169,81 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     const int d_c16 = (((d_pos >> 1) ^ d_f) << 1) | (d_pos & 1);
     const int d_off = d_t * 256 + d_c16 * 16;
     const unsigned char *const zsrc = reinterpret_cast<const unsigned char *>(zero_line) + d_pos * 16;
-    const int total = ntl * G::BPT * (HR / G::NPW);           // rows of this producer: sequence numbers p, p + NPW, ...
-    int min_done = 0;                                         // cached min over done[w]
-    int issued = 0, published = 0;
-    int cur_it = -1;
-    TileCoord t = {0, 0, 0};
-    auto publish = [&]() { lds_st32(f_landed + 4 * p, (unsigned)(p + G::NPW * published)); };
+    const int nblk = ntl * G::BPT;                            // blocks of this workgroup, in sequence
+    int min_done = 0;                                         // cached min over done[w]: blocks every consumer is past
+    int published = 0;                                        // blocks of mine announced in landed[p]
+    __builtin_amdgcn_s_setprio(2);                            // few instructions, all of them on the critical path
+    auto publish = [&]() {
+      lds_st32(f_landed + 4 * p, (unsigned)published);
+      stamp(3);                                               // a block announced
+    };
     auto reload_done = [&]() {
       const uint4 a = lds_ld128(f_done), b = lds_ld128(f_done + 16);
       const unsigned m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
       min_done = __builtin_amdgcn_readfirstlane((int)m);
     };
-    for (int kk = 0; kk < total; ++kk) {
-      const int seq = p + G::NPW * kk;
-      const int B = seq / HR, r = seq - B * HR;
-      const int it = B >> 2, b = B & 3;
-      if (it != cur_it) {
-        cur_it = it;
-        t = decode_tile(tile0 + it * gxw, tiles_x, per_img, G::TH, G::TW);
-      }
-      // the slot of row seq held row seq - NSLOT: free once every consumer is past it
-      int spins = 0;
-      while (seq - G::NSLOT >= min_done) {
-        if (published < issued) {                             // let the consumers have what has landed meanwhile
-          wait_rows<G::IPR>(issued - published - 1);
-          ++published;
-          publish();
-        } else {
-          __builtin_amdgcn_s_sleep(2);
-        }
-        reload_done();
-        if (++spins > SPIN_LIMIT) {
-          if (lane == 0) atomicAdd(&timeouts, 1u);
-          break;
-        }
-      }
-      const __half *src = b < 2 ? k : v;
-      const int gy = t.y0 - 4 + r;
-      const bool y_ok = gy >= 0 && gy < H;
-      const unsigned char *base = reinterpret_cast<const unsigned char *>(src) +
-                                  ((long long)(t.img * H + gy) * W + (t.x0 - 4)) * 256 + (b & 1) * 128 + d_off;
-      const unsigned dst = lds0 + (B % G::NBLK) * G::BLKB + r * ROWB;
+    for (int it = 0; it < ntl; ++it) {
+      const TileCoord t = decode_tile(tile0 + it * gxw, tiles_x, per_img, G::TH, G::TW);
+      const bool interior = t.y0 >= 4 && t.x0 >= 4 && t.y0 - 4 + HR <= H && t.x0 - 4 + G::HC <= W;
+      const long long tile_off = ((long long)(t.img * H + t.y0 - 4) * W + (t.x0 - 4)) * 256 + d_off;
+      bool x_ok[G::IPR];
 #pragma unroll
       for (int j = 0; j < G::IPR; ++j) {
         const int gx = t.x0 - 4 + 8 * j + d_t;
-        const bool ok = y_ok && gx >= 0 && gx < W;
-        const unsigned char *gp = ok ? base + j * 2048 : zsrc;
-        dma16(gp, __builtin_amdgcn_readfirstlane(dst + j * 1024));
+        x_ok[j] = gx >= 0 && gx < W;
       }
-      ++issued;
-      if (issued - published > G::DEPTH) {
-        wait_rows<G::IPR>(G::DEPTH);
-        published = issued - G::DEPTH;
-        publish();
+#pragma unroll
+      for (int b = 0; b < G::BPT; ++b) {
+        const int B = it * G::BPT + b;
+        // the buffer of block B held block B - 3: free once every consumer is past it
+        int spins = 0;
+        while (B - G::NBLK >= min_done) {
+          if (published < B) {                                // meanwhile: announce the oldest block of mine that is in flight
+            wait_blocks<G::IPB>(B - published - 1);
+            ++published;
+            publish();
+          } else {
+            __builtin_amdgcn_s_sleep(1);
+          }
+          reload_done();
+          if (++spins > SPIN_LIMIT) {
+            if (lane == 0) atomicAdd(&timeouts, 1u);
+            break;
+          }
+        }
+        stamp(1);                                             // buffer free
+        const unsigned dst = lds0 + (B % G::NBLK) * G::BLKB;
+        {
+        const int bb = b;
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(bb < 2 ? k : v) + tile_off + (bb & 1) * 128;
+#pragma unroll
+        for (int rr = 0; rr < G::RPB; ++rr) {
+          const int r = p + rr * G::NPW;
+          const unsigned char *row = src + (long long)r * W * 256;
+          const int gy = t.y0 - 4 + r;
+          const bool y_ok = gy >= 0 && gy < H;
+#pragma unroll
+          for (int j = 0; j < G::IPR; ++j) {
+            const unsigned char *gp = row + j * 2048;
+            if (!interior) gp = (y_ok && x_ok[j]) ? gp : zsrc;
+            if (!(dbg & 4)) dma16(gp, __builtin_amdgcn_readfirstlane(dst + r * ROWB + j * 1024));
+          }
+        }
+        }
+        stamp(2);                                             // issued
+        if (B - published >= 2) {                             // never more than two blocks unannounced (vmcnt is 6 bits)
+          wait_blocks<G::IPB>(2);
+          published = B - 1;
+          publish();
+        }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no DMA may outlive the workgroup's LDS
-    published = issued;
-    publish();
+    while (published < nblk) {                                // drain: no DMA may outlive the workgroup's LDS
+      wait_blocks<G::IPB>(nblk - published - 1);
+      ++published;
+      publish();
+    }
+    dump_ts();
     return;
   }
 
@@ -232,37 +273,51 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     nm_last[r] = (in_band && qrow == 1) ? 0.f : -INFINITY;   // key row 9: only the lower query row
   }
 
-  // rows [.., last] of the sequence are in LDS: producer p has published a count above the last of ITS rows <= last
-  int seen = 0;                                              // rows [.., seen) are known to have landed
-  auto wait_landed = [&](int last) {
+  // block B is in LDS once every producer has announced more than B blocks
+  int seen = 0;                                              // blocks [0, seen) are known to have landed
+  auto wait_landed = [&](int B) {
     int spins = 0;
-    while (seen <= last) {
-      unsigned l[8];
+    stamp(4);                                                 // starts waiting for a block
+    while (seen <= B) {
+      unsigned m;
       if constexpr (G::NPW == 2) {
         const unsigned long long v2 = lds_ld64(f_landed);
-        l[0] = (unsigned)v2, l[1] = (unsigned)(v2 >> 32);
+        m = min((unsigned)v2, (unsigned)(v2 >> 32));
       } else {
         const uint4 a = lds_ld128(f_landed);
-        l[0] = a.x, l[1] = a.y, l[2] = a.z, l[3] = a.w;
+        m = min(min(a.x, a.y), min(a.z, a.w));
         if constexpr (G::NPW == 8) {
           const uint4 b = lds_ld128(f_landed + 16);
-          l[4] = b.x, l[5] = b.y, l[6] = b.z, l[7] = b.w;
+          m = min(m, min(min(b.x, b.y), min(b.z, b.w)));
         }
       }
-      // producer p: all its rows below l[p] are in; the first row of p NOT known to be in is l[p] (= p mod NPW)
-      unsigned m = l[0];
-#pragma unroll
-      for (int pp = 1; pp < G::NPW; ++pp) m = min(m, l[pp]);
       seen = __builtin_amdgcn_readfirstlane((int)m);
-      if (seen > last) break;
+      if (seen > B) break;
       __builtin_amdgcn_s_sleep(1);
       if (++spins > SPIN_LIMIT) {
         if (lane == 0) atomicAdd(&timeouts, 1u);
         break;
       }
     }
+    stamp(5);                                                 // has it
   };
-  auto release = [&](int seq) { lds_st32(f_done + 4 * wave, (unsigned)seq); };   // rows below `seq`: not needed by this wave
+  // the flags read AHEAD: issued before a block's MFMA loop, looked at after it - when the next block has landed meanwhile
+  // (the usual case) wait_landed() returns without an LDS round trip (~300 clocks on a busy LDS, 20 times per 5 tiles)
+  unsigned long long peek0 = 0, peek1 = 0;
+  auto peek_begin = [&]() {
+    if constexpr (G::NPW == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(peek0) : "v"(f_landed) : "memory");
+  };
+  auto peek_end = [&]() {
+    if constexpr (G::NPW == 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(peek0) : : "memory");
+      const unsigned m = min((unsigned)peek0, (unsigned)(peek0 >> 32));
+      seen = max(seen, __builtin_amdgcn_readfirstlane((int)m));
+    }
+  };
+  auto release = [&](int nb) {
+    lds_st32(f_done + 4 * wave, (unsigned)nb);                // this wave is past blocks [0, nb)
+    stamp(6);
+  };
 
   // Q^T fragments (query i, channels kk*32 + 8g .. +7) straight from global; queries beyond the map edge (ragged tiles)
   // read a clamped texel, their results are never stored
@@ -275,7 +330,160 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
   };
 
   TileCoord cur = decode_tile(tile0, tiles_x, per_img, G::TH, G::TW);
-  load_q(cur);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = h8{1, 1, 1, 1, 1, 1, 1, 1};
+  if (!(dbg & 2)) load_q(cur);
+  for (int it = 0; it < ntl; ++it) {
+      const TileCoord t = decode_tile(tile0 + it * gxw, tiles_x, per_img, G::TH, G::TW);
+      const bool interior = t.y0 >= 4 && t.x0 >= 4 && t.y0 - 4 + HR <= H && t.x0 - 4 + G::HC <= W;
+      const long long tile_off = ((long long)(t.img * H + t.y0 - 4) * W + (t.x0 - 4)) * 256 + d_off;
+      bool x_ok[G::IPR];
+#pragma unroll
+      for (int j = 0; j < G::IPR; ++j) {
+        const int gx = t.x0 - 4 + 8 * j + d_t;
+        x_ok[j] = gx >= 0 && gx < W;
+      }
+#pragma unroll
+      for (int b = 0; b < G::BPT; ++b) {
+        const int B = it * G::BPT + b;
+        // the buffer of block B held block B - 3: free once every consumer is past it
+        int spins = 0;
+        while (B - G::NBLK >= min_done) {
+          if (published < B) {                                // meanwhile: announce the oldest block of mine that is in flight
+            wait_blocks<G::IPB>(B - published - 1);
+            ++published;
+            publish();
+          } else {
+            __builtin_amdgcn_s_sleep(1);
+          }
+          reload_done();
+          if (++spins > SPIN_LIMIT) {
+            if (lane == 0) atomicAdd(&timeouts, 1u);
+            break;
+          }
+        }
+        stamp(1);                                             // buffer free
+        const unsigned dst = lds0 + (B % G::NBLK) * G::BLKB;
+        {
+        const int bb = b;
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(bb < 2 ? k : v) + tile_off + (bb & 1) * 128;
+#pragma unroll
+        for (int rr = 0; rr < G::RPB; ++rr) {
+          const int r = p + rr * G::NPW;
+          const unsigned char *row = src + (long long)r * W * 256;
+          const int gy = t.y0 - 4 + r;
+          const bool y_ok = gy >= 0 && gy < H;
+#pragma unroll
+          for (int j = 0; j < G::IPR; ++j) {
+            const unsigned char *gp = row + j * 2048;
+            if (!interior) gp = (y_ok && x_ok[j]) ? gp : zsrc;
+            if (!(dbg & 4)) dma16(gp, __builtin_amdgcn_readfirstlane(dst + r * ROWB + j * 1024));
+          }
+        }
+        }
+        stamp(2);                                             // issued
+        if (B - published >= 2) {                             // never more than two blocks unannounced (vmcnt is 6 bits)
+          wait_blocks<G::IPB>(2);
+          published = B - 1;
+          publish();
+        }
+      }
+    }
+    while (published < nblk) {                                // drain: no DMA may outlive the workgroup's LDS
+      wait_blocks<G::IPB>(nblk - published - 1);
+      ++published;
+      publish();
+    }
+    dump_ts();
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- consumer
+  const int wx = wave % G::WX, wy = wave / G::WX;
+  const int i = lane & 15, g = lane >> 4;
+  const int j = i & 7, qrow = i >> 3;
+  // ---- fragment constants (the LDS image of local_attn_mfma2.hip with 128-byte slices: 32-B segments XOR-swizzled by
+  // (texel / 2) % 4)
+  const int hcq = wx * 8 + i;                                // K fragment: key column i of the wave's 16
+  const int fq = (hcq >> 1) & 3;
+  int koff[2];
+#pragma unroll
+  for (int kl = 0; kl < 2; ++kl) koff[kl] = wy * 2 * ROWB + hcq * S + ((((kl * 4 + g) >> 1) ^ fq) << 5) + (((kl * 4 + g) & 1) << 4);
+  const int kcv = wx * 8 + 4 * g + (i >> 2);                 // V^T fragment: key column addressed by this lane
+  const int vsw = (kcv >> 1) & 3;
+  const int vbase = wy * 2 * ROWB + kcv * S + (i & 3) * 8;
+  // additive softmax masks: 0 where key c = 4g + r lies in the band of query column j (j <= c <= j + 8) and the key row
+  // belongs to the window of the query's row, -inf elsewhere
+  const float cs = scale * 1.44269504088896f;                // scores in log2 units
+  f4 nm_mid, nm_first, nm_last;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool in_band = 4 * g + r >= j && 4 * g + r <= j + 8;
+    nm_mid[r] = in_band ? 0.f : -INFINITY;
+    nm_first[r] = (in_band && qrow == 0) ? 0.f : -INFINITY;  // key row 0: only the upper query row
+    nm_last[r] = (in_band && qrow == 1) ? 0.f : -INFINITY;   // key row 9: only the lower query row
+  }
+
+  // block B is in LDS once every producer has announced more than B blocks
+  int seen = 0;                                              // blocks [0, seen) are known to have landed
+  auto wait_landed = [&](int B) {
+    int spins = 0;
+    stamp(4);                                                 // starts waiting for a block
+    while (seen <= B) {
+      unsigned m;
+      if constexpr (G::NPW == 2) {
+        const unsigned long long v2 = lds_ld64(f_landed);
+        m = min((unsigned)v2, (unsigned)(v2 >> 32));
+      } else {
+        const uint4 a = lds_ld128(f_landed);
+        m = min(min(a.x, a.y), min(a.z, a.w));
+        if constexpr (G::NPW == 8) {
+          const uint4 b = lds_ld128(f_landed + 16);
+          m = min(m, min(min(b.x, b.y), min(b.z, b.w)));
+        }
+      }
+      seen = __builtin_amdgcn_readfirstlane((int)m);
+      if (seen > B) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > SPIN_LIMIT) {
+        if (lane == 0) atomicAdd(&timeouts, 1u);
+        break;
+      }
+    }
+    stamp(5);                                                 // has it
+  };
+  // the flags read AHEAD: issued before a block's MFMA loop, looked at after it - when the next block has landed meanwhile
+  // (the usual case) wait_landed() returns without an LDS round trip (~300 clocks on a busy LDS, 20 times per 5 tiles)
+  unsigned long long peek0 = 0, peek1 = 0;
+  auto peek_begin = [&]() {
+    if constexpr (G::NPW == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(peek0) : "v"(f_landed) : "memory");
+  };
+  auto peek_end = [&]() {
+    if constexpr (G::NPW == 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(peek0) : : "memory");
+      const unsigned m = min((unsigned)peek0, (unsigned)(peek0 >> 32));
+      seen = max(seen, __builtin_amdgcn_readfirstlane((int)m));
+    }
+  };
+  auto release = [&](int nb) {
+    lds_st32(f_done + 4 * wave, (unsigned)nb);                // this wave is past blocks [0, nb)
+    stamp(6);
+  };
+
+  // Q^T fragments (query i, channels kk*32 + 8g .. +7) straight from global; queries beyond the map edge (ragged tiles)
+  // read a clamped texel, their results are never stored
+  h8 qf[4];
+  auto load_q = [&](const TileCoord &t) {
+    const int gy = min(t.y0 + 2 * wy + qrow, H - 1), gx = min(t.x0 + 8 * wx + j, W - 1);
+    const unsigned char *qb = reinterpret_cast<const unsigned char *>(q) + ((unsigned)((t.img * H + gy) * W + gx) << 8) + g * 16;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(qb + kk * 64));
+  };
+
+  TileCoord cur = decode_tile(tile0, tiles_x, per_img, G::TH, G::TW);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = h8{1, 1, 1, 1, 1, 1, 1, 1};
+  if (!(dbg & 2)) load_q(cur);
   for (int it = 0; it < ntl; ++it) {
     const bool has_next = it + 1 < ntl;
     TileCoord nxt = cur;
@@ -289,8 +497,10 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     static_for<0, 2>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       const int B = B0 + u;
-      wait_landed(B * HR + 2 * wy + 9);
+      wait_landed(B);
+      if constexpr (G::SCHED == 2) peek_begin();
       const unsigned char *buf = lds + (B % G::NBLK) * G::BLKB;
+      if (!(dbg & 8))
 #pragma unroll
       for (int kl = 0; kl < 2; ++kl) {                       // k-step outer: an accumulator's two MFMAs are 10 apart
 #pragma unroll
@@ -299,16 +509,18 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
           s[rr] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, raw), qf[u * 2 + kl], s[rr], 0, 0, 0);
         }
       }
-      if constexpr (G::SCHED == 1) {                         // 6 reads ahead, then one read per MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+      if constexpr (G::SCHED >= 1) {                         // AH reads ahead, then one read per MFMA (a wave's LDS reads return
+        constexpr int AH = G::SCHED == 1 ? 6 : 12;            // one per ~50 clocks with 6 in flight: the block was LDS-latency bound)
+        __builtin_amdgcn_sched_group_barrier(0x100, AH, 0);
 #pragma unroll
-        for (int e = 0; e < 14; ++e) {
+        for (int e = 0; e < 20 - AH; ++e) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, AH, 0);
       }
-      release((B + 1) * HR + 2 * wy);
+      if constexpr (G::SCHED == 2) peek_end();
+      release(B + 1);
     });
 
     // ---------------- softmax over the 81 window slots of query i, in log2 units: y = s*cs + mask
@@ -344,7 +556,7 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
     }
-    if (has_next) load_q(nxt);                               // qf is dead until the next tile's first block
+    if (has_next && !(dbg & 2)) load_q(nxt);                               // qf is dead until the next tile's first block
 
     // ---------------- O^T = V^T . P^T over the two V blocks, each block finishes 64 output channels
     const float inv = 1.f / sum;
@@ -354,11 +566,13 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     static_for<0, 2>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       const int B = B0 + 2 + u;
-      wait_landed(B * HR + 2 * wy + 9);
+      wait_landed(B);
+      if constexpr (G::SCHED == 2) peek_begin();
       const unsigned char *buf = lds + (B % G::NBLK) * G::BLKB;
       f4 acc[4];
 #pragma unroll
       for (int nl = 0; nl < 4; ++nl) acc[nl] = f4{0.f, 0.f, 0.f, 0.f};
+      if (!(dbg & 8))
 #pragma unroll
       for (int pr = 0; pr < 5; ++pr) {
 #pragma unroll
@@ -372,17 +586,19 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
           acc[nl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pf[pr], acc[nl], 0, 0, 0);
         }
       }
-      if constexpr (G::SCHED == 1) {                         // 8 transposed reads ahead, then two per MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      if constexpr (G::SCHED >= 1) {                         // 2 AH transposed reads ahead, then two per MFMA
+        constexpr int AH = G::SCHED == 1 ? 4 : 9;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * AH, 0);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < 20 - AH; ++e) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, AH, 0);
       }
-      release((B + 1) * HR + 2 * wy);
-      if (pix_ok) {
+      if constexpr (G::SCHED == 2) peek_end();
+      release(B + 1);
+      if (pix_ok && !(dbg & 1)) {
 #pragma unroll
         for (int nl = 0; nl < 4; ++nl) {
           const f4 o = acc[nl] * inv;
@@ -395,6 +611,17 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     });
     cur = nxt;
   }
+  dump_ts();
+}
+
+// measurement (DI_RING_DBG & 16): 16 waves x 128 stamps, dumped by `di_local_attn_ring_stamps`
+static unsigned long long *ts_buffer(int dbg) {
+  static unsigned long long *buf = nullptr;
+  if ((dbg & 16) && buf == nullptr) {
+    if (hipMalloc((void **)&buf, 16 * 128 * 8) != hipSuccess) buf = nullptr;
+    else (void)hipMemset(buf, 0, 16 * 128 * 8);
+  }
+  return buf;
 }
 
 template <class G>
@@ -411,29 +638,35 @@ static int launch(const void *q, const void *k, const void *v, void *out, int n,
   if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
   static const int grid_env = getenv("DI_LA_GRID") ? atoi(getenv("DI_LA_GRID")) : 0;
   if (grid_env > 0 && grid_env < grid) grid = grid_env / 8 * 8;
+  static const int dbg_env = getenv("DI_RING_DBG") ? atoi(getenv("DI_RING_DBG")) : 0;
   hipLaunchKernelGGL(local_attn_ring_kernel<G>, dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, stream,
                      (const __half *)q, (const __half *)k, (const __half *)v, (__half *)out, n, H, W, scale, tiles_x,
-                     tiles_y);
+                     tiles_y, dbg_env, ts_buffer(dbg_env));
   return check_launch("local_attn_ring");
 }
 
 }  // namespace ring
 
-// cfg 0: 16 x 8 query tiles (halo 24 x 16);  cfg 1: 8 x 16 tiles (halo 16 x 24: 112 x 200 maps leave no ragged tile);
-// + 2: the same with the LDS fragment reads interleaved with the MFMAs by sched_group_barrier
+// cfg 0: 16 x 8 query tiles (halo 24 x 16), 12-deep LDS read-ahead, flags read ahead (the AUTO choice for large maps);
+// cfg 1: 8 x 16 tiles (halo 16 x 24: 112 x 200 maps leave no ragged tile); cfg 2-4: measurement variants
 int launch_local_attn_ring(const void *q, const void *k, const void *v, void *out, int n, int H, int W, float scale,
                            int cfg, hipStream_t stream) {
   switch (cfg) {
-    case 0: return ring::launch<ring::Cfg<2, 4>>(q, k, v, out, n, H, W, scale, stream);
-    case 1: return ring::launch<ring::Cfg<1, 8>>(q, k, v, out, n, H, W, scale, stream);
-    case 2: return ring::launch<ring::Cfg<2, 4, 1>>(q, k, v, out, n, H, W, scale, stream);
-    case 3: return ring::launch<ring::Cfg<1, 8, 1>>(q, k, v, out, n, H, W, scale, stream);
-    case 4: return ring::launch<ring::Cfg<2, 4, 1, 4>>(q, k, v, out, n, H, W, scale, stream);   // four producer wavefronts
-    case 5: return ring::launch<ring::Cfg<2, 4, 1, 8>>(q, k, v, out, n, H, W, scale, stream);   // eight
-    case 6: return ring::launch<ring::Cfg<1, 8, 1, 8>>(q, k, v, out, n, H, W, scale, stream);
+    case 0: return ring::launch<ring::Cfg<2, 4, 2, 2>>(q, k, v, out, n, H, W, scale, stream);
+    case 1: return ring::launch<ring::Cfg<1, 8, 2, 2>>(q, k, v, out, n, H, W, scale, stream);
+    case 2: return ring::launch<ring::Cfg<2, 4, 1, 2>>(q, k, v, out, n, H, W, scale, stream);   // shallower LDS read-ahead, no flag peek
+    case 3: return ring::launch<ring::Cfg<2, 4, 0, 2>>(q, k, v, out, n, H, W, scale, stream);   // the compiler's own schedule
+    case 4: return ring::launch<ring::Cfg<2, 4, 2, 4>>(q, k, v, out, n, H, W, scale, stream);   // four producer wavefronts
   }
   set_error("unknown local_attn_ring configuration %d", cfg);
   return DI_ERR_ARG;
+}
+
+int ring_stamps(unsigned long long *host_out, hipStream_t stream) {
+  unsigned long long *buf = ring::ts_buffer(16);
+  if (buf == nullptr) return DI_ERR_LAUNCH;
+  if (hipStreamSynchronize(stream) != hipSuccess) return DI_ERR_LAUNCH;
+  return hipMemcpy(host_out, buf, 16 * 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? DI_OK : DI_ERR_LAUNCH;
 }
 
 // bounded spins that gave up since the library was loaded (tests: must stay 0)

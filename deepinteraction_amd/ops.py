@@ -74,8 +74,7 @@ def _f32(t):
 # ------------------------------------------------------------------ local-window attention
 LA_AUTO, LA_VALU = 0, 1
 LA_MFMA = 3           # + configuration 0..4 of the persistent pipelined row-pair kernel (1 = 8x8 tiles)
-LA_DMA = 16           # + 0 / 1: the LDS-DMA generation at three / two workgroups per CU; + 2: producer / consumer waves
-LA_RING = 24          # + 0 / 1: the ring generation (one workgroup per CU, flag-synchronised), 16x8 / 8x16 tiles; + 2 / 3: hand-interleaved reads
+LA_RING = 24          # + 0 / 1: the ring generation (one workgroup per CU, LDS-DMA rows, flag-synchronised), 16x8 / 8x16 tiles; + 2..4: measurement variants
 
 
 def local_attention(q, k, v, kH, kW, scale, variant=LA_AUTO):
@@ -92,7 +91,8 @@ def local_attention(q, k, v, kH, kW, scale, variant=LA_AUTO):
 
 def local_attention_kernel_name():
     """What LA_AUTO launches for fp16 / C=128 / 9x9 maps (bench.py's roofline line names it)."""
-    return 'local_attn_m2_kernel, 8x8 tiles, 2 persistent workgroups per CU'
+    return ('local_attn_ring_kernel: one workgroup per CU, 16x8 tiles, 144 KB ring of 128-byte halo rows by LDS-DMA, '
+            'flag-synchronised producer / consumer wavefronts (small maps: local_attn_m2_kernel, 8x8 tiles)')
 
 
 def similar_forward(x_ori, x_loc, kH, kW):

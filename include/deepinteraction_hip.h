@@ -60,25 +60,27 @@ long long di_graph_node_count(void *graph_host);
  * Supported windows: kH,kW odd in {3,5,7,9}. */
 int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                       int C, int kH, int kW, float scale, int dtype, void *stream);
-/* Same op with an explicit kernel choice.  DI_LA_AUTO picks, for fp16 / C=128 / 9x9, the persistent
- * software-pipelined matrix-core kernel (row-pair 16x16x32 MFMA tiles, local_attn_mfma2.hip), else the
- * generic LDS-tiled VALU kernel (any C, fp32 or fp16, windows 3..9).  The other codes select one implementation
- * (tests, measurements).  Three further matrix-core generations (one tile per workgroup; producer/consumer waves with
- * direct-to-LDS loads; vertical streaming with an LDS halo ring) were measured in round 1, lost to this one and are
- * gone. */
+/* Same op with an explicit kernel choice.  DI_LA_AUTO picks, for fp16 / C=128 / 9x9: on large maps the ring generation
+ * (local_attn_ring.hip: one workgroup per CU, a 144 KB ring of 128-byte halo rows filled by producer wavefronts with LDS-DMA,
+ * eight consumer wavefronts synchronised by LDS flag words, no workgroup barrier), on small maps the persistent
+ * software-pipelined register-staged kernel (local_attn_mfma2.hip); both compute the same row-pair 16x16x32 MFMA tiles and are
+ * bit-identical.  Everything else runs the generic LDS-tiled VALU kernel (any C, fp32 or fp16, windows 3..9).  The other codes
+ * select one implementation (tests, measurements).  Five further matrix-core generations (one tile per workgroup; producer /
+ * consumer waves with direct-to-LDS loads; vertical streaming with an LDS halo ring; LDS-DMA in 16 KB units at three
+ * workgroups per CU; the same with producer / consumer wavefronts) were measured in rounds 1-3, lost and are gone. */
 enum { DI_LA_AUTO = 0, DI_LA_VALU = 1,
        DI_LA_MFMA = 3 /* + configuration: 3 = 16x8 tiles, 4 = 8x8 tiles, 5 = 16x4 tiles, 6 = 8x16 tiles, 7 = timestamps */,
-       DI_LA_DMA = 16 /* local_attn_mfma3.hip (halo and queries by LDS-DMA, 16 KB units): + 0 / 1 = three / two
-                         workgroups per CU, + 2 = producer / consumer wavefronts */,
-       DI_LA_RING = 24 /* local_attn_ring.hip (one workgroup per CU, 144 KB ring of 128-byte halo rows filled by two producer
-                          wavefronts, eight consumer wavefronts synchronised by LDS flag words, no workgroup barrier):
-                          + 0 = 16x8 query tiles, + 1 = 8x16, + 2 / + 3 = the same with hand-interleaved fragment reads */ };
+       DI_LA_RING = 24 /* + 0 = 16x8 query tiles (AUTO on large maps), + 1 = 8x16 tiles, + 2..4 = measurement variants
+                          (shallower LDS read-ahead, the compiler's schedule, four producer wavefronts) */ };
 int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                          int C, int kH, int kW, float scale, int dtype, int variant, void *stream);
 /* The DI_LA_RING kernel bounds every flag spin; a pipeline that gave up produced wrong results instead of hanging the
  * device.  Returns the number of spins that gave up since the library was loaded (0 on a healthy run; synchronises
  * `stream`), -1 on a HIP error. */
 int di_local_attn_ring_timeouts(void *stream);
+/* Measurement (environment DI_RING_DBG & 16): the phase time stamps of workgroup 0's wavefronts of the last DI_LA_RING launch,
+ * 16 x 128 uint64 (tag << 56 | shader clock; entry 127 of a wave = its count) copied to `host_out`. */
+int di_local_attn_ring_stamps(void *host_out, void *stream);
 
 /* The five entry points of locatt_ops (localAttention.h:11-40), channels-last features,
  * float32 window tensors of shape (n,H,W,kH*kW):

@@ -3,7 +3,7 @@ shape R, 2 interaction layers), produced by the REFERENCE'S OWN Python (its auto
 locatt kernels compiled for the host, F.grid_sample, nn.MultiheadAttention through group_attn, the CPU depth completion),
 imported unmodified from /root/reference (TEST INFRASTRUCTURE; run in the build container):
 
-    python -m oracle.refpin.make_golden_grad_shapeR          (~5 min, ~25 GB of host memory)
+    python -m oracle.refpin.make_golden_grad_shapeR          (~30 min on ONE thread, ~25 GB of host memory)
 
 Inputs, weights and the linear functional are regenerated from seeds by `case()` (shared with
 tests/test_training_gpu.py::test_encoder_gradients_at_shape_R_match_reference_golden), so only the gradients are stored:
@@ -47,7 +47,15 @@ def sample(t, n=4096):
 def main():
     from oracle.refpin import load_reference
     ref = load_reference('reference')
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    # ONE thread, on purpose: the reference scatters the sparse depth with `depth_map[i, rows, cols] = depth` (encoder_utils.py
+    # :172-174), an index_put_ with duplicate indices whose winner is the write ORDER.  torch parallelises index_put_ over
+    # threads for 262 144 points: with 8 threads ~25 000 of the 134 400 depth pixels get a different winner than in sequential
+    # order, and two 8-thread runs differ from EACH OTHER (the first golden file, made with 8 threads, disagreed with the
+    # oracle and the product on 47 % of the image-map samples; per module at shape R the reference's I2P and window attention
+    # agree with the oracle to 3e-7, only BEVWarp does not).  Sequential order (highest point index wins) is the contract the
+    # oracle (oracle/encoder.py::scatter_depth) and the product's 64-bit atomicMax implement; with one thread the reference
+    # follows it exactly.
+    torch.set_num_threads(1)
     inp = case()
     R = ref.encoder.DeepInteractionEncoder(num_layers=2, in_channels_img=SHAPE['c_img'], in_channels_pts=SHAPE['c_pts'],
                                            hidden_channel=128)

@@ -49,8 +49,7 @@ _VARIANT_CASES = {}
 
 
 @pytest.mark.parametrize('variant', [ops.LA_AUTO, ops.LA_VALU, ops.LA_MFMA, ops.LA_MFMA + 1, ops.LA_MFMA + 2, ops.LA_MFMA + 3,
-                                     ops.LA_DMA, ops.LA_DMA + 1, ops.LA_DMA + 2,
-                                     ops.LA_RING, ops.LA_RING + 1, ops.LA_RING + 2, ops.LA_RING + 3])
+                                     ops.LA_RING, ops.LA_RING + 1, ops.LA_RING + 2, ops.LA_RING + 3, ops.LA_RING + 4])
 @pytest.mark.parametrize('shape', [(2, 13, 37), (1, 4, 16), (3, 9, 200), (1, 180, 180), (1, 1, 5), (6, 112, 200)])
 def test_local_attention_fp16_kernel_variants(variant, shape):
     """Both fp16 kernels of the fused op (LDS-tiled VALU; banded 16x16x32 MFMA) against the
@@ -88,7 +87,7 @@ def test_local_attention_ring_is_bit_identical_to_the_register_staged_kernel(sha
                for _ in range(3))
     sc = 1.0 / math.sqrt(128)
     ref = ops.local_attention(q, k, v, 9, 9, sc, variant=ops.LA_MFMA + 1)
-    for var in range(ops.LA_RING, ops.LA_RING + 4):
+    for var in range(ops.LA_RING, ops.LA_RING + 5):
         for rep in range(3):
             out = ops.local_attention(q, k, v, 9, 9, sc, variant=var)
             assert torch.equal(out, ref), (var, rep, (out.float() - ref.float()).abs().max().item())
