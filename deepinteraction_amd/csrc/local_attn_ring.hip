@@ -334,157 +334,6 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
   for (int kk = 0; kk < 4; ++kk) qf[kk] = h8{1, 1, 1, 1, 1, 1, 1, 1};
   if (!(dbg & 2)) load_q(cur);
   for (int it = 0; it < ntl; ++it) {
-      const TileCoord t = decode_tile(tile0 + it * gxw, tiles_x, per_img, G::TH, G::TW);
-      const bool interior = t.y0 >= 4 && t.x0 >= 4 && t.y0 - 4 + HR <= H && t.x0 - 4 + G::HC <= W;
-      const long long tile_off = ((long long)(t.img * H + t.y0 - 4) * W + (t.x0 - 4)) * 256 + d_off;
-      bool x_ok[G::IPR];
-#pragma unroll
-      for (int j = 0; j < G::IPR; ++j) {
-        const int gx = t.x0 - 4 + 8 * j + d_t;
-        x_ok[j] = gx >= 0 && gx < W;
-      }
-#pragma unroll
-      for (int b = 0; b < G::BPT; ++b) {
-        const int B = it * G::BPT + b;
-        // the buffer of block B held block B - 3: free once every consumer is past it
-        int spins = 0;
-        while (B - G::NBLK >= min_done) {
-          if (published < B) {                                // meanwhile: announce the oldest block of mine that is in flight
-            wait_blocks<G::IPB>(B - published - 1);
-            ++published;
-            publish();
-          } else {
-            __builtin_amdgcn_s_sleep(1);
-          }
-          reload_done();
-          if (++spins > SPIN_LIMIT) {
-            if (lane == 0) atomicAdd(&timeouts, 1u);
-            break;
-          }
-        }
-        stamp(1);                                             // buffer free
-        const unsigned dst = lds0 + (B % G::NBLK) * G::BLKB;
-        {
-        const int bb = b;
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(bb < 2 ? k : v) + tile_off + (bb & 1) * 128;
-#pragma unroll
-        for (int rr = 0; rr < G::RPB; ++rr) {
-          const int r = p + rr * G::NPW;
-          const unsigned char *row = src + (long long)r * W * 256;
-          const int gy = t.y0 - 4 + r;
-          const bool y_ok = gy >= 0 && gy < H;
-#pragma unroll
-          for (int j = 0; j < G::IPR; ++j) {
-            const unsigned char *gp = row + j * 2048;
-            if (!interior) gp = (y_ok && x_ok[j]) ? gp : zsrc;
-            if (!(dbg & 4)) dma16(gp, __builtin_amdgcn_readfirstlane(dst + r * ROWB + j * 1024));
-          }
-        }
-        }
-        stamp(2);                                             // issued
-        if (B - published >= 2) {                             // never more than two blocks unannounced (vmcnt is 6 bits)
-          wait_blocks<G::IPB>(2);
-          published = B - 1;
-          publish();
-        }
-      }
-    }
-    while (published < nblk) {                                // drain: no DMA may outlive the workgroup's LDS
-      wait_blocks<G::IPB>(nblk - published - 1);
-      ++published;
-      publish();
-    }
-    dump_ts();
-    return;
-  }
-
-  // -------------------------------------------------------------------------------------------------- consumer
-  const int wx = wave % G::WX, wy = wave / G::WX;
-  const int i = lane & 15, g = lane >> 4;
-  const int j = i & 7, qrow = i >> 3;
-  // ---- fragment constants (the LDS image of local_attn_mfma2.hip with 128-byte slices: 32-B segments XOR-swizzled by
-  // (texel / 2) % 4)
-  const int hcq = wx * 8 + i;                                // K fragment: key column i of the wave's 16
-  const int fq = (hcq >> 1) & 3;
-  int koff[2];
-#pragma unroll
-  for (int kl = 0; kl < 2; ++kl) koff[kl] = wy * 2 * ROWB + hcq * S + ((((kl * 4 + g) >> 1) ^ fq) << 5) + (((kl * 4 + g) & 1) << 4);
-  const int kcv = wx * 8 + 4 * g + (i >> 2);                 // V^T fragment: key column addressed by this lane
-  const int vsw = (kcv >> 1) & 3;
-  const int vbase = wy * 2 * ROWB + kcv * S + (i & 3) * 8;
-  // additive softmax masks: 0 where key c = 4g + r lies in the band of query column j (j <= c <= j + 8) and the key row
-  // belongs to the window of the query's row, -inf elsewhere
-  const float cs = scale * 1.44269504088896f;                // scores in log2 units
-  f4 nm_mid, nm_first, nm_last;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const bool in_band = 4 * g + r >= j && 4 * g + r <= j + 8;
-    nm_mid[r] = in_band ? 0.f : -INFINITY;
-    nm_first[r] = (in_band && qrow == 0) ? 0.f : -INFINITY;  // key row 0: only the upper query row
-    nm_last[r] = (in_band && qrow == 1) ? 0.f : -INFINITY;   // key row 9: only the lower query row
-  }
-
-  // block B is in LDS once every producer has announced more than B blocks
-  int seen = 0;                                              // blocks [0, seen) are known to have landed
-  auto wait_landed = [&](int B) {
-    int spins = 0;
-    stamp(4);                                                 // starts waiting for a block
-    while (seen <= B) {
-      unsigned m;
-      if constexpr (G::NPW == 2) {
-        const unsigned long long v2 = lds_ld64(f_landed);
-        m = min((unsigned)v2, (unsigned)(v2 >> 32));
-      } else {
-        const uint4 a = lds_ld128(f_landed);
-        m = min(min(a.x, a.y), min(a.z, a.w));
-        if constexpr (G::NPW == 8) {
-          const uint4 b = lds_ld128(f_landed + 16);
-          m = min(m, min(min(b.x, b.y), min(b.z, b.w)));
-        }
-      }
-      seen = __builtin_amdgcn_readfirstlane((int)m);
-      if (seen > B) break;
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > SPIN_LIMIT) {
-        if (lane == 0) atomicAdd(&timeouts, 1u);
-        break;
-      }
-    }
-    stamp(5);                                                 // has it
-  };
-  // the flags read AHEAD: issued before a block's MFMA loop, looked at after it - when the next block has landed meanwhile
-  // (the usual case) wait_landed() returns without an LDS round trip (~300 clocks on a busy LDS, 20 times per 5 tiles)
-  unsigned long long peek0 = 0, peek1 = 0;
-  auto peek_begin = [&]() {
-    if constexpr (G::NPW == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(peek0) : "v"(f_landed) : "memory");
-  };
-  auto peek_end = [&]() {
-    if constexpr (G::NPW == 2) {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(peek0) : : "memory");
-      const unsigned m = min((unsigned)peek0, (unsigned)(peek0 >> 32));
-      seen = max(seen, __builtin_amdgcn_readfirstlane((int)m));
-    }
-  };
-  auto release = [&](int nb) {
-    lds_st32(f_done + 4 * wave, (unsigned)nb);                // this wave is past blocks [0, nb)
-    stamp(6);
-  };
-
-  // Q^T fragments (query i, channels kk*32 + 8g .. +7) straight from global; queries beyond the map edge (ragged tiles)
-  // read a clamped texel, their results are never stored
-  h8 qf[4];
-  auto load_q = [&](const TileCoord &t) {
-    const int gy = min(t.y0 + 2 * wy + qrow, H - 1), gx = min(t.x0 + 8 * wx + j, W - 1);
-    const unsigned char *qb = reinterpret_cast<const unsigned char *>(q) + ((unsigned)((t.img * H + gy) * W + gx) << 8) + g * 16;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(qb + kk * 64));
-  };
-
-  TileCoord cur = decode_tile(tile0, tiles_x, per_img, G::TH, G::TW);
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) qf[kk] = h8{1, 1, 1, 1, 1, 1, 1, 1};
-  if (!(dbg & 2)) load_q(cur);
-  for (int it = 0; it < ntl; ++it) {
     const bool has_next = it + 1 < ntl;
     TileCoord nxt = cur;
     if (has_next) nxt = decode_tile(tile0 + (it + 1) * gxw, tiles_x, per_img, G::TH, G::TW);
