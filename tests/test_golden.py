@@ -91,3 +91,25 @@ def test_pp_decoder_matches_reference_golden():
         assert np.allclose(v.numpy(), g['dec_' + k], rtol=0, atol=3e-5), k
     assert np.array_equal(m.query_labels.numpy(), g['dec_query_labels'])              # INT: bit-exact
     assert np.array_equal(torch.stack(m.on_the_image_mask).numpy(), g['dec_on_the_image_mask'])
+
+
+def test_oracle_encoder_matches_reference_golden_at_shape_R():
+    """The oracle's MMRI encoder (2 layers, eval) at the BENCHED shape (Fusion_0075_refactor shape R) against the forward
+    samples the reference's own Python produced there (tests/golden/grad_shapeR.npz, oracle/refpin/make_golden_grad_shapeR.py):
+    the pin of the oracle at full size, not only at the small test shape.  The golden run is single-threaded on purpose: the
+    reference's depth scatter is an index_put_ with duplicate indices whose winner depends on the thread schedule (with 8
+    threads ~25 000 of 134 400 depth pixels change and the maps differ by up to 8 % of their range - from the oracle AND
+    between two reference runs); sequential order is the contract the oracle and the product implement."""
+    from oracle import encoder as oenc
+    from oracle.refpin import make_golden as mg, make_golden_grad_shapeR as gg
+    gold = np.load(os.path.join(GOLD, 'grad_shapeR.npz'))
+    inp = gg.case()
+    O = oenc.DeepInteractionEncoder(2, gg.SHAPE['c_img'], gg.SHAPE['c_pts'], 128)
+    mg.randomize(O, gg.SEED_WEIGHTS)
+    O.eval()
+    with torch.no_grad():
+        im, (p0, p1) = O(inp['img_feats'], inp['pts_feats'], inp['img_metas'], inp['pts_metas'])
+    for name, t in (('out_img', im), ('out_pts_conv', p0), ('out_pts', p1)):
+        s, _, _ = gg.sample(t)
+        d = np.abs(s - gold[name + '.sample'])
+        assert d.max() <= 2e-6 * max(1.0, float(gold[name + '.absmax'])), (name, d.max())
