@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdeepinteraction_hip.so')
 
 DI_F32, DI_F16, DI_F16_HL = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_p, _c_i, _c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
@@ -89,7 +89,7 @@ class TokStep(ctypes.Structure):
 class TokHeads(ctypes.Structure):
     _fields_ = [('w2', _c_p), ('b2', _c_p), ('qpos', _c_p), ('keep', _c_p), ('pos_out', _c_p),
                 ('out', _c_p * TOK_MAX_HEADS), ('first', _c_p * TOK_MAX_HEADS), ('cls', _c_i * TOK_MAX_HEADS),
-                ('nheads', _c_i), ('center_head', _c_i), ('ldo', _c_i), ('col0', _c_i)]
+                ('nheads', _c_i), ('center_head', _c_i), ('ldo', _c_i), ('col0', _c_i), ('qpos2', _c_p), ('pos2_out', _c_p)]
 
 
 _lib = None

@@ -24,7 +24,7 @@ int check_launch(const char *what) {
 }  // namespace di
 
 extern "C" {
-int di_abi_version(void) { return 1; }
+int di_abi_version(void) { return 2; }   // 2: di_tok_heads gained qpos2 / pos2_out
 const char *di_last_error(void) { return di::g_err; }
 
 // number of nodes of a captured hipGraph_t (measurement plumbing for bench.py: "graph_nodes"); < 0 on error

@@ -104,6 +104,8 @@ struct Heads {          // mirrors di_tok_heads
   const float *first[DI_TOK_MAX_HEADS];
   int cls[DI_TOK_MAX_HEADS];
   int nheads, center_head, ldo, col0;
+  const float *qpos2;     // DeepInteraction++ look-forward update: pos2_out = (centre head's raw output) + qpos2
+  float *pos2_out;
 };
 struct Program {
   int n;
@@ -540,6 +542,9 @@ __device__ __forceinline__ void step_heads(const Step &s, const Heads &ho, const
       a = fmaf(wv[j][2], x[2], a);
       a = fmaf(wv[j][3], x[3], a);
     }
+    // DeepInteraction++ (deepinteractionplusplus_decoder.py:291-294): the NEXT stage's look-forward centre is this
+    // stage's raw offset + the previous stage's centre, whatever the on-the-image merge does to the stored value
+    if (h == ho.center_head && ho.pos2_out != nullptr) ho.pos2_out[bq * 2 + cidx] = a + ho.qpos2[bq * 2 + cidx];
     a += qp;
     if (merge) a = fv;
     ho.out[h][((size_t)b * ncls + cidx) * ho.ldo + ho.col0 + q] = a;

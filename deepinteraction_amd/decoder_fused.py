@@ -26,18 +26,23 @@ from .utils import fork_join, param_key
 
 def usable(dec, lidar_feat, img_feat):
     """The fused path covers the fp16-map inference form of the reference configs (v1 RoI blocks, 128 channels, 8 heads)."""
-    from .mmdet3d_plugin.models.utils.decoder_utils import ImageRCNNBlock, PointRCNNBlock
+    from .mmdet3d_plugin.models.utils.decoder_utils import ImageRCNNBlock, ImageRCNNBlockV2, PointRCNNBlock, PointRCNNBlockV2
     if torch.is_grad_enabled() or dec.training or not lidar_feat.is_cuda or lidar_feat.dtype != torch.float16:
         return False
+    pp = is_plusplus(dec)
     if lidar_feat.shape[1] != 128 or dec.num_heads != 8 or dec.num_decoder_layers != 1 or not dec.auxiliary:
         return False
     if dec.num_proposals > 512 or dec.num_classes * lidar_feat.shape[2] * lidar_feat.shape[3] > (1 << 20):
         return False
     for l, blk in enumerate(dec.decode_head):
-        if type(blk) is not (ImageRCNNBlock if l % 2 == 0 else PointRCNNBlock):
+        want = ((ImageRCNNBlockV2, PointRCNNBlockV2) if pp else (ImageRCNNBlock, PointRCNNBlock))[l % 2]
+        if type(blk) is not want:
             return False
         sfx = '' if l % 2 == 0 else '_pts'
-        if getattr(blk, 'linear1' + sfx).out_features not in (128, 256, 384, 512):
+        hidden = blk.ffn.feedforward_channels if pp else getattr(blk, 'linear1' + sfx).out_features
+        if hidden not in (128, 256, 384, 512):
+            return False
+        if pp and not (blk.ffn.num_fcs == 2 and blk.self_ffn.num_fcs == 2 and blk.ffn.add_identity and blk.self_ffn.add_identity):
             return False
     layer = dec.decoder[0]
     if layer.cross_only or layer.self_posembed is None or layer.cross_posembed is None:
@@ -51,6 +56,11 @@ def usable(dec, lidar_feat, img_feat):
                 or not isinstance(cm.activate, torch.nn.ReLU) or cm.conv.out_channels != 128 or last.out_channels > 16):
             return False
     return all(ffn._fusable() and len(ffn.heads) * 64 <= 512 for ffn in list(dec.prediction_heads) + list(dec.pred_head))
+
+
+def is_plusplus(dec):
+    """DeepInteraction++ head (V2 RoI blocks, 128-channel prediction heads, look-forward centres, cumulative image mask)."""
+    return type(dec).__name__ == 'DeepInteractionPlusPlusDecoder'
 
 
 class _Cache:
@@ -148,8 +158,72 @@ class FusedDecoder:
                         dn1=_ln(dy.norm1), dn2=_ln(dy.norm2), dn3=_ln(dy.norm3), deps=(dy.norm1.eps, dy.norm3.eps),
                         wout=ops.pack_ksteps(dy.out_layer.weight.detach().float()), bout=_f32(dy.out_layer.bias),
                         w1=_pack(g('linear1').weight), b1=_f32(g('linear1').bias),
-                        w2=_pack(g('linear2').weight), b2=_f32(g('linear2').bias))
+                        w2=_pack(g('linear2').weight), b2=_f32(g('linear2').bias), act=2)
         return self._c(('blk', id(blk)), blk, build)
+
+    def _block_consts_v2(self, blk, sfx):
+        """`ImageRCNNBlockV2` / `PointRCNNBlockV2` (decoder_utils.py:844-1089): the v1 stack with an mmcv FFN (ReLU) in the
+        main branch, whose closing LayerNorm carries the learnable `scale` (the mix is `main * scale + self * self_scale`),
+        and the constants of the self branch (FFN + LayerNorm on ONE token per query group; evaluated with torch in float32)."""
+        g = lambda n: getattr(blk, n + sfx)
+
+        def build():
+            sa, dy = g('dyconv_pre_self_attn'), g('dyconv')
+            wd, bd = _dyn_layout(dy.dynamic_layer.weight, dy.dynamic_layer.bias)
+            l1, l2 = blk.ffn.layers[0][0], blk.ffn.layers[1]
+            s1, s2 = blk.self_ffn.layers[0][0], blk.self_ffn.layers[1]
+            sc, ssc = blk.scale.detach().float(), blk.self_scale.detach().float()
+            E = sa.embed_dim
+            return dict(sa=_mha_consts(sa), scale=float(sa.head_dim) ** -0.5,
+                        n1=_ln(g('norm1')), n2=_ln(g('norm2')),
+                        n3=((_f32(g('norm3').weight) * sc).contiguous(), (_f32(g('norm3').bias) * sc).contiguous()),
+                        eps=(g('norm1').eps, g('norm2').eps, g('norm3').eps),
+                        wd=wd, bd=bd,
+                        dn1=_ln(dy.norm1), dn2=_ln(dy.norm2), dn3=_ln(dy.norm3), deps=(dy.norm1.eps, dy.norm3.eps),
+                        wout=ops.pack_ksteps(dy.out_layer.weight.detach().float()), bout=_f32(dy.out_layer.bias),
+                        w1=_pack(l1.weight), b1=_f32(l1.bias), w2=_pack(l2.weight), b2=_f32(l2.bias), act=1,
+                        # self branch (float32 torch): attention output projection + norm1, self FFN + its LayerNorm
+                        wo=_f32(sa.out_proj.weight), bo=_f32(sa.out_proj.bias), heads=sa.num_heads,
+                        sw1=_f32(s1.weight), sb1=_f32(s1.bias), sw2=_f32(s2.weight), sb2=_f32(s2.bias),
+                        sn=_ln(g('self_norm')), sn_eps=g('self_norm').eps, self_scale=ssc)
+        return self._c(('blk2', id(blk)), blk, build)
+
+    @staticmethod
+    def _self_ffn(c, y):
+        """self_norm(y + self_ffn(y)) * self_scale on a handful of float32 tokens."""
+        h = torch.relu(F.linear(y, c['sw1'], c['sb1']))
+        return F.layer_norm(y + F.linear(h, c['sw2'], c['sb2']), (y.shape[-1],), c['sn'][0], c['sn'][1], c['sn_eps']) * c['self_scale']
+
+    def _self_feature_img(self, c, x, qkv, view, member, B, Q, V):
+        """decoder_utils.py:970-990 as the product restates it (`ImageRCNNBlockV2._refine_views`): per valid view the FIRST
+        query of the view attends to the view's queries (q / k / v rows are the ones the main attention uses), goes
+        through norm1 and the self FFN + LayerNorm; query q then receives the feature of ITS view v*(q) (the published
+        broadcast keeps row 0 of every group).  (B*Q, 128) float32, already times `self_scale`."""
+        H = c['heads']
+        qk, vt = qkv
+        q = qk[:, :128].reshape(B, Q, H, -1)
+        k = qk[:, 128:].reshape(B, Q, H, -1)
+        v = vt[:, :, :Q].transpose(1, 2).reshape(B, Q, H, -1)
+        dev = x.device
+        sel = ((member.view(B, 1, Q).to(torch.int32) >> torch.arange(V, device=dev, dtype=torch.int32).view(1, V, 1)) & 1).bool()
+        ar = torch.arange(Q, device=dev).view(1, 1, Q)
+        first = torch.where(sel, ar, torch.full_like(ar, Q)).min(-1).values          # (B,V); Q when the view is unused
+        firstc = first.clamp(max=Q - 1)
+        qf = q.gather(1, firstc.view(B, V, 1, 1).expand(B, V, H, q.shape[-1]))
+        allowed = sel | (first >= Q).unsqueeze(-1)
+        sc = torch.einsum('bvhd,bqhd->bvhq', qf, k) * c['scale']
+        sc = sc.masked_fill(~allowed.unsqueeze(2), float('-inf'))
+        o = torch.einsum('bvhq,bqhd->bvhd', torch.softmax(sc, -1), v).reshape(B, V, -1)
+        xf = x.view(B, Q, -1).gather(1, firstc.unsqueeze(-1).expand(B, V, x.shape[-1]))
+        yf = F.layer_norm(xf + F.linear(o, c['wo'], c['bo']), (x.shape[-1],), c['n1'][0], c['n1'][1], c['eps'][0])
+        sf = self._self_ffn(c, yf)                                                   # (B,V,C)
+        vc = view.view(B, Q).to(torch.int64).clamp(min=0)
+        return sf.gather(1, vc.unsqueeze(-1).expand(B, Q, sf.shape[-1])).reshape(B * Q, -1).contiguous()
+
+    def _self_feature_pts(self, c, y, B, Q):
+        """decoder_utils.py:1086-1089 (`PointRCNNBlockV2._refine_all`): the self feature of query 0, for every query."""
+        s0 = self._self_ffn(c, y.view(B, Q, -1)[:, 0])                               # (B,C)
+        return s0.unsqueeze(1).expand(B, Q, s0.shape[-1]).reshape(B * Q, -1).contiguous()
 
     def _layer_consts(self, layer):
         def build():
@@ -200,10 +274,13 @@ class FusedDecoder:
             p.store(qkv_buf, qkv_out[0], roles=(nh, nh + 1), n=128, role_offset=128)
             p.store_t(qkv_buf, qkv_out[1], roles=(nh + 2, nh + 2))
 
+    def _consts_of(self, blk, sfx):
+        return self._block_consts_v2(blk, sfx) if hasattr(blk, 'self_ffn') else self._block_consts(blk, sfx)
+
     def _attend(self, blk, sfx, x, qkv, B, Q, member=None, view=None):
         """decoder_utils.py:743-746 / :824-826: y = norm1(x + self_attention(x)) from the packed projection `qkv` = (rows
         [q | k], V^T) the previous program wrote."""
-        c = self._block_consts(blk, sfx)
+        c = self._consts_of(blk, sfx)
         y = torch.empty((B * Q, 128), dtype=torch.float32, device=x.device)
         y_hl = torch.empty((B * Q, 256), dtype=torch.float16, device=x.device)      # the same rows split: the generator's operand
         p = ops.TokenProgram()
@@ -215,12 +292,12 @@ class FusedDecoder:
         p.run(B, Q)
         return y, y_hl
 
-    def _refine(self, blk, sfx, x, y, roi, B, Q, heads, next_qkv_w, keep=None):
+    def _refine(self, blk, sfx, x, y, roi, B, Q, heads, next_qkv_w, keep=None, self_feat=None):
         """decoder_utils.py:747-756 / :827-837 on y (B*Q,128) and the RoI features, then this stage's prediction heads
         (`heads` = the arguments of TokenProgram.heads, on [x' ; x]) and the next block's packed projection.  Returns
         (x', qkv').  Two programs around the DynamicConv kernels; the weights of a token group are spread over the roles
         (<= 128 KB per workgroup)."""
-        c = self._block_consts(blk, sfx)
+        c = self._consts_of(blk, sfx)                                               # self_feat: the V2 blocks' self branch
         M, dev = B * Q, x.device
         f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         y, y_hl = y
@@ -236,7 +313,7 @@ class FusedDecoder:
         p.load(1, y)
         p.rowop(0, 0, aux=1, ln=c['n2'], eps=c['eps'][1])                            # z
         p.store(0, z, roles=(0, 0))
-        p.linear(0, 1, c['w1'], c['b1'], act=2, n_per_role=128)
+        p.linear(0, 1, c['w1'], c['b1'], act=c['act'], n_per_role=128)          # GELU (v1) / ReLU (the mmcv FFN of V2)
         p.linear(1, 2, c['w2'], None, k_per_role=128)
         p.store(2, ws2, n=128, role_offset=M * 128)
         p.run(B, Q)
@@ -246,9 +323,15 @@ class FusedDecoder:
         p = ops.TokenProgram(roles=nhd + (3 if next_qkv_w is not None else 0))
         p.load_parts(2, ws2, nh, M, c['b2'])
         p.load(0, z)
-        p.rowop(2, 2, aux=0, ln=c['n3'], eps=c['eps'][2], keep=keep)                 # x'
-        p.store(2, xn, roles=(0, 0))
-        p.load(2, x, col=128)                                                        # [x' ; x]
+        if self_feat is None:
+            p.rowop(2, 2, aux=0, ln=c['n3'], eps=c['eps'][2], keep=keep)             # x'
+            p.store(2, xn, roles=(0, 0))
+            p.load(2, x, col=128)                                                    # [x' ; x]
+        else:       # V2: x' = keep * (norm3(.) * scale + self * self_scale); the 128-channel heads see x' alone
+            p.rowop(2, 2, aux=0, ln=c['n3'], eps=c['eps'][2])                        # (norm3's affine carries `scale`)
+            p.load(0, self_feat)
+            p.rowop(2, 2, aux=0, keep=keep)
+            p.store(2, xn, roles=(0, 0))
         self._heads_and_next(p, 2, 0, 1, heads, next_qkv_w, qkv_n)
         p.run(B, Q)
         return xn, qkv_n
@@ -294,7 +377,8 @@ class FusedDecoder:
         L = dec.num_mmpi
         first = [torch.empty((B, n, Q), dtype=torch.float32, device=dev) for n in cls]
         final = [torch.empty((B, n, L * Q), dtype=torch.float32, device=dev) for n in cls]
-        blk_consts = [self._block_consts(dec.decode_head[l], '' if l % 2 == 0 else '_pts') for l in range(L)]
+        pp = is_plusplus(dec)
+        blk_consts = [self._consts_of(dec.decode_head[l], '' if l % 2 == 0 else '_pts') for l in range(L)]
         f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
 
         # ---- decoder layer (decoder_utils.py:83-113: post-norm; positional embeddings added to q, k and v)
@@ -350,6 +434,7 @@ class FusedDecoder:
         cfg, bc = dec.test_cfg, dec.bbox_coder
         cell_bev = bc.out_size_factor * bc.voxel_size[0]
         dec.on_the_image_mask = []
+        look, keep_cum = pos, None                   # ++: look-forward centres (:281), cumulative on-the-image mask (:295-302)
         res, ld, col = dict(zip(names, first)), Q, 0                                 # where the previous stage's boxes are
         for l in range(L):
             blk = dec.decode_head[l]
@@ -359,6 +444,9 @@ class FusedDecoder:
             nxt = (blk_consts[l + 1]['sa'][0], blk_consts[l + 1]['sa'][1]) if l + 1 < L else None
             heads = dict(w1=hc[0], b1=hc[1], w2=hc[2], b2=hc[3], qpos=pos, outs=final, cls=cls, center_head=ic, ldo=L * Q,
                          col0=l * Q, pos_out=pos_next)
+            if pp:      # centre = offset + look-forward (:293); the next look-forward = offset + this stage's query position (:294)
+                look_next = f32e(B, Q, 2)
+                heads.update(qpos=look, qpos2=pos, pos2_out=look_next)
             # The RoI side (box geometry -> RoIs -> RoIAlign) and the token side (self attention among the queries) of a
             # block are independent up to the DynamicConv core and CAN run as two branches (DI_OVERLAP bit 32; the image
             # block's attention is masked by the per-view membership, so only its RoIAlign runs beside it).  Measured on
@@ -370,19 +458,29 @@ class FusedDecoder:
                                                  cfg['out_size_factor'] * cfg['voxel_size'][0], cfg['pc_range'][:2],
                                                  1.0, 1.0, True, False, ld=ld)
                 rois, view, member, keep, on_img = ops.roi_select(rect, on)
+                sfeat = self._self_feature_img(blk_consts[l], x, qkv_b, view, member, B, Q, V) if pp else None
                 y, roi = par(lambda: self._attend(blk, '', x, qkv_b, B, Q, member, view),
                              lambda: ops.roi_align(maps, rois, 1.0 / blk.out_size_factor_img, out_hl=True))   # (B*Q,49,2C) hi | lo
-                heads.update(keep=keep, first=first)
-                x, qkv_b = self._refine(blk, '', x, y, roi, B, Q, heads, nxt, keep)
-                dec.on_the_image_mask.append(keep.view(B, Q).bool())
+                if pp:
+                    keep_cum = keep if keep_cum is None else keep & keep_cum
+                heads.update(keep=keep_cum if pp else keep, first=first)
+                x, qkv_b = self._refine(blk, '', x, y, roi, B, Q, heads, nxt, keep, sfeat)
+                dec.on_the_image_mask.append((keep_cum if pp else keep).view(B, Q).bool())
             else:
                 def rois_bev():
                     _, _, rect = ops.query_geometry(r32, None, None, None, cell_bev, bc.pc_range[:2], cell_bev, 2.0,
                                                     False, True, ld=ld)
                     return ops.roi_align(new_lidar_feat, ops.roi_select(rect), 1.0, out_hl=True)
                 y, roi = par(lambda: self._attend(blk, '_pts', x, qkv_b, B, Q), rois_bev)
-                x, qkv_b = self._refine(blk, '_pts', x, y, roi, B, Q, heads, nxt)
+                sfeat = None
+                if pp:                                        # every stage is merged with the first one's result (:299-302)
+                    sfeat = self._self_feature_pts(blk_consts[l], y[0], B, Q)
+                    heads.update(keep=keep_cum, first=first)
+                    dec.on_the_image_mask.append(dec.on_the_image_mask[-1])
+                x, qkv_b = self._refine(blk, '_pts', x, y, roi, B, Q, heads, nxt, None, sfeat)
             pos = pos_next
+            if pp:
+                look = look_next
             res, ld, col = dict(zip(names, final)), L * Q, l * Q
 
         out = dict(zip(names, final))

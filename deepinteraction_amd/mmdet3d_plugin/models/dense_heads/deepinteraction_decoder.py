@@ -161,7 +161,7 @@ class DeepInteractionDecoder(nn.Module):
         return out.float() if out_f32 else out
 
     def forward(self, pts_inputs, img_inputs, img_metas):
-        if self.fused and type(self)._mmpi is DeepInteractionDecoder._mmpi \
+        if self.fused and (type(self)._mmpi is DeepInteractionDecoder._mmpi or decoder_fused.is_plusplus(self)) \
                 and decoder_fused.usable(self, pts_inputs[0], img_inputs):
             if self._fused_path is None:
                 self._fused_path = decoder_fused.FusedDecoder()

@@ -885,7 +885,7 @@ class TokenProgram:
         return self._add(_lib.TOK_STORE, src=src, N=y_hl.shape[-1] // 2, a=col, b=2, p0=y_hl, ld0=y_hl.stride(-2), roles=roles)
 
     def heads(self, src, w2, b2, qpos, outs, cls, center_head, ldo, col0, keep=None, first=None, pos_out=None, roles=None,
-              per_role=False):
+              per_role=False, qpos2=None, pos2_out=None):
         """Second layers of the prediction heads on the hidden rows in buf[src] (see include/deepinteraction_hip.h);
         per_role: role r evaluates head r only, its 64 hidden channels at columns 0..63."""
         h = _lib.TokHeads()
@@ -894,12 +894,15 @@ class TokenProgram:
         h.w2, h.b2, h.qpos = w2.data_ptr(), b2.data_ptr(), qpos.data_ptr()
         h.keep = None if keep is None else keep.data_ptr()
         h.pos_out = None if pos_out is None else pos_out.data_ptr()
+        assert (qpos2 is None) == (pos2_out is None)
+        h.qpos2 = None if qpos2 is None else _f32c(qpos2).data_ptr()          # ++: pos2_out = raw centre offset + qpos2
+        h.pos2_out = None if pos2_out is None else _f32c(pos2_out).data_ptr()
         for i in range(n):
             h.out[i] = outs[i].data_ptr()
             h.first[i] = first[i].data_ptr() if first is not None else None
             h.cls[i] = int(cls[i])
         h.nheads, h.center_head, h.ldo, h.col0 = n, center_head, ldo, col0
-        self.refs += [w2, b2, qpos, keep, pos_out] + list(outs) + (list(first) if first is not None else [])
+        self.refs += [w2, b2, qpos, keep, pos_out, qpos2, pos2_out] + list(outs) + (list(first) if first is not None else [])
         self.head_desc = h
         return self._add(_lib.TOK_HEADS, src=src, a=int(bool(per_role)), roles=roles)
 

@@ -452,6 +452,8 @@ typedef struct di_tok_heads {
   const float *first[DI_TOK_MAX_HEADS];   /* (B, cls_h, Q) of the first stage (needed with keep) */
   int cls[DI_TOK_MAX_HEADS];
   int nheads, center_head, ldo, col0;
+  const float *qpos2;              /* ABI 2 - DeepInteraction++ look-forward (deepinteractionplusplus_decoder.py:291-294): with */
+  float *pos2_out;                 /* pos2_out (B,Q,2) != NULL, pos2_out = raw centre offset + qpos2 (B,Q,2); else both NULL */
 } di_tok_heads;
 int di_token_program(const di_tok_step *steps_host, int nsteps, const di_tok_heads *heads_host, int B, int Q,
                      void *stream);

@@ -203,6 +203,47 @@ def test_pp_head_matches_oracle_and_golden():
         assert np.abs(a.numpy() - gold['dec_' + k]).max() <= 2e-3 * scale, k
 
 
+def test_pp_head_fused_token_path_matches_oracle():
+    """Round 4: the ++ head on the float32 token kernels (decoder_fused.FusedDecoder: V2 RoI blocks - main branch on the
+    token programs with the mmcv FFN, the self branch of the first query per view / per sample, the look-forward centre
+    update and the cumulative on-the-image mask in the heads step).  fp16 maps in, float32 token path: the oracle sees the
+    same fp16-representable maps and float32 parameters (heat-map heads rounded through fp16 as `half_maps_` holds them)."""
+    from deepinteraction_amd import decoder_fused, precision
+    from deepinteraction_amd.mmdet3d_plugin import DeepInteractionPlusPlusDecoder
+    O, (pts, img, metas) = mg.decoder_pp_case(opp.DeepInteractionPlusPlusDecoder)
+    for m in (O.heatmap_head, O.heatmap_head_img):
+        for t in list(m.parameters()) + list(m.buffers()):
+            if t.is_floating_point():
+                t.data = t.data.half().float()
+    pts, img = [p.half().float() for p in pts], img.half().float()
+    M = DeepInteractionPlusPlusDecoder(**configs.decoder_cfg(bev=36, num_proposals=40))
+    M.load_state_dict(O.state_dict())
+    M = M.eval().to(DEV)
+    M.float()
+    M.heatmap_head.half()
+    M.heatmap_head_img.half()
+    cl = lambda t: t.to(DEV, torch.float16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        assert decoder_fused.usable(M, cl(pts[0]), cl(img))
+        got = M([cl(p) for p in pts], cl(img), metas)[0][0]
+        free_top = O(pts, img, metas) and O.top_proposals.clone()
+        # fp16 heat-map convolutions may reorder near-tied scores: the same SET of proposals, the oracle then runs on the
+        # product's order (`top_override`, an oracle-side switch)
+        assert sorted(M.top_proposals.cpu().flatten().tolist()) == sorted(free_top.flatten().tolist())
+        want = O(pts, img, metas, top_override=M.top_proposals.cpu())[0][0]
+    assert M._fused_path is not None                                                  # the fused path really ran
+    assert torch.equal(M.query_labels.cpu(), O.query_labels)
+    assert len(M.on_the_image_mask) == 4
+    for a, b in zip(M.on_the_image_mask, O.on_the_image_mask):
+        assert torch.equal(a.cpu(), b)
+    for k in want:
+        a = got[k].float().cpu()
+        assert a.shape == want[k].shape, k
+        scale = max(1.0, want[k].abs().max().item())
+        tol = 1e-3 if k in ('dense_heatmap', 'query_heatmap_score') else 2e-4      # heat maps: fp16 convolutions
+        assert (a - want[k]).abs().max().item() <= tol * scale, (k, (a - want[k]).abs().max().item(), scale)
+
+
 def test_v2_block_first_query_quirk():
     """Direct check of the published broadcasting behaviour the product reproduces: with the self branch switched
     on alone (scale 0, self_scale 1) every query of a sample gets the SAME vector out of the point block."""
