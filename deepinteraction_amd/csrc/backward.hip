@@ -290,7 +290,8 @@ __global__ __launch_bounds__(256) void i2p_attn_bwd_kernel(
     const float *__restrict__ pillars, const int32_t *__restrict__ coors, const int32_t *__restrict__ num_points,
     const float *__restrict__ proj, const float *__restrict__ aug, float *__restrict__ grad_img,
     float *__restrict__ grad_qfold, int P, int Tp, int D, int V, int Hi, int Wi, int Hb, int Wb, int C,
-    float ori_H, float ori_W, float drop_p, unsigned long long seed) {
+    float ori_H, float ori_W, float drop_p, unsigned long long seed, const unsigned long long *__restrict__ seed_add) {
+  if (seed_add != nullptr) seed += *seed_add;
   __shared__ KeyEntB s_list[4][kMaxSlotsB];
   __shared__ float slots[16 * kSlotFloats];            // one transposition slot per 16-lane group
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
@@ -488,11 +489,11 @@ int di_i2p_attn_bwd_mass(const void *img, const void *qfold, const void *grad_ct
   if (dtype == DI_F16)
     hipLaunchKernelGGL(di::i2p_attn_bwd_kernel<__half>, dim3(blocks), dim3(256), 0, s, (const __half *)img,
                        (const __half *)qfold, (const __half *)grad_ctx, (const __half *)grad_mass, pillars, coors, num_points, proj, aug_rev,
-                       grad_img, grad_qfold, P, T, D, n_views, Hi, Wi, Hb, Wb, C, ori_H, ori_W, dropout_p, seed);
+                       grad_img, grad_qfold, P, T, D, n_views, Hi, Wi, Hb, Wb, C, ori_H, ori_W, dropout_p, seed, di::i2p_seed_ptr());
   else if (dtype == DI_F32)
     hipLaunchKernelGGL(di::i2p_attn_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float *)img,
                        (const float *)qfold, (const float *)grad_ctx, (const float *)grad_mass, pillars, coors, num_points, proj, aug_rev,
-                       grad_img, grad_qfold, P, T, D, n_views, Hi, Wi, Hb, Wb, C, ori_H, ori_W, dropout_p, seed);
+                       grad_img, grad_qfold, P, T, D, n_views, Hi, Wi, Hb, Wb, C, ori_H, ori_W, dropout_p, seed, di::i2p_seed_ptr());
   else {
     di::set_error("unsupported dtype %d", dtype);
     return DI_ERR_ARG;

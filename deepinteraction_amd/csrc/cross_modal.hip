@@ -187,8 +187,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 5 : 4) void i2p_attn_kernel(
     const T *__restrict__ img, const T *__restrict__ qfold, const int *__restrict__ cnt_tab,
     const int *__restrict__ pil_tab, const KeyEnt *__restrict__ keys, const int *__restrict__ order,
     T *__restrict__ ctx, T *__restrict__ valid_out, int ncell, int nslots, int Wi, int C_, float drop_p,
-    unsigned long long seed, T *__restrict__ mass_out = nullptr) {
+    unsigned long long seed, T *__restrict__ mass_out = nullptr, const unsigned long long *__restrict__ seed_add = nullptr) {
   typedef typename Vec8<T>::type V8;
+  if (seed_add != nullptr) seed += *seed_add;
   const int C = FULLC ? 128 : C_;                // 128 channels: the row offsets are shifts
   const int tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
   const int l16 = lane & 15, sub = lane >> 4;
@@ -479,11 +480,11 @@ int di_i2p_attn_fwd_mass(const void *img, const void *qfold, const void *key_tab
     if (mass)                                                                                            \
       hipLaunchKernelGGL((di::i2p_attn_kernel<TT, FULL, true>), dim3(blocks), dim3(256), 0, s, (const TT *)img, \
                          (const TT *)qfold, cnt, pil, keys, cell_order, (TT *)ctx, (TT *)valid, ncell, T * n_views, \
-                         Wi, C, dropout_p, seed, (TT *)mass);                                            \
+                         Wi, C, dropout_p, seed, (TT *)mass, di::i2p_seed_ptr());                                          \
     else                                                                                                 \
       hipLaunchKernelGGL((di::i2p_attn_kernel<TT, FULL, false>), dim3(blocks), dim3(256), 0, s, (const TT *)img, \
                          (const TT *)qfold, cnt, pil, keys, cell_order, (TT *)ctx, (TT *)valid, ncell, T * n_views, \
-                         Wi, C, dropout_p, seed, (TT *)nullptr);                                         \
+                         Wi, C, dropout_p, seed, (TT *)nullptr, di::i2p_seed_ptr());                                         \
   } while (0)
   if (dtype == DI_F16) {
     if (C == 128) DI_I2P_GO(__half, true); else DI_I2P_GO(__half, false);

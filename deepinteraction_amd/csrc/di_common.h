@@ -8,6 +8,10 @@
 #include "../../include/deepinteraction_hip.h"
 
 namespace di {
+// Device word ADDED to the attention-dropout seed of the pillar attention (forward and backward) when set: a captured
+// training step bakes the host seed into its graph, the device word is rewritten before every replay (di_i2p_set_seed_ptr).
+const unsigned long long *i2p_seed_ptr();
+
 
 // ---- host side: error plumbing (no exceptions across the C ABI)
 void set_error(const char *fmt, ...);

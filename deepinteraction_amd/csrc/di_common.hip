@@ -23,7 +23,16 @@ int check_launch(const char *what) {
 }
 }  // namespace di
 
+namespace di {
+static const unsigned long long *g_i2p_seed_ptr = nullptr;
+const unsigned long long *i2p_seed_ptr() { return g_i2p_seed_ptr; }
+}  // namespace di
+
 extern "C" {
+int di_i2p_set_seed_ptr(const void *dev_ptr) {
+  di::g_i2p_seed_ptr = reinterpret_cast<const unsigned long long *>(dev_ptr);
+  return 0;
+}
 int di_abi_version(void) { return 2; }   // 2: di_tok_heads gained qpos2 / pos2_out
 const char *di_last_error(void) { return di::g_err; }
 

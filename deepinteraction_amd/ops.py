@@ -313,6 +313,18 @@ def bev_sector_order(Hb, Wb, device):
     return hit
 
 
+_I2P_SEED_REF = [None]
+
+
+def set_i2p_seed_tensor(t):
+    """Register (or clear with None) the device int64 word that every pillar-attention launch adds to its dropout seed when
+    it runs - what a graph-replayed training step rewrites before each replay (`train_step.GraphedTrainer`)."""
+    if t is not None:
+        assert t.is_cuda and t.dtype == torch.int64 and t.numel() == 1
+    _I2P_SEED_REF[0] = t
+    _lib.call('di_i2p_set_seed_ptr', 0 if t is None else t.data_ptr())
+
+
 def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p=0.0, seed=0, keys=None,
                   sector_order=True, with_mass=False):
     """One sample.  img (V,C,Hi,Wi), qfold (1,C,Hb,Wb) channels-last; pillars (P,T,D) f32,

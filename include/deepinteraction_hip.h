@@ -165,6 +165,10 @@ int di_i2p_attn_bwd(const void *img, const void *qfold, const void *grad_ctx, co
                     float *grad_img, float *grad_qfold, int P, int T, int D, int n_views, int Hi, int Wi, int Hb,
                     int Wb, int C, float ori_H, float ori_W, float dropout_p, unsigned long long seed, int dtype,
                     void *stream);
+/* Training under hipGraph replay: a captured launch has its `seed` argument baked in.  With a device word registered here
+ * (NULL to clear) every di_i2p_attn_fwd* / di_i2p_attn_bwd* launch ADDS *dev_ptr to its seed when it RUNS; the caller rewrites
+ * the word before each replay (forward and backward of one step then see the same value). */
+int di_i2p_set_seed_ptr(const void *dev_ptr);
 /* The same with the gradient of the kept mass (Hb*Wb, the maps' element type; NULL = di_i2p_attn_bwd). */
 int di_i2p_attn_bwd_mass(const void *img, const void *qfold, const void *grad_ctx, const void *grad_mass, const float *pillars,
                          const int32_t *coors, const int32_t *num_points, const float *proj, const float *aug_rev,

@@ -405,3 +405,36 @@ def test_full_training_step_with_loss():
     with torch.no_grad():
         l1 = total_loss()
     assert torch.isfinite(l0) and l1 < l0, (float(l0), float(l1))
+
+
+def test_graphed_training_step():
+    """`train_step.GraphedTrainer`: forward and backward of the hot path replayed as two captured hipGraphs around the eager
+    head loss (host Hungarian step).  (i) it trains: finite losses, every trainable parameter except the detached heat-map
+    head gets a finite gradient; (ii) replay is deterministic given the dropout seed word and the torch RNG state: the same
+    step from the same weights gives the same loss twice; (iii) the device seed word - rewritten before every replay - really
+    drives the pillar attention's dropout mask: another word, another loss."""
+    from deepinteraction_amd import ops, train_step
+    torch.backends.cudnn.deterministic = True
+    tr = train_step.GraphedTrainer(synth.SHAPE_TINY, 24, torch.device(DEV), 1, pool=2)
+    try:
+        losses = [float(tr.step()) for _ in range(3)]
+        assert all(math.isfinite(l) for l in losses), losses
+        missing = [n for m in (tr.enc, tr.dec) for n, p in m.named_parameters() if p.grad is None]
+        assert all(n.startswith('heatmap_head.') for n in missing), missing[:5]
+        assert all(torch.isfinite(p.grad).all() for p in tr.params if p.grad is not None)
+
+        def forward_loss(word):
+            tr.h.load(tr.records[0])
+            tr.seed_word.fill_(word)
+            torch.manual_seed(5)
+            torch.cuda.manual_seed(5)
+            with torch.no_grad():
+                outs = tr.graphed(tr.h.img_feats, tr.h.pts_feats)
+                preds = [[dict(zip(tr.module.keys, outs))]]
+                ls = tr.dec.loss([g[0] for g in tr.pool[0][1]], [g[1] for g in tr.pool[0][1]], preds)
+            return float(sum(v for k, v in ls.items() if k != 'matched_ious'))
+        a, b, c = forward_loss(1234), forward_loss(1234), forward_loss(99991)
+        assert a == b, (a, b)
+        assert a != c, (a, c)
+    finally:
+        ops.set_i2p_seed_tensor(None)
