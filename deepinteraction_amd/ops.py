@@ -313,6 +313,13 @@ def bev_sector_order(Hb, Wb, device):
     return hit
 
 
+def copy_bytes(dst, src):
+    """dst <- src for two dense uint8 device buffers of the same size, in ONE streaming launch (`GraphedHotPath.load`)."""
+    assert dst.is_cuda and src.is_cuda and dst.dtype == torch.uint8 and src.dtype == torch.uint8
+    assert dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel()
+    _lib.call('di_copy_d2d', dst.data_ptr(), src.data_ptr(), dst.numel(), _stream())
+
+
 _I2P_SEED_REF = [None]
 
 

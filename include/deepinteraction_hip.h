@@ -46,6 +46,9 @@ enum {
 };
 
 int di_abi_version(void);
+/* One-launch device-to-device copy of a large 16-byte-aligned buffer (the per-sample `load()` into the captured input arena;
+ * plumbing of bench.py's step protocol, not a kernel of the reference path). */
+int di_copy_d2d(void *dst, const void *src, long long bytes, void *stream);
 const char *di_last_error(void);
 /* Measurement plumbing: number of nodes of a captured hipGraph_t (HOST handle), < 0 on error.  bench.py reports
  * it as `graph_nodes` of the captured forward. */
