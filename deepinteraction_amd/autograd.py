@@ -5,20 +5,28 @@ feature maps receive gradients: sampling coordinates are functions of points, me
 predictions, exactly as in the reference (F.grid_sample's grid at encoder_utils.py:195,:297 is built from
 data; the RoI boxes come from deep-copied, decoded predictions, decoder_utils.py:672-679)."""
 import torch
+from torch.amp import custom_bwd, custom_fwd
 
 from . import ops
+
+# Mixed precision (torch.autocast): the gather kernels take fp16 or float32 maps as they come; `custom_fwd` / `custom_bwd` make
+# a Function's backward run under the autocast state of its forward (PixelLinear's GEMMs then run in the forward's dtype).
+_fwd = custom_fwd(device_type='cuda')
+_bwd = custom_bwd(device_type='cuda')
 
 
 class BEVWarpGather(torch.autograd.Function):
     """warped = bilinear(bev, unproject(depth)) masked to pc_range  (encoder_utils.py:183-196)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, bev, depth, img2lidar, aug_fwd, xs, ys, pc_range):
         ctx.save_for_backward(depth, img2lidar, aug_fwd, xs, ys, pc_range)
         ctx.bev_hw, ctx.bev_dtype = tuple(bev.shape[-2:]), bev.dtype
         return ops.bevwarp_gather(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         depth, img2lidar, aug_fwd, xs, ys, pc_range = ctx.saved_tensors
         g = ops.bevwarp_gather_bwd(grad_out, depth, img2lidar, aug_fwd, xs, ys, pc_range, ctx.bev_hw)
@@ -29,12 +37,14 @@ class RoIAlign(torch.autograd.Function):
     """detectron2 ROIAlign(7x7, ratio 2, aligned) on channels-last maps, output (R,49,C)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, feat, rois, spatial_scale):
         ctx.save_for_backward(rois)
         ctx.shape, ctx.dtype, ctx.scale = tuple(feat.shape), feat.dtype, float(spatial_scale)
         return ops.roi_align(feat, rois, spatial_scale)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         (rois,) = ctx.saved_tensors
         g = ops.roi_align_bwd(grad_out, rois, ctx.shape, ctx.scale)
@@ -49,6 +59,7 @@ class PixelLinear(torch.autograd.Function):
     are a BATCHED GEMM (S x 16 workgroups) and the S partial results are summed."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -62,10 +73,15 @@ class PixelLinear(torch.autograd.Function):
         return 1
 
     @staticmethod
+    @_bwd
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gx = gw = gb = None
         gy = gy.contiguous()
+        if gy.dtype != weight.dtype:                 # autocast: the forward's GEMM ran in fp16
+            weight = weight.to(gy.dtype)
+        if x.dtype != gy.dtype:
+            x = x.to(gy.dtype)
         if ctx.needs_input_grad[0]:
             gx = gy @ weight
         if ctx.needs_input_grad[1]:
@@ -86,6 +102,7 @@ class I2PAttention(torch.autograd.Function):
     value bias enters the module's output scaled by it, and its gradient flows back into the scores."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw, dropout_p, seed, keys=None):
         ctx.save_for_backward(img, qfold, pillars, coors, num_points, proj, aug_rev)
         ctx.ori_hw, ctx.dropout_p, ctx.seed = ori_hw, float(dropout_p), int(seed)
@@ -95,6 +112,7 @@ class I2PAttention(torch.autograd.Function):
         return out, valid, mass
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_ctx, _grad_valid, grad_mass):
         img, qfold, pillars, coors, num_points, proj, aug_rev = ctx.saved_tensors
         g_img, g_q = ops.i2p_attention_bwd(img, qfold, grad_ctx, pillars, coors, num_points, proj, aug_rev,
@@ -108,6 +126,7 @@ class MSDeformAttn(torch.autograd.Function):
     plusplus_bwd.hip).  Gradients: value, packed projection.  Reference points are constants."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, value, proj, ref, level_hw, n_points):
         L = len(level_hw)
         n_off = 8 * L * n_points * 2
@@ -116,6 +135,7 @@ class MSDeformAttn(torch.autograd.Function):
         return ops.ms_deform_attn(value, proj[..., :n_off], proj[..., n_off:], ref, level_hw, n_points)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         value, proj, ref = ctx.saved_tensors
         n_off = ctx.n_off
@@ -129,12 +149,14 @@ class GridGather(torch.autograd.Function):
     geometry, the additive term a constant encoding)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, feat, grid, add, grids_per_feat):
         ctx.save_for_backward(grid)
         ctx.shape, ctx.dtype, ctx.per = tuple(feat.shape), feat.dtype, grids_per_feat
         return ops.grid_gather(feat, grid, add, grids_per_feat)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         (grid,) = ctx.saved_tensors
         return ops.grid_gather_bwd(grid, grad_out, ctx.shape, ctx.per).to(ctx.dtype), None, None, None
@@ -144,12 +166,14 @@ class PolarBEVSample(torch.autograd.Function):
     """out = mean over seeing cameras of bilinear(polar[cam], loc(cell, cam)) + bev  (fusion_transformerv4.py:581-640)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, polar, bev, proj, aug_rev, cam_xy, params):
         ctx.save_for_backward(proj, aug_rev, cam_xy, params)
         ctx.shape, ctx.dtype = tuple(polar.shape), polar.dtype
         return ops.polar_bev_sample(polar, bev, proj, aug_rev, cam_xy, params)
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         proj, aug_rev, cam_xy, params = ctx.saved_tensors
         gp = ops.polar_bev_sample_bwd(grad_out, proj, aug_rev, cam_xy, params, ctx.shape)

@@ -226,16 +226,21 @@ def mix2_folded(proj1, a, fold, mask, b, proj2, c, cache):
                                relu2=proj2.use_activation, x3=c, mask=mask, bm=cache['bm'])
 
 
+from torch.amp import custom_bwd as _cbwd, custom_fwd as _cfwd
+
+
 class similarFunction(torch.autograd.Function):
     """Reference encoder_utils.py:36-57, bound to the HIP window kernels."""
 
     @staticmethod
+    @_cfwd(device_type='cuda')
     def forward(ctx, x_ori, x_loc, kH, kW):
         ctx.save_for_backward(x_ori, x_loc)
         ctx.kHW = (kH, kW)
         return ops.similar_forward(x_ori, x_loc, kH, kW)
 
     @staticmethod
+    @_cbwd(device_type='cuda')
     def backward(ctx, grad_outputs):
         x_ori, x_loc = ctx.saved_tensors
         kH, kW = ctx.kHW
@@ -248,12 +253,14 @@ class weightingFunction(torch.autograd.Function):
     """Reference encoder_utils.py:60-81, bound to the HIP window kernels."""
 
     @staticmethod
+    @_cfwd(device_type='cuda')
     def forward(ctx, x_ori, x_weight, kH, kW):
         ctx.save_for_backward(x_ori, x_weight)
         ctx.kHW = (kH, kW)
         return ops.weighting_forward(x_ori, x_weight, kH, kW)
 
     @staticmethod
+    @_cbwd(device_type='cuda')
     def backward(ctx, grad_outputs):
         x_ori, x_weight = ctx.saved_tensors
         kH, kW = ctx.kHW

@@ -56,8 +56,12 @@ class Trainer:
     def step(self):
         d, gts = self.pool[self.i % len(self.pool)]
         self.i += 1
-        img, pts = self.enc(d['img_feats'], d['pts_feats'], d['img_metas'], dict(d['pts_metas']))
-        losses = self.dec.loss([g[0] for g in gts], [g[1] for g in gts], self.dec(pts, img, d['img_metas']))
+        import os
+        with torch.autocast('cuda', dtype=torch.float16, enabled=os.environ.get('DI_TRAIN_AMP', '0') == '1'):
+            img, pts = self.enc(d['img_feats'], d['pts_feats'], d['img_metas'], dict(d['pts_metas']))
+            preds = self.dec(pts, img, d['img_metas'])
+        preds = [[{k: v.float() for k, v in preds[0][0].items()}]]
+        losses = self.dec.loss([g[0] for g in gts], [g[1] for g in gts], preds)
         loss = sum(v for k, v in losses.items() if k != 'matched_ious')
         self.opt.zero_grad(set_to_none=True)
         loss.backward()                                               # bucket all-reduces start inside
@@ -82,13 +86,15 @@ class _HotPathModule(torch.nn.Module):
         for g in o.sample_geom:
             g.forget()
         self.dec.static_geometry = o.query_geom
+        import os
         try:
-            img, pts = self.enc(img_feats, pts_feats, o.img_metas, o._pts_metas())
-            out = self.dec(pts, img, o.img_metas)[0][0]
+            with torch.autocast('cuda', dtype=torch.float16, enabled=os.environ.get('DI_TRAIN_AMP', '0') == '1', cache_enabled=False):
+                img, pts = self.enc(img_feats, pts_feats, o.img_metas, o._pts_metas())
+                out = self.dec(pts, img, o.img_metas)[0][0]
         finally:
             self.dec.static_geometry = None
         self.keys = sorted(out)
-        return tuple(out[k] for k in self.keys)
+        return tuple(out[k].float() for k in self.keys)
 
 
 class GraphedTrainer(Trainer):
