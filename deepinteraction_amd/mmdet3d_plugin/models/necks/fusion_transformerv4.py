@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .... import ops
+from .... import ops, utils
 from ....autograd import GridGather, PolarBEVSample
 from ....geometry import PC_RANGE, aug_affine
 from ....registry import ATTENTION, NECKS, TRANSFORMER_LAYER
@@ -437,11 +437,21 @@ class FusionTransformerv4(nn.Module):
         if own_cache:
             pts_metas[eu.GEOM_KEY] = [None] * len(img_metas)                    # per-forward geometry / depth cache
         try:
+            # The two sides of a layer read the previous layer's maps only: on the device they run as two branches (image
+            # side on the caller's stream, BEV side - 32 400 tokens, launches that fill a fraction of the chip - on the side
+            # stream; parallel paths under hipGraph capture), as the v1 neck does.  Every lazily cached per-sample product
+            # belongs to ONE side (completed depth: image side; pillar key table, polar rays: BEV side), so each is created
+            # and re-used on its own stream.
+            fork = utils.OVERLAP & 1 and dev.type == 'cuda' and not torch.is_grad_enabled()
             for i in range(self.num_layers):
-                t_img = self.img_fusion_blocks[i](new_img, new_pts, img_flat, ref_img, shapes_img, None, img_metas,
-                                                  pts_metas)
-                t_pts = self.pts_fusion_blocks[i](new_pts, new_img, pts_flat, ref_pts, shapes_pts, None, img_metas,
-                                                  pts_metas)
+                img_side = lambda i=i, a=new_img, b=new_pts: self.img_fusion_blocks[i](
+                    a, b, img_flat, ref_img, shapes_img, None, img_metas, pts_metas)
+                pts_side = lambda i=i, a=new_img, b=new_pts: self.pts_fusion_blocks[i](
+                    b, a, pts_flat, ref_pts, shapes_pts, None, img_metas, pts_metas)
+                if fork:
+                    t_img, t_pts = utils.fork_join(dev, img_side, pts_side)
+                else:
+                    t_img, t_pts = img_side(), pts_side()
                 new_img, new_pts = t_img, t_pts
         finally:
             if own_cache:
