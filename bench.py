@@ -222,8 +222,8 @@ def run_dry(args, parallel, rank, world):
 
 def main():
     args = parse()
-    if args.eager or args.dry_run or args.model != 'v1' or args.mode != 'forward':
-        args.inflight = 1          # several samples in flight exist for the graph-replayed v1 forward only
+    if args.eager or args.dry_run or args.mode != 'forward' or (args.model == 'pp' and args.from_images):
+        args.inflight = 1          # several samples in flight exist for the graph-replayed forwards only
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(args))
     import torch
@@ -515,17 +515,39 @@ def bench_forward_pp(args, rank, world, device):
                 eager(pool[it[0] % len(pool)])
                 it[0] += 1
         else:
-            g = GraphedHotPath(enc, dec, pool[max(range(len(pool)), key=lambda i: n_pillars[i])], image_net=image_net)
+            cap = pool[max(range(len(pool)), key=lambda i: n_pillars[i])]
+            graphs = [GraphedHotPath(enc, dec, cap, image_net=image_net) for _ in range(max(1, args.inflight))]
+            g = graphs[-1]                                  # (the modules' output attributes point at the last capture)
             records = [g.prepare(d) for d in pool]
+            lanes = [torch.cuda.Stream() for _ in graphs] if len(graphs) > 1 else [None]
+            for lane in lanes:
+                if lane is not None:
+                    lane.wait_stream(torch.cuda.current_stream())
 
-            def step():
-                g.load(records[it[0] % len(records)])
-                it[0] += 1
-                g()
+            def step():                                     # as the v1 line: N independent captured forwards, own sample each
+                for gi, lane in zip(graphs, lanes):
+                    with torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext():
+                        gi.load(records[it[0] % len(records)])
+                        it[0] += 1
+                        gi()
         settle(step, args.settle_ms)
         for _ in range(args.warmup):
             step()
         elapsed = parallel.timed_region(step, args.steps, device)
+        single = None
+        if not args.eager and len(graphs) > 1:              # the one-sample-at-a-time figure beside the line's value
+            torch.cuda.synchronize()
+            one = [0]
+
+            def step1():
+                g.load(records[one[0] % len(records)])
+                one[0] += 1
+                g()
+            for _ in range(max(2, args.warmup // 2)):
+                step1()
+            e1 = parallel.timed_region(step1, args.steps, device)
+            single = dict(value=round(parallel.throughput(args.batch, args.steps, e1, world), 3), unit='samples/s',
+                          ms_per_step=round(e1 / args.steps * 1e3, 3), inflight=1)
         product_out = graph_vs_eager = None
         want_cpu = rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and not args.from_images
         if want_cpu:               # the product's outputs on pool[0], in the benched launch mode
@@ -562,18 +584,21 @@ def bench_forward_pp(args, rank, world, device):
     durs = sorted(durs)[len(durs) // 2:]
     avg = sum(durs) / max(len(durs), 1)
     out = _line(args, 'samples/sec forward (Fusion_0075_plusplus synthetic)',
-                parallel.throughput(args.batch, args.steps, elapsed, world), elapsed,
+                parallel.throughput(args.batch * max(1, args.inflight), args.steps, elapsed, world), elapsed,
                 'f16' if dtype == torch.float16 else 'f32',
                 'DeepInteraction++ forward: FusionTransformerv4 neck (2 layers) + DeepInteractionPlusPlusDecoder, '
                 'Fusion_0075_plusplus shapes (2 image levels 112x200 / 56x100, BEV 180x180), random-init weights',
                 dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(pool), from_images=bool(args.from_images),
-                     launch='eager' if args.eager else 'per step: load() + hipGraph replay',
+                     inflight=max(1, args.inflight),
+                     launch='eager' if args.eager else 'per step and sample in flight: load() + hipGraph replay',
                      graph_nodes=None if g is None else g.num_nodes()))
     out['roofline'] = dict(bound='hbm', kernel='pp::ms_deform_attn_kernel, image self-attention (2 levels)',
                            achieved=round(alg / avg / 1e9, 1) if durs else None, peak=HBM_PEAK_GBS, unit='GB/s',
                            frac=round(alg / avg / 1e9 / HBM_PEAK_GBS, 4) if durs else None,
                            traffic=pmc_file('pmc_ms_deform_attn.json').get('hbm_bytes_per_launch'),
                            avg_launch_us=round(avg * 1e6, 2), launches=len(durs), algorithmic_bytes=alg)
+    if single is not None:
+        out['single_sample'] = single
     if want_cpu:
         e32, d32 = harness.build_models_pp(shape, nprop, torch.float32, 'cpu')      # same seed / init, before half_maps_
         base, par = cpu_baseline_pp(shape, nprop, (e32.state_dict(), d32.state_dict()), host_pool[0], product_out)
