@@ -18,7 +18,8 @@ Other workloads of BASELINE.json `configs` (parity-test configurations; not the 
 The path shards by sample with no data-path collective in the forward: every rank runs its own replica
 on its own samples ("weak" scaling); the collectives are the timing barrier, the max-over-ranks reduction and - in
 training - the gradient all-reduce over RCCL.  Rank 0 prints ONE JSON line, with
-  roofline      the dominant kernel (fused local-window attention on the 6x112x200 image maps): algorithmic bytes
+  roofline      the dominant kernel (fused local-window attention on the 6x112x200 image maps; round 4: the ring generation,
+                csrc/local_attn_ring.hip): algorithmic bytes
                 4*n*C*H*W*2 = 137.6 MB per launch / average launch duration measured live with HIP events on the
                 launch stream; `traffic`, `mfma_busy`, `lds_busy` from the committed rocprofv3 --pmc passes (profiles/)
   cpu_baseline  the CPU oracle (PyTorch fp32 restatement of the reference path, kind "port") timed on this box's
@@ -441,6 +442,9 @@ def bench_forward(args, rank, world, device):
                      launch='eager' if args.eager else 'per step and sample in flight: load() of the next pool sample into the '
                                                        'captured buffers + hipGraph replay of the captured forward',
                      graph_nodes=None if g is None else g.num_nodes()))
+    from deepinteraction_amd import _lib
+    roofline['ring_spin_timeouts'] = int(_lib.lib().di_local_attn_ring_timeouts(None))     # bounded flag spins that gave up: must be 0
+    assert roofline['ring_spin_timeouts'] == 0, 'the ring window-attention kernel gave up on a flag spin: results are invalid'
     out['roofline'] = roofline
     if single is not None:
         out['single_sample'] = single
