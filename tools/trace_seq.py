@@ -15,3 +15,17 @@ for r in rows[a:b]:
     print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:7.1f}  gap {gap:6.1f}  {r['Kernel_Name'][:90]}")
     prev_end = max(e, prev_end or 0)
 print('span', (prev_end - t0) / 1e3, 'us,', b - a, 'kernels')
+
+# mean duration per position over the last forwards whose kernel sequence equals the printed one
+names = [r['Kernel_Name'] for r in rows[a:b]]
+acc, cnt = [0.0] * len(names), 0
+for j in range(len(idx) - 1):
+    seg = rows[idx[j]:idx[j + 1]]
+    if [r['Kernel_Name'] for r in seg] != names:
+        continue
+    cnt += 1
+    for i, r in enumerate(seg):
+        acc[i] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+print(f'--- mean duration per position over {cnt} forwards with this sequence (sum {sum(acc) / max(cnt, 1):.1f} us)')
+for i, n in enumerate(names):
+    print(f'{i:4d} {acc[i] / max(cnt, 1):7.1f}  {n[:100]}')
