@@ -18,6 +18,8 @@ _c_p, _c_i, _c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 SIGNATURES = {
     'di_local_attn_fwd': [_c_p] * 4 + [_c_i] * 6 + [_c_f, _c_i, _c_p],
     'di_local_attn_fwd_ex': [_c_p] * 4 + [_c_i] * 6 + [_c_f, _c_i, _c_i, _c_p],
+    'di_local_attn_train_fwd': [_c_p] * 5 + [_c_i] * 3 + [_c_f, _c_p],
+    'di_local_attn_train_bwd': [_c_p] * 10 + [_c_i] * 3 + [_c_f, _c_p],
     'di_locatt_similar_fwd': [_c_p] * 3 + [_c_i] * 7 + [_c_p],
     'di_locatt_similar_bwd': [_c_p] * 3 + [_c_i] * 8 + [_c_p],
     'di_locatt_weighting_fwd': [_c_p] * 3 + [_c_i] * 7 + [_c_p],

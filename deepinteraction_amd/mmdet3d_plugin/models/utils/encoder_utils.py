@@ -16,6 +16,7 @@ GPU->CPU->GPU round trip.  Dense 1x1 projections are plain library GEMMs (hipBLA
 torch) on the (pixels, C) view of the channels-last maps.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -228,6 +229,9 @@ def mix2_folded(proj1, a, fold, mask, b, proj2, c, cache):
 
 from torch.amp import custom_bwd as _cbwd, custom_fwd as _cfwd
 
+# measurement switch: 0 = mixed-precision training keeps the unfused float32 window operators (round 4's first AMP figure)
+FUSED_TRAINING_ATTENTION = os.environ.get('DI_TRAIN_FUSED_LA', '1') != '0'
+
 
 class similarFunction(torch.autograd.Function):
     """Reference encoder_utils.py:36-57, bound to the HIP window kernels."""
@@ -269,6 +273,28 @@ class weightingFunction(torch.autograd.Function):
         return grad_ori, grad_weight, None, None
 
 
+class fusedWindowAttention(torch.autograd.Function):
+    """similarFunction -> softmax(. * scale) -> weightingFunction (reference encoder_utils.py:132-134) as ONE differentiable
+    operator for mixed-precision training: fp16 maps, forward keeps the log-sum-exp of every query, backward recomputes the
+    probabilities on the matrix cores (csrc/local_attn_train.hip) - no (n, H, W, 81) tensor in either direction.  Under
+    `torch.autocast` the inputs are cast to fp16; in float32 training the unfused float32 operators above stay in use."""
+
+    @staticmethod
+    @_cfwd(device_type='cuda', cast_inputs=torch.float16)
+    def forward(ctx, query, key, value, scale):
+        out, lse = ops.local_attention_train_fwd(query, key, value, scale)
+        ctx.save_for_backward(query, key, value, out, lse)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    @_cbwd(device_type='cuda')
+    def backward(ctx, grad_out):
+        query, key, value, out, lse = ctx.saved_tensors
+        gq, gk, gv = ops.local_attention_train_bwd(query, key, value, out, grad_out, lse, ctx.scale)
+        return gq, gk, gv, None
+
+
 class LocalContextAttentionBlock(nn.Module):
     """Reference encoder_utils.py:84-135."""
 
@@ -305,6 +331,9 @@ class LocalContextAttentionBlock(nn.Module):
         if not (torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)):
             # inference: one fused kernel, the (n,H,W,81) weights stay in registers
             return ops.local_attention(query, key, value, ks, ks, scale)
+        half = torch.is_autocast_enabled() or query.dtype == torch.float16
+        if half and query.is_cuda and query.size(1) == 128 and ks == 9 and FUSED_TRAINING_ATTENTION:
+            return fusedWindowAttention.apply(query, key, value, scale)
         weight = self.f_similar(query, key, ks, ks)
         weight = F.softmax(weight * scale, -1)
         return self.f_weighting(value, weight, ks, ks)

@@ -89,6 +89,39 @@ def local_attention(q, k, v, kH, kW, scale, variant=LA_AUTO):
     return out
 
 
+def local_attention_train_usable(q, k, v, kH, kW):
+    """The fused training kernels take fp16 maps of 128 channels and 9 x 9 windows (the configuration of every
+    `LocalContextAttentionBlock` of Fusion_0075_refactor under autocast)."""
+    return (q.is_cuda and q.dtype == torch.float16 and k.dtype == torch.float16 and v.dtype == torch.float16 and
+            q.shape[1] == 128 and kH == 9 and kW == 9 and q.shape == k.shape == v.shape)
+
+
+def local_attention_train_fwd(q, k, v, scale):
+    """(out, lse): the fused window attention with the per-query log2-sum-exp2 kept for the backward."""
+    _dev(q, k, v)
+    q, k, v = cl(q), cl(k), cl(v)
+    n, C, H, W = q.shape
+    out = empty_cl(n, C, H, W, q)
+    lse = torch.empty((n, H, W), dtype=torch.float32, device=q.device)
+    _profiled('local_attn_train_fwd', n, lambda: _lib.call(
+        'di_local_attn_train_fwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), n, H, W,
+        float(scale), _stream()))
+    return out, lse
+
+
+def local_attention_train_bwd(q, k, v, out, grad_out, lse, scale):
+    """(grad_q, grad_k, grad_v) of the fused window attention; the soft-max is recomputed from `lse`."""
+    _dev(q, k, v, out, grad_out, lse)
+    q, k, v, out, grad_out = cl(q), cl(k), cl(v), cl(out), cl(grad_out.to(q.dtype))
+    n, C, H, W = q.shape
+    gq, gk, gv = (empty_cl(n, C, H, W, q) for _ in range(3))
+    dsum = torch.empty((n, H, W), dtype=torch.float32, device=q.device)
+    _profiled('local_attn_train_bwd', n, lambda: _lib.call(
+        'di_local_attn_train_bwd', q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), grad_out.data_ptr(),
+        lse.data_ptr(), dsum.data_ptr(), gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), n, H, W, float(scale), _stream()))
+    return gq, gk, gv
+
+
 def local_attention_kernel_name():
     """What LA_AUTO launches for fp16 / C=128 / 9x9 maps (bench.py's roofline line names it)."""
     return ('local_attn_ring_kernel: one workgroup per CU, 16x8 tiles, 144 KB ring of 128-byte halo rows by LDS-DMA, '

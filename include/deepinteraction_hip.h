@@ -77,6 +77,20 @@ enum { DI_LA_AUTO = 0, DI_LA_VALU = 1,
                           (shallower LDS read-ahead, the compiler's schedule, four producer wavefronts) */ };
 int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                          int C, int kH, int kW, float scale, int dtype, int variant, void *stream);
+/* TRAINING form of the same attention, mixed precision (fp16 maps, C = 128, 9 x 9; float32 accumulation): replaces the chain
+ * similarFunction -> F.softmax -> weightingFunction and ITS BACKWARD (encoder_utils.py:36-81,132-134; similar.cu:43-92,
+ * weighting.cu:44-122), whose (n, H, W, 81) float32 weight tensor never exists here.
+ * fwd: out as di_local_attn_fwd, plus lse[n, H, W] = log2 sum_k exp2(scale * log2(e) * <q, k>) over the 81 slots (zero-padded
+ *      keys take part with logit 0, as in the reference).
+ * bwd: recomputes the probabilities from lse on the matrix cores; dsum[n, H, W] is scratch (receives <grad_out, out> per
+ *      query).  Three launches: the row dot product, a query-centred pass (grad_q) and a key-centred pass (grad_k, grad_v) -
+ *      the window relation is symmetric, so the key-centred pass gathers instead of scattering (no atomics).
+ * All maps channels-last [n, H, W, 128] fp16. */
+int di_local_attn_train_fwd(const void *q, const void *k, const void *v, void *out, float *lse, int n, int H, int W,
+                            float scale, void *stream);
+int di_local_attn_train_bwd(const void *q, const void *k, const void *v, const void *out, const void *grad_out,
+                            const float *lse, float *dsum, void *grad_q, void *grad_k, void *grad_v, int n, int H, int W,
+                            float scale, void *stream);
 /* The DI_LA_RING kernel bounds every flag spin; a pipeline that gave up produced wrong results instead of hanging the
  * device.  Returns the number of spins that gave up since the library was loaded (0 on a healthy run; synchronises
  * `stream`), -1 on a HIP error. */
