@@ -58,6 +58,13 @@ def parse():
                          'on its own stream (a step = N x batch samples; 2 = the reference\'s samples_per_gpu, '
                          'Fusion_0075_refactor.py:94); 1 = one sample at a time (the latency figure, also reported as '
                          '`single_sample` in the default line)')
+    ap.add_argument('--amp', action='store_true',
+                    help='train mode: mixed precision - the hot path under torch.autocast(fp16) (fp16 activations, the fused '
+                         'matrix-core window attention forward / backward of csrc/local_attn_train.hip), float32 master weights, '
+                         'BatchNorm statistics, soft-max, scatter accumulation and loss; the line then says dtype f16.  Default: '
+                         'float32, the arithmetic of the reference configuration')
+    ap.add_argument('--train-eager', action='store_true',
+                    help='train mode: host launches instead of the two replayed hipGraphs (forward, backward) around the eager loss')
     ap.add_argument('--from-images', action='store_true',
                     help='forward mode: the captured forward starts from the six camera images - the frozen ResNet-50 + FPN '
                          'stand-in (FrozenResNetFPN, torch / MIOpen, random init) runs inside every replay; with --model pp '

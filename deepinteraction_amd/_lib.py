@@ -70,6 +70,7 @@ SIGNATURES = {
     'di_local_attn_ring_stamps': [_c_p, _c_p],
     'di_i2p_set_seed_ptr': [_c_p],
     'di_copy_d2d': [_c_p, _c_p, ctypes.c_longlong, _c_p],
+    'di_iou3d_lidar': [_c_p, _c_i, _c_i, _c_p, _c_i, _c_i, _c_p, _c_p],
     'di_mha_decode_x_fwd': [_c_p] * 4 + [_c_i] * 3 + [_c_f, _c_p],
 }
 # helpers that return a value instead of an error code

@@ -45,6 +45,9 @@ class _BboxOverlaps3D:
         assert coordinate == 'lidar'
 
     def __call__(self, b1, b2):
+        if b1.is_cuda:                       # one launch (csrc/iou3d.hip); host tensors: the torch statement of the same clipper
+            from deepinteraction_amd import ops
+            return ops.iou3d_lidar(b1, b2)
         return boxes_iou3d_lidar(b1[:, :7], b2[:, :7])
 
 

@@ -252,6 +252,38 @@ class DeepInteractionDecoder(nn.Module):
         """The on-the-image mask that weights the targets of MMPI layer `l` (reference :506-508), or None."""
         return self.on_the_image_mask[l // 2] if l % 2 == 0 else None
 
+    # ------------------------------------------------------------------ ground-truth-only targets
+    def dense_heatmap_target(self, gt_bboxes_3d, gt_labels_3d, device):
+        """The dense heat-map target of one sample (reference :450-475): one Gaussian per GT box on the BEV grid.  The boxes
+        are host data: radius, centre and the element-wise max are evaluated on the host (the same float32 arithmetic, no
+        device round trip per box) and the finished map is uploaded once.  Returns (map on `device`, number of peaks)."""
+        tc = self.train_cfg
+        gt_labels_host = gt_labels_3d.cpu()
+        gt = torch.cat([gt_bboxes_3d.gravity_center, gt_bboxes_3d.tensor[:, 3:]], dim=1).float().cpu()
+        grid_size = torch.tensor(tc['grid_size'])
+        pc_range = torch.tensor(tc['point_cloud_range'])
+        voxel_size = torch.tensor(tc['voxel_size'])
+        fmap = grid_size[:2] // tc['out_size_factor']           # [x_len, y_len]
+        heatmap = np.zeros((self.num_classes, int(fmap[1]), int(fmap[0])), dtype=np.float32)
+        for idx in range(len(gt)):
+            width = gt[idx][3] / voxel_size[0] / tc['out_size_factor']
+            length = gt[idx][4] / voxel_size[1] / tc['out_size_factor']
+            if width > 0 and length > 0:
+                radius = gaussian_radius((length, width), min_overlap=tc['gaussian_overlap'])
+                radius = max(tc['min_radius'], int(radius))
+                coor_x = (gt[idx][0] - pc_range[0]) / voxel_size[0] / tc['out_size_factor']
+                coor_y = (gt[idx][1] - pc_range[1]) / voxel_size[1] / tc['out_size_factor']
+                center_int = torch.tensor([coor_x, coor_y], dtype=torch.float32).to(torch.int32)
+                draw_heatmap_gaussian_host(heatmap[int(gt_labels_host[idx])], center_int, radius)
+        peaks = int((heatmap == 1).sum())
+        return torch.from_numpy(heatmap).to(device), peaks
+
+    def prepare_targets(self, gt_bboxes_3d, gt_labels_3d, device):
+        """Optional, ahead of `loss`: evaluate the targets that depend on the ground truth ALONE (the dense heat map) - e.g.
+        while the device runs the forward the loss will wait for.  `loss` / `get_targets` pick them up (same objects) and
+        compute whatever was not prepared; the values are the same either way."""
+        self._gt_targets = {id(b): self.dense_heatmap_target(b, l, device) for b, l in zip(gt_bboxes_3d, gt_labels_3d)}
+
     # ------------------------------------------------------------------ targets (reference :315-482)
     def get_targets(self, gt_bboxes_3d, gt_labels_3d, preds_dict):
         """gt_bboxes_3d: list of LiDARInstance3DBoxes-like (`.tensor`, `.gravity_center`); preds_dict: the
@@ -325,29 +357,12 @@ class DeepInteractionDecoder(nn.Module):
         if len(neg_inds) > 0:
             label_weights[neg_inds] = 1.0
 
-        # dense heat-map target: one Gaussian per GT box on the BEV grid (:450-475).  The boxes are host data: radius,
-        # centre and the element-wise max are evaluated on the host (the same float32 arithmetic, no device round trip
-        # per box) and the finished map is uploaded once
-        gt = torch.cat([gt_bboxes_3d.gravity_center, gt_bboxes_3d.tensor[:, 3:]], dim=1).float().cpu()
-        grid_size = torch.tensor(tc['grid_size'])
-        pc_range = torch.tensor(tc['point_cloud_range'])
-        voxel_size = torch.tensor(tc['voxel_size'])
-        fmap = grid_size[:2] // tc['out_size_factor']           # [x_len, y_len]
-        heatmap = np.zeros((self.num_classes, int(fmap[1]), int(fmap[0])), dtype=np.float32)
-        for idx in range(len(gt)):
-            width = gt[idx][3] / voxel_size[0] / tc['out_size_factor']
-            length = gt[idx][4] / voxel_size[1] / tc['out_size_factor']
-            if width > 0 and length > 0:
-                radius = gaussian_radius((length, width), min_overlap=tc['gaussian_overlap'])
-                radius = max(tc['min_radius'], int(radius))
-                coor_x = (gt[idx][0] - pc_range[0]) / voxel_size[0] / tc['out_size_factor']
-                coor_y = (gt[idx][1] - pc_range[1]) / voxel_size[1] / tc['out_size_factor']
-                center_int = torch.tensor([coor_x, coor_y], dtype=torch.float32).to(torch.int32)
-                draw_heatmap_gaussian_host(heatmap[int(gt_labels_host[idx])], center_int, radius)
+        # dense heat-map target: a function of the ground truth alone (see `dense_heatmap_target`)
         if getattr(self, '_heatmap_peaks', None) is None:                # (get_targets_single called on its own)
             self._heatmap_peaks = {}
-        self._heatmap_peaks[batch_idx] = int((heatmap == 1).sum())       # `loss` normalises by it: known on the host
-        heatmap = torch.from_numpy(heatmap).to(dev)
+        ready = getattr(self, '_gt_targets', {}).pop(id(gt_bboxes_3d), None)
+        heatmap, peaks = ready if ready is not None else self.dense_heatmap_target(gt_bboxes_3d, gt_labels_host, dev)
+        self._heatmap_peaks[batch_idx] = peaks                           # `loss` normalises by it: known on the host
         mean_iou = ious[pos_inds].sum() / max(len(pos_inds), 1)
         return (labels[None], label_weights[None], bbox_targets[None], bbox_weights[None], ious[None],
                 int(pos_inds.shape[0]), float(mean_iou), heatmap[None])

@@ -353,6 +353,17 @@ def copy_bytes(dst, src):
     _lib.call('di_copy_d2d', dst.data_ptr(), src.data_ptr(), dst.numel(), _stream())
 
 
+def iou3d_lidar(b1, b2):
+    """(N, >=7), (M, >=7) float32 LiDAR boxes on the device -> (N, M) 3-D IoU, ONE launch (`BboxOverlaps3D` of the
+    Hungarian assigner; csrc/iou3d.hip)."""
+    _dev(b1, b2)
+    b1, b2 = b1.detach().float().contiguous(), b2.detach().float().contiguous()
+    out = torch.empty((b1.shape[0], b2.shape[0]), dtype=torch.float32, device=b1.device)
+    _lib.call('di_iou3d_lidar', b1.data_ptr(), b1.shape[0], b1.shape[1], b2.data_ptr(), b2.shape[0], b2.shape[1],
+              out.data_ptr(), _stream())
+    return out
+
+
 _I2P_SEED_REF = [None]
 
 

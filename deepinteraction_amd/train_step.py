@@ -34,7 +34,10 @@ def synth_gt(seed, n=30):
 
 
 class Trainer:
-    def __init__(self, shape, num_proposals, device, world, batch=1, pool=2, rank=0, seed=0):
+    def __init__(self, shape, num_proposals, device, world, batch=1, pool=2, rank=0, seed=0, amp=None):
+        import os
+        # mixed precision (opt-in; the reference trains this configuration in float32): the hot path under torch.autocast(fp16)
+        self.amp = os.environ.get('DI_TRAIN_AMP', '0') == '1' if amp is None else bool(amp)
         bev = shape['bev_hw'][0]
         tc = dict(TRAIN_CFG, grid_size=[bev * 8, bev * 8, 40], voxel_size=[108.0 / (bev * 8)] * 2 + [0.2])
         self.enc, self.dec = harness.build_models(shape, num_proposals, torch.float32, device, seed=seed, train_cfg=tc)
@@ -56,8 +59,7 @@ class Trainer:
     def step(self):
         d, gts = self.pool[self.i % len(self.pool)]
         self.i += 1
-        import os
-        with torch.autocast('cuda', dtype=torch.float16, enabled=os.environ.get('DI_TRAIN_AMP', '0') == '1'):
+        with torch.autocast('cuda', dtype=torch.float16, enabled=self.amp):
             img, pts = self.enc(d['img_feats'], d['pts_feats'], d['img_metas'], dict(d['pts_metas']))
             preds = self.dec(pts, img, d['img_metas'])
         preds = [[{k: v.float() for k, v in preds[0][0].items()}]]
@@ -75,9 +77,9 @@ class _HotPathModule(torch.nn.Module):
     """encoder + decoder as ONE callable of the two static feature-map tensors (what `make_graphed_callables` captures):
     points / pillars / geometry are the owner's static buffers, refreshed in place between replays."""
 
-    def __init__(self, enc, dec, owner):
+    def __init__(self, enc, dec, owner, amp=False):
         super().__init__()
-        self.enc, self.dec = enc, dec
+        self.enc, self.dec, self.amp = enc, dec, amp
         self._owner = [owner]                 # (a list: not a submodule)
         self.keys = None
 
@@ -86,9 +88,8 @@ class _HotPathModule(torch.nn.Module):
         for g in o.sample_geom:
             g.forget()
         self.dec.static_geometry = o.query_geom
-        import os
         try:
-            with torch.autocast('cuda', dtype=torch.float16, enabled=os.environ.get('DI_TRAIN_AMP', '0') == '1', cache_enabled=False):
+            with torch.autocast('cuda', dtype=torch.float16, enabled=self.amp, cache_enabled=False):
                 img, pts = self.enc(img_feats, pts_feats, o.img_metas, o._pts_metas())
                 out = self.dec(pts, img, o.img_metas)[0][0]
         finally:
@@ -104,8 +105,8 @@ class GraphedTrainer(Trainer):
     replayed, the step is bound by its kernels.  Static input buffers, padded points / pillars and in-place geometry
     refresh are the inference graph's (`graphed.GraphedHotPath`)."""
 
-    def __init__(self, shape, num_proposals, device, world, batch=1, pool=2, rank=0, seed=0):
-        super().__init__(shape, num_proposals, device, world, batch=batch, pool=pool, rank=rank, seed=seed)
+    def __init__(self, shape, num_proposals, device, world, batch=1, pool=2, rank=0, seed=0, amp=None):
+        super().__init__(shape, num_proposals, device, world, batch=batch, pool=pool, rank=rank, seed=seed, amp=amp)
         from .graphed import GraphedHotPath
         cap = max(range(len(self.pool)), key=lambda i: int(self.pool[i][0]['pts_metas']['pillars'].shape[0]))
         h = GraphedHotPath.__new__(GraphedHotPath)           # the static-buffer half of the inference graph, no capture
@@ -131,7 +132,7 @@ class GraphedTrainer(Trainer):
         from . import ops
         self.seed_word = torch.zeros(1, dtype=torch.int64, device=h.img_feats.device)
         ops.set_i2p_seed_tensor(self.seed_word)
-        self.module = _HotPathModule(self.enc, self.dec, h)
+        self.module = _HotPathModule(self.enc, self.dec, h, amp=self.amp)
         self.graphed = torch.cuda.make_graphed_callables(self.module, (h.img_feats, h.pts_feats), allow_unused_input=True)
 
     def step(self):
@@ -141,6 +142,7 @@ class GraphedTrainer(Trainer):
         self.h.load(self.records[i])
         self.seed_word.random_(0, 2 ** 62)                                            # a fresh dropout mask for this step
         outs = self.graphed(self.h.img_feats, self.h.pts_feats)                       # replay: forward graph
+        self.dec.prepare_targets([g[0] for g in gts], [g[1] for g in gts], outs[0].device)   # host work under the replay
         preds = [[dict(zip(self.module.keys, outs))]]
         losses = self.dec.loss([g[0] for g in gts], [g[1] for g in gts], preds)
         loss = sum(v for k, v in losses.items() if k != 'matched_ious')
@@ -156,8 +158,11 @@ def bench(args, rank, world, device):
     """`bench.py --mode train`: returns rank 0's JSON line (a dict)."""
     shape = harness.SHAPES[args.shape]
     import os
-    cls = GraphedTrainer if os.environ.get('DI_TRAIN_GRAPH', '0') == '1' else Trainer
-    tr = cls(shape, args.proposals, device, world, batch=args.batch, pool=max(2, min(args.pool, 2)), rank=rank)
+    # --amp / --train-eager of bench.py; the environment switches of round 4's first measurements still work
+    amp = bool(getattr(args, 'amp', False)) or os.environ.get('DI_TRAIN_AMP', '0') == '1'
+    eager = bool(getattr(args, 'train_eager', False)) or os.environ.get('DI_TRAIN_GRAPH', '1') == '0' or args.batch != 1
+    cls = Trainer if eager else GraphedTrainer
+    tr = cls(shape, args.proposals, device, world, batch=args.batch, pool=max(2, min(args.pool, 2)), rank=rank, amp=amp)
     losses = []
     for _ in range(args.warmup):
         tr.step()
@@ -166,11 +171,16 @@ def bench(args, rank, world, device):
     return dict(metric='samples/sec training step (forward + loss + backward + gradient all-reduce + AdamW)',
                 value=round(parallel.throughput(args.batch, args.steps, elapsed, world), 3), unit='samples/s',
                 n_gpus=args.gpus, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 2),
-                higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f16' if amp else 'f32', data='synthetic',
                 config=dict(workload=f'Fusion_0075_refactor training step (shape {args.shape}): MMRI encoder + MMPI '
                                      'decoder forward, head loss (Hungarian assignment on the host), backward, '
                                      'bucketed gradient all-reduce launched from backward hooks, AdamW + grad clip',
                             batch_per_gpu=args.batch, global_batch=args.batch * args.gpus,
                             num_proposals=args.proposals, pool=len(tr.pool),
+                            precision=('mixed: fp16 activations under torch.autocast incl. the fused window attention forward / '
+                                       'backward; float32 master weights, BatchNorm statistics, soft-max, scatter accumulation, '
+                                       'loss; no loss scaling') if amp else 'float32',
+                            launch='host launches' if eager else 'forward and backward of the hot path as two replayed hipGraphs '
+                                                                 'around the eager loss (Hungarian assignment on the host)',
                             parallelism=f'dp{args.gpus} by sample, RCCL all-reduce of gradients only'),
                 first_loss=round(losses[0], 4), last_loss=round(losses[-1], 4))

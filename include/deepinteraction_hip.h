@@ -512,6 +512,12 @@ int di_voxel_scatter(const float *pts, int n_pts, int pt_stride, int n_feat, con
                      int gx, int gy, int max_points, int max_voxels, float *voxels, int32_t *coords,
                      int32_t *num_points, void *stream);
 
+/* Pairwise 3-D IoU of LiDAR boxes, the IoU3DCost / max_overlaps input of the Hungarian assigner of the head loss:
+ * `BboxOverlaps3D(coordinate='lidar')(boxes1, boxes2)` as called at core/bbox/assigners/hungarian_assigner.py:127 (mmdet3d 0.17.1
+ * iou3d semantics: rotated BEV intersection x height overlap / union, a positive yaw turns the box clockwise in the BEV plane).
+ * boxes1 [n, stride1], boxes2 [m, stride2] float32 rows (x, y, z_bottom, dx, dy, dz, yaw, ...), out [n, m] float32. */
+int di_iou3d_lidar(const float *boxes1, int n, int stride1, const float *boxes2, int m, int stride2, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -407,15 +407,18 @@ def test_full_training_step_with_loss():
     assert torch.isfinite(l0) and l1 < l0, (float(l0), float(l1))
 
 
-def test_graphed_training_step():
-    """`train_step.GraphedTrainer`: forward and backward of the hot path replayed as two captured hipGraphs around the eager
+@pytest.mark.parametrize('amp', [False, True])
+def test_graphed_training_step(amp):
+    """(`amp`: the same under torch.autocast(fp16) with the fused window attention of csrc/local_attn_train.hip inside the
+    captured forward and backward.)
+    `train_step.GraphedTrainer`: forward and backward of the hot path replayed as two captured hipGraphs around the eager
     head loss (host Hungarian step).  (i) it trains: finite losses, every trainable parameter except the detached heat-map
     head gets a finite gradient; (ii) replay is deterministic given the dropout seed word and the torch RNG state: the same
     step from the same weights gives the same loss twice; (iii) the device seed word - rewritten before every replay - really
     drives the pillar attention's dropout mask: another word, another loss."""
     from deepinteraction_amd import ops, train_step
     torch.backends.cudnn.deterministic = True
-    tr = train_step.GraphedTrainer(synth.SHAPE_TINY, 24, torch.device(DEV), 1, pool=2)
+    tr = train_step.GraphedTrainer(synth.SHAPE_TINY, 24, torch.device(DEV), 1, pool=2, amp=amp)
     try:
         losses = [float(tr.step()) for _ in range(3)]
         assert all(math.isfinite(l) for l in losses), losses
@@ -483,3 +486,34 @@ def test_autocast_encoder_gradients_close_to_float32():
             bad.append((n, round(cos, 4), a.norm().item(), b.norm().item()))
     assert not bad, bad[:8]
     assert worst < 1.0 - 1e-9            # fp16 really ran somewhere
+
+
+def test_iou3d_kernel_matches_the_torch_clipper():
+    """`di_iou3d_lidar` (the Hungarian cost's IoU, one launch) against the vectorised torch statement of the same
+    Sutherland-Hodgman clipper it replaces (`det3d_compat.boxes_iou3d_lidar`, itself tested against known answers in
+    tests/test_targets_loss.py): random boxes of 9 columns, identical boxes (IoU 1), touching and disjoint boxes, zero-size
+    boxes, 90-degree rotations; empty sides."""
+    from deepinteraction_amd import det3d_compat as dc
+    g = torch.Generator().manual_seed(3)
+    n, m = 1000, 30
+    def boxes(k, spread):
+        xy = (torch.rand(k, 2, generator=g) - 0.5) * spread
+        z = torch.rand(k, 1, generator=g) * 2 - 2.5
+        dims = torch.rand(k, 3, generator=g) * 4 + 0.3
+        yaw = (torch.rand(k, 1, generator=g) - 0.5) * 12.0
+        return torch.cat([xy, z, dims, yaw, torch.randn(k, 2, generator=g)], 1)
+    b2 = boxes(m, 20.0)
+    b1 = boxes(n, 20.0)
+    b1[:m, :7] = b2[:, :7]                                     # identical boxes
+    b1[m:2 * m, :7] = b2[:, :7]
+    b1[m:2 * m, 6] += math.pi / 2                              # same centre, turned by 90 degrees
+    b1[2 * m:3 * m, :7] = b2[:, :7]
+    b1[2 * m:3 * m, 0] += b2[:, 3]                             # shifted by the box's own length along x (yaw-dependent overlap)
+    b1[3 * m, 3:6] = 0.0                                       # a zero-size box
+    b1[3 * m + 1, :2] = 1e4                                    # far away
+    ref = dc.boxes_iou3d_lidar(b1[:, :7], b2[:, :7])
+    got = ops.iou3d_lidar(b1.cuda(), b2.cuda()).cpu()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 2e-6, float((got - ref).abs().max())
+    assert float((got[:m].diag() - 1).abs().max()) <= 1e-5
+    assert ops.iou3d_lidar(b1[:0].cuda(), b2.cuda()).shape == (0, m) and ops.iou3d_lidar(b1.cuda(), b2[:0].cuda()).shape == (n, 0)

@@ -45,6 +45,37 @@ def step(record):
             acc[i].append(t[i + 1] - t[i])
 
 
+def step_graphed(record):
+    i = tr.i % len(tr.pool)
+    tr.i += 1
+    _, gts = tr.pool[i]
+    t = [tick()]
+    tr.h.load(tr.records[i])
+    tr.seed_word.random_(0, 2 ** 62)
+    outs = tr.graphed(tr.h.img_feats, tr.h.pts_feats)
+    t.append(tick())
+    t.append(t[-1])
+    preds = [[dict(zip(tr.module.keys, outs))]]
+    losses = tr.dec.loss([g[0] for g in gts], [g[1] for g in gts], preds)
+    loss = sum(v for k, v in losses.items() if k != 'matched_ious')
+    t.append(tick())
+    tr.opt.zero_grad(set_to_none=True)
+    t.append(tick())
+    loss.backward()
+    t.append(tick())
+    tr.reducer.finish()
+    torch.nn.utils.clip_grad_norm_([p for p in tr.params if p.grad is not None], max_norm=0.1, norm_type=2)
+    tr.opt.step()
+    t.append(tick())
+    if record:
+        for i in range(len(names)):
+            acc[i].append(t[i + 1] - t[i])
+
+
+if os.environ.get('DI_TRAIN_GRAPH', '0') == '1':        # forward graph (load + replay) | - | loss | zero_grad | backward graph | ...
+    tr = train_step.GraphedTrainer(harness.SHAPES['R'], 200, dev, 1)
+    names[0], names[1] = 'load + forward graph', '-'
+    step = step_graphed
 for _ in range(3):
     step(False)
 N = int(os.environ.get('STEPS', '20'))
