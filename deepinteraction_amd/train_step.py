@@ -43,7 +43,25 @@ class Trainer:
         self.enc, self.dec = harness.build_models(shape, num_proposals, torch.float32, device, seed=seed, train_cfg=tc)
         self.enc.train(), self.dec.train()                            # identical initial weights on every rank
         self.params = [p for m in (self.enc, self.dec) for p in m.parameters()]
-        self.opt = torch.optim.AdamW(self.params, lr=1e-4, weight_decay=0.01)
+        # Mixed precision keeps the convolution / linear / attention-projection parameters of the MODEL in fp16 and their
+        # float32 MASTER copies in the optimizer (the values autocast would produce by casting the float32 weight in every
+        # step - 216 cast launches forward and as many backward, 2 ms of a captured step - are the fp16 rounding of the
+        # master, which one multi-tensor copy per step now writes).  Normalisation layers stay float32.
+        self._half, self._master = [], []
+        if self.amp and os.environ.get('DI_TRAIN_HALF_WEIGHTS', '1') != '0':
+            nn = torch.nn
+            for m in (self.enc, self.dec):
+                for mod in m.modules():
+                    if isinstance(mod, (nn.Conv1d, nn.Conv2d, nn.Linear, nn.MultiheadAttention)):
+                        for p in mod.parameters(recurse=False):
+                            if p.dtype == torch.float32:
+                                self._master.append(torch.nn.Parameter(p.detach().clone()))
+                                p.data = p.data.half()
+                                self._half.append(p)
+        self._master_grad = [torch.empty_like(m) for m in self._master]
+        master_of = {id(p): m for p, m in zip(self._half, self._master)}
+        self.opt_params = [master_of.get(id(p), p) for p in self.params]
+        self.opt = torch.optim.AdamW(self.opt_params, lr=1e-4, weight_decay=0.01)
         self.world = world
         self.reducer = parallel.GradientReducer(self.params, world)
         # a small pool of device-resident batches per rank, built before the timed region (the data loader is out
@@ -65,12 +83,33 @@ class Trainer:
         preds = [[{k: v.float() for k, v in preds[0][0].items()}]]
         losses = self.dec.loss([g[0] for g in gts], [g[1] for g in gts], preds)
         loss = sum(v for k, v in losses.items() if k != 'matched_ious')
-        self.opt.zero_grad(set_to_none=True)
+        self._zero_grad()
         loss.backward()                                               # bucket all-reduces start inside
         self.reducer.finish()
-        torch.nn.utils.clip_grad_norm_([p for p in self.params if p.grad is not None], max_norm=0.1, norm_type=2)
-        self.opt.step()
+        self._update()
         return loss
+
+    def _zero_grad(self):
+        self.opt.zero_grad(set_to_none=True)
+        for p in self._half:
+            p.grad = None
+
+    def _update(self):
+        """Gradient clipping + AdamW (reference Fusion_0075_refactor.py:252-253) on the float32 parameters / masters."""
+        if self._half:
+            src, dst = [], []
+            for p, m, buf in zip(self._half, self._master, self._master_grad):
+                m.grad = None if p.grad is None else buf
+                if p.grad is not None:
+                    src.append(p.grad)
+                    dst.append(buf)
+            if dst:
+                torch._foreach_copy_(dst, src)                       # fp16 gradients -> float32 master gradients
+        torch.nn.utils.clip_grad_norm_([p for p in self.opt_params if p.grad is not None], max_norm=0.1, norm_type=2)
+        self.opt.step()
+        if self._half:
+            with torch.no_grad():
+                torch._foreach_copy_(self._half, self._master)       # the model's fp16 weights = the rounded masters
 
 
 class _HotPathModule(torch.nn.Module):
@@ -146,11 +185,10 @@ class GraphedTrainer(Trainer):
         preds = [[dict(zip(self.module.keys, outs))]]
         losses = self.dec.loss([g[0] for g in gts], [g[1] for g in gts], preds)
         loss = sum(v for k, v in losses.items() if k != 'matched_ious')
-        self.opt.zero_grad(set_to_none=True)
+        self._zero_grad()
         loss.backward()                                                              # eager loss backward + backward graph
         self.reducer.finish()
-        torch.nn.utils.clip_grad_norm_([p for p in self.params if p.grad is not None], max_norm=0.1, norm_type=2)
-        self.opt.step()
+        self._update()
         return loss
 
 
