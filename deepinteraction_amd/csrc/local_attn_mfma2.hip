@@ -40,6 +40,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
 template <int WX_, int WY_, int CU_, int WPS_, int DBG_ = 0>
 struct Cfg {
@@ -214,11 +215,17 @@ __global__ __launch_bounds__(G::NT, G::WPS) void local_attn_m2_kernel(
   };
   auto ld_q = [&](int kk) { qf[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(qbase + kk * 64)); };
   // finished output channels of a V unit wait here and are stored during the next pass
-  h4 pend[G::NN];
+  // (after a v_permlane16_swap between the blocks of a pair a lane owns 8 consecutive channels: block pair pr is ONE 16-byte
+  // store per lane, 64 contiguous bytes per pixel, instead of two 8-byte stores in 32-byte pieces)
+  static_assert(G::NN % 2 == 0, "output blocks are stored in pairs");
+  constexpr int NP = G::NN / 2;
+  unsigned pend[G::NN][2];
   __half *pend_dst = nullptr;
   bool pend_ok = false;
-  auto st_pend = [&](int nl) {
-    if (pend_ok) *reinterpret_cast<h4 *>(pend_dst + 16 * nl) = pend[nl];
+  auto st_pend = [&](int pr) {
+    if (pend_ok)
+      *reinterpret_cast<uint4 *>(pend_dst + 32 * pr) =
+          make_uint4(pend[2 * pr][0], pend[2 * pr][1], pend[2 * pr + 1][0], pend[2 * pr + 1][1]);
   };
 
   // ---- prologue: unit u of a tile (K units 0..NU-1, V units NU..2NU-1) uses LDS buffer u & 1 and
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(G::NT, G::WPS) void local_attn_m2_kernel(
       constexpr int un = u + 2;
       if constexpr (u & 1) prep(okB, un < NU ? k : v, cur, (un % NU) * G::CU);
       else prep(okA, un < NU ? k : v, cur, (un % NU) * G::CU);
-      constexpr int nbg = NLD + (u == 0 ? G::NN : 0);
+      constexpr int nbg = NLD + (u == 0 ? NP : 0);
       constexpr int per = (nbg + 9) / 10;
       DI_TS();
       const unsigned char *buf = lds + (u & 1) * G::UNITB;
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(G::NT, G::WPS) void local_attn_m2_kernel(
     const float inv = 1.f / sum;
     const int gy = cur.y0 + 2 * wy + qrow, gx = cur.x0 + 8 * wx + j;
     const bool pix_ok = gy < H && gx < W;
-    __half *dst = out + ((long long)(cur.img * H + gy) * W + gx) * 128 + 4 * g;
+    __half *dst = out + ((long long)(cur.img * H + gy) * W + gx) * 128 + (g & 1) * 16 + (g >> 1) * 8;
     static_for<0, NU>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int U = NU + u;                    // unit index in the tile
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(G::NT, G::WPS) void local_attn_m2_kernel(
       }
       constexpr bool with_q = next_tile && uk == 0;
       if (with_q && do_ld) prep_q(nxt);
-      constexpr int nst = u > 0 ? G::NN : 0;       // stores of the previous V unit
+      constexpr int nst = u > 0 ? NP : 0;          // stores of the previous V unit
       constexpr int nbg = NLD + (with_q ? 4 : 0) + nst;
       constexpr int per = (nbg + 4) / 5;
       DI_TS();
@@ -377,9 +384,21 @@ __global__ __launch_bounds__(G::NT, G::WPS) void local_attn_m2_kernel(
 #pragma unroll
       for (int nl = 0; nl < G::NN; ++nl) {
         const f4 o = acc[nl] * inv;
+        h4 ov;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pend[nl][r] = (_Float16)o[r];
+        for (int r = 0; r < 4; ++r) ov[r] = (_Float16)o[r];
+        const uint2 raw = __builtin_bit_cast(uint2, ov);
+        pend[nl][0] = raw.x;
+        pend[nl][1] = raw.y;
       }
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const u2v sw = __builtin_amdgcn_permlane16_swap(pend[2 * pr][d], pend[2 * pr + 1][d], false, false);
+          pend[2 * pr][d] = sw[0];
+          pend[2 * pr + 1][d] = sw[1];
+        }
       pend_dst = dst + u * G::CU;
       pend_ok = pix_ok;
       DI_TS();
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(G::NT, G::WPS) void local_attn_m2_kernel(
     tile += gxw;
   }
 #pragma unroll
-  for (int nl = 0; nl < G::NN; ++nl) st_pend(nl);   // the last V unit of the last tile
+  for (int pr = 0; pr < NP; ++pr) st_pend(pr);      // the last V unit of the last tile
 
   if (G::TS && blockIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

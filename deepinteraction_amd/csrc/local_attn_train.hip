@@ -37,6 +37,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
 enum { FWD = 0, BWD_Q = 1, BWD_V = 2, BWD_K = 3 };
 constexpr bool key_centred(int mode) { return mode >= BWD_V; }
@@ -210,11 +211,15 @@ __global__ __launch_bounds__(G::NT, G::WPS) void window_train_kernel(
       Dc = dsum[cpix];
     }
   };
-  h4 pend[G::NN];
+  // (output blocks are stored in pairs: after a v_permlane16_swap a lane owns 8 consecutive channels - one 16-byte store)
+  constexpr int NP = G::NN / 2;
+  unsigned pend[G::NN][2];
   __half *pend_dst = nullptr;
   bool pend_ok = false;
-  auto st_pend = [&](int nl) {
-    if (pend_ok) *reinterpret_cast<h4 *>(pend_dst + 16 * nl) = pend[nl];
+  auto st_pend = [&](int pr) {
+    if (pend_ok)
+      *reinterpret_cast<uint4 *>(pend_dst + 32 * pr) =
+          make_uint4(pend[2 * pr][0], pend[2 * pr][1], pend[2 * pr + 1][0], pend[2 * pr + 1][1]);
   };
   auto halo_src = [&](int kind) { return src_of(kind) ? h1 : h0; };
 
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(G::NT, G::WPS) void window_train_kernel(
       constexpr int ncl = (with_c || with_b1) ? 4 : 0;
       constexpr int cfirst = with_b1 ? 4 : 0;
       constexpr int pkind = unit_kind(MODE, U == 0 ? NUNITS - 1 : U - 1);
-      constexpr int nst = is_s(pkind) ? 0 : G::NN;              // stores of the previous O unit
+      constexpr int nst = is_s(pkind) ? 0 : NP;                 // stores of the previous O unit
       constexpr int nbg = NLD + ncl + nst;
       constexpr int steps = is_s(kind) ? 10 : 5;
       constexpr int per = (nbg + steps - 1) / steps;
@@ -424,10 +429,22 @@ __global__ __launch_bounds__(G::NT, G::WPS) void window_train_kernel(
 #pragma unroll
         for (int nl = 0; nl < G::NN; ++nl) {
           const f4 o = acc[nl] * os;
+          h4 ov;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pend[nl][r] = (_Float16)o[r];
+          for (int r = 0; r < 4; ++r) ov[r] = (_Float16)o[r];
+          const uint2 raw = __builtin_bit_cast(uint2, ov);
+          pend[nl][0] = raw.x;
+          pend[nl][1] = raw.y;
         }
-        pend_dst = (kind == O0 ? out0 : out1) + pix * 128 + 4 * g + (U & 1) * G::CU;
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const u2v sw = __builtin_amdgcn_permlane16_swap(pend[2 * pr][d], pend[2 * pr + 1][d], false, false);
+            pend[2 * pr][d] = sw[0];
+            pend[2 * pr + 1][d] = sw[1];
+          }
+        pend_dst = (kind == O0 ? out0 : out1) + pix * 128 + (g & 1) * 16 + (g >> 1) * 8 + (U & 1) * G::CU;
         pend_ok = pix_ok;
       }
       if constexpr (with_c) {
@@ -450,7 +467,7 @@ __global__ __launch_bounds__(G::NT, G::WPS) void window_train_kernel(
     tile += gxw;
   }
 #pragma unroll
-  for (int nl = 0; nl < G::NN; ++nl) st_pend(nl);
+  for (int pr = 0; pr < NP; ++pr) st_pend(pr);
 }
 
 // D[p] = <a[p, :], b[p, :]> over 128 fp16 channels (16 lanes per pixel)
