@@ -41,9 +41,9 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 __device__ __attribute__((aligned(128))) unsigned int zero_line[32];   // what a texel outside the map reads (128 B)
 __device__ unsigned int timeouts;                                       // bounded spins that gave up (0 on a healthy run)
 
-template <int WX_, int WY_, int SCHED_ = 0, int NPW_ = 2>
+template <int WX_, int WY_, int SCHED_ = 0, int NPW_ = 2, int POL_ = 0>
 struct Cfg {
-  static constexpr int WX = WX_, WY = WY_;
+  static constexpr int WX = WX_, WY = WY_, POL = POL_;    // POL: cache policy of the halo DMA (measurement)
   static constexpr int SCHED = SCHED_;                 // 1: LDS fragment reads interleaved with the MFMAs by sched_group_barrier
   static constexpr int NCW = WX * WY, NPW = NPW_;        // consumer / producer wavefronts
   static constexpr int NT = (NCW + NPW) * 64;
@@ -98,6 +98,15 @@ __device__ __forceinline__ void lds_st32(unsigned addr, unsigned val) {
 }
 __device__ __forceinline__ void dma16(const void *gp, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gp), "s"(lds_addr) : "memory", "m0");
+}
+// the same as a group-scope load (sc0): the halo has no reuse in the vector L1 (compile-time choice: a run-time switch per
+// instruction costs the producers 20 us)
+template <int POL>
+__device__ __forceinline__ void dma16_policy(const void *gp, unsigned lds_addr) {
+  if constexpr (POL == 2)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc0" : : "v"(gp), "s"(lds_addr) : "memory", "m0");
+  else
+    dma16(gp, lds_addr);
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void *p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
           for (int j = 0; j < G::IPR; ++j) {
             const unsigned char *gp = row + j * 2048;
             if (!interior) gp = (y_ok && x_ok[j]) ? gp : zsrc;
-            if (!(dbg & 4)) dma16(gp, __builtin_amdgcn_readfirstlane(dst + r * ROWB + j * 1024));
+            if (!(dbg & 4)) dma16_policy<G::POL>(gp, __builtin_amdgcn_readfirstlane(dst + r * ROWB + j * 1024));
           }
         }
         }
@@ -524,11 +533,14 @@ static int launch(const void *q, const void *k, const void *v, void *out, int n,
 int launch_local_attn_ring(const void *q, const void *k, const void *v, void *out, int n, int H, int W, float scale,
                            int cfg, hipStream_t stream) {
   switch (cfg) {
-    case 0: return ring::launch<ring::Cfg<2, 4, 2, 2>>(q, k, v, out, n, H, W, scale, stream);
-    case 1: return ring::launch<ring::Cfg<1, 8, 2, 2>>(q, k, v, out, n, H, W, scale, stream);
-    case 2: return ring::launch<ring::Cfg<2, 4, 1, 2>>(q, k, v, out, n, H, W, scale, stream);   // shallower LDS read-ahead, no flag peek
-    case 3: return ring::launch<ring::Cfg<2, 4, 0, 2>>(q, k, v, out, n, H, W, scale, stream);   // the compiler's own schedule
-    case 4: return ring::launch<ring::Cfg<2, 4, 2, 4>>(q, k, v, out, n, H, W, scale, stream);   // four producer wavefronts
+    // (last parameter: cache policy of the halo DMA.  2 = sc0, 35.3 us on cold inputs against 36.4 for plain loads, 35.6 for sc1 and
+    // 38.6-38.7 for nt / sc0 nt on one box)
+    case 0: return ring::launch<ring::Cfg<2, 4, 2, 2, 2>>(q, k, v, out, n, H, W, scale, stream);
+    case 1: return ring::launch<ring::Cfg<1, 8, 2, 2, 2>>(q, k, v, out, n, H, W, scale, stream);
+    case 2: return ring::launch<ring::Cfg<2, 4, 1, 2, 2>>(q, k, v, out, n, H, W, scale, stream);   // shallower LDS read-ahead, no flag peek
+    case 3: return ring::launch<ring::Cfg<2, 4, 0, 2, 2>>(q, k, v, out, n, H, W, scale, stream);   // the compiler's own schedule
+    case 4: return ring::launch<ring::Cfg<2, 4, 2, 4, 2>>(q, k, v, out, n, H, W, scale, stream);   // four producer wavefronts
+    case 5: return ring::launch<ring::Cfg<2, 4, 2, 2, 0>>(q, k, v, out, n, H, W, scale, stream);   // plain DMA loads
   }
   set_error("unknown local_attn_ring configuration %d", cfg);
   return DI_ERR_ARG;

@@ -73,8 +73,8 @@ int di_local_attn_fwd(const void *q, const void *k, const void *v, void *out, in
  * workgroups per CU; the same with producer / consumer wavefronts) were measured in rounds 1-3, lost and are gone. */
 enum { DI_LA_AUTO = 0, DI_LA_VALU = 1,
        DI_LA_MFMA = 3 /* + configuration: 3 = 16x8 tiles, 4 = 8x8 tiles, 5 = 16x4 tiles, 6 = 8x16 tiles, 7 = timestamps */,
-       DI_LA_RING = 24 /* + 0 = 16x8 query tiles (AUTO on large maps), + 1 = 8x16 tiles, + 2..4 = measurement variants
-                          (shallower LDS read-ahead, the compiler's schedule, four producer wavefronts) */ };
+       DI_LA_RING = 24 /* + 0 = 16x8 query tiles (AUTO on large maps), + 1 = 8x16 tiles, + 2..5 = measurement variants
+                          (shallower LDS read-ahead, the compiler's schedule, four producer wavefronts, plain instead of sc0 DMA loads) */ };
 int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                          int C, int kH, int kW, float scale, int dtype, int variant, void *stream);
 /* TRAINING form of the same attention, mixed precision (fp16 maps, C = 128, 9 x 9; float32 accumulation): replaces the chain
