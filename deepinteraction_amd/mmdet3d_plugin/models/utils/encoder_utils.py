@@ -30,6 +30,30 @@ from ....utils import param_key
 GEOM_KEY = '_di_geometry'      # per-forward cache placed in pts_metas by DeepInteractionEncoder
 
 
+# measurement switch: 0 = the training BatchNorm + ReLU of ConvBNReLU through torch / MIOpen
+FUSED_TRAINING_BN = os.environ.get('DI_TRAIN_FUSED_BN', '1') != '0'
+
+
+class BatchNormReLU(torch.autograd.Function):
+    """nn.BatchNorm2d in train() mode followed by nn.ReLU (reference ConvBNReLU, encoder_utils.py:11-34) on a channels-last
+    map as one differentiable operator: batch statistics in float32, running statistics updated in place, the ReLU mask
+    recomputed in the backward (csrc/batchnorm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, relu, workspace):
+        y, saved = ops.bn_train_fwd(x, weight, bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.eps,
+                                    bn.momentum, relu, workspace)
+        ctx.save_for_backward(x, saved)
+        ctx.relu, ctx.ws, ctx.affine = bool(relu), workspace, weight is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, saved = ctx.saved_tensors
+        gx, gg, gb = ops.bn_train_bwd(x, grad_y, saved, ctx.relu, ctx.ws, ctx.affine)
+        return gx, gg, gb, None, None, None
+
+
 class ConvBNReLU(nn.Module):
     """Reference encoder_utils.py:11-34."""
 
@@ -48,6 +72,7 @@ class ConvBNReLU(nn.Module):
         if self.use_activation:
             self.activation = activation_layer(inplace=inplace)
         self._fold_cache = None
+        self._bn_ws = None
 
     def forward(self, x):
         if not self.training and not torch.is_grad_enabled() and self.conv.kernel_size == (1, 1) and x.is_cuda:
@@ -69,10 +94,23 @@ class ConvBNReLU(nn.Module):
         else:
             x = c(x)
         if self.use_norm:
+            if self._fused_bn_ok(x):
+                # training: batch statistics, normalisation and the ReLU in three launches (csrc/batchnorm.hip)
+                if self._bn_ws is None or self._bn_ws.device != x.device:
+                    self._bn_ws = ops.bn_workspace(self.bn.num_features, x.device)
+                return BatchNormReLU.apply(x, self.bn.weight, self.bn.bias, self.bn, self.use_activation, self._bn_ws)
             x = self.bn(x)
         if self.use_activation:
             x = self.activation(x)
         return x
+
+    def _fused_bn_ok(self, x):
+        bn = self.bn
+        return (FUSED_TRAINING_BN and self.training and x.is_cuda and type(bn) is nn.BatchNorm2d and bn.track_running_stats
+                and bn.momentum is not None and x.dim() == 4 and ops._is_cl(x) and x.dtype in (torch.float16, torch.float32)
+                and bn.num_features % 8 == 0 and bn.num_features <= 256
+                and (not self.use_activation or type(self.activation) is nn.ReLU)
+                and (bn.weight is None or bn.weight.dtype == torch.float32))
 
     def folded(self, dtype):
         """Inference form `y = act(x W'^T + b')` with the BatchNorm folded in (fp32 math)."""

@@ -364,6 +364,43 @@ def iou3d_lidar(b1, b2):
     return out
 
 
+def bn_workspace(C, device):
+    """Scratch of one training BatchNorm (partial sums + coefficients); one per module, not shared between launches in flight."""
+    return torch.empty(int(_lib.lib().di_bn_workspace_floats(int(C))), dtype=torch.float32, device=device)
+
+
+def bn_train_fwd(x, weight, bias, running_mean, running_var, num_batches, eps, momentum, relu, workspace):
+    """Training BatchNorm2d (+ ReLU) of a channels-last map (csrc/batchnorm.hip): (y, saved[4C] = mean | rstd | gamma | beta);
+    the running statistics are updated in place."""
+    _dev(x)
+    assert _is_cl(x), 'the map must be channels-last'
+    n, C, H, W = x.shape
+    y = torch.empty_like(x)
+    saved = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    for t in (weight, bias, running_mean, running_var):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    assert num_batches is None or num_batches.dtype == torch.int64
+    _lib.call('di_bn_train_fwd', x.data_ptr(), n * H * W, C, _code(x), ptr(weight), ptr(bias), float(eps), float(momentum),
+              ptr(running_mean), ptr(running_var), ptr(num_batches), int(bool(relu)), y.data_ptr(), saved.data_ptr(),
+              workspace.data_ptr(), _stream())
+    return y, saved
+
+
+def bn_train_bwd(x, grad_y, saved, relu, workspace, affine):
+    """(grad_x, grad_gamma, grad_beta) of `bn_train_fwd`; the ReLU mask is recomputed from x."""
+    _dev(x, grad_y, saved)
+    grad_y = cl(grad_y.to(x.dtype))
+    n, C, H, W = x.shape
+    gx = torch.empty_like(x)
+    gg = torch.empty(C, dtype=torch.float32, device=x.device) if affine else None
+    gb = torch.empty(C, dtype=torch.float32, device=x.device) if affine else None
+    _lib.call('di_bn_train_bwd', x.data_ptr(), grad_y.data_ptr(), n * H * W, C, _code(x), saved.data_ptr(), int(bool(relu)),
+              gx.data_ptr(), 0 if gg is None else gg.data_ptr(), 0 if gb is None else gb.data_ptr(), workspace.data_ptr(),
+              _stream())
+    return gx, gg, gb
+
+
 _I2P_SEED_REF = [None]
 
 

@@ -172,7 +172,17 @@ class GraphedTrainer(Trainer):
         self.seed_word = torch.zeros(1, dtype=torch.int64, device=h.img_feats.device)
         ops.set_i2p_seed_tensor(self.seed_word)
         self.module = _HotPathModule(self.enc, self.dec, h, amp=self.amp)
-        self.graphed = torch.cuda.make_graphed_callables(self.module, (h.img_feats, h.pts_feats), allow_unused_input=True)
+        # no garbage collection INSIDE the captures: a collected autograd graph of a warm-up iteration (Python Function nodes are
+        # freed by the collector, not by reference counting) releases device memory through calls a capturing process may not make
+        import gc
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self.graphed = torch.cuda.make_graphed_callables(self.module, (h.img_feats, h.pts_feats), allow_unused_input=True)
+        finally:
+            if was_enabled:
+                gc.enable()
 
     def step(self):
         i = self.i % len(self.pool)

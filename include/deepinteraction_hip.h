@@ -518,6 +518,21 @@ int di_voxel_scatter(const float *pts, int n_pts, int pt_stride, int n_feat, con
  * boxes1 [n, stride1], boxes2 [m, stride2] float32 rows (x, y, z_bottom, dx, dy, dz, yaw, ...), out [n, m] float32. */
 int di_iou3d_lidar(const float *boxes1, int n, int stride1, const float *boxes2, int m, int stride2, float *out, void *stream);
 
+/* Training-mode BatchNorm2d (+ ReLU) of the necks' ConvBNReLU blocks (encoder_utils.py:11-34 in train() mode) on a
+ * channels-last map seen as (npix, C), C a multiple of 8 and <= 256, fp16 or float32; statistics float32.
+ * fwd: y = relu?(gamma * (x - mean) / sqrt(var + eps) + beta) with the batch statistics (biased variance); `saved` [4 C] =
+ *      [mean | rstd | gamma | beta] for the backward; running_mean / running_var (momentum update, unbiased variance) and
+ *      num_batches (+= 1) are updated in place when given; gamma / beta may be NULL (affine=False).
+ * bwd: grad_x (the ReLU mask is recomputed from x), grad_gamma / grad_beta (may be NULL).
+ * Three launches per direction: partial sums per workgroup, a fixed-order finalisation (bit-reproducible), the apply pass.
+ * `workspace`: di_bn_workspace_floats(C) floats, not shared between launches in flight. */
+int di_bn_workspace_floats(int C);
+int di_bn_train_fwd(const void *x, long long npix, int C, int dtype, const float *gamma, const float *beta, float eps,
+                    float momentum, float *running_mean, float *running_var, long long *num_batches, int relu, void *y,
+                    float *saved, float *workspace, void *stream);
+int di_bn_train_bwd(const void *x, const void *grad_y, long long npix, int C, int dtype, const float *saved, int relu,
+                    void *grad_x, float *grad_gamma, float *grad_beta, float *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

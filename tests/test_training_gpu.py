@@ -517,3 +517,49 @@ def test_iou3d_kernel_matches_the_torch_clipper():
     assert float((got - ref).abs().max()) <= 2e-6, float((got - ref).abs().max())
     assert float((got[:m].diag() - 1).abs().max()) <= 1e-5
     assert ops.iou3d_lidar(b1[:0].cuda(), b2.cuda()).shape == (0, m) and ops.iou3d_lidar(b1.cuda(), b2[:0].cuda()).shape == (n, 0)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('C,affine,relu', [(128, True, True), (256, True, True), (128, False, False), (64, True, False)])
+def test_fused_training_batchnorm_relu_matches_torch(dtype, C, affine, relu):
+    """`BatchNormReLU` (csrc/batchnorm.hip: partial sums, fixed-order finalisation, apply) against nn.BatchNorm2d in train()
+    mode + nn.ReLU with autograd, float64 statistics as the reference: outputs, input / affine gradients, running mean /
+    variance (unbiased) and the batch counter; two steps (the running statistics accumulate); bit-reproducible."""
+    from deepinteraction_amd.mmdet3d_plugin.models.utils.encoder_utils import BatchNormReLU
+    g = torch.Generator().manual_seed(C + 7)
+    n, H, W = 3, 13, 21
+    bn = torch.nn.BatchNorm2d(C, affine=affine).to(DEV).train()
+    ref = torch.nn.BatchNorm2d(C, affine=affine).to(DEV).double().train()
+    if affine:
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, generator=g) + 0.5), bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+            ref.weight.copy_(bn.weight.double()), ref.bias.copy_(bn.bias.double())
+    ws = ops.bn_workspace(C, DEV)
+    tol = 2e-3 if dtype == torch.float16 else 2e-5
+    for step in range(2):
+        x = (torch.randn(n, C, H, W, generator=g) * 1.5 + 0.4).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(n, C, H, W, generator=g).to(DEV, dtype).contiguous(memory_format=torch.channels_last)
+        xa = x.clone().requires_grad_(True)
+        y = BatchNormReLU.apply(xa, bn.weight, bn.bias, bn, relu, ws)
+        y.backward(gy)
+        xr = x.double().requires_grad_(True)
+        yr = ref(xr)
+        yr = torch.relu(yr) if relu else yr
+        yr.backward(gy.double())
+        rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-12))
+        assert y.dtype == dtype and rel(y, yr) <= tol, rel(y, yr)
+        assert rel(xa.grad, xr.grad) <= 2 * tol, rel(xa.grad, xr.grad)
+        if affine:
+            assert rel(bn.weight.grad, ref.weight.grad) <= 2 * tol and rel(bn.bias.grad, ref.bias.grad) <= 2 * tol
+            bn.weight.grad = bn.bias.grad = ref.weight.grad = ref.bias.grad = None
+        assert rel(bn.running_mean, ref.running_mean) <= 1e-5 and rel(bn.running_var, ref.running_var) <= 1e-5
+        assert int(bn.num_batches_tracked) == step + 1
+        if step == 1:
+            rm = bn.running_mean.clone()
+            bn2 = torch.nn.BatchNorm2d(C, affine=affine).to(DEV).train()
+            if affine:
+                with torch.no_grad():
+                    bn2.weight.copy_(bn.weight), bn2.bias.copy_(bn.bias)
+            y2 = BatchNormReLU.apply(x, bn2.weight, bn2.bias, bn2, relu, ws)
+            y3 = BatchNormReLU.apply(x, bn2.weight, bn2.bias, bn2, relu, ws)
+            assert torch.equal(y2, y3) and torch.equal(y2, y.detach())
