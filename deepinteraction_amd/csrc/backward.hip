@@ -13,6 +13,7 @@
 // accumulate with float32 atomics into float32 gradient maps (the caller casts); 16 lanes own one texel
 // (8 channels each), as in the forward kernels.
 #include <limits.h>
+#include <stdlib.h>
 
 #include "di_common.h"
 
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void bevwarp_gather_bwd_kernel(
     const T *__restrict__ grad_out, const float *__restrict__ depth, const float *__restrict__ img2lidar,
     const float *__restrict__ aug, const float *__restrict__ xs, const float *__restrict__ ys,
     const float *__restrict__ pc_range, float *__restrict__ grad_bev, int V, int Hi, int Wi, int Hb, int Wb,
-    int C) {
+    int C, int dbg) {
   __shared__ float slots[16 * kSlotFloats];            // one transposition slot per 16-lane group
   const int l16 = threadIdx.x & 15;
   float *slot = slots + (threadIdx.x >> 4) * kSlotFloats;
@@ -154,8 +155,17 @@ __global__ __launch_bounds__(256) void bevwarp_gather_bwd_kernel(
   const float r3 = pc_range[3], r4 = pc_range[4], r5 = pc_range[5];
   const int runs_per_row = (Wi + kRunB - 1) / kRunB;
   const int total = V * Hi * runs_per_row;
-  const int ngrp = gridDim.x * (blockDim.x >> 4);
-  for (int run = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); run < total; run += ngrp) {
+  // What a group still holds at the END of its run is merged over the workgroup's 16 groups (16 consecutive runs = 256
+  // consecutive pixels) before it goes out: the cells every depth-less pixel lands on (the camera centre: half of the pixels
+  // of a synthetic sample, whole image rows) then receive one set of atomics per workgroup round instead of one per run -
+  // 502 -> ~60 us per launch (26 us without any atomics).
+  __shared__ float mbuf[16][4][128];
+  __shared__ int mid[16][2];
+  const int grp = threadIdx.x >> 4;
+  const int ngrp = gridDim.x * 16;
+  for (int base = blockIdx.x * 16; base < total; base += ngrp) {
+    const int run = min(base + grp, total - 1);
+    const bool run_ok = base + grp < total;
     const int row = run / runs_per_row, x_beg = (run - row * runs_per_row) * kRunB;
     const int v = row / Hi, yy = row - v * Hi;
     const float *M = img2lidar + v * 16;
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(256) void bevwarp_gather_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) a00[i] = a01[i] = a10[i] = a11[i] = 0.f;
     auto flush = [&]() {
-      if (cx0 == INT_MIN) return;                       // (uniform over the 16-lane group)
+      if (cx0 == INT_MIN || (dbg & 1)) return;          // (uniform over the 16-lane group; dbg & 1: measurement, no atomics)
       const bool xl = cx0 >= 0 && cx0 < Wb, xh = cx0 + 1 >= 0 && cx0 + 1 < Wb;
       const bool yl = cy0 >= 0 && cy0 < Hb, yh = cy0 + 1 >= 0 && cy0 + 1 < Hb;
       float *p = grad_bev + ((long long)cy0 * Wb + cx0) * C;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(256) void bevwarp_gather_bwd_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i) a00[i] = a01[i] = a10[i] = a11[i] = 0.f;
     };
-    for (int xx = x_beg; xx < min(x_beg + kRunB, Wi); ++xx) {
+    for (int xx = x_beg; xx < (run_ok ? min(x_beg + kRunB, Wi) : x_beg); ++xx) {
       const int pix = (v * Hi + yy) * Wi + xx;
       const float d = depth[pix];
       const float X = xs[xx] * d, Y = ys[yy] * d;
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256) void bevwarp_gather_bwd_kernel(
       float g[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) g[i] = 0.f;
-      if (ch_ok) unpack8(ld8(grad_out + (size_t)pix * C + ch0), g);
+      if (ch_ok && !(dbg & 2)) unpack8(ld8(grad_out + (size_t)pix * C + ch0), g);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         a00[i] = fmaf(b.w00, g[i], a00[i]);
@@ -212,7 +222,37 @@ __global__ __launch_bounds__(256) void bevwarp_gather_bwd_kernel(
         a11[i] = fmaf(b.w11, g[i], a11[i]);
       }
     }
-    flush();
+    // ---- merge over the workgroup: the lowest group holding a cell collects what the others hold for it
+    if (l16 == 0) {
+      mid[grp][0] = cx0;
+      mid[grp][1] = cy0;
+    }
+    if (ch_ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        mbuf[grp][0][ch0 + i] = a00[i];
+        mbuf[grp][1][ch0 + i] = a01[i];
+        mbuf[grp][2][ch0 + i] = a10[i];
+        mbuf[grp][3][ch0 + i] = a11[i];
+      }
+    }
+    __syncthreads();
+    bool leader = cx0 != INT_MIN;
+    for (int g2 = 0; g2 < grp; ++g2) leader = leader && !(mid[g2][0] == cx0 && mid[g2][1] == cy0);
+    if (leader) {
+      for (int g2 = grp + 1; g2 < 16; ++g2)
+        if (mid[g2][0] == cx0 && mid[g2][1] == cy0 && ch_ok) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            a00[i] += mbuf[g2][0][ch0 + i];
+            a01[i] += mbuf[g2][1][ch0 + i];
+            a10[i] += mbuf[g2][2][ch0 + i];
+            a11[i] += mbuf[g2][3][ch0 + i];
+          }
+        }
+      flush();
+    }
+    __syncthreads();
   }
 }
 
@@ -441,12 +481,13 @@ int di_bevwarp_gather_bwd(const void *grad_out, const float *depth, const float 
   const int total = n_views * Hi * ((Wi + di::kRunB - 1) / di::kRunB);   // one 16-lane group per run of pixels
   const int blocks = min((total + 15) / 16, 256 * 16);
   hipStream_t s = (hipStream_t)stream;
+  static const int dbg = getenv("DI_BW_DBG") ? atoi(getenv("DI_BW_DBG")) : 0;   // measurement: 1 = no atomics, 2 = no gradient loads
   if (dtype == DI_F16)
     hipLaunchKernelGGL(di::bevwarp_gather_bwd_kernel<__half>, dim3(blocks), dim3(256), 0, s, (const __half *)grad_out,
-                       depth, img2lidar, aug_fwd, xs, ys, pc_range, grad_bev, n_views, Hi, Wi, Hb, Wb, C);
+                       depth, img2lidar, aug_fwd, xs, ys, pc_range, grad_bev, n_views, Hi, Wi, Hb, Wb, C, dbg);
   else if (dtype == DI_F32)
     hipLaunchKernelGGL(di::bevwarp_gather_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float *)grad_out,
-                       depth, img2lidar, aug_fwd, xs, ys, pc_range, grad_bev, n_views, Hi, Wi, Hb, Wb, C);
+                       depth, img2lidar, aug_fwd, xs, ys, pc_range, grad_bev, n_views, Hi, Wi, Hb, Wb, C, dbg);
   else {
     di::set_error("unsupported dtype %d", dtype);
     return DI_ERR_ARG;
