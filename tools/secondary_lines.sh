@@ -10,10 +10,13 @@ except Exception as e:
     print(sys.argv[1], 'FAILED', e)
 P
 }
+# (the training lines first: MIOpen's user find-db is still empty then)
+run bench_mode_train_amp --steps 10 --warmup 3 --mode train --amp
+run bench_mode_train --steps 10 --warmup 3 --mode train
+run bench_mode_train_eager --steps 10 --warmup 3 --mode train --train-eager
 run bench_inflight3 --steps 20 --warmup 5 --inflight 3
 run bench_from_raw --steps 20 --warmup 5 --from-raw
 run bench_from_points --steps 20 --warmup 5 --from-points
 run bench_model_pp --steps 20 --warmup 5 --model pp
-run bench_mode_train --steps 5 --warmup 2 --mode train
 run bench_shapeA --steps 20 --warmup 5 --shape A
 echo done
