@@ -264,7 +264,7 @@ class FocalLoss(torch.nn.Module):
         assert use_sigmoid
         self.gamma, self.alpha, self.reduction, self.loss_weight = gamma, alpha, reduction, loss_weight
 
-    def forward(self, pred, target, weight=None, avg_factor=None):
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
         C = pred.shape[1]
         t = F.one_hot(target.clamp(max=C), C + 1)[:, :C].to(pred.dtype)
         p = pred.sigmoid()
@@ -273,7 +273,7 @@ class FocalLoss(torch.nn.Module):
         loss = F.binary_cross_entropy_with_logits(pred, t, reduction='none') * fw
         if weight is not None:
             weight = weight.to(pred.dtype).view(-1, 1)
-        return self.loss_weight * _reduce(loss, weight, self.reduction, avg_factor)
+        return self.loss_weight * _reduce(loss, weight, reduction_override or self.reduction, avg_factor)
 
 
 class L1Loss(torch.nn.Module):
@@ -281,8 +281,8 @@ class L1Loss(torch.nn.Module):
         super().__init__()
         self.reduction, self.loss_weight = reduction, loss_weight
 
-    def forward(self, pred, target, weight=None, avg_factor=None):
-        return self.loss_weight * _reduce((pred - target).abs(), weight, self.reduction, avg_factor)
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        return self.loss_weight * _reduce((pred - target).abs(), weight, reduction_override or self.reduction, avg_factor)
 
 
 class GaussianFocalLoss(torch.nn.Module):

@@ -371,33 +371,39 @@ class DeepInteractionDecoder(nn.Module):
     def loss(self, gt_bboxes_3d, gt_labels_3d, preds_dicts, **kwargs):
         (labels, label_weights, bbox_targets, bbox_weights, ious, _num_pos, matched_ious,
          heatmap) = self.get_targets(gt_bboxes_3d, gt_labels_3d, preds_dicts[0])
-        Q = self.num_proposals
-        num_pos = []
-        for l in range(self.num_mmpi):
-            sl = slice(l * Q, (l + 1) * Q)
-            m = self._layer_mask(l)
-            if m is not None:                                   # image layers: only queries some camera sees
-                label_weights[..., sl] = label_weights[..., sl] * m
-                bbox_weights[:, sl, :] = bbox_weights[:, sl, :] * m[:, :, None]
-            num_pos.append(bbox_weights.max(-1).values[..., sl].sum().clamp(min=1))      # = max(num_pos, 1), on the device
+        Q, L = self.num_proposals, self.num_mmpi
+        B = labels.shape[0]
+        # The per-layer terms of the reference (one classification and one box loss per MMPI layer, each normalised by that
+        # layer's number of positives, :506-540) evaluated for ALL layers at once: the element-wise losses over (B, L*Q, .)
+        # in one pass, then a sum per layer - 5 x fewer launches in the phase the device spends waiting for Python.
+        masks = [self._layer_mask(l) for l in range(L)]
+        if any(m is not None for m in masks):                   # image layers: only queries some camera sees
+            full = torch.cat([torch.ones_like(label_weights[..., :Q], dtype=bbox_weights.dtype) if m is None
+                              else m.to(bbox_weights.dtype) for m in masks], dim=-1)            # (B, L*Q)
+            label_weights = label_weights * full.to(label_weights.dtype)        # (0 / 1 masks: exact in any dtype)
+            bbox_weights = bbox_weights * full[:, :, None]
+        num_pos = bbox_weights.max(-1).values.view(B, L, Q).sum((0, 2)).clamp(min=1)            # (L,) = max(num_pos, 1)
         preds_dict = preds_dicts[0][0]
         loss_dict = dict()
         loss_dict['loss_heatmap'] = self.loss_heatmap(clip_sigmoid(preds_dict['dense_heatmap'].float()), heatmap,
                                                       avg_factor=max(float(sum(self._heatmap_peaks.values())), 1))
         code_weights = self.train_cfg.get('code_weights', None)
-        for l in range(self.num_mmpi):
-            sl = slice(l * Q, (l + 1) * Q)
-            layer_cls_score = preds_dict['heatmap'][..., sl].permute(0, 2, 1).reshape(-1, self.num_classes)
-            layer_loss_cls = self.loss_cls(layer_cls_score.float(), labels[..., sl].reshape(-1),
-                                           label_weights[..., sl].reshape(-1), avg_factor=num_pos[l])
-            parts = [preds_dict[k][..., sl] for k in ('center', 'height', 'dim', 'rot')]
-            if 'vel' in preds_dict:
-                parts.append(preds_dict['vel'][..., sl])
-            preds = torch.cat(parts, dim=1).permute(0, 2, 1).float()     # (B, Q, code_size)
-            reg_w = bbox_weights[:, sl, :] * bbox_weights.new_tensor(code_weights)
-            layer_loss_bbox = self.loss_bbox(preds, bbox_targets[:, sl, :], reg_w, avg_factor=num_pos[l])
-            loss_dict[f'layer_{l}_loss_cls'] = layer_loss_cls
-            loss_dict[f'layer_{l}_loss_bbox'] = layer_loss_bbox
+        per_layer = lambda t: t.view(B, L, Q, -1).sum((0, 2, 3))                                 # (B, L*Q, .) -> (L,)
+        cls_score = preds_dict['heatmap'][..., :L * Q].permute(0, 2, 1).reshape(-1, self.num_classes).float()
+        cls_el = self.loss_cls(cls_score, labels[..., :L * Q].reshape(-1), label_weights[..., :L * Q].reshape(-1),
+                               reduction_override='none')
+        loss_cls = per_layer(cls_el.view(B, L * Q, -1)) / num_pos
+        parts = [preds_dict[k][..., :L * Q] for k in ('center', 'height', 'dim', 'rot')]
+        if 'vel' in preds_dict:
+            parts.append(preds_dict['vel'][..., :L * Q])
+        preds = torch.cat(parts, dim=1).permute(0, 2, 1).float()                                 # (B, L*Q, code_size)
+        reg_w = bbox_weights[:, :L * Q, :] * bbox_weights.new_tensor(code_weights)
+        box_el = self.loss_bbox(preds, bbox_targets[:, :L * Q, :], reg_w, reduction_override='none')
+        loss_bbox = per_layer(box_el) / num_pos
+        for l in range(L):
+            loss_dict[f'layer_{l}_loss_cls'] = loss_cls[l]
+            loss_dict[f'layer_{l}_loss_bbox'] = loss_bbox[l]
+        layer_loss_cls = loss_cls[-1]
         loss_dict['matched_ious'] = layer_loss_cls.new_tensor(matched_ious)
         return loss_dict
 
