@@ -206,7 +206,15 @@ class TransformerDecoderLayer(nn.Module):
             qh = q.view(Bq, Lq, H, D).transpose(1, 2) * (float(D) ** -0.5)
             kh = kv[..., :E].reshape(Bq, -1, H, D).transpose(1, 2)
             vh = kv[..., E:].reshape(Bq, -1, H, D).transpose(1, 2)
-            a = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)).float(), -1).to(vh.dtype)
+            sc = torch.matmul(qh, kh.transpose(-1, -2))
+            if sc.dtype == torch.float16:
+                # mixed precision: the soft-max kernel accumulates in float32 whatever its operand type; fp16 in / fp16 out is the
+                # value of float() -> softmax -> half() without two cast passes and a float32 copy of the (H, Q, 32 400) scores
+                # in each direction (autocast would up-cast the operand: switched off for this one call)
+                with torch.autocast('cuda', enabled=False):
+                    a = torch.softmax(sc, -1)
+            else:
+                a = torch.softmax(sc.float(), -1).to(vh.dtype)
             if self.training and ca.dropout > 0:
                 a = F.dropout(a, ca.dropout)
             o = torch.matmul(a, vh).transpose(1, 2).reshape(Bq, Lq, E)
