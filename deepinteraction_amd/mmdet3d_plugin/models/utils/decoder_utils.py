@@ -28,6 +28,20 @@ from ....geometry import aug_affine
 from ....utils import param_key
 
 
+class PointwiseConv1d(nn.Conv1d):
+    """nn.Conv1d; with kernel size 1 on the device it is evaluated as the matrix product it is.  The library convolution path for
+    these shapes ((B, 256 | 64, 200 tokens), 60 calls per training step) is layout transposes + a generic convolution kernel forward
+    and a naive one backward - 2.7 ms of a 32 ms step; as (O, C) @ (B, C, Q) it is a GEMM and its autograd.  Same parameters, same
+    `state_dict` keys."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dim() == 3 and self.kernel_size == (1,) and self.stride == (1,) and self.padding == (0,)
+                and self.dilation == (1,) and self.groups == 1):
+            y = torch.matmul(self.weight.squeeze(-1), x)
+            return y if self.bias is None else y + self.bias.view(1, -1, 1)
+        return super().forward(x)
+
+
 class ConvModule(nn.Module):
     """mmcv `ConvModule(conv -> BN -> ReLU)` surface used by the head (sub-modules `.conv`,
     `.bn`, `.activate`; bias='auto' => no conv bias when a norm follows)."""
@@ -36,7 +50,7 @@ class ConvModule(nn.Module):
                  conv_cfg=None, norm_cfg=None, **kwargs):
         super().__init__()
         typ = 'Conv2d' if conv_cfg is None else conv_cfg['type']
-        conv = {'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d}[typ]
+        conv = {'Conv1d': PointwiseConv1d, 'Conv2d': nn.Conv2d}[typ]
         self.with_norm = norm_cfg is not None
         if bias == 'auto':
             bias = not self.with_norm
@@ -56,7 +70,7 @@ class ConvModule(nn.Module):
 
 def build_conv_layer(cfg, *args, **kwargs):
     typ = 'Conv2d' if cfg is None else cfg['type']
-    return {'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d}[typ](*args, **kwargs)
+    return {'Conv1d': PointwiseConv1d, 'Conv2d': nn.Conv2d}[typ](*args, **kwargs)
 
 
 class PositionEmbeddingLearned(nn.Module):
@@ -66,8 +80,8 @@ class PositionEmbeddingLearned(nn.Module):
     def __init__(self, input_channel, num_pos_feats=288):
         super().__init__()
         self.position_embedding_head = nn.Sequential(
-            nn.Conv1d(input_channel, num_pos_feats, kernel_size=1), nn.BatchNorm1d(num_pos_feats),
-            nn.ReLU(inplace=True), nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
+            PointwiseConv1d(input_channel, num_pos_feats, kernel_size=1), nn.BatchNorm1d(num_pos_feats),
+            nn.ReLU(inplace=True), PointwiseConv1d(num_pos_feats, num_pos_feats, kernel_size=1))
         self._fold_cache = None
 
     def forward(self, xyz):

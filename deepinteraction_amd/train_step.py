@@ -61,7 +61,9 @@ class Trainer:
         self._master_grad = [torch.empty_like(m) for m in self._master]
         master_of = {id(p): m for p, m in zip(self._half, self._master)}
         self.opt_params = [master_of.get(id(p), p) for p in self.params]
-        self.opt = torch.optim.AdamW(self.opt_params, lr=1e-4, weight_decay=0.01)
+        # (fused: one multi-tensor launch for the whole update instead of ~15 foreach passes - the update sits on the device's
+        # critical path between two steps)
+        self.opt = torch.optim.AdamW(self.opt_params, lr=1e-4, weight_decay=0.01, fused=torch.device(device).type == 'cuda')
         self.world = world
         self.reducer = parallel.GradientReducer(self.params, world)
         # a small pool of device-resident batches per rank, built before the timed region (the data loader is out

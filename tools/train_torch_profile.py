@@ -26,3 +26,11 @@ tot = sum(r[0] for r in rows)
 print(f'{len(rows)} element-wise / copy operators of >= {thr} us: {tot / 1e3:.2f} ms')
 for t, n, sh, st in rows[:70]:
     print(f'{t:8.1f} us  {n:22s} {sh:90s} {st}')
+print()
+print('aggregated by (operator, input shapes), device time of the operator itself:')
+ka = prof.key_averages(group_by_input_shape=True)
+agg = sorted(ka, key=lambda e: -e.self_device_time_total)
+tot = sum(e.self_device_time_total for e in agg)
+print(f'total self device time {tot / 1e3:.2f} ms')
+for e in agg[:int(os.environ.get('ROWS', '60'))]:
+    print(f'{e.self_device_time_total:9.1f} us  x{e.count:4d}  {e.key[:40]:40s} {str(e.input_shapes)[:110]}')
