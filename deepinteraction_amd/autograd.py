@@ -95,6 +95,43 @@ class PixelLinear(torch.autograd.Function):
         return gx, gw, gb
 
 
+class WideLinear(torch.autograd.Function):
+    """y = x @ W^T + b for a FEW rows and VERY MANY outputs (DynamicConv's parameter generator: 200 tokens x 128 -> 32 768,
+    reference decoder_utils.py:584-600).  The input gradient  dx = dy @ W  reduces over the 32 768 outputs into a 200 x 128
+    result: as one GEMM the library launches a handful of workgroups without split-K (94 us per call for 8 MB of weights);
+    here the reduction is cut into S slabs, the slabs are a batched GEMM and the partial results are summed."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        gy = gy.contiguous()
+        if gy.dtype != weight.dtype:
+            weight = weight.to(gy.dtype)
+        if x.dtype != gy.dtype:
+            x = x.to(gy.dtype)
+        N, K = gy.shape
+        if ctx.needs_input_grad[0]:
+            S = next((s_ for s_ in (64, 32, 16, 8) if K % s_ == 0 and K // s_ >= 256), 1)
+            if S > 1:
+                gx = torch.bmm(gy.view(N, S, K // S).transpose(0, 1), weight.view(S, K // S, -1)).sum(0)
+            else:
+                gx = gy @ weight
+        if ctx.needs_input_grad[1]:
+            gw = gy.t() @ x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
+
+
 class I2PAttention(torch.autograd.Function):
     """ctx[cell] = sum_j d_j softmax_j(<qfold[cell], s_j>) s_j over the pillar's valid image keys
     (encoder_utils.py:257-320 with the single-head attention folded, see MMRI_I2P), d_j the attention dropout factor.

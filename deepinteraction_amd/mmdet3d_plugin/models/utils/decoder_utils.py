@@ -16,6 +16,7 @@ rectangles, RoIAlign and the 200 x 32400 cross attention are HIP kernels (C ABI 
 include/deepinteraction_hip.h); the dense projections are library GEMMs.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -23,9 +24,13 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import ops
-from ....autograd import RoIAlign
+from ....autograd import PixelLinear, RoIAlign, WideLinear
 from ....geometry import aug_affine
 from ....utils import param_key
+
+
+# measurement switch: 1 = the library's single-GEMM gradients in the decoder's training path
+SLABBED_GEMMS = os.environ.get('DI_TRAIN_PLAIN_GEMMS', '0') != '1'
 
 
 class PointwiseConv1d(nn.Conv1d):
@@ -209,7 +214,12 @@ class TransformerDecoderLayer(nn.Module):
         ca = self.multihead_attn
         E = ca.embed_dim
         q = F.linear(x + qpe, ca.in_proj_weight[:E], ca.in_proj_bias[:E])
-        kv = F.linear(ktok + kpe, ca.in_proj_weight[E:], ca.in_proj_bias[E:])  # (B,Pk,2C) = [K | V]
+        kin = ktok + kpe
+        if kin.is_cuda and torch.is_grad_enabled() and ca.in_proj_weight.requires_grad and SLABBED_GEMMS:
+            # training: the weight gradient reduces over the 32 400 keys - through the slab-batched GEMM of PixelLinear
+            kv = PixelLinear.apply(kin.reshape(-1, E), ca.in_proj_weight[E:], ca.in_proj_bias[E:]).view(*kin.shape[:-1], 2 * E)
+        else:
+            kv = F.linear(kin, ca.in_proj_weight[E:], ca.in_proj_bias[E:])     # (B,Pk,2C) = [K | V]
         if x.is_cuda and not (torch.is_grad_enabled() and (q.requires_grad or kv.requires_grad)):
             o = ops.mha_decode(q, kv, ca.num_heads, float(ca.head_dim) ** -0.5)
         else:
@@ -328,7 +338,11 @@ class DynamicConv(nn.Module):
 
     def forward_nk(self, pro, roi):
         """pro (n,128), roi (n,49,128) (the RoIAlign kernel's native output) -> (n,128)."""
-        params = self.dynamic_layer(pro)                                    # (n, 2*128*128)
+        dl = self.dynamic_layer
+        if pro.is_cuda and torch.is_grad_enabled() and dl.weight.requires_grad and pro.dim() == 2 and SLABBED_GEMMS:
+            params = WideLinear.apply(pro, dl.weight, dl.bias)              # training: slabbed input gradient
+        else:
+            params = dl(pro)                                                # (n, 2*128*128)
         p1 = params[:, :self.num_params].view(-1, self.hidden_dim, self.dim_dynamic)
         p2 = params[:, self.num_params:].view(-1, self.dim_dynamic, self.hidden_dim)
         f = self.activation(_post_norm(self.norm1, torch.bmm(roi, p1)))
