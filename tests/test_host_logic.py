@@ -4,7 +4,7 @@ import math
 import torch
 
 from deepinteraction_amd import ops
-from deepinteraction_amd.autograd import PixelLinear
+from deepinteraction_amd.autograd import PixelLinear, WideLinear
 
 
 def test_pixel_linear_matches_autograd_of_linear():
@@ -21,6 +21,27 @@ def test_pixel_linear_matches_autograd_of_linear():
             assert torch.allclose(r, o, rtol=1e-12, atol=1e-9)
         S = PixelLinear._slabs(M)
         assert M % S == 0 and (S == 1 or M // S >= 512)
+
+
+def test_wide_linear_matches_autograd_of_linear():
+    """`WideLinear` (DynamicConv's 128 -> 32 768 parameter generator in the training path): the slab-batched input
+    gradient, the weight and bias gradients against autograd of F.linear, float64; also an output width the slabs do not
+    divide (single-GEMM path)."""
+    g = torch.Generator().manual_seed(4)
+    for n, k in ((20, 32768), (7, 1000)):
+        x = torch.randn(n, 128, generator=g, dtype=torch.float64, requires_grad=True)
+        W = torch.randn(k, 128, generator=g, dtype=torch.float64, requires_grad=True)
+        b = torch.randn(k, generator=g, dtype=torch.float64, requires_grad=True)
+        gy = torch.randn(n, k, generator=g, dtype=torch.float64)
+        y = WideLinear.apply(x, W, b)
+        y.backward(gy)
+        got = (x.grad.clone(), W.grad.clone(), b.grad.clone())
+        x.grad = W.grad = b.grad = None
+        y2 = torch.nn.functional.linear(x, W, b)
+        y2.backward(gy)
+        assert torch.equal(y, y2)
+        for a, c in zip(got, (x.grad, W.grad, b.grad)):
+            assert float((a - c).abs().max()) <= 1e-10 * float(c.abs().max())
 
 
 def test_bev_sector_order_is_an_azimuth_sorted_permutation():

@@ -287,6 +287,15 @@ def test_loss_has_gradients_and_empty_gt():
     empty = M.get_targets([dc.LiDARBoxes(torch.zeros(0, 9))], [torch.zeros(0, dtype=torch.long)],
                           [{k: v.detach() for k, v in pd.items()}])
     assert (empty[0] == 10).all() and empty[5] == 0 and empty[7].abs().sum() == 0
+    # `prepare_targets` (the ground-truth-only heat map drawn ahead of the loss, e.g. under the forward's graph replay)
+    # changes nothing: same losses, and the prepared entries are consumed
+    labels = [torch.tensor([0, 8])]
+    M.prepare_targets(gt, labels, 'cpu')
+    assert len(M._gt_targets) == 1
+    again = M.loss(gt, labels, [[{k: v.detach() for k, v in pd.items()}]])
+    assert len(M._gt_targets) == 0
+    for k in loss:
+        assert torch.equal(again[k].float(), loss[k].detach().float()), k
 
 
 def test_pp_head_loss_matches_reference(ref):
