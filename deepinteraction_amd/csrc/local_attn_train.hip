@@ -4,7 +4,7 @@
 // similar.cu:43-92, weighting.cu:44-122) never exists.  Mixed-precision training path (torch.autocast): operands and
 // results fp16, every accumulation float32.
 //
-// One kernel template, three unit programs.  The data flow is the second inference generation's
+// One kernel template, four unit programs.  The data flow is the second inference generation's
 // (local_attn_mfma2.hip): persistent workgroups of 4 wavefronts, 8 x 8 CENTRE pixels per workgroup (a wavefront owns
 // 8 x 2 = 16 MFMA columns), the 16 x 16 HALO staged through two LDS buffers in 64-channel units, the loads of unit u + 2
 // in flight during the MFMA pass of unit u, XCD-contiguous tile ranges, swizzled LDS.  A unit is one of
@@ -14,7 +14,7 @@
 // masks serve a query-centred and a key-centred pass:
 //   FWD    centre = queries (b0 = Q), halo = K, V:   S0 S0 | soft-max, L = log-sum-exp out | O0 O0 -> out
 //   BWD_Q  centre = queries (b0 = Q, b1 = dO), halo = K, V:
-//          S0 S0 | P = exp(S - L) | S1 S1 (dP = <V, dO>) | dS = P (dP - D) | O1 O1 (K^T dS) -> dQ
+//          S0 S0 | P = exp(S - L) | S1 S1 (dP - D = <V, dO> - D: the accumulators start at -D) | dS = P (dP - D) | O1 O1 (K^T dS) -> dQ
 //   BWD_V  centre = KEYS (b0 = K), halo = Q, dO, with L of the halo pixels in an LDS table:
 //          S0 S0 | P | O0 O0 (dO^T P) -> dV
 //   BWD_K  centre = KEYS (b0 = K, b1 = V), halo = Q, dO, L and D of the halo pixels in LDS tables:
