@@ -250,6 +250,9 @@ def main():
     parallel.init('nccl', device)                 # RCCL over xGMI
     ranks_seen = int(parallel.sum_over_ranks(1, device))
     if args.mode == 'train':
+        if args.model != 'v1':
+            sys.exit('--mode train runs the Fusion_0075_refactor model (BASELINE configs[2] / [3]); the DeepInteraction++ training '
+                     'forward / backward is timed by tools/pp_train_bench.py')
         from deepinteraction_amd import train_step
         out = train_step.bench(args, rank, world, device)
     elif args.model == 'pp':
