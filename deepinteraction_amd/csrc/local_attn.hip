@@ -418,7 +418,8 @@ int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out,
     // gives the better step (953.6 against 947.9 samples/s, one sample at a time 1.415 against 1.452 ms).  Maps with fewer
     // than two 16 x 8 tiles per CU (the 180 x 180 BEV map: 276 tiles) stay on the second generation (16.0 against 16.3 us).
     const long long ring_tiles = (long long)n * ((W + 15) / 16) * ((H + 7) / 8);
-    if (ring_tiles >= 2 * 256) return di::launch_local_attn_ring(q, k, v, out, n, H, W, scale, 0, (hipStream_t)stream);
+    const int cus = di::device_cus();                        // (the ring form runs one workgroup per CU)
+    if (cus > 0 && ring_tiles >= 2ll * cus) return di::launch_local_attn_ring(q, k, v, out, n, H, W, scale, 0, (hipStream_t)stream);
     return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, 1, (hipStream_t)stream);
   }
   return di::run_la(di::OP_FUSED, dtype, kH, kW, A);

@@ -21,8 +21,10 @@
 //     bit-identical results) never touch the vector-memory path except for their 4 query loads and 8 output stores per
 //     tile; they wait on `landed` with an LDS poll only when the producers are not ahead, and never on each other.
 //     Flags are plain LDS words (one writer each, monotonic): no atomics, no s_barrier after the prologue.
-//   * 10 waves at <= 168 VGPRs; every spin is bounded (a stuck pipeline gives wrong results and sets `di_ring_timeouts`,
-//     it does not hang the device).
+//   * 10 waves at <= 168 VGPRs; every spin is bounded and a spin that gives up is LOUD: it bumps `di_ring_timeouts`, a producer
+//     that gave up issues no further DMA (it never overwrites a block a consumer may still read), and a consumer that gave up
+//     stores NaN for that tile and every later tile of its workgroup - a stuck pipeline can neither hang the device nor hand
+//     back plausible numbers (tests: DI_RING_DBG=32 kills the producers after their first tile).
 #include <stdlib.h>
 #include <type_traits>
 
@@ -128,13 +130,15 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     __half *__restrict__ out, int n, int H, int W, float scale, int tiles_x, int tiles_y, int dbg,
     unsigned long long *__restrict__ ts_out) {
   // dbg (measurement only, DI_RING_DBG): 1 = no output stores, 2 = no query loads, 4 = no DMA (blocks announced at once),
-  // 8 = consumers skip the LDS reads and MFMAs, 16 = phase time stamps of workgroup 0 (tools/ring_timeline.py)
+  // 8 = consumers skip the LDS reads and MFMAs, 16 = phase time stamps of workgroup 0 (tools/ring_timeline.py),
+  // 32 = fault injection: the producers give up after their first tile and every spin is short (tests of the NaN poisoning)
   extern __shared__ __align__(1024) unsigned char lds[];
   constexpr int ROWB = G::ROWB, S = G::S, HR = G::HR;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds0 = lds_addr_of(lds);
   const unsigned f_landed = lds0 + G::RING, f_done = lds0 + G::RING + 32;
+  const int spin_limit = (dbg & 32) ? 4096 : SPIN_LIMIT;
   // measurement: lane 0 of every wave of workgroup 0 stamps the shader clock into its own KB of LDS (no vector-memory traffic:
   // the producers count theirs); copied out at the end
   const bool ts_on = (dbg & 16) && blockIdx.x == 0;
@@ -182,6 +186,8 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     const int nblk = ntl * G::BPT;                            // blocks of this workgroup, in sequence
     int min_done = 0;                                         // cached min over done[w]: blocks every consumer is past
     int published = 0;                                        // blocks of mine announced in landed[p]
+    int issued = 0;                                           // blocks whose DMA this wave has issued
+    bool dead = false;                                        // a spin gave up: nothing more is issued
     __builtin_amdgcn_s_setprio(2);                            // few instructions, all of them on the critical path
     auto publish = [&]() {
       lds_st32(f_landed + 4 * p, (unsigned)published);
@@ -216,11 +222,17 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
             __builtin_amdgcn_s_sleep(1);
           }
           reload_done();
-          if (++spins > SPIN_LIMIT) {
+          if (++spins > spin_limit) {
             if (lane == 0) atomicAdd(&timeouts, 1u);
+            dead = true;
             break;
           }
         }
+        if ((dbg & 32) && it >= 1 && !dead) {                 // fault injection
+          if (lane == 0) atomicAdd(&timeouts, 1u);
+          dead = true;
+        }
+        if (dead) break;                                      // never write into a block a consumer may still be reading
         stamp(1);                                             // buffer free
         const unsigned dst = lds0 + (B % G::NBLK) * G::BLKB;
         {
@@ -241,15 +253,17 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
         }
         }
         stamp(2);                                             // issued
+        issued = B + 1;
         if (B - published >= 2) {                             // never more than two blocks unannounced (vmcnt is 6 bits)
           wait_blocks<G::IPB>(2);
           published = B - 1;
           publish();
         }
       }
+      if (dead) break;
     }
-    while (published < nblk) {                                // drain: no DMA may outlive the workgroup's LDS
-      wait_blocks<G::IPB>(nblk - published - 1);
+    while (published < issued) {                              // drain: no DMA may outlive the workgroup's LDS
+      wait_blocks<G::IPB>(issued - published - 1);
       ++published;
       publish();
     }
@@ -285,7 +299,9 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
 
   // block B is in LDS once every producer has announced more than B blocks
   int seen = 0;                                              // blocks [0, seen) are known to have landed
+  bool bad = false;                                          // a wait gave up: this and every later tile is stored as NaN
   auto wait_landed = [&](int B) {
+    if (bad) return;
     int spins = 0;
     stamp(4);                                                 // starts waiting for a block
     while (seen <= B) {
@@ -304,8 +320,9 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
       seen = __builtin_amdgcn_readfirstlane((int)m);
       if (seen > B) break;
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > SPIN_LIMIT) {
+      if (++spins > spin_limit) {
         if (lane == 0) atomicAdd(&timeouts, 1u);
+        bad = true;
         break;
       }
     }
@@ -484,10 +501,16 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
           wv[2 * pr + 1][d] = sw[1];
         }
       if (pix_ok && !(dbg & 1)) {
+        if (__builtin_expect(bad, 0)) {                       // a block never arrived: the tile is poisoned, not guessed
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr)
-          *reinterpret_cast<uint4 *>(dst + u * 64 + 32 * pr) =
-              make_uint4(wv[2 * pr][0], wv[2 * pr][1], wv[2 * pr + 1][0], wv[2 * pr + 1][1]);
+          for (int pr = 0; pr < 2; ++pr)
+            *reinterpret_cast<uint4 *>(dst + u * 64 + 32 * pr) = make_uint4(0x7E007E00u, 0x7E007E00u, 0x7E007E00u, 0x7E007E00u);
+        } else {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr)
+            *reinterpret_cast<uint4 *>(dst + u * 64 + 32 * pr) =
+                make_uint4(wv[2 * pr][0], wv[2 * pr][1], wv[2 * pr + 1][0], wv[2 * pr + 1][1]);
+        }
       }
     });
     cur = nxt;

@@ -178,6 +178,12 @@ class GraphedHotPath:
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.out = self._forward()
 
+    def check_health(self):
+        """Synchronises and raises when a captured kernel reported a fault it could only report through device memory (the
+        ring window attention's bounded spins: affected tiles are NaN in the outputs).  Call it where the outputs are read."""
+        from . import ops
+        ops.check_ring_health()
+
     def num_nodes(self):
         """Nodes (kernel launches, copies, memsets) of the captured forward, or None when torch does not expose it."""
         return self._nodes

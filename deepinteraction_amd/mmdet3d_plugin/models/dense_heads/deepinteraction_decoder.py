@@ -282,7 +282,8 @@ class DeepInteractionDecoder(nn.Module):
         """Optional, ahead of `loss`: evaluate the targets that depend on the ground truth ALONE (the dense heat map) - e.g.
         while the device runs the forward the loss will wait for.  `loss` / `get_targets` pick them up (same objects) and
         compute whatever was not prepared; the values are the same either way."""
-        self._gt_targets = {id(b): self.dense_heatmap_target(b, l, device) for b, l in zip(gt_bboxes_3d, gt_labels_3d)}
+        # (replaces whatever an earlier call left behind; an entry keeps its box object so that a recycled id() cannot match)
+        self._gt_targets = {id(b): (b, self.dense_heatmap_target(b, l, device)) for b, l in zip(gt_bboxes_3d, gt_labels_3d)}
 
     # ------------------------------------------------------------------ targets (reference :315-482)
     def get_targets(self, gt_bboxes_3d, gt_labels_3d, preds_dict):
@@ -293,6 +294,7 @@ class DeepInteractionDecoder(nn.Module):
         res = [self.get_targets_single(gt_bboxes_3d[b], gt_labels_3d[b],
                                        {k: v[b:b + 1] for k, v in preds_dict[0].items()}, b)
                for b in range(len(gt_bboxes_3d))]
+        self._gt_targets = {}                                    # prepared targets do not outlive the call they were made for
         cat = lambda i: torch.cat([r[i] for r in res], dim=0)
         num_pos = int(np.sum([r[5] for r in res]))
         matched_ious = float(np.mean([r[6] for r in res]))
@@ -360,7 +362,8 @@ class DeepInteractionDecoder(nn.Module):
         # dense heat-map target: a function of the ground truth alone (see `dense_heatmap_target`)
         if getattr(self, '_heatmap_peaks', None) is None:                # (get_targets_single called on its own)
             self._heatmap_peaks = {}
-        ready = getattr(self, '_gt_targets', {}).pop(id(gt_bboxes_3d), None)
+        entry = getattr(self, '_gt_targets', {}).pop(id(gt_bboxes_3d), None)
+        ready = entry[1] if entry is not None and entry[0] is gt_bboxes_3d else None
         heatmap, peaks = ready if ready is not None else self.dense_heatmap_target(gt_bboxes_3d, gt_labels_host, dev)
         self._heatmap_peaks[batch_idx] = peaks                           # `loss` normalises by it: known on the host
         mean_iou = ious[pos_inds].sum() / max(len(pos_inds), 1)

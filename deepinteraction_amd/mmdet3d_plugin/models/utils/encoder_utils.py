@@ -106,7 +106,7 @@ class ConvBNReLU(nn.Module):
 
     def _fused_bn_ok(self, x):
         bn = self.bn
-        return (FUSED_TRAINING_BN and self.training and x.is_cuda and type(bn) is nn.BatchNorm2d and bn.track_running_stats
+        return (FUSED_TRAINING_BN and bn.training and x.is_cuda and type(bn) is nn.BatchNorm2d and bn.track_running_stats
                 and bn.momentum is not None and x.dim() == 4 and ops._is_cl(x) and x.dtype in (torch.float16, torch.float32)
                 and bn.num_features % 8 == 0 and bn.num_features <= 256
                 and (not self.use_activation or type(self.activation) is nn.ReLU)

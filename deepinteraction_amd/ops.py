@@ -89,6 +89,23 @@ def local_attention(q, k, v, kH, kW, scale, variant=LA_AUTO):
     return out
 
 
+def ring_timeouts():
+    """Bounded flag spins of the ring window-attention kernel that gave up since the library was loaded (synchronises the
+    current stream).  0 on a healthy device; the affected query tiles hold NaN (csrc/local_attn_ring.hip)."""
+    n = int(_lib.lib().di_local_attn_ring_timeouts(_stream()))
+    if n < 0:
+        raise _lib.HipLibraryError('di_local_attn_ring_timeouts failed: ' + _lib.lib().di_last_error().decode())
+    return n
+
+
+def check_ring_health():
+    """Raise when a window-attention launch gave up on a flag spin (its output tiles are NaN-poisoned)."""
+    n = ring_timeouts()
+    if n:
+        raise _lib.HipLibraryError(f'local_attn_ring: {n} bounded spins gave up - the affected output tiles hold NaN; '
+                                   'the device (or another process sharing it) stalled a workgroup for > 0.1 s')
+
+
 def local_attention_train_usable(q, k, v, kH, kW):
     """The fused training kernels take fp16 maps of 128 channels and 9 x 9 windows (the configuration of every
     `LocalContextAttentionBlock` of Fusion_0075_refactor under autocast)."""

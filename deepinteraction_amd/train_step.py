@@ -33,6 +33,35 @@ def synth_gt(seed, n=30):
     return dc.LiDARBoxes(torch.cat([xy, z, dims, yaw, vel], 1)), torch.randint(0, 10, (n,), generator=g)
 
 
+class LossScaler:
+    """Dynamic loss scaling for the mixed-precision step, with `torch.amp.GradScaler`'s rules (scale * backoff on a step whose
+    gradients hold inf / NaN - that step is SKIPPED - and * growth after `growth_interval` clean steps) but no host round trip:
+    the overflow flag stays on the device and the fused AdamW consumes it (`optimizer.found_inf`), so the step can sit between
+    two hipGraph replays.  fp16 activation gradients flush below 6e-8 and overflow above 65504; the reference trains this
+    configuration in float32 (no scaler needed), or in fp16 through mmcv's Fp16OptimizerHook with a loss scale."""
+
+    def __init__(self, device, init_scale=2.0 ** 10, growth_factor=2.0, backoff_factor=0.5, growth_interval=200):
+        dev = torch.device(device)
+        self.scale = torch.full((), float(init_scale), dtype=torch.float32, device=dev)
+        self.inv_scale = torch.empty_like(self.scale)
+        self.growth_tracker = torch.zeros((), dtype=torch.int32, device=dev)
+        self.found_inf = torch.zeros((), dtype=torch.float32, device=dev)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.skipped = torch.zeros((), dtype=torch.float32, device=dev)     # steps skipped so far (read by tests / bench)
+
+    def unscale_(self, grads):
+        """grads /= scale in place (float32 tensors); `found_inf` = 1 when any of them holds inf / NaN."""
+        self.found_inf.zero_()
+        torch.reciprocal(self.scale, out=self.inv_scale)
+        if grads:
+            torch._amp_foreach_non_finite_check_and_unscale_(list(grads), self.found_inf, self.inv_scale)
+
+    def update(self):
+        self.skipped += self.found_inf
+        torch._amp_update_scale_(self.scale, self.growth_tracker, self.found_inf, self.growth_factor, self.backoff_factor,
+                                 self.growth_interval)
+
+
 class Trainer:
     def __init__(self, shape, num_proposals, device, world, batch=1, pool=2, rank=0, seed=0, amp=None):
         import os
@@ -63,7 +92,10 @@ class Trainer:
         self.opt_params = [master_of.get(id(p), p) for p in self.params]
         # (fused: one multi-tensor launch for the whole update instead of ~15 foreach passes - the update sits on the device's
         # critical path between two steps)
-        self.opt = torch.optim.AdamW(self.opt_params, lr=1e-4, weight_decay=0.01, fused=torch.device(device).type == 'cuda')
+        self._fused_opt = torch.device(device).type == 'cuda'
+        self.opt = torch.optim.AdamW(self.opt_params, lr=1e-4, weight_decay=0.01, fused=self._fused_opt)
+        # mixed precision backpropagates fp16 gradients: dynamic loss scaling + an overflow guard in front of the update
+        self.scaler = LossScaler(device) if self.amp else None
         self.world = world
         self.reducer = parallel.GradientReducer(self.params, world)
         # a small pool of device-resident batches per rank, built before the timed region (the data loader is out
@@ -86,10 +118,16 @@ class Trainer:
         losses = self.dec.loss([g[0] for g in gts], [g[1] for g in gts], preds)
         loss = sum(v for k, v in losses.items() if k != 'matched_ious')
         self._zero_grad()
-        loss.backward()                                               # bucket all-reduces start inside
+        self._backward(loss)                                          # bucket all-reduces start inside
         self.reducer.finish()
         self._update()
         return loss
+
+    def _backward(self, loss):
+        if self.scaler is None:
+            loss.backward()
+        else:
+            loss.backward(self.scaler.scale.to(loss.dtype))           # d(scale * loss): the scale is a device scalar, no sync
 
     def _zero_grad(self):
         self.opt.zero_grad(set_to_none=True)
@@ -107,8 +145,21 @@ class Trainer:
                     dst.append(buf)
             if dst:
                 torch._foreach_copy_(dst, src)                       # fp16 gradients -> float32 master gradients
-        torch.nn.utils.clip_grad_norm_([p for p in self.opt_params if p.grad is not None], max_norm=0.1, norm_type=2)
-        self.opt.step()
+        live = [p for p in self.opt_params if p.grad is not None]
+        skip = False
+        if self.scaler is not None:
+            # (after the all-reduce: every rank sees the same summed gradients, so every rank takes the same decision)
+            self.scaler.unscale_([p.grad for p in live])
+            if self._fused_opt:
+                self.opt.grad_scale, self.opt.found_inf = None, self.scaler.found_inf   # the fused update skips itself on the device
+            else:
+                skip = bool(self.scaler.found_inf.item())
+        if not skip:
+            # (on an overflow step the clip factor is 0 or NaN: those gradients are never applied)
+            torch.nn.utils.clip_grad_norm_(live, max_norm=0.1, norm_type=2)
+            self.opt.step()
+        if self.scaler is not None:
+            self.scaler.update()
         if self._half:
             with torch.no_grad():
                 torch._foreach_copy_(self._half, self._master)       # the model's fp16 weights = the rounded masters
@@ -171,6 +222,8 @@ class GraphedTrainer(Trainer):
         self.records = [h.prepare(d) for d, _ in self.pool]
         # attention dropout of the pillar attention: the captured launches add this device word to their (baked) seed
         from . import ops
+        # (registered for the duration of the captures only: the pointer is baked into the captured launches, whose lifetime is
+        # this object's, and no launch outside them - another trainer, inference - ever sees it)
         self.seed_word = torch.zeros(1, dtype=torch.int64, device=h.img_feats.device)
         ops.set_i2p_seed_tensor(self.seed_word)
         self.module = _HotPathModule(self.enc, self.dec, h, amp=self.amp)
@@ -183,6 +236,7 @@ class GraphedTrainer(Trainer):
         try:
             self.graphed = torch.cuda.make_graphed_callables(self.module, (h.img_feats, h.pts_feats), allow_unused_input=True)
         finally:
+            ops.set_i2p_seed_tensor(None)
             if was_enabled:
                 gc.enable()
 
@@ -198,7 +252,7 @@ class GraphedTrainer(Trainer):
         losses = self.dec.loss([g[0] for g in gts], [g[1] for g in gts], preds)
         loss = sum(v for k, v in losses.items() if k != 'matched_ious')
         self._zero_grad()
-        loss.backward()                                                              # eager loss backward + backward graph
+        self._backward(loss)                                                         # eager loss backward + backward graph
         self.reducer.finish()
         self._update()
         return loss
@@ -229,7 +283,8 @@ def bench(args, rank, world, device):
                             num_proposals=args.proposals, pool=len(tr.pool),
                             precision=('mixed: fp16 activations under torch.autocast incl. the fused window attention forward / '
                                        'backward; float32 master weights, BatchNorm statistics, soft-max, scatter accumulation, '
-                                       'loss; no loss scaling') if amp else 'float32',
+                                       'loss; dynamic loss scaling with the overflow flag kept on the device (a step with inf / NaN '
+                                       'gradients is skipped by the fused AdamW)') if amp else 'float32',
                             launch='host launches' if eager else 'forward and backward of the hot path as two replayed hipGraphs '
                                                                  'around the eager loss (Hungarian assignment on the host)',
                             parallelism=f'dp{args.gpus} by sample, RCCL all-reduce of gradients only'),

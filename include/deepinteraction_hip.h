@@ -91,9 +91,11 @@ int di_local_attn_train_fwd(const void *q, const void *k, const void *v, void *o
 int di_local_attn_train_bwd(const void *q, const void *k, const void *v, const void *out, const void *grad_out,
                             const float *lse, float *dsum, void *grad_q, void *grad_k, void *grad_v, int n, int H, int W,
                             float scale, void *stream);
-/* The DI_LA_RING kernel bounds every flag spin; a pipeline that gave up produced wrong results instead of hanging the
- * device.  Returns the number of spins that gave up since the library was loaded (0 on a healthy run; synchronises
- * `stream`), -1 on a HIP error. */
+/* The DI_LA_RING kernel bounds every flag spin.  A spin that gives up never hangs the device and never hands back plausible
+ * numbers: a producer wavefront that gave up issues no further loads, a consumer wavefront that gave up stores NaN for that
+ * query tile and every later tile of its workgroup, and a device counter is bumped.  Returns the number of spins that gave up
+ * since the library was loaded (0 on a healthy run; synchronises `stream`), -1 on a HIP error.  Host code checks it where it
+ * synchronises anyway (`GraphedHotPath.check_health()`, bench.py); environment DI_RING_DBG=32 injects the fault (tests). */
 int di_local_attn_ring_timeouts(void *stream);
 /* Measurement (environment DI_RING_DBG & 16): the phase time stamps of workgroup 0's wavefronts of the last DI_LA_RING launch,
  * 16 x 128 uint64 (tag << 56 | shader clock; entry 127 of a wave = its count) copied to `host_out`. */
@@ -184,7 +186,10 @@ int di_i2p_attn_bwd(const void *img, const void *qfold, const void *grad_ctx, co
                     void *stream);
 /* Training under hipGraph replay: a captured launch has its `seed` argument baked in.  With a device word registered here
  * (NULL to clear) every di_i2p_attn_fwd* / di_i2p_attn_bwd* launch ADDS *dev_ptr to its seed when it RUNS; the caller rewrites
- * the word before each replay (forward and backward of one step then see the same value). */
+ * the word before each replay (forward and backward of one step then see the same value).  Process-wide state: register it
+ * for the duration of the capture only and clear it right after (`train_step.GraphedTrainer` does) - the pointer a launch
+ * read while it was captured stays baked into that graph, so the word must outlive the graph, and launches issued after the
+ * clear (another trainer, inference) are not affected. */
 int di_i2p_set_seed_ptr(const void *dev_ptr);
 /* The same with the gradient of the kept mass (Hb*Wb, the maps' element type; NULL = di_i2p_attn_bwd). */
 int di_i2p_attn_bwd_mass(const void *img, const void *qfold, const void *grad_ctx, const void *grad_mass, const float *pillars,

@@ -95,6 +95,53 @@ def test_local_attention_ring_is_bit_identical_to_the_register_staged_kernel(sha
     assert _lib.lib().di_local_attn_ring_timeouts(None) == 0
 
 
+_RING_FAULT_SCRIPT = r'''
+import math, sys, torch
+from deepinteraction_amd import ops
+g = torch.Generator().manual_seed(11)
+q, k, v = (torch.randn(6, 128, 112, 200, generator=g).relu().half().cuda().contiguous(memory_format=torch.channels_last)
+           for _ in range(3))
+sc = 1.0 / math.sqrt(128)
+ref = ops.local_attention(q, k, v, 9, 9, sc, variant=ops.LA_MFMA + 1)
+out = ops.local_attention(q, k, v, 9, 9, sc, variant=ops.LA_RING)
+torch.cuda.synchronize()
+nan = torch.isnan(out.float()).permute(0, 2, 3, 1)          # (n, H, W, C)
+pix_nan, pix_any = nan.all(-1), nan.any(-1)
+assert torch.equal(pix_nan, pix_any), 'a pixel is either whole or poisoned'
+good = ~pix_any
+assert bool(good.any()) and bool(pix_nan.any())
+# every pixel that is not poisoned carries the right value: no plausible-but-wrong output anywhere
+o, r = out.permute(0, 2, 3, 1)[good], ref.permute(0, 2, 3, 1)[good]
+assert torch.equal(o, r)
+frac = float(pix_nan.float().mean())
+assert 0.5 < frac < 0.9, frac                                # the first tile of each of the 256 workgroups survives
+n = ops.ring_timeouts()
+assert n > 0
+try:
+    ops.check_ring_health()
+except Exception as e:
+    assert 'NaN' in str(e)
+else:
+    raise AssertionError('check_ring_health did not raise')
+print('POISON_OK', n, round(frac, 3))
+'''
+
+
+def test_local_attention_ring_timeout_poisons_its_tiles_with_nan():
+    """A bounded spin of the ring kernel that gives up must be LOUD (round-4 advice): with the fault injected (DI_RING_DBG=32:
+    both producer wavefronts of every workgroup stop after their first tile), the consumers' waits give up, every affected
+    tile is stored as NaN, every other pixel is bit-identical to the second generation, the device counter is non-zero and
+    `ops.check_ring_health()` raises.  (Own process: the switch is read at the first launch.)"""
+    _require_gpu()
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DI_RING_DBG='32', PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    r = subprocess.run([sys.executable, '-c', _RING_FAULT_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'POISON_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_local_attention_mfma_rejects_unsupported():
     from deepinteraction_amd import _lib
     x = torch.zeros(1, 64, 8, 16, device=DEV, dtype=torch.float16)

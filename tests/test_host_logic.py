@@ -100,3 +100,30 @@ def test_graph_input_arena_layout():
     g._arena.copy_(other)
     for a, b in zip(g._input_list(), before):
         assert torch.equal(a, b * 2 if b.is_floating_point() else b + 1)
+
+
+def test_loss_scaler_skips_an_overflow_step_and_backs_off():
+    """`train_step.LossScaler` (mixed-precision training; round-4 advice): GradScaler's rules with the overflow flag consumed by
+    the fused AdamW - a step whose gradients hold inf / NaN changes neither the parameters nor the optimizer state and halves
+    the scale; clean steps unscale the gradients exactly and grow the scale after `growth_interval` of them."""
+    from deepinteraction_amd.train_step import LossScaler
+    p = torch.nn.Parameter(torch.ones(4))
+    opt = torch.optim.AdamW([p], lr=0.1, fused=True)
+    sc = LossScaler('cpu', init_scale=8.0, growth_interval=2)
+
+    def step(grad):
+        p.grad = grad.clone()
+        sc.unscale_([p.grad])
+        opt.grad_scale, opt.found_inf = None, sc.found_inf
+        opt.step()
+        sc.update()
+    step(torch.tensor([8.0, 16.0, float('inf'), 1.0]))
+    assert torch.equal(p.detach(), torch.ones(4)) and float(sc.scale) == 4.0 and float(sc.skipped) == 1.0
+    assert float(opt.state[p]['step']) == 0.0
+    step(torch.tensor([4.0, 8.0, -4.0, 0.0]))
+    assert torch.equal(p.grad, torch.tensor([1.0, 2.0, -1.0, 0.0]))          # unscaled exactly (powers of two)
+    assert float(opt.state[p]['step']) == 1.0 and bool((p.detach()[:3] != 1.0).all()) and float(sc.scale) == 4.0
+    step(torch.tensor([4.0, 4.0, 4.0, 4.0]))
+    assert float(sc.scale) == 8.0 and float(sc.skipped) == 1.0                # two clean steps: the scale grows
+    step(torch.tensor([float('nan'), 0.0, 0.0, 0.0]))
+    assert float(sc.scale) == 4.0 and float(sc.skipped) == 2.0 and torch.isfinite(p).all()

@@ -424,7 +424,11 @@ def test_graphed_training_step(amp):
         assert all(math.isfinite(l) for l in losses), losses
         missing = [n for m in (tr.enc, tr.dec) for n, p in m.named_parameters() if p.grad is None]
         assert all(n.startswith('heatmap_head.') for n in missing), missing[:5]
-        assert all(torch.isfinite(p.grad).all() for p in tr.params if p.grad is not None)
+        if amp:     # fp16 gradients are loss-scaled: a step may overflow (and is then skipped); the weights stay finite
+            assert all(torch.isfinite(m).all() for m in tr._master) and float(tr.scaler.scale) > 0
+            assert float(tr.scaler.skipped) < 3, 'every step overflowed at the initial loss scale'
+        else:
+            assert all(torch.isfinite(p.grad).all() for p in tr.params if p.grad is not None)
 
         def forward_loss(word):
             tr.h.load(tr.records[0])
@@ -439,6 +443,44 @@ def test_graphed_training_step(amp):
         a, b, c = forward_loss(1234), forward_loss(1234), forward_loss(99991)
         assert a == b, (a, b)
         assert a != c, (a, c)
+    finally:
+        ops.set_i2p_seed_tensor(None)
+
+
+@pytest.mark.parametrize('graphed', [False, True])
+def test_amp_overflow_step_is_skipped_and_the_loss_scale_backs_off(graphed):
+    """Round-4 advice: the mixed-precision step backpropagates fp16 gradients, so it carries dynamic loss scaling and an
+    overflow guard (`train_step.LossScaler`).  Injected overflow (loss scale 2^40): the step changes neither the float32
+    masters, nor the model's fp16 weights, nor AdamW's step counter / moments, and the scale is halved; the next step at a sane
+    scale updates the weights and everything stays finite.  Eager and graph-replayed trainer."""
+    from deepinteraction_amd import ops, train_step
+    torch.backends.cudnn.deterministic = True
+    cls = train_step.GraphedTrainer if graphed else train_step.Trainer
+    tr = cls(synth.SHAPE_TINY, 24, torch.device(DEV), 1, pool=1, amp=True)
+    try:
+        assert tr.scaler is not None and tr._master
+        tr.scaler.scale.fill_(1.0)
+        tr.step()                                                        # a clean step (round 4 ran at scale 1)
+        torch.cuda.synchronize()
+        assert float(tr.scaler.skipped) == 0.0
+        masters = [m.detach().clone() for m in tr._master]
+        halves = [p.detach().clone() for p in tr._half]
+        st = tr.opt.state[tr._master[0]]
+        n_steps, exp_avg = float(st['step']), st['exp_avg'].clone()
+        tr.scaler.scale.fill_(2.0 ** 40)
+        tr.step()
+        torch.cuda.synchronize()
+        assert float(tr.scaler.skipped) == 1.0 and float(tr.scaler.scale) == 2.0 ** 39
+        assert all(torch.equal(a, b) for a, b in zip(masters, tr._master))
+        assert all(torch.equal(a, b) for a, b in zip(halves, tr._half))
+        assert float(st['step']) == n_steps and torch.equal(st['exp_avg'], exp_avg)
+        tr.scaler.scale.fill_(256.0)
+        loss = tr.step()
+        torch.cuda.synchronize()
+        assert float(tr.scaler.skipped) == 1.0 and math.isfinite(float(loss))
+        assert any(not torch.equal(a, b) for a, b in zip(masters, tr._master))
+        assert all(torch.isfinite(m).all() for m in tr._master)
+        assert float(st['step']) == n_steps + 1
     finally:
         ops.set_i2p_seed_tensor(None)
 
