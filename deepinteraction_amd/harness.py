@@ -45,7 +45,8 @@ def condition_head(dec, branch=0.5, cross=None):
     perturbation of its inputs by 2-3 (oracle, tests/tools/conditioned_head.py: an exact float32 encoder whose three maps
     are rounded ONCE to fp16 - the least any fp16-map implementation can do - already moves the last block's `dim` by
     3.7e-3 of its scale; per block the p99.9 goes 1e-4 -> 2e-4 -> 9e-4 -> 2.8e-3).  `branch` scales the three residual
-    branches of every RoI block (self-attention out_proj, DynamicConv's final LayerNorm, the FFN's second Linear): with
+    branches of every RoI block (self-attention out_proj, DynamicConv's final LayerNorm, the FFN's second Linear - for the
+    ++ V2 blocks the second Linear of both mmcv FFNs): with
     0.5 the refinement is a perturbation of the residual stream, as in a trained head, and the same input error stays
     below 1e-3.  `cross` (optional) scales the q / k projections of the decoder layer's cross attention (logits |s| ~ 500 as
     initialised); it turned out NOT to be what sets the tail."""
@@ -53,8 +54,12 @@ def condition_head(dec, branch=0.5, cross=None):
         for l, blk in enumerate(dec.decode_head):
             sfx = '' if l % 2 == 0 else '_pts'
             g = lambda n: getattr(blk, n + sfx)
-            for t in (g('dyconv').norm3.weight, g('dyconv').norm3.bias, g('linear2').weight, g('linear2').bias,
-                      g('dyconv_pre_self_attn').out_proj.weight, g('dyconv_pre_self_attn').out_proj.bias):
+            if hasattr(blk, 'linear2' + sfx):
+                ffn_out = [g('linear2')]
+            else:      # DeepInteraction++ V2 blocks: mmcv FFNs (`ffn`, and `self_ffn` of the parallel self branch)
+                ffn_out = [blk.ffn.layers[1], blk.self_ffn.layers[1]]
+            for t in [g('dyconv').norm3.weight, g('dyconv').norm3.bias, g('dyconv_pre_self_attn').out_proj.weight,
+                      g('dyconv_pre_self_attn').out_proj.bias] + [x for lin in ffn_out for x in (lin.weight, lin.bias)]:
                 t.mul_(branch)
         if cross is not None:
             for layer in dec.decoder:

@@ -33,6 +33,22 @@ def synth_gt(seed, n=30):
     return dc.LiDARBoxes(torch.cat([xy, z, dims, yaw, vel], 1)), torch.randint(0, 10, (n,), generator=g)
 
 
+def half_weights_(models):
+    """Mixed precision: turn the convolution / linear / attention-projection parameters of `models` into fp16 IN PLACE and
+    return (those parameters, their float32 master copies).  Normalisation layers stay float32."""
+    nn = torch.nn
+    half, master = [], []
+    for m in models:
+        for mod in m.modules():
+            if isinstance(mod, (nn.Conv1d, nn.Conv2d, nn.Linear, nn.MultiheadAttention)):
+                for p in mod.parameters(recurse=False):
+                    if p.dtype == torch.float32:
+                        master.append(torch.nn.Parameter(p.detach().clone()))
+                        p.data = p.data.half()
+                        half.append(p)
+    return half, master
+
+
 class LossScaler:
     """Dynamic loss scaling for the mixed-precision step, with `torch.amp.GradScaler`'s rules (scale * backoff on a step whose
     gradients hold inf / NaN - that step is SKIPPED - and * growth after `growth_interval` clean steps) but no host round trip:
@@ -78,15 +94,7 @@ class Trainer:
         # master, which one multi-tensor copy per step now writes).  Normalisation layers stay float32.
         self._half, self._master = [], []
         if self.amp and os.environ.get('DI_TRAIN_HALF_WEIGHTS', '1') != '0':
-            nn = torch.nn
-            for m in (self.enc, self.dec):
-                for mod in m.modules():
-                    if isinstance(mod, (nn.Conv1d, nn.Conv2d, nn.Linear, nn.MultiheadAttention)):
-                        for p in mod.parameters(recurse=False):
-                            if p.dtype == torch.float32:
-                                self._master.append(torch.nn.Parameter(p.detach().clone()))
-                                p.data = p.data.half()
-                                self._half.append(p)
+            self._half, self._master = half_weights_((self.enc, self.dec))
         self._master_grad = [torch.empty_like(m) for m in self._master]
         master_of = {id(p): m for p, m in zip(self._half, self._master)}
         self.opt_params = [master_of.get(id(p), p) for p in self.params]
@@ -197,8 +205,13 @@ class GraphedTrainer(Trainer):
     replayed, the step is bound by its kernels.  Static input buffers, padded points / pillars and in-place geometry
     refresh are the inference graph's (`graphed.GraphedHotPath`)."""
 
-    def __init__(self, shape, num_proposals, device, world, batch=1, pool=2, rank=0, seed=0, amp=None):
+    def __init__(self, shape, num_proposals, device, world, batch=1, pool=2, rank=0, seed=0, amp=None, prepare_model=None):
+        """batch: samples per rank inside ONE capture (the reference config trains with `samples_per_gpu=2`,
+        Fusion_0075_refactor.py:94: BatchNorm statistics then run over both samples, as they do there).
+        prepare_model: optional callable(encoder, decoder) applied before the capture (tests switch dropout off with it)."""
         super().__init__(shape, num_proposals, device, world, batch=batch, pool=pool, rank=rank, seed=seed, amp=amp)
+        if prepare_model is not None:
+            prepare_model(self.enc, self.dec)
         from .graphed import GraphedHotPath
         cap = max(range(len(self.pool)), key=lambda i: int(self.pool[i][0]['pts_metas']['pillars'].shape[0]))
         h = GraphedHotPath.__new__(GraphedHotPath)           # the static-buffer half of the inference graph, no capture
@@ -209,9 +222,29 @@ class GraphedTrainer(Trainer):
         h.batch = len(inputs['img_metas'])
         h.img_metas = [dict(m) for m in inputs['img_metas']]
         h.pts = [p.clone() for p in pm['pts']]
-        h.pillars, h.pillar_coors, h.pillars_num_points = pm['pillars'].clone(), pm['pillar_coors'].clone(), pm['pillars_num_points'].clone()
-        assert h.batch == 1, 'the graphed training step captures one sample per rank'
-        h.bounds = [0, h.pillars.shape[0]]
+        if h.batch == 1:
+            h.pillars, h.pillar_coors, h.pillars_num_points = pm['pillars'].clone(), pm['pillar_coors'].clone(), pm['pillars_num_points'].clone()
+            h.bounds = [0, h.pillars.shape[0]]
+        else:
+            # one fixed slice of the static pillar buffers per sample slot, as large as the largest count any pool batch has
+            # in that slot (padding pillars carry num_points = 0: every kernel skips them before touching memory)
+            B = h.batch
+            counts = [torch.bincount(d['pts_metas']['pillar_coors'][:, 0].long(), minlength=B).cpu().tolist() for d, _ in self.pool]
+            h.bounds = [0]
+            for s_ in range(B):
+                h.bounds.append(h.bounds[-1] + max(c[s_] for c in counts))
+            total = h.bounds[-1]
+            h.pillars = pm['pillars'].new_zeros((total,) + tuple(pm['pillars'].shape[1:]))
+            h.pillar_coors = pm['pillar_coors'].new_zeros((total, pm['pillar_coors'].shape[1]))
+            h.pillars_num_points = pm['pillars_num_points'].new_zeros((total,))
+            slot = pm['pillar_coors'][:, 0].long()
+            for s_ in range(B):
+                lo = h.bounds[s_]
+                sel = (slot == s_).nonzero().flatten()
+                h.pillars[lo:lo + sel.numel()] = pm['pillars'][sel]
+                h.pillar_coors[lo:lo + sel.numel()] = pm['pillar_coors'][sel]
+                h.pillar_coors[lo:h.bounds[s_ + 1], 0] = s_
+                h.pillars_num_points[lo:lo + sel.numel()] = pm['pillars_num_points'][sel]
         from .geometry import SampleGeometry
         from .mmdet3d_plugin.models.utils.decoder_utils import QueryGeometry
         Hi, Wi = h.img_feats.shape[-2:]
@@ -264,8 +297,13 @@ def bench(args, rank, world, device):
     import os
     # --amp / --train-eager of bench.py; the environment switches of round 4's first measurements still work
     amp = bool(getattr(args, 'amp', False)) or os.environ.get('DI_TRAIN_AMP', '0') == '1'
-    eager = bool(getattr(args, 'train_eager', False)) or os.environ.get('DI_TRAIN_GRAPH', '1') == '0' or args.batch != 1
+    eager = bool(getattr(args, 'train_eager', False)) or os.environ.get('DI_TRAIN_GRAPH', '1') == '0'
     cls = Trainer if eager else GraphedTrainer
+    if rank == 0:
+        import sys
+        print(f'[train] {cls.__name__}, {args.batch} sample(s) per rank'
+              f'{" (the reference configuration: samples_per_gpu=2)" if args.batch == 2 else ""}, '
+              f'{"mixed precision" if amp else "float32"}', file=sys.stderr)
     tr = cls(shape, args.proposals, device, world, batch=args.batch, pool=max(2, min(args.pool, 2)), rank=rank, amp=amp)
     losses = []
     for _ in range(args.warmup):
@@ -279,7 +317,7 @@ def bench(args, rank, world, device):
                 config=dict(workload=f'Fusion_0075_refactor training step (shape {args.shape}): MMRI encoder + MMPI '
                                      'decoder forward, head loss (Hungarian assignment on the host), backward, '
                                      'bucketed gradient all-reduce launched from backward hooks, AdamW + grad clip',
-                            batch_per_gpu=args.batch, global_batch=args.batch * args.gpus,
+                            batch_per_gpu=args.batch, global_batch=args.batch * args.gpus, trainer=cls.__name__,
                             num_proposals=args.proposals, pool=len(tr.pool),
                             precision=('mixed: fp16 activations under torch.autocast incl. the fused window attention forward / '
                                        'backward; float32 master weights, BatchNorm statistics, soft-max, scatter accumulation, '
@@ -288,4 +326,5 @@ def bench(args, rank, world, device):
                             launch='host launches' if eager else 'forward and backward of the hot path as two replayed hipGraphs '
                                                                  'around the eager loss (Hungarian assignment on the host)',
                             parallelism=f'dp{args.gpus} by sample, RCCL all-reduce of gradients only'),
-                first_loss=round(losses[0], 4), last_loss=round(losses[-1], 4))
+                first_loss=round(losses[0], 4), last_loss=round(losses[-1], 4),
+                **({} if tr.scaler is None else {'loss_scale': float(tr.scaler.scale), 'skipped_steps': int(tr.scaler.skipped)}))

@@ -113,3 +113,28 @@ def test_oracle_encoder_matches_reference_golden_at_shape_R():
         s, _, _ = gg.sample(t)
         d = np.abs(s - gold[name + '.sample'])
         assert d.max() <= 2e-6 * max(1.0, float(gold[name + '.absmax'])), (name, d.max())
+
+
+def test_oracle_head_gradients_match_reference_golden_at_shape_R():
+    """The oracle's MMPI decoder at the BENCHED shape (Q = 200, train mode, dropout 0, default initialisation) against what
+    the reference's own Python produced there (tests/golden/grad_head_shapeR.npz, oracle/refpin/make_golden_grad_more.py head):
+    proposals / labels / masks bit-exact, outputs to float32 round-off, the gradients of the three feature maps and of all
+    286 parameter tensors to 1e-4 in relative L2 (measured <= 3e-6) - the pin of the oracle's BACKWARD at full size."""
+    from oracle import decoder as odec
+    from oracle.refpin import make_golden_grad_more as gm
+    gold = np.load(os.path.join(GOLD, 'grad_head_shapeR.npz'))
+    feats, metas = gm.head_case()
+    O, res, grads = gm._head_run(odec.DeepInteractionDecoder, feats, metas)
+    assert np.array_equal(O.query_labels.numpy(), gold['query_labels'])                # INT: bit-exact
+    assert np.array_equal(torch.stack(O.on_the_image_mask).numpy(), gold['on_the_image_mask'])
+    for k, v in res.items():
+        assert np.allclose(v.detach().numpy(), gold['out.' + k], rtol=0, atol=3e-5), k
+    names = sorted(k[:-len('.sample')] for k in gold.files if k.endswith('.sample'))
+    assert len(names) > 250 and set(names) <= set(grads)
+    for name in names:
+        ref = gold[name + '.sample']
+        if float(gold[name + '.absmax']) < 1e-5:
+            continue
+        s = gm.sample(grads[name], n=1024 if name.startswith('p.') else 4096)['sample']
+        e = np.linalg.norm(s - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert e <= 1e-4, (name, e)

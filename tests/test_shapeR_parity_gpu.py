@@ -169,7 +169,8 @@ def test_fp16_conditioned_head_B1_Q200(ctx):
     """is the fp16 decoder's 1-3e-3 tail the kernels or the head?  The SAME encoder, the
     same fp16 mixed mode and kernels, but a head whose four RoI blocks are conditioned as in a trained network
     (`harness.condition_head`: residual branches x 0.5; with random-init weights every block multiplies its input error by
-    2-3, tests/tools/conditioned_head.py).  Here the contract holds: p99.9 <= 1e-3 and max <= 3e-3 on every box output.
+    2-3, tests/tools/conditioned_head.py).  Here the contract holds: p99.9 <= 1e-3 and max <= 1.5e-3 on every box output
+    (measured in round 4: p99.9 <= 5.7e-4, max <= 9.2e-4).
     The oracle is the float32-parameter one (the comparison that showed the tail on the unconditioned head)."""
     import copy
     enc, dec = ctx['models'][200]
@@ -189,7 +190,7 @@ def test_fp16_conditioned_head_B1_Q200(ctx):
     for k, s in ds['keys'].items():
         if k == 'query_heatmap_score':
             continue
-        assert s['p999'] <= 1e-3 and s['max'] <= 3e-3, (k, s)
+        assert s['p999'] <= 1e-3 and s['max'] <= 1.5e-3, (k, s)           # measured: p99.9 <= 5.7e-4, max <= 9.2e-4 (round 4)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])

@@ -364,6 +364,163 @@ def test_encoder_gradients_at_shape_R_match_reference_golden():
     assert np.median([w['frac_beyond_5e4'] for w in worst.values()]) == 0.0
 
 
+def _golden(name):
+    import os
+
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name)
+    if not os.path.exists(path):
+        pytest.skip(f'{name} not generated (oracle/refpin/make_golden_grad_more.py)')
+    return np.load(path)
+
+
+def _report(name, obj):
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, name), 'w') as f:
+        json.dump(obj, f, indent=1)
+
+
+def _grad_stats(got, gold, names, sampler):
+    """Per gradient tensor, on the golden file's strided sample: relative L2 error, the fraction of entries beyond
+    2e-3 / 5e-4 of the tensor's gradient scale, the largest error in units of the scale, and the relative difference of
+    the absolute sums (over the WHOLE tensor: mass lost to an fp16 flush would show there)."""
+    import numpy as np
+    stats = {}
+    for name in names:
+        ref, scale = gold[name + '.sample'], float(gold[name + '.absmax'])
+        if scale < 1e-7:
+            continue
+        s, a = sampler(got[name])
+        d = np.abs(s - ref)
+        stats[name] = dict(rel_l2=float(np.linalg.norm(s - ref) / max(np.linalg.norm(ref), 1e-30)),
+                           frac_beyond_2e3=float((d > 2e-3 * scale + 2e-4).mean()),
+                           frac_beyond_5e4=float((d > 5e-4 * scale + 2e-4).mean()), max_rel=float(d.max() / scale),
+                           abssum_rel=abs(float(a) - float(gold[name + '.abssum'])) / max(float(gold[name + '.abssum']), 1e-12))
+    return stats
+
+
+@pytest.mark.parametrize('amp', [False, True])
+def test_encoder_train_mode_gradients_at_shape_R_match_reference_golden(amp):
+    """The TRAINING forward / backward of the MMRI encoder at the benched shape (BASELINE.json configs[2]) against gradients the
+    REFERENCE'S OWN Python produced in train() mode for the same seeded inputs, weights and functional
+    (tests/golden/grad_shapeR_train.npz, oracle/refpin/make_golden_grad_more.py enc_train; pillar-attention dropout off on both
+    sides): BatchNorm batch statistics and their backward at full size, every window-attention / pillar-attention / BEV-gather
+    gradient, every 1x1 / 3x3 weight gradient.
+      * float32 (the reference's arithmetic): the same bounds as the eval-mode golden test above;
+      * `amp` = what `bench.py --mode train --amp` runs - fp16 model weights with float32 masters (`train_step.half_weights_`),
+        torch.autocast(fp16) with the fused window attention (csrc/local_attn_train.hip) and the own BatchNorm + ReLU kernels
+        (csrc/batchnorm.hip), the functional scaled by the trainer's initial loss scale: per-tensor bounds against the REFERENCE
+        gradients (round-4 verdict: not cosine against the product's own float32), and no tensor loses more than 1e-2 of its
+        absolute mass (an fp16 flush of small gradients would)."""
+    import numpy as np
+    from deepinteraction_amd import train_step
+    from deepinteraction_amd.mmdet3d_plugin import DeepInteractionEncoder
+    from oracle.refpin import make_golden_grad_more as gm, make_golden_grad_shapeR as gg
+    assert torch.cuda.is_available(), 'gpu tests need a HIP device'
+    torch.backends.cudnn.deterministic = True
+    gold = _golden('grad_shapeR_train.npz')
+    inp = gg.case()
+    M = DeepInteractionEncoder(num_layers=2, in_channels_img=gg.SHAPE['c_img'], in_channels_pts=gg.SHAPE['c_pts'],
+                               hidden_channel=128)
+    mg.randomize(M, gg.SEED_WEIGHTS)
+    M = gm.enc_train_prepare(M).to(DEV)
+    scale = 1.0
+    if amp:
+        half, _ = train_step.half_weights_([M])
+        assert len(half) > 40
+        scale = float(train_step.LossScaler('cpu').scale)
+    pm = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
+    pm['pts'] = [p.to(DEV) for p in inp['pts_metas']['pts']]
+    img = inp['img_feats'].to(DEV).requires_grad_(True)
+    pts = inp['pts_feats'].to(DEV).requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.float16, enabled=amp):
+        im, (p0, p1) = M(img, pts, inp['img_metas'], pm)
+    if amp:
+        assert im.dtype == torch.float16
+    fwd = {}
+    for name, t in (('out_img', im), ('out_pts_conv', p0), ('out_pts', p1)):
+        s = gg.sample(t)[0]
+        d = np.abs(s - gold[name + '.sample']) / max(1.0, float(gold[name + '.absmax']))
+        fwd[name] = dict(max=float(d.max()), p99=float(np.quantile(d, 0.99)), median=float(np.median(d)),
+                         frac_gt_1e3=float((d > 1e-3).mean()))
+    (gg.functional((im, p0, p1), DEV) * scale).backward()
+    torch.cuda.synchronize()
+    got = dict([('d_img_feats', img.grad / scale), ('d_pts_feats', pts.grad / scale)] +
+               [('p.' + n, p.grad.float() / scale) for n, p in M.named_parameters() if p.grad is not None])
+    assert all(torch.isfinite(g).all() for g in got.values()), 'overflow at the initial loss scale'
+    names = sorted(k[:-len('.sample')] for k in gold.files if k.endswith('.sample') and not k.startswith('out_'))
+    assert len(names) > 60 and set(names) <= set(got), set(names) - set(got)
+    stats = _grad_stats(got, gold, names, lambda t: gg.sample(t)[:2])
+    _report(f'grad_parity_shapeR_train_{"amp" if amp else "f32"}.json', dict(forward=fwd, gradients=stats))
+    if not amp:
+        for name, f in fwd.items():
+            # train-mode BatchNorm: batch statistics are 134 400-term sums in another order (1e-6), no fp16 anywhere
+            assert f['p99'] <= 5e-5 and f['frac_gt_1e3'] <= 5e-3, (name, f)
+        fails = [(n, w) for n, w in stats.items()
+                 if w['frac_beyond_2e3'] > 1e-2 or w['max_rel'] > 5e-2 + 1e-3 or w['abssum_rel'] > 2e-3]
+        assert not fails, fails[:5]
+        assert np.median([w['frac_beyond_5e4'] for w in stats.values()]) <= 1e-3
+    else:
+        for name, f in fwd.items():
+            assert f['median'] <= 1e-3 and f['p99'] <= 1e-2, (name, f)
+        # measured (session r05a, see DESIGN 12.1): rel L2 <= ... ; asserted with head-room
+        fails = [(n, w) for n, w in stats.items() if w['rel_l2'] > 6e-2 or w['abssum_rel'] > 3e-2]
+        assert not fails, fails[:5]
+        assert np.median([w['rel_l2'] for w in stats.values()]) <= 2e-2
+
+
+def test_head_gradients_at_shape_R_match_reference_golden():
+    """Head gradients at the BENCHED shape (round-4 verdict, weak 4): `DeepInteractionDecoder` (Q = 200, one decoder layer +
+    four RoI layers) in train() mode with dropout 0 on seeded shape-R feature maps, default initialisation, against the
+    gradients the REFERENCE'S OWN Python produced (tests/golden/grad_head_shapeR.npz, make_golden_grad_more.py head): the
+    proposals, labels and image masks are identical, the outputs agree to float32 round-off, and every gradient - the three
+    feature maps and all parameters - lies within max(2e-3, 4 x the reference's own sensitivity to a 1e-6 input change) in
+    relative L2 (the file's `.noise`: RoIs over the map edge + LayerNorm of constant rows make the last RoI blocks'
+    gradients move by up to 3 % on the reference itself)."""
+    import numpy as np
+    from deepinteraction_amd.mmdet3d_plugin import DeepInteractionDecoder
+    from oracle.refpin import make_golden_grad_more as gm
+    torch.backends.cudnn.deterministic = True
+    gold = _golden('grad_head_shapeR.npz')
+    M = DeepInteractionDecoder(**gm.head_cfg())
+    M.load_state_dict(gm.head_state())
+    M = M.to(DEV).train()
+    feats, metas = gm.head_case()
+    f = [t.to(DEV).requires_grad_(True) for t in feats]
+    res = M([f[1], f[2]], f[0], metas)[0][0]
+    assert torch.equal(M.query_labels.cpu(), torch.from_numpy(gold['query_labels']))
+    masks = torch.stack([m.cpu() for m in M.on_the_image_mask])
+    assert torch.equal(masks, torch.from_numpy(gold['on_the_image_mask']).to(masks.dtype))
+    fwd = {}
+    for k, v in res.items():
+        r = torch.from_numpy(gold['out.' + k])
+        fwd[k] = float((v.detach().cpu() - r).abs().max() / max(1.0, float(r.abs().max())))
+        assert fwd[k] <= 5e-4, (k, fwd[k])
+    gm.head_functional(res, DEV).backward()
+    torch.cuda.synchronize()
+    got = dict(zip(('d_img', 'd_pts_conv', 'd_pts'), (t.grad for t in f)))
+    got.update({'p.' + n: p.grad for n, p in M.named_parameters() if p.grad is not None})
+    names = sorted(k[:-len('.sample')] for k in gold.files if k.endswith('.sample'))
+    assert len(names) > 250 and set(names) <= set(got), sorted(set(names) - set(got))[:5]
+    stats, fails = {}, []
+    for name in names:
+        ref = gold[name + '.sample']
+        if float(gold[name + '.absmax']) < 1e-5:
+            continue                                          # exact zeros / pure round-off on both sides
+        s = gm.sample(got[name], n=1024 if name.startswith('p.') else 4096)['sample']
+        e = float(np.linalg.norm(s - ref) / max(np.linalg.norm(ref), 1e-30))
+        noise = float(gold[name + '.noise'])
+        stats[name] = dict(rel_l2=e, reference_noise=noise)
+        if e > max(2e-3, 4.0 * noise):
+            fails.append((name, e, noise))
+    _report('grad_parity_head_shapeR.json', dict(forward=fwd, gradients=stats))
+    assert len(stats) > 250
+    assert not fails, fails[:8]
+
+
 def test_full_training_step_with_loss():
     """Forward (train mode, dropout on) -> head.loss against ground truth -> backward -> one SGD step, all on
     the HIP path: every trainable parameter gets a finite gradient and the loss goes down."""
