@@ -43,9 +43,11 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 __device__ __attribute__((aligned(128))) unsigned int zero_line[32];   // what a texel outside the map reads (128 B)
 __device__ unsigned int timeouts;                                       // bounded spins that gave up (0 on a healthy run)
 
-template <int WX_, int WY_, int SCHED_ = 0, int NPW_ = 2, int POL_ = 0>
+template <int WX_, int WY_, int SCHED_ = 0, int NPW_ = 2, int POL_ = 0, int POISON_ = 3>
 struct Cfg {
   static constexpr int WX = WX_, WY = WY_, POL = POL_;    // POL: cache policy of the halo DMA (measurement)
+  static constexpr bool POISON = (POISON_ & 1) != 0;   // consumers poison their stores; 0: measurement only (round 4: a timed-out wait computes on)
+  static constexpr bool PDEAD = (POISON_ & 2) != 0;    // producers stop issuing after a timeout
   static constexpr int SCHED = SCHED_;                 // 1: LDS fragment reads interleaved with the MFMAs by sched_group_barrier
   static constexpr int NCW = WX * WY, NPW = NPW_;        // consumer / producer wavefronts
   static constexpr int NT = (NCW + NPW) * 64;
@@ -187,7 +189,6 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     int min_done = 0;                                         // cached min over done[w]: blocks every consumer is past
     int published = 0;                                        // blocks of mine announced in landed[p]
     int issued = 0;                                           // blocks whose DMA this wave has issued
-    bool dead = false;                                        // a spin gave up: nothing more is issued
     __builtin_amdgcn_s_setprio(2);                            // few instructions, all of them on the critical path
     auto publish = [&]() {
       lds_st32(f_landed + 4 * p, (unsigned)published);
@@ -224,15 +225,15 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
           reload_done();
           if (++spins > spin_limit) {
             if (lane == 0) atomicAdd(&timeouts, 1u);
-            dead = true;
             break;
           }
         }
-        if ((dbg & 32) && it >= 1 && !dead) {                 // fault injection
-          if (lane == 0) atomicAdd(&timeouts, 1u);
-          dead = true;
-        }
-        if (dead) break;                                      // never write into a block a consumer may still be reading
+        // (decided AFTER the loop from a value forced uniform: a flag assigned inside the timeout branch is a divergent
+        // live-out of the loop for the compiler, which then runs the whole producer under exec masks - 3 us per launch)
+        // a producer that gave up issues nothing more: it never writes into a block a consumer may still be reading.
+        // ((dbg & 32): fault injection - the consumers' waits then give up and count)
+        if constexpr (G::PDEAD)
+          if (__builtin_amdgcn_readfirstlane((int)(spins > spin_limit)) != 0 || ((dbg & 32) && it >= 1)) goto drain;
         stamp(1);                                             // buffer free
         const unsigned dst = lds0 + (B % G::NBLK) * G::BLKB;
         {
@@ -260,8 +261,8 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
           publish();
         }
       }
-      if (dead) break;
     }
+  drain:
     while (published < issued) {                              // drain: no DMA may outlive the workgroup's LDS
       wait_blocks<G::IPB>(issued - published - 1);
       ++published;
@@ -299,9 +300,10 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
 
   // block B is in LDS once every producer has announced more than B blocks
   int seen = 0;                                              // blocks [0, seen) are known to have landed
-  bool bad = false;                                          // a wait gave up: this and every later tile is stored as NaN
+  // a wait that gave up: `seen` jumps past every block (no later wait spins again) and `poison` turns every value this wave
+  // stores from then on into NaN (ORed into the bits of 1 / sum: no branch on the store path, the MFMA / store schedule is untouched)
+  unsigned poison = 0;
   auto wait_landed = [&](int B) {
-    if (bad) return;
     int spins = 0;
     stamp(4);                                                 // starts waiting for a block
     while (seen <= B) {
@@ -322,9 +324,13 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
       __builtin_amdgcn_s_sleep(1);
       if (++spins > spin_limit) {
         if (lane == 0) atomicAdd(&timeouts, 1u);
-        bad = true;
         break;
       }
+    }
+    if constexpr (G::POISON) {                                // (after the loop, from a value forced uniform: see the producer)
+      const bool gave_up = __builtin_amdgcn_readfirstlane((int)(spins > spin_limit)) != 0;
+      poison = gave_up ? 0x7FFF7FFFu : poison;
+      seen = gave_up ? 0x3FFFFFFF : seen;
     }
     stamp(5);                                                 // has it
   };
@@ -481,10 +487,12 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
       // 16-lane rows of one register with the even rows of another - a 2 x 2 transposition between (g & 1) and the block
       // pair - after which a lane owns 8 consecutive channels: two 16-byte stores, each 64 contiguous bytes per pixel
       // (38.1 -> 35.5 us on cold inputs; without any store 31.4).
+      // (a block that never arrived: 1 / sum becomes NaN, and with it every value of the tile - poisoned, not guessed)
+      const float inv_b = G::POISON ? __builtin_bit_cast(float, __builtin_bit_cast(unsigned, inv) | poison) : inv;
       unsigned wv[4][2];
 #pragma unroll
       for (int nl = 0; nl < 4; ++nl) {
-        const f4 o = acc[nl] * inv;
+        const f4 o = acc[nl] * inv_b;
         h4 ov;
 #pragma unroll
         for (int r = 0; r < 4; ++r) ov[r] = (_Float16)o[r];
@@ -501,16 +509,10 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
           wv[2 * pr + 1][d] = sw[1];
         }
       if (pix_ok && !(dbg & 1)) {
-        if (__builtin_expect(bad, 0)) {                       // a block never arrived: the tile is poisoned, not guessed
 #pragma unroll
-          for (int pr = 0; pr < 2; ++pr)
-            *reinterpret_cast<uint4 *>(dst + u * 64 + 32 * pr) = make_uint4(0x7E007E00u, 0x7E007E00u, 0x7E007E00u, 0x7E007E00u);
-        } else {
-#pragma unroll
-          for (int pr = 0; pr < 2; ++pr)
-            *reinterpret_cast<uint4 *>(dst + u * 64 + 32 * pr) =
-                make_uint4(wv[2 * pr][0], wv[2 * pr][1], wv[2 * pr + 1][0], wv[2 * pr + 1][1]);
-        }
+        for (int pr = 0; pr < 2; ++pr)
+          *reinterpret_cast<uint4 *>(dst + u * 64 + 32 * pr) =
+              make_uint4(wv[2 * pr][0], wv[2 * pr][1], wv[2 * pr + 1][0], wv[2 * pr + 1][1]);
       }
     });
     cur = nxt;
@@ -564,6 +566,9 @@ int launch_local_attn_ring(const void *q, const void *k, const void *v, void *ou
     case 3: return ring::launch<ring::Cfg<2, 4, 0, 2, 2>>(q, k, v, out, n, H, W, scale, stream);   // the compiler's own schedule
     case 4: return ring::launch<ring::Cfg<2, 4, 2, 4, 2>>(q, k, v, out, n, H, W, scale, stream);   // four producer wavefronts
     case 5: return ring::launch<ring::Cfg<2, 4, 2, 2, 0>>(q, k, v, out, n, H, W, scale, stream);   // plain DMA loads
+    case 6: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 0>>(q, k, v, out, n, H, W, scale, stream);   // cfg 0 without the NaN poisoning (A/B)
+    case 7: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 1>>(q, k, v, out, n, H, W, scale, stream);   // consumer side only (A/B)
+    case 8: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 2>>(q, k, v, out, n, H, W, scale, stream);   // producer side only (A/B)
   }
   set_error("unknown local_attn_ring configuration %d", cfg);
   return DI_ERR_ARG;

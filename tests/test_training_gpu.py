@@ -604,6 +604,47 @@ def test_graphed_training_step(amp):
         ops.set_i2p_seed_tensor(None)
 
 
+def _no_dropout(enc, dec):
+    for m in list(enc.modules()) + list(dec.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        elif isinstance(getattr(m, 'dropout', None), float):
+            m.dropout = 0.0
+
+
+def test_graphed_training_step_two_samples_per_rank():
+    """BASELINE configs[3] names the reference's `samples_per_gpu=2` (Fusion_0075_refactor.py:94): `GraphedTrainer(batch=2)`
+    captures ONE forward / backward over both samples (BatchNorm statistics over the 12 images, as in the reference), every
+    sample's pillars in its fixed slice of the static buffers.  (i) with dropout off, the replayed forward equals the eager
+    train-mode forward of the same modules on the unpadded batch; (ii) it trains: finite losses, gradients everywhere but the
+    detached heat-map head; (iii) a second pool batch with other pillar counts goes through the same capture."""
+    from deepinteraction_amd import ops, train_step
+    torch.backends.cudnn.deterministic = True
+    tr = train_step.GraphedTrainer(synth.SHAPE_TINY, 24, torch.device(DEV), 1, batch=2, pool=2, prepare_model=_no_dropout)
+    try:
+        assert tr.h.batch == 2 and len(tr.h.bounds) == 3
+        for i in range(2):
+            d, _ = tr.pool[i]
+            tr.h.load(tr.records[i])
+            with torch.no_grad():
+                outs = tr.graphed(tr.h.img_feats, tr.h.pts_feats)
+                got = {k: v.clone() for k, v in zip(tr.module.keys, outs)}
+                img, pts = tr.enc(d['img_feats'], d['pts_feats'], d['img_metas'], dict(d['pts_metas']))
+                ref = tr.dec(pts, img, d['img_metas'])[0][0]
+            torch.cuda.synchronize()
+            for k in got:
+                assert got[k].shape == ref[k].shape and got[k].shape[0] == 2, k
+                err = float((got[k] - ref[k].float()).abs().max() / max(1.0, float(ref[k].abs().max())))
+                assert err <= 2e-4, (i, k, err)
+        losses = [float(tr.step()) for _ in range(3)]
+        assert all(math.isfinite(l) for l in losses), losses
+        missing = [n for m in (tr.enc, tr.dec) for n, p in m.named_parameters() if p.grad is None]
+        assert all(n.startswith('heatmap_head.') for n in missing), missing[:5]
+        assert all(torch.isfinite(p.grad).all() for p in tr.params if p.grad is not None)
+    finally:
+        ops.set_i2p_seed_tensor(None)
+
+
 @pytest.mark.parametrize('graphed', [False, True])
 def test_amp_overflow_step_is_skipped_and_the_loss_scale_backs_off(graphed):
     """Round-4 advice: the mixed-precision step backpropagates fp16 gradients, so it carries dynamic loss scaling and an
