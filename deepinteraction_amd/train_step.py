@@ -306,6 +306,16 @@ def bench(args, rank, world, device):
               f'{"mixed precision" if amp else "float32"}', file=sys.stderr)
     tr = cls(shape, args.proposals, device, world, batch=args.batch, pool=max(2, min(args.pool, 2)), rank=rank, amp=amp)
     losses = []
+    calibration = 0
+    if tr.scaler is not None:
+        # settle the dynamic loss scale BEFORE warm-up and the timed region (untimed, not counted as warm-up): a step that
+        # overflows at the initial scale is skipped and halves the scale - the timed steps should be steps that update
+        while calibration < 24:
+            before = float(tr.scaler.skipped)
+            tr.step()
+            calibration += 1
+            if float(tr.scaler.skipped) == before:
+                break
     for _ in range(args.warmup):
         tr.step()
     elapsed = parallel.timed_region(lambda: losses.append(tr.step()), args.steps, device)
@@ -327,4 +337,5 @@ def bench(args, rank, world, device):
                                                                  'around the eager loss (Hungarian assignment on the host)',
                             parallelism=f'dp{args.gpus} by sample, RCCL all-reduce of gradients only'),
                 first_loss=round(losses[0], 4), last_loss=round(losses[-1], 4),
-                **({} if tr.scaler is None else {'loss_scale': float(tr.scaler.scale), 'skipped_steps': int(tr.scaler.skipped)}))
+                **({} if tr.scaler is None else {'loss_scale': float(tr.scaler.scale), 'skipped_steps': int(tr.scaler.skipped),
+                                                  'loss_scale_calibration_steps': calibration}))

@@ -119,7 +119,8 @@ def test_oracle_head_gradients_match_reference_golden_at_shape_R():
     """The oracle's MMPI decoder at the BENCHED shape (Q = 200, train mode, dropout 0, default initialisation) against what
     the reference's own Python produced there (tests/golden/grad_head_shapeR.npz, oracle/refpin/make_golden_grad_more.py head):
     proposals / labels / masks bit-exact, outputs to float32 round-off, the gradients of the three feature maps and of all
-    286 parameter tensors to 1e-4 in relative L2 (measured <= 3e-6) - the pin of the oracle's BACKWARD at full size."""
+    286 parameter tensors to 1e-4 in relative L2 (measured <= 3e-6) - the pin of the oracle's BACKWARD at full size.
+    (The case's head is conditioned as in a trained network, `make_golden_grad_more.head_prepare`.)"""
     from oracle import decoder as odec
     from oracle.refpin import make_golden_grad_more as gm
     gold = np.load(os.path.join(GOLD, 'grad_head_shapeR.npz'))

@@ -412,7 +412,7 @@ def test_encoder_train_mode_gradients_at_shape_R_match_reference_golden(amp):
       * float32 (the reference's arithmetic): the same bounds as the eval-mode golden test above;
       * `amp` = what `bench.py --mode train --amp` runs - fp16 model weights with float32 masters (`train_step.half_weights_`),
         torch.autocast(fp16) with the fused window attention (csrc/local_attn_train.hip) and the own BatchNorm + ReLU kernels
-        (csrc/batchnorm.hip), the functional scaled by the trainer's initial loss scale: per-tensor bounds against the REFERENCE
+        (csrc/batchnorm.hip): per-tensor bounds against the REFERENCE
         gradients (round-4 verdict: not cosine against the product's own float32), and no tensor loses more than 1e-2 of its
         absolute mass (an fp16 flush of small gradients would)."""
     import numpy as np
@@ -427,11 +427,13 @@ def test_encoder_train_mode_gradients_at_shape_R_match_reference_golden(amp):
                                hidden_channel=128)
     mg.randomize(M, gg.SEED_WEIGHTS)
     M = gm.enc_train_prepare(M).to(DEV)
+    # (no loss scale HERE: the seeded functional weights every output element with an N(0, 1) number - gradients 1e3-1e5 times a
+    # normalised loss's - so the stricter statement is made: even unscaled, no tensor loses mass to an fp16 flush.  The trainer's
+    # dynamic scale has its own tests: test_amp_overflow_step_..., tests/test_host_logic.py::test_loss_scaler_...)
     scale = 1.0
     if amp:
         half, _ = train_step.half_weights_([M])
         assert len(half) > 40
-        scale = float(train_step.LossScaler('cpu').scale)
     pm = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
     pm['pts'] = [p.to(DEV) for p in inp['pts_metas']['pts']]
     img = inp['img_feats'].to(DEV).requires_grad_(True)
@@ -450,44 +452,57 @@ def test_encoder_train_mode_gradients_at_shape_R_match_reference_golden(amp):
     torch.cuda.synchronize()
     got = dict([('d_img_feats', img.grad / scale), ('d_pts_feats', pts.grad / scale)] +
                [('p.' + n, p.grad.float() / scale) for n, p in M.named_parameters() if p.grad is not None])
-    assert all(torch.isfinite(g).all() for g in got.values()), 'overflow at the initial loss scale'
+    assert all(torch.isfinite(g).all() for g in got.values()), 'fp16 overflow'
     names = sorted(k[:-len('.sample')] for k in gold.files if k.endswith('.sample') and not k.startswith('out_'))
     assert len(names) > 60 and set(names) <= set(got), set(names) - set(got)
+    # The BatchNorm bias of an `*_out_proj` feeds a 1x1 convolution that is batch-normalised again (`*_integration`,
+    # deepinteraction_encoder.py:26-27,31-32): in train mode a constant per channel is removed by the next layer's mean, so its
+    # exact gradient is 0 and both sides hold only the round-off of a 134 400-term sum (their ratio is O(1)).  Compared against
+    # the scale of the same layer's weight gradient instead.
+    zero_grad = [n for n in names if n.endswith('_out_proj.bn.bias')]
+    assert len(zero_grad) == 4
+    for n in zero_grad:
+        w = n[:-len('bias')] + 'weight'
+        assert float(got[n].abs().max()) <= 1e-3 * float(gold[w + '.absmax']), (n, float(got[n].abs().max()), float(gold[w + '.absmax']))
+    names = [n for n in names if n not in zero_grad]
     stats = _grad_stats(got, gold, names, lambda t: gg.sample(t)[:2])
     _report(f'grad_parity_shapeR_train_{"amp" if amp else "f32"}.json', dict(forward=fwd, gradients=stats))
     if not amp:
         for name, f in fwd.items():
             # train-mode BatchNorm: batch statistics are 134 400-term sums in another order (1e-6), no fp16 anywhere
             assert f['p99'] <= 5e-5 and f['frac_gt_1e3'] <= 5e-3, (name, f)
-        fails = [(n, w) for n, w in stats.items()
-                 if w['frac_beyond_2e3'] > 1e-2 or w['max_rel'] > 5e-2 + 1e-3 or w['abssum_rel'] > 2e-3]
+        # measured (session r05b): relative L2 <= 3.6e-3 (median 6e-4), single entries <= 1.2 % of the tensor's scale, absolute
+        # sums within 8e-4.  Batch statistics summed in another order move pre-activations by ~1e-6 and a handful of them flip
+        # their ReLU gate - a discrete change of the gradient around that pixel, on the reference's CPU run against itself with
+        # another thread count just the same (test_training_step_gradients_match_oracle): hence L2 and not a bulk bound.
+        fails = [(n, w) for n, w in stats.items() if w['rel_l2'] > 1e-2 or w['max_rel'] > 5e-2 or w['abssum_rel'] > 5e-3]
         assert not fails, fails[:5]
-        assert np.median([w['frac_beyond_5e4'] for w in stats.values()]) <= 1e-3
+        assert np.median([w['rel_l2'] for w in stats.values()]) <= 2e-3
     else:
         for name, f in fwd.items():
-            assert f['median'] <= 1e-3 and f['p99'] <= 1e-2, (name, f)
-        # measured (session r05a): rel L2 <= ... ; asserted with head-room
-        fails = [(n, w) for n, w in stats.items() if w['rel_l2'] > 6e-2 or w['abssum_rel'] > 3e-2]
+            assert f['median'] <= 2e-4 and f['p99'] <= 1e-3 and f['max'] <= 2e-3, (name, f)
+        # measured (session r05h): outputs max 7.7e-4 / p99 3.9e-4 of their range; gradients relative L2 <= 5.1e-2 (median
+        # 1.4e-2), absolute sums within 7.7e-3 - no tensor loses mass to an fp16 flush.  Asserted with head-room.
+        fails = [(n, w) for n, w in stats.items() if w['rel_l2'] > 8e-2 or w['abssum_rel'] > 1.5e-2]
         assert not fails, fails[:5]
         assert np.median([w['rel_l2'] for w in stats.values()]) <= 2e-2
 
 
 def test_head_gradients_at_shape_R_match_reference_golden():
     """Head gradients at the BENCHED shape (round-4 verdict, weak 4): `DeepInteractionDecoder` (Q = 200, one decoder layer +
-    four RoI layers) in train() mode with dropout 0 on seeded shape-R feature maps, default initialisation, against the
+    four RoI layers) in train() mode with dropout 0 on seeded shape-R feature maps, default initialisation with the RoI blocks
+    conditioned as in a trained head (`make_golden_grad_more.head_prepare`), against the
     gradients the REFERENCE'S OWN Python produced (tests/golden/grad_head_shapeR.npz, make_golden_grad_more.py head): the
     proposals, labels and image masks are identical, the outputs agree to float32 round-off, and every gradient - the three
     feature maps and all parameters - lies within max(2e-3, 4 x the reference's own sensitivity to a 1e-6 input change) in
-    relative L2 (the file's `.noise`: RoIs over the map edge + LayerNorm of constant rows make the last RoI blocks'
-    gradients move by up to 3 % on the reference itself)."""
+    relative L2 (the file's `.noise`, the largest of three perturbed reference runs: RoIs over the map edge + LayerNorm of
+    constant rows make single tensors move by up to 1.2 % on the reference itself, the median tensor by 5e-5)."""
     import numpy as np
     from deepinteraction_amd.mmdet3d_plugin import DeepInteractionDecoder
     from oracle.refpin import make_golden_grad_more as gm
     torch.backends.cudnn.deterministic = True
     gold = _golden('grad_head_shapeR.npz')
-    M = DeepInteractionDecoder(**gm.head_cfg())
-    M.load_state_dict(gm.head_state())
-    M = M.to(DEV).train()
+    M = gm.head_prepare(DeepInteractionDecoder(**gm.head_cfg())).to(DEV)
     feats, metas = gm.head_case()
     f = [t.to(DEV).requires_grad_(True) for t in feats]
     res = M([f[1], f[2]], f[0], metas)[0][0]
@@ -498,7 +513,8 @@ def test_head_gradients_at_shape_R_match_reference_golden():
     for k, v in res.items():
         r = torch.from_numpy(gold['out.' + k])
         fwd[k] = float((v.detach().cpu() - r).abs().max() / max(1.0, float(r.abs().max())))
-        assert fwd[k] <= 5e-4, (k, fwd[k])
+        # (`.noise`: what the reference's own outputs move by when its inputs move by 1e-6 - up to 2.5e-4 here)
+        assert fwd[k] <= max(2e-4, 4.0 * float(gold['out.' + k + '.noise'])), (k, fwd[k], float(gold['out.' + k + '.noise']))
     gm.head_functional(res, DEV).backward()
     torch.cuda.synchronize()
     got = dict(zip(('d_img', 'd_pts_conv', 'd_pts'), (t.grad for t in f)))
@@ -672,7 +688,7 @@ def test_amp_overflow_step_is_skipped_and_the_loss_scale_backs_off(graphed):
         assert all(torch.equal(a, b) for a, b in zip(masters, tr._master))
         assert all(torch.equal(a, b) for a, b in zip(halves, tr._half))
         assert float(st['step']) == n_steps and torch.equal(st['exp_avg'], exp_avg)
-        tr.scaler.scale.fill_(256.0)
+        tr.scaler.scale.fill_(2.0)
         loss = tr.step()
         torch.cuda.synchronize()
         assert float(tr.scaler.skipped) == 1.0 and math.isfinite(float(loss))
