@@ -38,6 +38,9 @@ SIGNATURES = {
     'di_depth_complete': [_c_p] * 4 + [_c_i] * 3 + [_c_p],
     'di_bevwarp_gather_fwd': [_c_p] * 8 + [_c_i] * 7 + [_c_p],
     'di_ms_deform_attn_fwd': [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_i, _c_p],
+    'di_ms_deform_attn_hm_fwd': [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p],
+    'di_pointwise_chain_hm_fwd': [_c_p, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_i, _c_i, _c_p],
+    'di_pointwise_multi_warp_hm_fwd': [_c_p] * 7 + [_c_i] * 6 + [_c_p] * 7,
     'di_grid_gather_fwd': [_c_p, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p],
     'di_polar_bev_sample_fwd': [_c_p] * 7 + [_c_i] * 8 + [_c_p],
     'di_mha_small_fwd': [_c_p, _c_i, _c_p, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_i, _c_p],
@@ -57,6 +60,7 @@ SIGNATURES = {
     'di_pointwise_multi_fwd': [_c_p, _c_i] + [_c_p] * 5 + [ctypes.c_longlong, _c_p],
     'di_pointwise_multi_warp_fwd': [_c_p] * 7 + [_c_i] * 6 + [_c_p] * 6,
     'di_ffn_ln_fwd': [_c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, ctypes.c_longlong, _c_p],
+    'di_ffn_ln_fwd_ex': [_c_p, _c_i, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, _c_p, ctypes.c_longlong, _c_p],
     'di_conv3x3_fwd': [_c_p] * 5 + [_c_i] * 7 + [_c_p],
     'di_token_program': [_c_p, _c_i, _c_p, _c_i, _c_i, _c_p],
     'di_token_program_timed': [_c_p, _c_i, _c_p, _c_i, _c_i, _c_p, _c_p],

@@ -14,6 +14,8 @@
 //                             flash-attn's role at fusion_transformerv4.py:697-700
 //
 // All are gather / HBM-bound: 16 lanes own one 128-channel texel row (16 B per lane), fp32 accumulation.
+#include <type_traits>
+
 #include "di_common.h"
 
 namespace di {
@@ -134,6 +136,131 @@ __global__ __launch_bounds__(256) void ms_deform_attn_kernel(const T *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Deformable attention over a HEAD-MAJOR value map (fp16 inference, round 5):  value (bs, 8, S, 16) - what the value
+// projection writes when asked to (di_pointwise_chain_hm_fwd / di_pointwise_multi_warp_hm_fwd).
+//
+// Why: the kernel above is bound by the texture addresser, not by bytes (PMC, round 3: traffic 1.05 x algorithmic at 0.15
+// of the HBM roofline).  A head's 16 channels are 32 B of a 256-B channels-last texel, so one wave-level load touches 32
+// distinct 32-B pieces - one per clock - and a query needs 8 heads x L*P points x 4 corners = 256 of them.  Head-major, the
+// two corners of a footprint ROW are 64 contiguous bytes: four lanes (corner x, channel half) fetch them as ONE piece,
+// half as many addresser cycles per query.  Lane = (query, head, corner column cx, channel half): 32 lanes per query; a
+// lane accumulates the left OR the right corners of every sample and the two are added at the end (DPP).  The geometry
+// of a sample (location, floor, bounds, the four weights times the soft-max probability) is evaluated ONCE per quad -
+// lane q of a quad owns the points q, q + 4 - and handed to the other lanes by quad broadcasts (DPP, no LDS); values go
+// into the fp32 accumulators as v_fma_mix_f32 (fp16 operand as is, no conversions).
+template <int SRC>
+__device__ __forceinline__ int quad_bcast(int v) {
+  constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
+  return __builtin_amdgcn_update_dpp(0, v, ctrl, 0xF, 0xF, true);
+}
+template <int SRC>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __builtin_bit_cast(float, quad_bcast<SRC>(__builtin_bit_cast(int, v)));
+}
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kQuadSwap1 = 0xB1;   // quad_perm [1, 0, 3, 2]
+constexpr int kQuadSwap2 = 0x4E;   // quad_perm [2, 3, 0, 1]
+
+typedef unsigned msda_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void axpy8_mix(float (&acc)[8], float c, const msda_u4 &u) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2 * j]) : "v"(u[j]), "v"(c));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * j + 1]) : "v"(u[j]), "v"(c));
+  }
+}
+
+template <int B, int E, class F>
+__device__ __forceinline__ void msda_static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    msda_static_for<B + 1, E>(f);
+  }
+}
+
+template <int L, int P>
+__global__ __launch_bounds__(256) void ms_deform_attn_hm_kernel(const __half *__restrict__ value, const __half *__restrict__ off,
+                                                                int off_rs, const __half *__restrict__ logit, int logit_rs,
+                                                                const float *__restrict__ ref, int ref_shared,
+                                                                __half *__restrict__ out, int bs, int nq, int S, Levels lv) {
+  static_assert(P == 4 && (L == 1 || L == 2), "a quad's four lanes own the four points of a level");
+  constexpr int NS = L;                        // points per lane: point s * 4 + q4 (level s)
+  const int l32 = threadIdx.x & 31, head = l32 >> 2, q4 = l32 & 3, cx = q4 >> 1, half = q4 & 1;
+  const long long total = (long long)bs * nq;
+  const long long row = (long long)xcd_remap(blockIdx.x, gridDim.x) * 8 + (threadIdx.x >> 5);
+  if (row >= total) return;                    // (whole 32-lane groups: the DPP exchanges stay inside a quad)
+  const int b = (int)(row / nq), q = (int)(row - (long long)b * nq);
+  const _Float16 *lg = reinterpret_cast<const _Float16 *>(logit) + (size_t)row * logit_rs + head * (L * P);
+  const _Float16 *of = reinterpret_cast<const _Float16 *>(off) + (size_t)row * off_rs + head * (L * P * 2);
+  // soft-max over the head's L*P logits: every lane holds NS of them
+  float e[NS], m = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    e[s] = (float)lg[s * 4 + q4];
+    m = fmaxf(m, e[s]);
+  }
+  m = fmaxf(m, quad_perm<kQuadSwap1>(m));
+  m = fmaxf(m, quad_perm<kQuadSwap2>(m));
+  float sum = 0.f;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    e[s] = __expf(e[s] - m);
+    sum += e[s];
+  }
+  sum += quad_perm<kQuadSwap1>(sum);
+  sum += quad_perm<kQuadSwap2>(sum);
+  const float inv = 1.f / sum;
+  const float *rf = ref + ((size_t)(ref_shared ? 0 : b) * nq + q) * L * 2;
+  // geometry of this lane's points: the clamped upper-left texel (index inside the head's plane), the steps to the right /
+  // lower corner (0 at the border: the weight is 0 there), the four weights (x the probability; 0 = zero padding)
+  unsigned info[NS];
+  float w00[NS], w01[NS], w10[NS], w11[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int H = lv.h[s], W = lv.w[s];
+    const float ox = (float)of[(s * 4 + q4) * 2], oy = (float)of[(s * 4 + q4) * 2 + 1];
+    // loc = ref + off / (W, H);  pixel = loc * size - 0.5   (grid_sample, align_corners=False)
+    const float px = (rf[s * 2] + ox / (float)W) * (float)W - 0.5f;
+    const float py = (rf[s * 2 + 1] + oy / (float)H) * (float)H - 0.5f;
+    const bool live = px > -1.f && px < (float)W && py > -1.f && py < (float)H;      // also rejects NaN / huge
+    const float fx = live ? floorf(px) : 0.f, fy = live ? floorf(py) : 0.f;
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float ax = live ? px - fx : 0.f, ay = live ? py - fy : 0.f;
+    const bool xl = live && x0 >= 0, xh = live && x0 + 1 < W, yl = y0 >= 0, yh = y0 + 1 < H;
+    const int xa = max(x0, 0), xb = min(x0 + 1, W - 1), ya = max(y0, 0), yb = min(y0 + 1, H - 1);
+    info[s] = (unsigned)(lv.start[s] + ya * W + xa) | ((unsigned)(xb - xa) << 30) | ((unsigned)(yb - ya) << 31);
+    const float a = e[s] * inv;
+    w00[s] = (yl && xl) ? a * (1.f - ay) * (1.f - ax) : 0.f;
+    w01[s] = (yl && xh) ? a * (1.f - ay) * ax : 0.f;
+    w10[s] = (yh && xl) ? a * ay * (1.f - ax) : 0.f;
+    w11[s] = (yh && xh) ? a * ay * ax : 0.f;
+  }
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const unsigned char *plane = reinterpret_cast<const unsigned char *>(value) + ((size_t)(b * 8 + head) * S) * 32 + half * 16;
+  msda_static_for<0, L * P>([&](auto pc) {
+    constexpr int p = decltype(pc)::value, src = p & 3, s = p >> 2;
+    const unsigned inf_ = (unsigned)quad_bcast<src>((int)info[s]);
+    const float a0 = quad_bcast<src>(w00[s]), a1 = quad_bcast<src>(w01[s]);
+    const float b0 = quad_bcast<src>(w10[s]), b1 = quad_bcast<src>(w11[s]);
+    const float wt = cx ? a1 : a0, wb = cx ? b1 : b0;
+    const unsigned it = (inf_ & 0x3FFFFFFFu) + (cx ? ((inf_ >> 30) & 1u) : 0u);
+    const unsigned ib = it + ((inf_ >> 31) ? (unsigned)lv.w[s] : 0u);
+    const msda_u4 top = *reinterpret_cast<const msda_u4 *>(plane + (size_t)it * 32);
+    const msda_u4 bot = *reinterpret_cast<const msda_u4 *>(plane + (size_t)ib * 32);
+    axpy8_mix(acc, wt, top);
+    axpy8_mix(acc, wb, bot);
+  });
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] += quad_perm<kQuadSwap2>(acc[i]);      // left + right corners
+  if (cx == 0) st8(out + (size_t)row * 128 + head * 16 + half * 8, pack8f(acc, __half()));
+}
+
+// ------------------------------------------------------------------------------------------------
 // out[g, n, :] = bilinear(feat[g / per_feat], grid[g, n]) (+ add[n, :]);  feat (Bf,H,W,C), grid (Bg,N,2) in [-1,1].
 template <typename T>
 __global__ __launch_bounds__(256) void grid_gather_kernel(const T *__restrict__ feat, const float *__restrict__ grid,
@@ -162,7 +289,10 @@ __global__ __launch_bounds__(256) void grid_gather_kernel(const T *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // polar (B, V, Wp, R, C) polar maps, RAY-major (texel (r, w) at (w*R + r)*C: the layout the ray transformer emits); bev (B, Hb, Wb, C) residual; proj (B, V, 4, 4); aug_rev (B, 12)
 // [A row-major, t: p' = p A + t]; cam_xy (B, V, 2); par = pc_range(6), input H, input W, r0, R.
-// One 16-lane group per BEV cell; the geometry is recomputed by every lane of the group (a few hundred flops).
+// One 16-lane group per BEV cell.  The geometry of a cell - 10 height samples projected into each of the V cameras: two
+// divides and a square root per (camera, sample) - does not depend on the channel: the group's lanes SHARE it (lane 2c + h
+// takes half h of the samples of camera c, eight cameras per pass) and exchange the per-camera results by lane shuffles.
+// (Round 1-4: every lane evaluated all V x 10 projections - ~3 600 VALU instructions per lane for 35 MB of traffic, 70 us.)
 template <typename T>
 __global__ __launch_bounds__(256) void polar_bev_sample_kernel(const T *__restrict__ polar, const T *__restrict__ bev,
                                                                const float *__restrict__ proj,
@@ -171,10 +301,12 @@ __global__ __launch_bounds__(256) void polar_bev_sample_kernel(const T *__restri
                                                                const float *__restrict__ par, T *__restrict__ out,
                                                                int B, int V, int R, int Wp, int Hb, int Wb, int C) {
   constexpr int ZS = 10;
-  const int l16 = threadIdx.x & 15, ch0 = l16 * kChPerLane;
+  const int l16 = threadIdx.x & 15;
+  const bool ch_ok = l16 * kChPerLane < C;                   // C < 128: the upper lanes only help with the geometry
+  const int ch0 = ch_ok ? l16 * kChPerLane : 0;
   const long long total = (long long)B * Hb * Wb;
   const long long cell = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-  if (cell >= total || ch0 >= C) return;
+  if (cell >= total) return;                                 // (whole groups: the shuffles below stay inside a group)
   const int b = (int)(cell / (Hb * Wb)), ij = (int)(cell - (long long)b * Hb * Wb);
   const int i = ij / Wb, j = ij - i * Wb;
   const float x0 = par[0], y0 = par[1], z0 = par[2], x1 = par[3], y1 = par[4], z1 = par[5];
@@ -187,34 +319,47 @@ __global__ __launch_bounds__(256) void polar_bev_sample_kernel(const T *__restri
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = 0.f;
   int vis = 0;
-  for (int v = 0; v < V; ++v) {
-    const float *M = proj + ((size_t)b * V + v) * 16;
-    const float cx = cam_xy[((size_t)b * V + v) * 2], cy = cam_xy[((size_t)b * V + v) * 2 + 1];
+  for (int v0 = 0; v0 < V; v0 += 8) {
+    const int v = v0 + (l16 >> 1), half = l16 & 1;
     float su = 0.f, sr = 0.f;
-    bool any = false;
+    int any = 0;
+    if (v < V) {
+      const float *M = proj + ((size_t)b * V + v) * 16;
+      const float cx = cam_xy[((size_t)b * V + v) * 2], cy = cam_xy[((size_t)b * V + v) * 2 + 1];
 #pragma unroll
-    for (int k = 0; k < ZS; ++k) {
-      const float bz = ((float)k + 0.5f) / (float)ZS * (z1 - z0) + z0;
-      const float px = bx * A[0] + by * A[3] + bz * A[6] + A[9];
-      const float py = bx * A[1] + by * A[4] + bz * A[7] + A[10];
-      const float pz = bx * A[2] + by * A[5] + bz * A[8] + A[11];
-      const float xc = M[0] * px + M[1] * py + M[2] * pz + M[3];
-      const float yc = M[4] * px + M[5] * py + M[6] * pz + M[7];
-      const float zc = M[8] * px + M[9] * py + M[10] * pz + M[11];
-      const float zd = fmaxf(zc, 1e-5f);
-      const float u = 2.f * (xc / zd / in_w) - 1.f, vv = 2.f * (yc / zd / in_h) - 1.f;
-      any |= (zc > 1e-5f) && u > -1.f && u < 1.f && vv > -1.f && vv < 1.f;
-      su += u;
-      const float dx = px - cx, dy = py - cy;
-      const float rad = sqrtf(dx * dx + dy * dy);
-      sr += fminf(fmaxf(2.f * (rad - r0) / Rf - 1.f, -1.f), 1.f);
+      for (int kk = 0; kk < ZS / 2; ++kk) {
+        const int k = half * (ZS / 2) + kk;
+        const float bz = ((float)k + 0.5f) / (float)ZS * (z1 - z0) + z0;
+        const float px = bx * A[0] + by * A[3] + bz * A[6] + A[9];
+        const float py = bx * A[1] + by * A[4] + bz * A[7] + A[10];
+        const float pz = bx * A[2] + by * A[5] + bz * A[8] + A[11];
+        const float xc = M[0] * px + M[1] * py + M[2] * pz + M[3];
+        const float yc = M[4] * px + M[5] * py + M[6] * pz + M[7];
+        const float zc = M[8] * px + M[9] * py + M[10] * pz + M[11];
+        const float zd = fmaxf(zc, 1e-5f);
+        const float u = 2.f * (xc / zd / in_w) - 1.f, vv = 2.f * (yc / zd / in_h) - 1.f;
+        any |= (int)((zc > 1e-5f) && u > -1.f && u < 1.f && vv > -1.f && vv < 1.f);
+        su += u;
+        const float dx = px - cx, dy = py - cy;
+        const float rad = sqrtf(dx * dx + dy * dy);
+        sr += fminf(fmaxf(2.f * (rad - r0) / Rf - 1.f, -1.f), 1.f);
+      }
     }
-    if (!any) continue;
-    ++vis;
-    const float lx = su / (float)ZS, ly = sr / (float)ZS;
-    const float fx = ((lx + 1.f) * (float)Wp - 1.f) * 0.5f, fy = ((ly + 1.f) * (float)R - 1.f) * 0.5f;
-    bilinear8(polar + ((size_t)b * V + v) * R * Wp * C + ch0, R, Wp, C, R * C, fx, fy, 1.f, acc);   // ray-major
+    su += __shfl_xor(su, 1);                                  // the two halves of a camera's samples
+    sr += __shfl_xor(sr, 1);
+    any |= __shfl_xor(any, 1);
+    const int nv = min(8, V - v0);
+    for (int c = 0; c < nv; ++c) {                            // every lane walks the cameras of this pass
+      const int any_c = __shfl(any, 2 * c, 16);
+      const float su_c = __shfl(su, 2 * c, 16), sr_c = __shfl(sr, 2 * c, 16);
+      if (!any_c) continue;
+      ++vis;
+      const float lx = su_c / (float)ZS, ly = sr_c / (float)ZS;
+      const float fx = ((lx + 1.f) * (float)Wp - 1.f) * 0.5f, fy = ((ly + 1.f) * (float)R - 1.f) * 0.5f;
+      if (ch_ok) bilinear8(polar + ((size_t)b * V + v0 + c) * R * Wp * C + ch0, R, Wp, C, R * C, fx, fy, 1.f, acc);   // ray-major
+    }
   }
+  if (!ch_ok) return;
   const float inv = 1.f / (float)(vis > 0 ? vis : 1);
   float res[8];
   unpack8(ld8(bev + (size_t)cell * C + ch0), res);
@@ -501,6 +646,37 @@ int di_ms_deform_attn_fwd(const void *value, const void *offsets, int off_row_st
   else { di::set_error("unsupported dtype %d", dtype); return DI_ERR_ARG; }
 #undef DI_MSDA
   return di::check_launch("ms_deform_attn_fwd");
+}
+
+int di_ms_deform_attn_hm_fwd(const void *value_hm, const void *offsets, int off_row_stride, const void *logits,
+                             int logit_row_stride, const float *ref, int ref_shared, void *out, int bs, int nq,
+                             int n_levels, int n_points, const int32_t *level_hw, void *stream) {
+  DI_REQUIRE(bs > 0 && nq > 0, "bad deformable attention shape");
+  DI_REQUIRE((n_levels == 1 || n_levels == 2) && n_points == 4, "levels %d / points %d unsupported (1|2 levels, 4 points)",
+             n_levels, n_points);
+  DI_REQUIRE(((uintptr_t)offsets % 4) == 0 && (off_row_stride % 2) == 0 && value_hm && logits && ref && out,
+             "offset rows must be 4-byte aligned");
+  di::pp::Levels lv;
+  lv.n = n_levels;
+  int S = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    lv.h[l] = level_hw[2 * l];
+    lv.w[l] = level_hw[2 * l + 1];
+    DI_REQUIRE(lv.h[l] > 0 && lv.w[l] > 0, "bad level shape");
+    lv.start[l] = S;
+    S += lv.h[l] * lv.w[l];
+  }
+  DI_REQUIRE(S < (1 << 30), "%d texels per map exceed the 30-bit index", S);
+  const long long rows = (long long)bs * nq;
+  const dim3 grid((unsigned)((rows + 7) / 8)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (n_levels == 1)
+    hipLaunchKernelGGL((di::pp::ms_deform_attn_hm_kernel<1, 4>), grid, blk, 0, s, (const __half *)value_hm, (const __half *)offsets,
+                       off_row_stride, (const __half *)logits, logit_row_stride, ref, ref_shared, (__half *)out, bs, nq, S, lv);
+  else
+    hipLaunchKernelGGL((di::pp::ms_deform_attn_hm_kernel<2, 4>), grid, blk, 0, s, (const __half *)value_hm, (const __half *)offsets,
+                       off_row_stride, (const __half *)logits, logit_row_stride, ref, ref_shared, (__half *)out, bs, nq, S, lv);
+  return di::check_launch("ms_deform_attn_hm_fwd");
 }
 
 int di_grid_gather_fwd(const void *feat, const float *grid, const void *add, void *out, int n_grids, int n_points,

@@ -89,7 +89,9 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
     const __half *__restrict__ x1, const __half *__restrict__ x2, const __half *__restrict__ x3,
     const __half *__restrict__ w1, const float *__restrict__ b1, const __half *__restrict__ w2,
     const float *__restrict__ b2, __half *__restrict__ y, long long M, int relu1, int relu2,
-    const __half *__restrict__ mask, const float *__restrict__ bm) {
+    const __half *__restrict__ mask, const float *__restrict__ bm, int hm_S = 0) {
+  // hm_S > 0 (single-link chains): the output is written HEAD-MAJOR - token t of map b, channels 16h .. 16h + 15 at
+  // ((b * 8 + h) * hm_S + t) * 16 - the layout ms_deform_attn_hm_kernel (csrc/plusplus.hip) gathers from
   extern __shared__ __align__(16) unsigned char lds[];
   unsigned char *lw1 = lds;
   unsigned char *lw2 = lds + 128 * K1 * 2;
@@ -202,6 +204,13 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
 #pragma unroll
       for (int pg = 0; pg < PG; ++pg)
         if (pix[pg] < M) {
+          // channels 32 p2 + 8 g .. + 7 = half (g & 1) of head 2 p2 + (g >> 1)
+          long long base = pix[pg] * 128 + 8 * g, step = 32;
+          if (hm_S > 0) {
+            const int bmap = (int)pix[pg] / hm_S, t = (int)pix[pg] - bmap * hm_S;
+            base = (((long long)bmap * 8 + (g >> 1)) * hm_S + t) * 16 + (g & 1) * 8;
+            step = 2ll * hm_S * 16;
+          }
 #pragma unroll
           for (int p2 = 0; p2 < 4; ++p2) {
             h8 o;
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
               o[r] = (_Float16)acc[pg][2 * p2][r];
               o[4 + r] = (_Float16)acc[pg][2 * p2 + 1][r];
             }
-            *reinterpret_cast<h8 *>(y + pix[pg] * 128 + 32 * p2 + 8 * g) = __builtin_elementwise_max(o, floor1);
+            *reinterpret_cast<h8 *>(y + base + p2 * step) = __builtin_elementwise_max(o, floor1);
           }
         }
       if (ch + chstep < nchunk) load_x(ch + chstep);
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(NT, 2) void pointwise_chain_kernel(
 template <int K1, int K2>
 static int launch(const void *x1, const void *x2, const void *x3, const void *w1, const float *b1,
                   const void *w2, const float *b2, void *y, long long M, int relu1, int relu2,
-                  const void *mask, const float *bm, hipStream_t stream) {
+                  const void *mask, const float *bm, hipStream_t stream, int hm_S = 0) {
   constexpr int LDS = 128 * K1 * 2 + 128 * K2 * 2 + 1536;
   static LdsRaised lds_raised;
   if (int rc = ensure_lds(lds_raised, (const void *)pointwise_chain_kernel<K1, K2>, LDS)) return rc;
@@ -312,7 +321,7 @@ static int launch(const void *x1, const void *x2, const void *x3, const void *w1
   if (grid * NW > nchunk) grid = (nchunk + NW - 1) / NW;
   hipLaunchKernelGGL((pointwise_chain_kernel<K1, K2>), dim3((unsigned)grid), dim3(NT), LDS, stream,
                      (const __half *)x1, (const __half *)x2, (const __half *)x3, (const __half *)w1, b1,
-                     (const __half *)w2, b2, (__half *)y, M, relu1, relu2, (const __half *)mask, bm);
+                     (const __half *)w2, b2, (__half *)y, M, relu1, relu2, (const __half *)mask, bm, hm_S);
   return check_launch("pointwise_chain");
 }
 
@@ -329,6 +338,7 @@ struct Chain {
   const unsigned char *img;  // kChainImage bytes, prepared once on the host (ops.chain_image)
   __half *y;
   int relu1, relu2, two;
+  int hm;                    // > 0 (single-link chains): head-major output, `hm` tokens per map (see pointwise_chain_kernel)
 };
 struct MultiArgs {
   Chain c[kMaxChains];
@@ -472,6 +482,12 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
 #pragma unroll
         for (int pg = 0; pg < NP; ++pg)
           if (pix[j0 + pg] < Mi) {
+            size_t base = (size_t)pix[j0 + pg] * 128 + 8 * g, stp = 32;
+            if (ch.hm > 0) {
+              const int bmap = pix[j0 + pg] / ch.hm, t = pix[j0 + pg] - bmap * ch.hm;
+              base = (((size_t)bmap * 8 + (g >> 1)) * ch.hm + t) * 16 + (g & 1) * 8;
+              stp = (size_t)2 * ch.hm * 16;
+            }
 #pragma unroll
             for (int p2 = 0; p2 < 4; ++p2) {
               h8 o;
@@ -480,7 +496,7 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
                 o[r] = (_Float16)acc[pg][2 * p2][r];
                 o[4 + r] = (_Float16)acc[pg][2 * p2 + 1][r];
               }
-              *reinterpret_cast<h8 *>(ch.y + (size_t)pix[j0 + pg] * 128 + 32 * p2 + 8 * g) = __builtin_elementwise_max(o, floor1);
+              *reinterpret_cast<h8 *>(ch.y + base + p2 * stp) = __builtin_elementwise_max(o, floor1);
             }
           }
         return;
@@ -592,6 +608,9 @@ struct FfnArgs {
   // one image holding a one-link chain (ops.chain_image(w, b)), the residual from `res` instead of x
   const __half *res;
   int single;
+  // optional second output: the PRE-normalisation sum  res + W . x + b  (fp16) - a DeepInteraction++ layer keeps the
+  // un-normalised self-attention output next to its LayerNorm (fusion_transformerv4.py:187-190, `self_feat`)
+  __half *presum;
 };
 
 __global__ __launch_bounds__(NT, 2) void ffn_ln_kernel(const __half *__restrict__ x, __half *__restrict__ y, FfnArgs A, long long M) {
@@ -720,6 +739,18 @@ __global__ __launch_bounds__(NT, 2) void ffn_ln_kernel(const __half *__restrict_
     var += __shfl_xor(var, 16);
     var += __shfl_xor(var, 32);
     const float rstd = rsqrtf(var * (1.f / 128.f) + A.eps);
+    if (A.presum != nullptr && pix[pg] < Mi) {
+#pragma unroll
+      for (int p2 = 0; p2 < 4; ++p2) {
+        h8 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (_Float16)out[pg][2 * p2][r];
+          o[4 + r] = (_Float16)out[pg][2 * p2 + 1][r];
+        }
+        *reinterpret_cast<h8 *>(A.presum + (size_t)pix[pg] * 128 + 32 * p2 + 8 * g) = o;
+      }
+    }
     if (pix[pg] < Mi) {
 #pragma unroll
       for (int p2 = 0; p2 < 4; ++p2) {
@@ -749,15 +780,17 @@ static int launch_multi(const void *x, const MultiArgs &A, long long M, long lon
 
 // chains of one launch + the split of the map over the workgroups (shared by the plain and the gathered form)
 static int multi_setup(MultiArgs &A, int n_chains, const void *const *image, void *const *y, const int *relu1, const int *relu2,
-                       const int *two_links, long long n_pixels, long long &grid, int &ng) {
+                       const int *two_links, long long n_pixels, long long &grid, int &ng, const int *hm = nullptr) {
   DI_REQUIRE(n_chains >= 1 && n_chains <= kMaxChains, "1..%d chains, got %d", kMaxChains, n_chains);
   A.n = n_chains;
   for (int c = 0; c < kMaxChains; ++c) {
     if (c < n_chains) {
       DI_REQUIRE(image[c] && y[c], "chain %d: image and y are required", c);
-      A.c[c] = Chain{(const unsigned char *)image[c], (__half *)y[c], relu1[c], relu2[c], two_links[c]};
+      A.c[c] = Chain{(const unsigned char *)image[c], (__half *)y[c], relu1[c], relu2[c], two_links[c], hm ? hm[c] : 0};
+      DI_REQUIRE(A.c[c].hm == 0 || (!two_links[c] && A.c[c].hm > 0 && n_pixels % A.c[c].hm == 0),
+                 "chain %d: a head-major output takes a single-link chain and whole maps (%d tokens per map)", c, A.c[c].hm);
     } else {
-      A.c[c] = Chain{nullptr, nullptr, 0, 0, 0};
+      A.c[c] = Chain{nullptr, nullptr, 0, 0, 0, 0};
     }
   }
   const int n_cu = di::device_cus();
@@ -778,8 +811,16 @@ static int multi_setup(MultiArgs &A, int n_chains, const void *const *image, voi
 }  // namespace pw
 }  // namespace di
 
+extern "C" int di_ffn_ln_fwd_ex(const void *x, int n_chunks, const void *const *image, const void *residual, const void *ln_w,
+                                const void *ln_b, float eps, void *y, void *presum, long long n_tokens, void *stream);
+
 extern "C" int di_ffn_ln_fwd(const void *x, int n_chunks, const void *const *image, const void *residual, const void *ln_w,
                              const void *ln_b, float eps, void *y, long long n_tokens, void *stream) {
+  return di_ffn_ln_fwd_ex(x, n_chunks, image, residual, ln_w, ln_b, eps, y, nullptr, n_tokens, stream);
+}
+
+extern "C" int di_ffn_ln_fwd_ex(const void *x, int n_chunks, const void *const *image, const void *residual, const void *ln_w,
+                                const void *ln_b, float eps, void *y, void *presum, long long n_tokens, void *stream) {
   using namespace di::pw;
   DI_REQUIRE(n_tokens > 0 && n_tokens < (1ll << 24) && x && y && ln_w && ln_b, "bad token count (1 .. 2^24 - 1)");
   DI_REQUIRE(n_chunks >= 1 && n_chunks <= 8 && image, "hidden width = 128 x (1 .. 8)");
@@ -792,6 +833,7 @@ extern "C" int di_ffn_ln_fwd(const void *x, int n_chunks, const void *const *ima
   A.eps = eps;
   A.res = (const __half *)residual;
   A.single = residual != nullptr;
+  A.presum = (__half *)presum;
   DI_REQUIRE(!A.single || n_chunks == 1, "the single-link form takes one image");
   constexpr int LDS = 2 * kChainImage;
   static di::LdsRaised raised;
@@ -831,6 +873,35 @@ extern "C" int di_pointwise_multi_warp_fwd(const void *bev, const float *depth, 
   long long grid;
   int ng;
   if (int rc = multi_setup(A, n_chains, image, y, relu1, relu2, two_links, n_pixels, grid, ng)) return rc;
+  const WarpArgs Wp{(const __half *)bev, depth, img2lidar, aug_fwd, xs, ys, pc_range, Hi, Wi, Hb, Wb};
+  hipStream_t s = (hipStream_t)stream;
+  if (ng <= 2) return launch_multi<2, true>(nullptr, A, n_pixels, grid, s, Wp);
+  if (ng <= 4) return launch_multi<4, true>(nullptr, A, n_pixels, grid, s, Wp);
+  return launch_multi<5, true>(nullptr, A, n_pixels, grid, s, Wp);
+}
+
+extern "C" int di_pointwise_chain_hm_fwd(const void *x, const void *w, const float *b, void *y_hm, long long n_tokens,
+                                         int tokens_per_map, int relu, void *stream) {
+  DI_REQUIRE(x && w && b && y_hm && n_tokens > 0 && n_tokens < (1ll << 31), "bad arguments");
+  DI_REQUIRE(tokens_per_map > 0 && n_tokens % tokens_per_map == 0, "whole maps of %d tokens", tokens_per_map);
+  return di::pw::launch<128, 0>(x, nullptr, nullptr, w, b, nullptr, nullptr, y_hm, n_tokens, relu, 0, nullptr, nullptr,
+                                (hipStream_t)stream, tokens_per_map);
+}
+
+extern "C" int di_pointwise_multi_warp_hm_fwd(const void *bev, const float *depth, const float *img2lidar, const float *aug_fwd,
+                                              const float *xs, const float *ys, const float *pc_range, int n_views, int Hi,
+                                              int Wi, int Hb, int Wb, int n_chains, const void *const *image, void *const *y,
+                                              const int *relu1, const int *relu2, const int *two_links, const int *hm_tokens,
+                                              void *stream) {
+  using namespace di::pw;
+  const long long n_pixels = (long long)n_views * Hi * Wi;
+  DI_REQUIRE(n_views > 0 && Hi > 0 && Wi > 0 && Hb > 0 && Wb > 0 && n_pixels < (1ll << 24), "bad gather shape");
+  DI_REQUIRE(bev && depth && img2lidar && aug_fwd && xs && ys && pc_range, "null geometry");
+  DI_REQUIRE(n_chains <= 2, "the gathered form keeps both weight images resident: at most 2 chains, got %d", n_chains);
+  MultiArgs A;
+  long long grid;
+  int ng;
+  if (int rc = multi_setup(A, n_chains, image, y, relu1, relu2, two_links, n_pixels, grid, ng, hm_tokens)) return rc;
   const WarpArgs Wp{(const __half *)bev, depth, img2lidar, aug_fwd, xs, ys, pc_range, Hi, Wi, Hb, Wb};
   hipStream_t s = (hipStream_t)stream;
   if (ng <= 2) return launch_multi<2, true>(nullptr, A, n_pixels, grid, s, Wp);

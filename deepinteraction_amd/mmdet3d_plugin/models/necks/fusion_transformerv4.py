@@ -21,7 +21,8 @@ from ....autograd import GridGather, PolarBEVSample
 from ....geometry import PC_RANGE, aug_affine
 from ....registry import ATTENTION, NECKS, TRANSFORMER_LAYER
 from ..utils import encoder_utils as eu
-from ..utils.transformer_bricks import MultiScaleDeformableAttention, TransFFN, post_norm
+from ..utils.transformer_bricks import (MultiScaleDeformableAttention, TransFFN, fused_tokens_ok, linear128, module_cache,
+                                        post_norm)
 
 if 'MultiScaleDeformableAttention' not in getattr(ATTENTION, 'module_dict', {}):
     ATTENTION.register_module(module=MultiScaleDeformableAttention)
@@ -53,8 +54,25 @@ class MMRI_P2I(nn.Module):
     def forward(self, img_feats, lidar_feats, img_metas, pts_metas, reference_points=None, then_norm=None, **kwargs):
         B = lidar_feats.size(0)
         _, C, H, W = img_feats.shape
-        warped = self.Warp(ops.cl(lidar_feats), img_feats.reshape(B, -1, C, H, W), img_metas, pts_metas)
         q = _tokens(img_feats)
+        lidar_feats = ops.cl(lidar_feats)
+        if C == 128 and fused_tokens_ok(q, self.Local) and lidar_feats.dtype == torch.float16:
+            # the value projection GATHERS its input: the warped map (34 MB per sample) is neither written nor read
+            # (ops.warp_project, the launch the v1 P2I block uses for its key / value projections)
+            vp = self.Local.value_proj
+            chain = module_cache(self.Local, '_value_chain', [vp],
+                                 lambda: (ops.chain_image(vp.weight.float(), vp.bias.float()), False, False, False))
+            vs = []
+            for b in range(B):
+                geom = eu.sample_geometry(img_metas, pts_metas, b, (H, W), lidar_feats.device)
+                depth = self.Warp.dense_depth(geom, pts_metas['pts'][b], H, W)
+                vs.append(ops.warp_project(lidar_feats[b:b + 1], depth, geom.img2lidar, geom.aug_fwd, geom.xs, geom.ys,
+                                           geom.pc_range, [chain], head_major=True)[0])
+            pv = vs[0] if B == 1 else torch.cat(vs, 0)                               # (B*V, 8, H*W, 16) head-major
+            out = self.Local(query=q, value=None, projected_value=pv, reference_points=reference_points,
+                             spatial_shapes=[(H, W)], level_start_index=None, then_norm=then_norm)
+            return _map(out, H, W)
+        warped = self.Warp(lidar_feats, img_feats.reshape(B, -1, C, H, W), img_metas, pts_metas)
         v = _tokens(warped.reshape(-1, C, H, W))
         out = self.Local(query=q, value=v, reference_points=reference_points, spatial_shapes=[(H, W)],
                          level_start_index=None, then_norm=then_norm)
@@ -78,7 +96,24 @@ class MMRI_I2P(eu.MMRI_I2P):
     def forward(self, lidar_feat, img_feat, img_metas, pts_metas, **kwargs):
         B = lidar_feat.size(0)
         _, C, H, W = img_feat.shape
-        return super().forward(lidar_feat, ops.cl(img_feat).reshape(B, -1, C, H, W), img_metas, pts_metas) + lidar_feat
+        img5 = ops.cl(img_feat).reshape(B, -1, C, H, W)
+        lidar_feat = ops.cl(lidar_feat)
+        if (C == 128 and lidar_feat.shape[1] == 128 and lidar_feat.is_cuda and lidar_feat.dtype == torch.float16
+                and not torch.is_grad_enabled() and not self.training):
+            # inference: the folded query / output projections through the fused chain kernels (no library GEMM); the output
+            # projection applies its bias on the cells that have keys (mask) - the attention's rows of the others are 0
+            def build():
+                w_qk, b_qk, w_ov, b_ov = self.folded(torch.float32)
+                return (w_qk.to(torch.float16).contiguous(), b_qk.contiguous(), w_ov.to(torch.float16).contiguous(),
+                        torch.zeros_like(b_ov), b_ov.contiguous())
+            w_qk, b_qk, w_ov, zero, b_ov = module_cache(self, '_pp_fold', [self.learnedAlign], build)
+            _, _, Hb, Wb = lidar_feat.shape
+            flat = lidar_feat.permute(0, 2, 3, 1).reshape(-1, 128)
+            qfold = ops.token_linear(flat, w_qk, b_qk).view(B, Hb, Wb, 128).permute(0, 3, 1, 2)
+            ctx, valid = self.attend(qfold, img5, img_metas, pts_metas)
+            out = ops.pointwise_chain(ctx, w_ov, zero, False, mask=valid.to(torch.float16).contiguous(), bm=b_ov)
+            return out + lidar_feat
+        return super().forward(lidar_feat, img5, img_metas, pts_metas) + lidar_feat
 
 
 def sine_position_tokens(n_x, n_y, num_feats, temperature=10000, x_major=False):
@@ -136,6 +171,35 @@ class PackedMHA(nn.Module):
         kv = F.linear(memory, self.in_proj_weight[E:], self.in_proj_bias[E:])   # (N,S,2E): k | v
         return self.out_proj(self._attend(q, kv[..., :E], kv[..., E:]))
 
+    # ---- fp16 inference: every projection through the fused chain kernels, the output projection with the residual and the
+    # layer's LayerNorm as its epilogue (ops.linear_ln)
+    def _images(self):
+        def build():
+            E = self.embed_dim
+            w, b = self.in_proj_weight.float(), self.in_proj_bias.float()
+            return ([ops.chain_image(w[k * E:(k + 1) * E], b[k * E:(k + 1) * E]) for k in range(3)],
+                    ops.chain_image(self.out_proj.weight.float(), self.out_proj.bias.float()))
+        return module_cache(self, '_di_images', [self], build)
+
+    def fused_self(self, x, norm):
+        """LayerNorm(x + out_proj(attention(q, k, v of x))) for (N, T, 128) fp16 tokens."""
+        N, T, E = x.shape
+        x2 = x.reshape(-1, E).contiguous()
+        qkv, out_image = self._images()
+        q, k, v = (t.view(N, T, E) for t in ops.token_linear_multi(x2, qkv))
+        a = ops.mha_small(q, k, v, self.num_heads)
+        return ops.linear_ln(a.view(-1, E), out_image, x2, norm.weight, norm.bias, norm.eps).view(N, T, E)
+
+    def fused_cross(self, x, memory, norm):
+        N, T, E = x.shape
+        S = memory.shape[1]
+        x2 = x.reshape(-1, E).contiguous()
+        qkv, out_image = self._images()
+        q = ops.token_linear_multi(x2, qkv[:1])[0].view(N, T, E)
+        k, v = (t.view(N, S, E) for t in ops.token_linear_multi(memory.reshape(-1, E).contiguous(), qkv[1:]))
+        a = ops.mha_small(q, k, v, self.num_heads)
+        return ops.linear_ln(a.view(-1, E), out_image, x2, norm.weight, norm.bias, norm.eps).view(N, T, E)
+
 
 class _RayDecoderLayer(nn.Module):
     """`FlashTransformerDecoderLayer` (:763-769) = torch 1.9 post-norm nn.TransformerDecoderLayer (ReLU) around two
@@ -149,6 +213,16 @@ class _RayDecoderLayer(nn.Module):
         self.drop = nn.Dropout(dropout)                        # torch's dropout / dropout1..3 (p = 0.1), training only
 
     def forward(self, tgt, memory):
+        if (tgt.shape[-1] == 128 and self.self_attn.num_heads == 8 and fused_tokens_ok(tgt, self) and memory.dtype == tgt.dtype
+                and self.norm1.weight.dtype == torch.float16 and self.linear1.out_features % 128 == 0
+                and self.linear1.out_features <= 1024):
+            tgt = self.self_attn.fused_self(tgt, self.norm1)
+            tgt = self.multihead_attn.fused_cross(tgt, memory, self.norm2)
+            images = module_cache(self, '_ffn_images', [self.linear1, self.linear2],
+                                  lambda: ops.ffn_images(self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                                         self.linear2.bias))
+            shape = tgt.shape
+            return ops.ffn_ln(tgt.reshape(-1, 128), images, self.norm3.weight, self.norm3.bias, self.norm3.eps).view(shape)
         dr = self.drop
         tgt = post_norm(self.norm1, tgt, dr(self.self_attn.self_attention(tgt)))
         tgt = post_norm(self.norm2, tgt, dr(self.multihead_attn.cross_attention(tgt, memory)))
@@ -335,11 +409,18 @@ class DeepInteractionLayer(nn.Module):
         for i, op in enumerate(order):
             nxt = self.norms[ni] if i + 1 < len(order) and order[i + 1] == 'norm' else None
             if op == 'self_attn':
-                query = self.attentions[ai](query=query, value=ms_query, identity=None,
-                                            reference_points=reference_points, spatial_shapes=spatial_shapes,
-                                            level_start_index=level_start_index)
+                att = self.attentions[ai]
+                if nxt is not None and isinstance(att, MultiScaleDeformableAttention) and att.can_fuse_norm(query, nxt):
+                    # output projection + residual + the following norm in one launch that also keeps the un-normalised sum
+                    query, self_feat = att(query=query, value=ms_query, identity=None, reference_points=reference_points,
+                                           spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                                           then_norm=nxt, with_sum=True)
+                    fused = True
+                else:
+                    query = att(query=query, value=ms_query, identity=None, reference_points=reference_points,
+                                spatial_shapes=spatial_shapes, level_start_index=level_start_index)
+                    self_feat = query
                 ai += 1
-                self_feat = query
             elif op == 'norm':
                 if not fused:
                     query = post_norm(self.norms[ni], query)
@@ -372,7 +453,7 @@ class DeepInteractionLayer(nn.Module):
                 elif op == 'ffn':
                     self_feat = self.ffns[fi](self_feat)
                     fi += 1
-        return _map(self_feat + self.scale * query, qh, qw)
+        return _map(torch.addcmul(self_feat, query, self.scale.to(query.dtype)), qh, qw)   # self_feat + scale * query
 
 
 def reference_points(H, W, device):

@@ -24,6 +24,41 @@ def post_norm(norm, x, branch=None):
     return norm(x if branch is None else x + branch)
 
 
+def fused_tokens_ok(x, *mods):
+    """fp16 inference on the GPU over 128-channel tokens: the form the fused chain kernels of csrc/pointwise.hip take (they
+    replace the library GEMM + bias + residual + LayerNorm launches of a transformer block)."""
+    return (x.is_cuda and x.dtype == torch.float16 and x.shape[-1] == 128 and not torch.is_grad_enabled()
+            and all(not m.training for m in mods))
+
+
+def module_cache(owner, name, key_mods, build):
+    """A derived constant of `owner` (packed / padded weights for a kernel), rebuilt when a parameter of `key_mods` changes."""
+    key = tuple(param_key(m) for m in key_mods)
+    hit = owner.__dict__.get(name)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, build())
+        owner.__dict__[name] = hit
+    return hit[1]
+
+
+def padded128(w, b):
+    """(rows <= 128, 128) weight and its bias padded with zero rows to the 128 outputs a chain computes (float32)."""
+    W = torch.zeros(128, 128, dtype=torch.float32, device=w.device)
+    B = torch.zeros(128, dtype=torch.float32, device=w.device)
+    W[:w.shape[0]] = w.float()
+    B[:b.shape[0]] = b.float()
+    return W, B
+
+
+def linear128(lin, x, relu=False):
+    """nn.Linear(128, 128) on fp16 inference tokens through the fused chain kernel (ops.token_linear)."""
+    w, b = module_cache(lin, '_di_w16', [lin], lambda: (lin.weight.detach().to(torch.float16).contiguous(),
+                                                        lin.bias.detach().float().contiguous()))
+    shape = x.shape
+    return ops.token_linear(x.reshape(-1, 128).contiguous(), w, b, relu).view(shape)
+
+
 class TransFFN(nn.Module):
     """mmcv `FFN`: identity + Dropout(Linear(Dropout(act(Linear(x))))); keys `layers.0.0.*`, `layers.1.*`."""
 
@@ -123,10 +158,29 @@ class MultiScaleDeformableAttention(nn.Module):
                                           torch.cat([self.sampling_offsets.bias, self.attention_weights.bias]).contiguous()))
         return self._pack_cache[1]
 
+    def projection_images(self):
+        """The offset / logit projections as chain images for the fused kernels (inference cache): one 128-output chain when
+        both fit (one level: 64 + 32 columns), else one chain per projection (two levels: 128 offsets | 64 logits + padding)."""
+        def build():
+            so, aw = self.sampling_offsets, self.attention_weights
+            if so.out_features + aw.out_features <= 128:
+                return [ops.chain_image(*padded128(torch.cat([so.weight, aw.weight]), torch.cat([so.bias, aw.bias])))]
+            assert so.out_features <= 128 and aw.out_features <= 128
+            return [ops.chain_image(*padded128(so.weight, so.bias)), ops.chain_image(*padded128(aw.weight, aw.bias))]
+        return module_cache(self, '_proj_images', [self.sampling_offsets, self.attention_weights], build)
+
+    def can_fuse_norm(self, query, norm):
+        """LayerNorm(identity + output_proj(.)) as the epilogue of the output projection (ops.linear_ln)."""
+        return (self.batch_first and self.embed_dims == 128 and fused_tokens_ok(query, self) and isinstance(norm, nn.LayerNorm)
+                and norm.elementwise_affine and norm.weight.dtype == torch.float16)
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
-                reference_points=None, spatial_shapes=None, level_start_index=None, then_norm=None, **kwargs):
+                reference_points=None, spatial_shapes=None, level_start_index=None, then_norm=None, with_sum=False,
+                projected_value=None, **kwargs):
         """`then_norm`: an nn.LayerNorm applied to the result (the layer's next 'norm' step) - the residual add is
-        then folded into the normalisation kernel."""
+        then folded into the normalisation kernel; `with_sum` (with `then_norm`, fused form only): also return the
+        un-normalised result -> (normed, sum).  `projected_value`: value_proj(value) when the caller already has it - HEAD-MAJOR
+        (bs, 8, S, 16) for the fused fp16 inference form (`fused_tokens_ok`), (bs, S, C) otherwise."""
         if value is None:
             value = query
         if identity is None:
@@ -137,32 +191,47 @@ class MultiScaleDeformableAttention(nn.Module):
             query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
         shapes = [(int(h), int(w)) for h, w in spatial_shapes]
         bs, nq, _ = query.shape
-        v = self.value_proj(value)
-        if key_padding_mask is not None:
-            v = v.masked_fill(key_padding_mask[..., None], 0.0)
+        fused = self.embed_dims == 128 and self.num_heads == 8 and fused_tokens_ok(query, self) and key_padding_mask is None
         n_off = self.num_heads * self.num_levels * self.num_points * 2
-        w, b = self.packed()
-        proj = F.linear(query, w, b)                                           # (bs, nq, heads*L*P*3)
+        n_log = n_off // 2
         ref = reference_points.to(torch.float32).contiguous()
-        if torch.is_grad_enabled() and (v.requires_grad or proj.requires_grad):
-            out = MSDeformAttn.apply(v.contiguous(), proj, ref, shapes, self.num_points)
+        if fused:
+            # every projection through the fused chain kernels: no library GEMM, the query is read once for offsets + logits;
+            # the value map HEAD-MAJOR (bs, 8, S, 16): the gathers of ops.ms_deform_attn fetch 64-byte pieces
+            if projected_value is not None:
+                v = projected_value
+            else:
+                wv, bv = module_cache(self.value_proj, '_di_w16', [self.value_proj],
+                                      lambda: (self.value_proj.weight.detach().to(torch.float16).contiguous(),
+                                               self.value_proj.bias.detach().float().contiguous()))
+                v = ops.token_linear_hm(value.reshape(-1, 128).contiguous(), wv, bv, value.shape[1])
+            images = self.projection_images()
+            ys = ops.token_linear_multi(query.reshape(-1, 128).contiguous(), images)
+            if len(images) == 1:
+                proj = ys[0].view(bs, nq, 128)
+                offsets, logits = proj[..., :n_off], proj[..., n_off:n_off + n_log]
+            else:
+                offsets, logits = ys[0].view(bs, nq, 128)[..., :n_off], ys[1].view(bs, nq, 128)[..., :n_log]
+            out = ops.ms_deform_attn(v, offsets, logits, ref, shapes, self.num_points, head_major=True)
         else:
-            out = ops.ms_deform_attn(v.contiguous(), proj[..., :n_off], proj[..., n_off:], ref, shapes, self.num_points)
-        if (then_norm is not None and self.batch_first and out.is_cuda and out.dtype == torch.float16
-                and not torch.is_grad_enabled() and not self.training and self.embed_dims == 128
-                and isinstance(then_norm, nn.LayerNorm) and then_norm.elementwise_affine
-                and then_norm.weight.dtype == torch.float16 and identity.shape == out.shape):
+            v = self.value_proj(value) if projected_value is None else projected_value
+            if key_padding_mask is not None:
+                v = v.masked_fill(key_padding_mask[..., None], 0.0)
+            w, b = self.packed()
+            proj = F.linear(query, w, b)                                           # (bs, nq, heads*L*P*3)
+            if torch.is_grad_enabled() and (v.requires_grad or proj.requires_grad):
+                out = MSDeformAttn.apply(v.contiguous(), proj, ref, shapes, self.num_points)
+            else:
+                out = ops.ms_deform_attn(v.contiguous(), proj[..., :n_off], proj[..., n_off:], ref, shapes, self.num_points)
+        if then_norm is not None and self.can_fuse_norm(out, then_norm) and identity.shape == out.shape:
             # output projection + residual + post-norm in one kernel (ops.linear_ln)
-            key = param_key(self.output_proj)
-            hit = self.__dict__.get('_out_image')
-            if hit is None or hit[0] != key:
-                with torch.no_grad():
-                    hit = (key, ops.chain_image(self.output_proj.weight.float(), self.output_proj.bias.float()))
-                self.__dict__['_out_image'] = hit
-            y = ops.linear_ln(out.reshape(-1, 128).contiguous(), hit[1], identity.reshape(-1, 128).contiguous(),
-                              then_norm.weight, then_norm.bias, then_norm.eps)
-            return y.view(out.shape)
-        out = self.output_proj(out)
+            image = module_cache(self, '_out_image', [self.output_proj],
+                                 lambda: ops.chain_image(self.output_proj.weight.float(), self.output_proj.bias.float()))
+            y = ops.linear_ln(out.reshape(-1, 128).contiguous(), image, identity.reshape(-1, 128).contiguous(),
+                              then_norm.weight, then_norm.bias, then_norm.eps, with_sum=with_sum)
+            return (y[0].view(out.shape), y[1].view(out.shape)) if with_sum else y.view(out.shape)
+        assert not with_sum, 'with_sum belongs to the fused form (check can_fuse_norm first)'
+        out = linear128(self.output_proj, out) if fused else self.output_proj(out)
         if not self.batch_first:
             out = out.permute(1, 0, 2)
         if then_norm is not None:

@@ -287,17 +287,62 @@ def ffn_ln(x, images, ln_w, ln_b, eps=1e-5):
     return y
 
 
-def linear_ln(x, image, residual, ln_w, ln_b, eps=1e-5):
-    """LayerNorm(residual + x @ W^T + b) over (M,128) fp16 tokens in one launch; image = chain_image(W, b) (128 x 128)."""
+def linear_ln(x, image, residual, ln_w, ln_b, eps=1e-5, with_sum=False):
+    """LayerNorm(residual + x @ W^T + b) over (M,128) fp16 tokens in one launch; image = chain_image(W, b) (128 x 128).
+    with_sum: also return the un-normalised sum (fp16) -> (y, sum)."""
     _dev(x, residual)
     assert x.dtype == torch.float16 and x.dim() == 2 and x.shape[1] == 128 and x.is_contiguous()
     assert residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous()
     assert ln_w.dtype == torch.float16 and ln_b.dtype == torch.float16 and ln_w.numel() == 128
     y = torch.empty_like(x)
+    pre = torch.empty_like(x) if with_sum else None
     arr = (ctypes.c_void_p * 1)(image.data_ptr())
-    _lib.call('di_ffn_ln_fwd', x.data_ptr(), 1, ctypes.addressof(arr), residual.data_ptr(), ln_w.data_ptr(),
-              ln_b.data_ptr(), float(eps), y.data_ptr(), x.shape[0], _stream())
+    _lib.call('di_ffn_ln_fwd_ex', x.data_ptr(), 1, ctypes.addressof(arr), residual.data_ptr(), ln_w.data_ptr(),
+              ln_b.data_ptr(), float(eps), y.data_ptr(), 0 if pre is None else pre.data_ptr(), x.shape[0], _stream())
+    return (y, pre) if with_sum else y
+
+
+def token_linear(x, w, b, relu=False):
+    """y = act(x @ w^T + b) over (M, 128) fp16 tokens with the fused chain kernel (csrc/pointwise.hip) instead of a library
+    GEMM: w (128, 128) fp16 contiguous, b (128) float32.  A channels-last map IS its token matrix, so this is
+    `pointwise_chain` without the 4-D view."""
+    _dev(x, w, b)
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.shape[1] == 128 and x.is_contiguous()
+    assert w.shape == (128, 128) and w.dtype == torch.float16 and w.is_contiguous() and b.dtype == torch.float32 and b.numel() == 128
+    y = torch.empty_like(x)
+    _lib.call('di_pointwise_chain_masked_fwd', x.data_ptr(), 0, 0, w.data_ptr(), b.data_ptr(), 0, 0, y.data_ptr(), x.shape[0],
+              128, 0, int(bool(relu)), 0, 0, 0, _stream())
     return y
+
+
+def token_linear_hm(x, w, b, tokens_per_map):
+    """`token_linear` whose output is written HEAD-MAJOR: x (bs * T, 128) fp16 tokens -> (bs, 8, T, 16), the value layout
+    `ms_deform_attn(..., head_major=True)` gathers from (two corners of a footprint row = 64 contiguous bytes)."""
+    _dev(x, w, b)
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.shape[1] == 128 and x.is_contiguous()
+    assert w.shape == (128, 128) and w.dtype == torch.float16 and w.is_contiguous() and b.dtype == torch.float32 and b.numel() == 128
+    T = int(tokens_per_map)
+    assert T > 0 and x.shape[0] % T == 0
+    y = torch.empty((x.shape[0] // T, 8, T, 16), dtype=x.dtype, device=x.device)
+    _lib.call('di_pointwise_chain_hm_fwd', x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), x.shape[0], T, 0, _stream())
+    return y
+
+
+def token_linear_multi(x, images):
+    """Several 128-output projections of the SAME (M, 128) fp16 tokens in one launch that reads x once (`pointwise_multi`):
+    images = [chain_image(w_k, b_k)] with w_k (128, 128) - pad narrower projections with zero rows.  Returns one (M, 128)
+    tensor per image."""
+    _dev(x)
+    assert x.dtype == torch.float16 and x.dim() == 2 and x.shape[1] == 128 and x.is_contiguous() and 1 <= len(images) <= 4
+    nc = len(images)
+    ys = [torch.empty_like(x) for _ in images]
+    P, I = ctypes.c_void_p * nc, ctypes.c_int * nc
+    for im in images:
+        assert im.dtype == torch.uint8 and im.numel() == 2 * 128 * 128 * 2 + 1024 and im.is_cuda
+    a_im, a_y, zero = P(*[im.data_ptr() for im in images]), P(*[y.data_ptr() for y in ys]), I(*([0] * nc))
+    _lib.call('di_pointwise_multi_fwd', x.data_ptr(), nc, ctypes.addressof(a_im), ctypes.addressof(a_y), ctypes.addressof(zero),
+              ctypes.addressof(zero), ctypes.addressof(zero), x.shape[0], _stream())
+    return ys
 
 
 def pointwise_multi(x, chains):
@@ -520,10 +565,11 @@ def bevwarp_gather(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range):
     return out
 
 
-def warp_project(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range, chains):
+def warp_project(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range, chains, head_major=False):
     """`pointwise_multi(bevwarp_gather(bev, depth, ...), chains)` in one launch: the warped map is gathered into the
     projection kernel's registers and never written (bit-identical outputs).  At most two chains (the P2I block's key / value
-    projections): both weight images stay resident in LDS.  bev (1,128,Hb,Wb) fp16 channels-last."""
+    projections): both weight images stay resident in LDS.  bev (1,128,Hb,Wb) fp16 channels-last.
+    head_major: the (single-link) chains write (V, 8, Hi*Wi, 16) - see `token_linear_hm`."""
     _dev(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range)
     bev = cl(bev)
     _, C, Hb, Wb = bev.shape
@@ -531,6 +577,17 @@ def warp_project(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range, chains):
     assert C == 128 and bev.dtype == torch.float16 and depth.dtype == torch.float32 and depth.is_contiguous()
     nc = len(chains)
     assert 1 <= nc <= 2, 'both weight images stay resident in LDS: at most two chains'
+    if head_major:
+        assert not any(c[3] for c in chains)
+        ys_ = [torch.empty((V, 8, Hi * Wi, 16), dtype=bev.dtype, device=bev.device) for _ in chains]
+        P, I = ctypes.c_void_p * nc, ctypes.c_int * nc
+        a_im, a_y = P(*[c[0].data_ptr() for c in chains]), P(*[y.data_ptr() for y in ys_])
+        a_r1, zero, a_hm = I(*[int(bool(c[1])) for c in chains]), I(*([0] * nc)), I(*([Hi * Wi] * nc))
+        _lib.call('di_pointwise_multi_warp_hm_fwd', bev.data_ptr(), depth.data_ptr(), img2lidar.data_ptr(), aug_fwd.data_ptr(),
+                  xs.data_ptr(), ys.data_ptr(), pc_range.data_ptr(), V, Hi, Wi, Hb, Wb, nc, ctypes.addressof(a_im),
+                  ctypes.addressof(a_y), ctypes.addressof(a_r1), ctypes.addressof(zero), ctypes.addressof(zero),
+                  ctypes.addressof(a_hm), _stream())
+        return ys_
     ys_ = [empty_cl(V, 128, Hi, Wi, bev) for _ in chains]
     P, I = ctypes.c_void_p * nc, ctypes.c_int * nc
     for (im, r1, r2, two) in chains:
@@ -711,11 +768,27 @@ def _rows(t):
     return t.data_ptr(), rs
 
 
-def ms_deform_attn(value, offsets, logits, ref, level_hw, n_points=4):
+def ms_deform_attn(value, offsets, logits, ref, level_hw, n_points=4, head_major=False):
     """mmcv MultiScaleDeformableAttention core.  value (bs,S,128) contiguous; offsets (bs,nq,8*L*P*2) and logits
     (bs,nq,8*L*P): views (possibly into one packed projection) with unit column stride; ref (1|bs,nq,L,2) float32;
-    level_hw [(H,W),...] -> (bs,nq,128)."""
+    level_hw [(H,W),...] -> (bs,nq,128).  head_major: value is (bs, 8, S, 16) fp16 (`token_linear_hm`)."""
     _dev(value, offsets, logits, ref)
+    if head_major:
+        bs, _, S, _ = value.shape
+        nq, L = offsets.shape[1], len(level_hw)
+        assert value.shape == (bs, 8, S, 16) and value.is_contiguous() and value.dtype == torch.float16
+        assert offsets.dtype == logits.dtype == torch.float16
+        assert offsets.shape[-1] == 8 * L * n_points * 2 and logits.shape[-1] == 8 * L * n_points
+        assert sum(h * w for h, w in level_hw) == S and ref.dtype == torch.float32 and ref.is_contiguous()
+        assert ref.shape[1:] == (nq, L, 2) and ref.shape[0] in (1, bs)
+        op, ors = _rows(offsets)
+        lp, lrs = _rows(logits)
+        out = torch.empty((bs, nq, 128), dtype=value.dtype, device=value.device)
+        hw = _level_array(level_hw)
+        _profiled('ms_deform_attn_fwd', bs * nq, lambda: _lib.call(
+            'di_ms_deform_attn_hm_fwd', value.data_ptr(), op, ors, lp, lrs, ref.data_ptr(), int(ref.shape[0] == 1),
+            out.data_ptr(), bs, nq, L, n_points, ctypes.addressof(hw), _stream()))
+        return out
     bs, S, E = value.shape
     nq, L = offsets.shape[1], len(level_hw)
     assert E == 128 and value.is_contiguous() and offsets.dtype == value.dtype == logits.dtype

@@ -329,6 +329,25 @@ int di_add_layernorm_fwd(const void *x, const void *res, const void *gamma, cons
 int di_ms_deform_attn_fwd(const void *value, const void *offsets, int off_row_stride, const void *logits,
                           int logit_row_stride, const float *ref, int ref_shared, void *out, int bs, int nq,
                           int n_levels, int n_points, const int32_t *level_hw, int dtype, void *stream);
+/* The same over a HEAD-MAJOR fp16 value map (bs, 8, sum H_l W_l, 16) - inference form, round 5.  The channels-last kernel
+ * is bound by the texture addresser (one 32-byte piece per clock: a head's 16 channels of one texel); head-major, the two
+ * corners of a footprint row are 64 contiguous bytes fetched by four lanes as one piece.  The value projection writes that
+ * layout directly:
+ *   di_pointwise_chain_hm_fwd: y_hm[(b * 8 + h) * T + t][16] = (x @ w^T + b)[b * T + t][16 h .. 16 h + 15]  over n_tokens =
+ *     bs * T fp16 tokens of 128 channels (w (128,128) fp16, b (128) float32; the arithmetic of di_pointwise_chain_fwd);
+ *   di_pointwise_multi_warp_hm_fwd: di_pointwise_multi_warp_fwd with a HOST array `hm_tokens` (per chain: tokens per map
+ *     for a head-major output, 0 for channels-last) - the ++ P2I block's value projection gathers the warped BEV map
+ *     itself AND writes head-major (necks/fusion_transformerv4.py:228-240). */
+int di_ms_deform_attn_hm_fwd(const void *value_hm, const void *offsets, int off_row_stride, const void *logits,
+                             int logit_row_stride, const float *ref, int ref_shared, void *out, int bs, int nq,
+                             int n_levels, int n_points, const int32_t *level_hw, void *stream);
+int di_pointwise_chain_hm_fwd(const void *x, const void *w, const float *b, void *y_hm, long long n_tokens,
+                              int tokens_per_map, int relu, void *stream);
+int di_pointwise_multi_warp_hm_fwd(const void *bev, const float *depth, const float *img2lidar, const float *aug_fwd,
+                                   const float *xs, const float *ys, const float *pc_range, int n_views, int Hi, int Wi,
+                                   int Hb, int Wb, int n_chains, const void *const *image_host, void *const *y_host,
+                                   const int *relu1_host, const int *relu2_host, const int *two_links_host,
+                                   const int *hm_tokens_host, void *stream);
 int di_grid_gather_fwd(const void *feat, const float *grid, const void *add, void *out, int n_grids, int n_points,
                        int grids_per_feat, int H, int W, int C, int dtype, void *stream);
 int di_polar_bev_sample_fwd(const void *polar, const void *bev, const float *proj, const float *aug_rev,
@@ -389,6 +408,11 @@ int di_pointwise_multi_warp_fwd(const void *bev, const float *depth, const float
  * block + its post-norm): n_chunks = 1, image[0] = the one-link chain image of (W, b). */
 int di_ffn_ln_fwd(const void *x, int n_chunks, const void *const *image, const void *residual, const void *ln_w,
                   const void *ln_b, float eps, void *y, long long n_tokens, void *stream);
+/* The same with a second output: presum (n_tokens, 128) fp16 = the sum BEFORE the normalisation (NULL = di_ffn_ln_fwd).  A
+ * DeepInteraction++ layer keeps the un-normalised self-attention output (`self_feat`, necks/fusion_transformerv4.py:187-190)
+ * next to its LayerNorm: output projection + residual + both results are then one launch. */
+int di_ffn_ln_fwd_ex(const void *x, int n_chunks, const void *const *image, const void *residual, const void *ln_w,
+                     const void *ln_b, float eps, void *y, void *presum, long long n_tokens, void *stream);
 
 /* ---------------------------------------------------------------- 3x3 convolutions (stride 1, pad 1), implicit GEMM
  * The shared convolutions of the MMRI encoder (necks/deepinteraction_encoder.py:45-62) and the heat-map heads of the

@@ -47,6 +47,47 @@ def test_ms_deform_attn_kernel(dtype, tol, levels):
     assert torch.equal(out_b, out)
 
 
+@pytest.mark.parametrize('levels', [[(9, 13)], [(12, 20), (6, 10)], [(112, 200), (56, 100)]])
+def test_ms_deform_attn_head_major_kernel(levels):
+    """Round 5: the inference form that gathers from a HEAD-MAJOR value map (bs, 8, S, 16) - lanes = (query, head, corner
+    column, channel half), a quad's geometry shared by DPP broadcasts - against the CPU restatement of mmcv's core, the value
+    map produced by the projection kernel that writes that layout (`ops.token_linear_hm`), many samples outside the map,
+    shared and per-batch reference points; and the head-major projection itself against the channels-last one (bit for bit,
+    same arithmetic, other addresses)."""
+    from deepinteraction_amd import ops
+    g = torch.Generator().manual_seed(5)
+    bs, L, P = 3, len(levels), 4
+    nq = levels[0][0] * levels[0][1] if levels[0][0] > 100 else 217
+    S = sum(h * w for h, w in levels)
+    x = torch.randn(bs * S, 128, generator=g).half().to(DEV)
+    wv = (torch.randn(128, 128, generator=g) * 0.1).half().to(DEV)
+    bv = (torch.randn(128, generator=g) * 0.1).to(DEV)
+    v_cl = ops.token_linear(x, wv, bv).view(bs, S, 128)
+    v_hm = ops.token_linear_hm(x, wv, bv, S)
+    assert v_hm.shape == (bs, 8, S, 16)
+    assert torch.equal(v_hm.permute(0, 2, 1, 3).reshape(bs, S, 128), v_cl)
+    off = (torch.randn(bs, nq, 8 * L * P * 2, generator=g) * 3.0).half()    # many samples leave the map
+    logit = (torch.randn(bs, nq, 8 * L * P, generator=g) * 2.0).half()
+    ref = torch.rand(1, nq, 1, 2, generator=g).repeat(1, 1, L, 1).contiguous()
+    n_off = off.shape[-1]
+    packed = torch.zeros(bs, nq, 256, dtype=torch.float16)                   # strided views into a wider row
+    packed[..., :n_off], packed[..., n_off:n_off + logit.shape[-1]] = off, logit
+    packed = packed.to(DEV)
+    o_v, l_v = packed[..., :n_off], packed[..., n_off:n_off + logit.shape[-1]]
+    out = ops.ms_deform_attn(v_hm, o_v, l_v, ref.to(DEV), levels, head_major=True)
+    w = logit.float().view(bs, nq, 8, L * P).softmax(-1).view(bs, nq, 8, L, P)
+    norm = torch.tensor([[w_, h_] for h_, w_ in levels], dtype=torch.float32)
+    loc = ref[:, :, None, :, None, :] + off.float().view(bs, nq, 8, L, P, 2) / norm[None, None, None, :, None, :]
+    want = tp.ms_deform_attn_core(v_cl.float().cpu().view(bs, S, 8, 16), levels, loc, w)
+    d = (out.float().cpu() - want).abs().max().item()
+    assert d <= 4e-3 * max(1.0, want.abs().max().item()), d
+    old = ops.ms_deform_attn(v_cl.contiguous(), o_v, l_v, ref.to(DEV), levels)      # the channels-last kernel: same maths
+    assert (out.float() - old.float()).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+    ref_b = ref.repeat(bs, 1, 1, 1).contiguous()
+    out_b = ops.ms_deform_attn(v_hm, o_v, l_v, ref_b.to(DEV), levels, head_major=True)
+    assert torch.equal(out_b, out)
+
+
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 1e-5), (torch.float16, 2e-3)])
 def test_grid_gather_kernel(dtype, tol):
     from deepinteraction_amd import ops

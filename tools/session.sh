@@ -49,7 +49,7 @@ for step in "$@"; do
     py)
       ( timeout 900 python $arg ) > $OUT/py_$n.log 2>&1; tail -40 $OUT/py_$n.log ;;
     sh)
-      ( eval "timeout 900 $arg" ) > $OUT/sh_$n.log 2>&1; tail -40 $OUT/sh_$n.log ;;
+      ( timeout 900 bash -c "$arg" ) > $OUT/sh_$n.log 2>&1; tail -40 $OUT/sh_$n.log ;;
     *) echo "unknown step $step" ;;
   esac
 done
