@@ -189,41 +189,18 @@ class FusedDecoder:
         return self._c(('blk2', id(blk)), blk, build)
 
     @staticmethod
-    def _self_ffn(c, y):
-        """self_norm(y + self_ffn(y)) * self_scale on a handful of float32 tokens."""
-        h = torch.relu(F.linear(y, c['sw1'], c['sb1']))
-        return F.layer_norm(y + F.linear(h, c['sw2'], c['sb2']), (y.shape[-1],), c['sn'][0], c['sn'][1], c['sn_eps']) * c['self_scale']
-
-    def _self_feature_img(self, c, x, qkv, view, member, B, Q, V):
+    def _self_feature_img(c, x, qkv, view, member, B, Q, V):
         """decoder_utils.py:970-990 as the product restates it (`ImageRCNNBlockV2._refine_views`): per valid view the FIRST
         query of the view attends to the view's queries (q / k / v rows are the ones the main attention uses), goes
         through norm1 and the self FFN + LayerNorm; query q then receives the feature of ITS view v*(q) (the published
-        broadcast keeps row 0 of every group).  (B*Q, 128) float32, already times `self_scale`."""
-        H = c['heads']
-        qk, vt = qkv
-        q = qk[:, :128].reshape(B, Q, H, -1)
-        k = qk[:, 128:].reshape(B, Q, H, -1)
-        v = vt[:, :, :Q].transpose(1, 2).reshape(B, Q, H, -1)
-        dev = x.device
-        sel = ((member.view(B, 1, Q).to(torch.int32) >> torch.arange(V, device=dev, dtype=torch.int32).view(1, V, 1)) & 1).bool()
-        ar = torch.arange(Q, device=dev).view(1, 1, Q)
-        first = torch.where(sel, ar, torch.full_like(ar, Q)).min(-1).values          # (B,V); Q when the view is unused
-        firstc = first.clamp(max=Q - 1)
-        qf = q.gather(1, firstc.view(B, V, 1, 1).expand(B, V, H, q.shape[-1]))
-        allowed = sel | (first >= Q).unsqueeze(-1)
-        sc = torch.einsum('bvhd,bqhd->bvhq', qf, k) * c['scale']
-        sc = sc.masked_fill(~allowed.unsqueeze(2), float('-inf'))
-        o = torch.einsum('bvhq,bqhd->bvhd', torch.softmax(sc, -1), v).reshape(B, V, -1)
-        xf = x.view(B, Q, -1).gather(1, firstc.unsqueeze(-1).expand(B, V, x.shape[-1]))
-        yf = F.layer_norm(xf + F.linear(o, c['wo'], c['bo']), (x.shape[-1],), c['n1'][0], c['n1'][1], c['eps'][0])
-        sf = self._self_ffn(c, yf)                                                   # (B,V,C)
-        vc = view.view(B, Q).to(torch.int64).clamp(min=0)
-        return sf.gather(1, vc.unsqueeze(-1).expand(B, Q, sf.shape[-1])).reshape(B * Q, -1).contiguous()
+        broadcast keeps row 0 of every group).  (B*Q, 128) float32, already times `self_scale`.  One launch
+        (csrc/v2_self.hip; rounds 3-4: ~35 float32 torch launches on <= 6 tokens)."""
+        return ops.v2_self_feature(c, x, B, Q, qkv=qkv, view=view, member=member, V=V)
 
-    def _self_feature_pts(self, c, y, B, Q):
+    @staticmethod
+    def _self_feature_pts(c, y, B, Q):
         """decoder_utils.py:1086-1089 (`PointRCNNBlockV2._refine_all`): the self feature of query 0, for every query."""
-        s0 = self._self_ffn(c, y.view(B, Q, -1)[:, 0])                               # (B,C)
-        return s0.unsqueeze(1).expand(B, Q, s0.shape[-1]).reshape(B * Q, -1).contiguous()
+        return ops.v2_self_feature(c, y, B, Q)
 
     def _layer_consts(self, layer):
         def build():

@@ -1193,6 +1193,31 @@ def roi_select(rect, on=None):
     return rois, view, member, keep, on_img
 
 
+def v2_self_feature(c, x, B, Q, qkv=None, view=None, member=None, V=0):
+    """The self branch of a ++ V2 RoI block in one launch (csrc/v2_self.hip): c = the block's constants
+    (decoder_fused._block_consts_v2); image block: x = the block's input tokens, qkv = ((B*Q,256) [q | k] rows, (B,128,Qp)
+    V^T), view int8 / member uint8 of ops.roi_select; point block (qkv None): x = norm1(x + attention).  -> (B*Q,128) float32,
+    already times `self_scale`."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape == (B * Q, 128)
+    out = torch.empty((B * Q, 128), dtype=torch.float32, device=x.device)
+    image = qkv is not None
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    qk, vt = qkv if image else (None, None)
+    if image:
+        assert qk.dtype == vt.dtype == torch.float32 and qk.is_contiguous() and vt.is_contiguous() and qk.shape == (B * Q, 256)
+        assert vt.shape[:2] == (B, 128) and view.dtype == torch.int8 and member.dtype == torch.uint8
+    hidden = c['sw1'].shape[0]
+    for k in ('sw1', 'sb1', 'sw2', 'sb2', 'wo', 'bo'):
+        assert c[k].dtype == torch.float32 and c[k].is_contiguous()
+    _lib.call('di_v2_self_feature', ptr(qk), ptr(vt), x.data_ptr(), ptr(view), ptr(member), c['wo'].data_ptr(), c['bo'].data_ptr(),
+              c['n1'][0].data_ptr(), c['n1'][1].data_ptr(), float(c['eps'][0]), float(c['scale']), c['sw1'].data_ptr(),
+              c['sb1'].data_ptr(), c['sw2'].data_ptr(), c['sb2'].data_ptr(), c['sn'][0].data_ptr(), c['sn'][1].data_ptr(),
+              float(c['sn_eps']), c['self_scale'].data_ptr(), out.data_ptr(), B, Q, int(vt.shape[2]) if image else Q, int(V),
+              int(hidden), int(image), _stream())
+    return out
+
+
 def query_init(bev, top, ce_w, ce_b, pe):
     """bev (B,128,H,W) channels-last fp16, top (B,Q) int64 flattened (class, cell) picks, ce_w (128,ncls) / ce_b (128)
     float32, pe = float32 (w1 (128,2), b1, w2 (128,128), b2) -> feat (B*Q,128), pos_embed (B*Q,128) float32, pos

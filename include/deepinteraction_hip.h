@@ -357,6 +357,19 @@ int di_mha_small_fwd(const void *q, int q_row_stride, const void *k, const void 
                      int out_row_stride, int n_seq, int Tq, int S, int num_heads, int head_dim, float scale, int dtype,
                      void *stream);
 
+/* The "self" branch of the ++ head's V2 RoI blocks (models/utils/decoder_utils.py:970-990 image, :1086-1089 point) in one
+ * launch, float32: as published, every query of a group receives the self-branch feature of the group's FIRST query, so the
+ * branch works on one token per (sample, view) [image = 1: that view's first query attends to the view's queries - q / k rows
+ * `qk` (B*Q, 256) and transposed values `vt` (B, 128, Qp) of the block's packed projection -, output projection `wo`, `bo`,
+ * residual with `x`, norm1] or one per sample [image = 0: `x` = norm1(x + attention), query 0], then the self FFN
+ * (sw1 (hidden,128), sw2 (128,hidden), ReLU) + residual + LayerNorm (snw, snb) times self_scale[0]; out (B*Q, 128) receives,
+ * per query, the feature of its last view (`view` int8, -1 -> view 0; `member` uint8 bit v = seen by view v). */
+int di_v2_self_feature(const float *qk, const float *vt, const float *x, const signed char *view,
+                       const unsigned char *member, const float *wo, const float *bo, const float *n1w, const float *n1b,
+                       float eps1, float scale, const float *sw1, const float *sb1, const float *sw2, const float *sb2,
+                       const float *snw, const float *snb, float eps_s, const float *self_scale, float *out, int B, int Q,
+                       int Qp, int V, int hidden, int image, void *stream);
+
 /* Backward of the ++ samplers (training).  Gradient maps are float32, zero-filled by the caller, accumulated with
  * atomics; sampling geometry carries no gradient (detached in the reference too).
  * di_ms_deform_attn_bwd: grad_out (bs,nq,128) -> grad_value (bs,S,128) float32 and grad_proj: bs*nq rows of
