@@ -53,11 +53,12 @@ def parse():
     ap.add_argument('--shape', default='R', choices=['R', 'A', 'TINY'])
     ap.add_argument('--model', default='v1', choices=['v1', 'pp'], help='pp = DeepInteraction++ (configs[4])')
     ap.add_argument('--mode', default='forward', choices=['forward', 'train'], help='train = configs[2]/[3]')
-    ap.add_argument('--inflight', type=int, default=2,
+    ap.add_argument('--inflight', type=int, default=3,
                     help='samples in flight per GPU: N independent captured forwards, each load()ed with its own sample and replayed '
-                         'on its own stream (a step = N x batch samples; 2 = the reference\'s samples_per_gpu, '
-                         'Fusion_0075_refactor.py:94); 1 = one sample at a time (the latency figure, also reported as '
-                         '`single_sample` in the default line)')
+                         'on its own stream (a step = N x batch samples).  3 since round 5: the decoder half of a forward is a chain '
+                         'of launches that fill a fraction of the chip, a third sample fills more of it (same box: 924 / 957 / 939 '
+                         'samples/s at 2 / 3 / 4); 2 = the reference\'s samples_per_gpu (Fusion_0075_refactor.py:94), the default of '
+                         'rounds 2-4; 1 = one sample at a time (the latency figure, also reported as `single_sample`)')
     ap.add_argument('--amp', action='store_true',
                     help='train mode: mixed precision - the hot path under torch.autocast(fp16) (fp16 activations, the fused '
                          'matrix-core window attention forward / backward of csrc/local_attn_train.hip), float32 master weights, '
@@ -428,6 +429,32 @@ def bench_forward(args, rank, world, device):
     durs, shared = la_times(prof), la_times(in_step)
     avg = sum(durs) / max(len(durs), 1)
     achieved = alg_bytes / avg / 1e9 if durs else None
+    # The streaming floor of THIS box for the launch's bytes: an element-wise kernel that reads three maps of the launch's size
+    # and writes one (torch.addcmul), cold inputs (three rotating sets > the 256 MB Infinity Cache), graph replay, HIP events.
+    # The fit of rounds 3-4 (launch time = 26 us + 0.047 us per MB through the vector L1) says the window attention cannot go
+    # below this figure: `frac_of_stream_floor` = floor / launch time is the fraction of the attainable it reaches.
+    stream_floor_us = None
+    if durs and device.type == 'cuda' and dtype == torch.float16:
+        gq = torch.Generator(device=device).manual_seed(0)
+        mk = lambda: torch.randn(n_img, 128, Hi, Wi, device=device, generator=gq).half().contiguous(memory_format=torch.channels_last)
+        sets = [(mk(), mk(), mk()) for _ in range(3)]
+        outs = [torch.empty_like(sets[0][0]) for _ in range(3)]
+        f3 = lambda i: torch.addcmul(sets[i][0], sets[i][1], sets[i][2], out=outs[i])
+        f3(0)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for r_ in range(9):
+                f3(r_ % 3)
+        gr.replay()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(5):
+            gr.replay()
+        ev1.record()
+        torch.cuda.synchronize()
+        stream_floor_us = ev0.elapsed_time(ev1) / 45 * 1e3
+        del gr, sets, outs
     pmc = pmc_file('pmc_local_attn.json')
     roofline = dict(bound='hbm', kernel=f'di_local_attn_fwd, image side {n_img}x{Hi}x{Wi}, 9x9, C=128 '
                                         f'({ops.local_attention_kernel_name()})',
@@ -438,6 +465,8 @@ def bench_forward(args, rank, world, device):
                     pmc_note='traffic / mfma_busy / lds_busy are read from the committed rocprofv3 --pmc session named in pmc_source '
                              '(profiles/pmc_local_attn.json), not measured by this run; achieved / frac / avg_launch_us are live',
                     avg_launch_us=round(avg * 1e6, 2), launches=len(durs), algorithmic_bytes=alg_bytes,
+                    stream_floor_us=None if stream_floor_us is None else round(stream_floor_us, 2),
+                    frac_of_stream_floor=None if not stream_floor_us or not durs else round(stream_floor_us / (avg * 1e6), 4),
                     in_step_avg_us=round(sum(shared) / max(len(shared), 1) * 1e6, 2),
                     timed_in=f'{args.roofline_steps} eager single-stream forwards right after the timed region, HIP '
                              'events on the launch stream; in_step_avg_us: the same with the two-stream schedule')
