@@ -635,7 +635,9 @@ def bench_forward_pp(args, rank, world, device):
                      inflight=max(1, args.inflight),
                      launch='eager' if args.eager else 'per step and sample in flight: load() + hipGraph replay',
                      graph_nodes=None if g is None else g.num_nodes()))
-    out['roofline'] = dict(bound='hbm', kernel='pp::ms_deform_attn_kernel, image self-attention (2 levels)',
+    out['roofline'] = dict(bound='hbm', kernel='pp::ms_deform_attn_hm_kernel<2, 4>, image self-attention (2 levels, 134 400 queries): '
+                                               'head-major value map (bs, 8, S, 16), lanes = (query, head, corner column, channel half), '
+                                               'quad-shared geometry (round 5; rounds 1-4: pp::ms_deform_attn_kernel on channels-last values)',
                            achieved=round(alg / avg / 1e9, 1) if durs else None, peak=HBM_PEAK_GBS, unit='GB/s',
                            frac=round(alg / avg / 1e9 / HBM_PEAK_GBS, 4) if durs else None,
                            traffic=pmc_file('pmc_ms_deform_attn.json').get('hbm_bytes_per_launch'),

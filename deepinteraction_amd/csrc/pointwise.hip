@@ -449,72 +449,86 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
     const h8 floor1 = {fh1, fh1, fh1, fh1, fh1, fh1, fh1, fh1}, floor2 = {fh2, fh2, fh2, fh2, fh2, fh2, fh2, fh2};
     auto step = [&](auto J0, auto NPc) {
       constexpr int j0 = decltype(J0)::value, NP = decltype(NPc)::value;
-      // ---- link 1
-      // the weight fragments of row block nb + 1 are read while the MFMAs of row block nb run
-      f4 acc[NP][8];
+      // ---- link 1, one PAIR of row blocks at a time: the pair (2p, 2p + 1) is stored (one-link chains) or becomes k-step p
+      // of link 2's B operand at once, so only 2 x NP accumulators are live and NP can be 4 - a weight fragment read from
+      // LDS then feeds four MFMAs instead of two (round 5: the 4-chain image launch issued 192 fragment reads per wave and
+      // chain, now 64-128; LDS reads and MFMAs cost the same number of clocks at two MFMAs per read).
+      // The weight fragments of row block nb + 1 are read while the MFMAs of row block nb run.
+      h8 hb[NP][4];
       h8 a[4], an[4];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) a[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(i, 4 * kk + g)));
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        if (nb < 7) {
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-            an[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(16 * (nb + 1) + i, 4 * kk + g)));
-          __builtin_amdgcn_sched_barrier(0);                     // reads first: they fly under this block's MFMAs
-        }
-        {
-          const f4 bias = *reinterpret_cast<const f4 *>(lb + 16 * nb + 4 * g);
-#pragma unroll
-          for (int pg = 0; pg < NP; ++pg) acc[pg][nb] = bias;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-          for (int pg = 0; pg < NP; ++pg) acc[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk], xb[j0 + pg][kk], acc[pg][nb], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) a[kk] = an[kk];
-      }
+      unsigned obase[NP], ostp = 32;                          // element offsets: < 2^24 pixels x 128 channels
       if (!two) {
+#pragma unroll
+        for (int pg = 0; pg < NP; ++pg) {
+          obase[pg] = (unsigned)pix[j0 + pg] * 128u + 8u * g;
+          if (ch.hm > 0) {
+            const int bmap = pix[j0 + pg] / ch.hm, t = pix[j0 + pg] - bmap * ch.hm;
+            obase[pg] = (((unsigned)bmap * 8u + (g >> 1)) * ch.hm + t) * 16u + (g & 1) * 8u;
+          }
+        }
+        if (ch.hm > 0) ostp = 2u * ch.hm * 16u;
+      }
+#pragma unroll
+      for (int p2 = 0; p2 < 4; ++p2) {
+        f4 acc[2][NP];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int nb = 2 * p2 + e;
+          // (NP <= 2: the whole next row block is read ahead into a second fragment set; NP >= 3: a fragment feeds 3-4
+          // MFMAs = 48-64 clocks of matrix work, the next FRAGMENT is read under them - one register set less)
+          if constexpr (NP <= 2) {
+            if (nb < 7) {
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk)
+                an[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(16 * (nb + 1) + i, 4 * kk + g)));
+              __builtin_amdgcn_sched_barrier(0);                   // reads first: they fly under this block's MFMAs
+            }
+          }
+          {
+            const f4 bias = *reinterpret_cast<const f4 *>(lb + 16 * nb + 4 * g);
+#pragma unroll
+            for (int pg = 0; pg < NP; ++pg) acc[e][pg] = bias;
+          }
+          if constexpr (NP <= 2) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+              for (int pg = 0; pg < NP; ++pg) acc[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk], xb[j0 + pg][kk], acc[e][pg], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) a[kk] = an[kk];
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              // the fragment after this one: (nb, kk + 1), or (nb + 1, 0)
+              const int nnb = kk < 3 ? nb : nb + 1, nkk = kk < 3 ? kk + 1 : 0;
+              h8 nxt = a[0];
+              if (nnb < 8) nxt = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(16 * nnb + i, 4 * nkk + g)));
+#pragma unroll
+              for (int pg = 0; pg < NP; ++pg) acc[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], xb[j0 + pg][kk], acc[e][pg], 0, 0, 0);
+              a[0] = nxt;
+            }
+          }
+        }
         // output rows of the LAST link are permuted in the image: fragment pair (2p, 2p+1) of lane group g holds
         // channels 32p + 8g + 0..7 -> one 16-B store per pair (8-B stores are store-issue bound: ~7 B/clk/CU)
 #pragma unroll
-        for (int pg = 0; pg < NP; ++pg)
-          if (pix[j0 + pg] < Mi) {
-            size_t base = (size_t)pix[j0 + pg] * 128 + 8 * g, stp = 32;
-            if (ch.hm > 0) {
-              const int bmap = pix[j0 + pg] / ch.hm, t = pix[j0 + pg] - bmap * ch.hm;
-              base = (((size_t)bmap * 8 + (g >> 1)) * ch.hm + t) * 16 + (g & 1) * 8;
-              stp = (size_t)2 * ch.hm * 16;
-            }
-#pragma unroll
-            for (int p2 = 0; p2 < 4; ++p2) {
-              h8 o;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                o[r] = (_Float16)acc[pg][2 * p2][r];
-                o[4 + r] = (_Float16)acc[pg][2 * p2 + 1][r];
-              }
-              *reinterpret_cast<h8 *>(ch.y + base + p2 * stp) = __builtin_elementwise_max(o, floor1);
-            }
-          }
-        return;
-      }
-      // ---- link 2: the hidden activations in registers are the B operand (k = 8g + 4t + r <-> channel 32kk + 16t + 4g + r)
-      h8 hb[NP][4];
-#pragma unroll
-      for (int pg = 0; pg < NP; ++pg)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          h8 t;
+        for (int pg = 0; pg < NP; ++pg) {
+          h8 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            t[r] = (_Float16)acc[pg][2 * kk][r];
-            t[4 + r] = (_Float16)acc[pg][2 * kk + 1][r];
+            o[r] = (_Float16)acc[0][pg][r];
+            o[4 + r] = (_Float16)acc[1][pg][r];
           }
-          hb[pg][kk] = __builtin_elementwise_max(t, floor1);
+          o = __builtin_elementwise_max(o, floor1);
+          if (two) hb[pg][p2] = o;
+          else if (pix[j0 + pg] < Mi) *reinterpret_cast<h8 *>(ch.y + (size_t)(obase[pg] + p2 * ostp)) = o;
         }
+      }
+      if (!two) return;
+      // ---- link 2: the hidden activations in registers are the B operand (k = 8g + 4t + r <-> channel 32kk + 16t + 4g + r)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) a[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(i, 4 * kk + g)));
 #pragma unroll
@@ -523,24 +537,38 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int nb = 2 * p2 + e;
-          if (nb < 7) {
+          if constexpr (NP <= 2) {
+            if (nb < 7) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-              an[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(16 * (nb + 1) + i, 4 * kk + g)));
-            __builtin_amdgcn_sched_barrier(0);
+              for (int kk = 0; kk < 4; ++kk)
+                an[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(16 * (nb + 1) + i, 4 * kk + g)));
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
           {
             const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
 #pragma unroll
             for (int pg = 0; pg < NP; ++pg) o2[e][pg] = bias;
           }
+          if constexpr (NP <= 2) {
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int pg = 0; pg < NP; ++pg) o2[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk], hb[pg][kk], o2[e][pg], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+              for (int pg = 0; pg < NP; ++pg) o2[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk], hb[pg][kk], o2[e][pg], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) a[kk] = an[kk];
+            for (int kk = 0; kk < 4; ++kk) a[kk] = an[kk];
+          } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int nnb = kk < 3 ? nb : nb + 1, nkk = kk < 3 ? kk + 1 : 0;
+              h8 nxt = a[0];
+              if (nnb < 8) nxt = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(16 * nnb + i, 4 * nkk + g)));
+#pragma unroll
+              for (int pg = 0; pg < NP; ++pg) o2[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], hb[pg][kk], o2[e][pg], 0, 0, 0);
+              a[0] = nxt;
+            }
+          }
         }
 #pragma unroll
         for (int pg = 0; pg < NP; ++pg)
@@ -557,8 +585,31 @@ __global__ __launch_bounds__(NT, 2) void pointwise_multi_kernel(const __half *__
       }
     };
 
-    // groups in pairs; a wave with an odd number of groups runs its last one alone (half the MFMA work).  All
-    // conditions are wave-uniform and there is no barrier inside a step.
+    // plain form: up to FOUR groups share every weight fragment (then the fifth alone / the rest in a pair); all conditions
+    // are wave-uniform and there is no barrier inside a step
+    if constexpr (!WARP) {
+      int nv = 0;
+#pragma unroll
+      for (int j = 0; j < NG; ++j) nv += (wg + j * stride < ngroups) ? 1 : 0;
+      using IC0 = std::integral_constant<int, 0>;
+      if constexpr (NG >= 4) {
+        if (nv >= 4) {
+          step(IC0{}, std::integral_constant<int, 4>{});
+          if constexpr (NG == 5) {
+            if (nv == 5) step(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+          }
+          return;
+        }
+        if (nv == 3) {
+          step(IC0{}, std::integral_constant<int, 3>{});
+          return;
+        }
+      }
+      if (nv == 2) step(IC0{}, std::integral_constant<int, 2>{});
+      else if (nv == 1) step(IC0{}, std::integral_constant<int, 1>{});
+      return;
+    }
+    // gathered form: groups in pairs; a wave with an odd number of groups runs its last one alone (half the MFMA work)
     static_for<0, (NG + 1) / 2>([&](auto S) {
       constexpr int j0 = 2 * decltype(S)::value;
       if constexpr (only < 0 || only == decltype(S)::value) {
