@@ -89,6 +89,96 @@ __global__ __launch_bounds__(256) void dc_box_kernel(const float *__restrict__ i
   out[i] = box_extreme<R, IS_MAX>(in + (size_t)v * H * W, H, W, y, x);
 }
 
+// ---- the morphological close (5x5 dilate then 5x5 erode, :198-200) in ONE launch: a 16 x 64 tile with a halo of 4; texels
+// outside the map are -inf for the dilation and +inf for the erosion (OpenCV's default border: ignored).  Same float
+// max / min over the same values as dc_box_kernel<2, true> followed by dc_box_kernel<2, false>: bit-identical.
+constexpr int kTH = 16, kTW = 64;
+__global__ __launch_bounds__(256) void dc_close_kernel(const float *__restrict__ in, float *__restrict__ out, int V, int H,
+                                                       int W) {
+  __shared__ float a[kTH + 8][kTW + 8 + 1], b[kTH + 4][kTW + 4 + 1];
+  const int v = blockIdx.z, y0 = blockIdx.y * kTH, x0 = blockIdx.x * kTW, tid = threadIdx.x;
+  const float *d = in + (size_t)v * H * W;
+  for (int e = tid; e < (kTH + 8) * (kTW + 8); e += 256) {
+    const int ly = e / (kTW + 8), lx = e - ly * (kTW + 8), gy = y0 - 4 + ly, gx = x0 - 4 + lx;
+    a[ly][lx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? d[gy * W + gx] : -INFINITY;
+  }
+  __syncthreads();
+  for (int e = tid; e < (kTH + 4) * (kTW + 4); e += 256) {
+    const int ly = e / (kTW + 4), lx = e - ly * (kTW + 4), gy = y0 - 2 + ly, gx = x0 - 2 + lx;
+    float m = INFINITY;                                      // outside the map: ignored by the erosion
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      m = -INFINITY;
+#pragma unroll
+      for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) m = fmaxf(m, a[ly + dy][lx + dx]);
+    }
+    b[ly][lx] = m;
+  }
+  __syncthreads();
+  for (int e = tid; e < kTH * kTW; e += 256) {
+    const int ly = e / kTW, lx = e - ly * kTW, gy = y0 + ly, gx = x0 + lx;
+    if (gy >= H || gx >= W) continue;
+    float m = INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) m = fminf(m, b[ly + dy][lx + dx]);
+    out[(size_t)v * H * W + gy * W + gx] = m;
+  }
+}
+
+// ---- the six hole-filling passes of :241-245 (`dc_fill_kernel<2, true>` six times) in ONE launch: a 16 x 64 tile with a
+// halo of 12 in two LDS buffers; pass k is evaluated on the region that still has valid neighbours (it shrinks by 2 per
+// pass), texels outside the map are -inf (ignored by the dilation) and never filled.  The same comparisons and maxima over
+// the same values: bit-identical.
+template <int ITERS>
+__global__ __launch_bounds__(256) void dc_fill_iter_kernel(const float *__restrict__ in, const int32_t *__restrict__ first,
+                                                           float *__restrict__ out, int V, int H, int W) {
+  constexpr int HALO = 2 * ITERS, LH = kTH + 2 * HALO, LW = kTW + 2 * HALO;
+  __shared__ float buf[2][LH][LW + 1];
+  __shared__ int s_first[LW];
+  const int v = blockIdx.z, y0 = blockIdx.y * kTH - HALO, x0 = blockIdx.x * kTW - HALO, tid = threadIdx.x;
+  const float *d = in + (size_t)v * H * W;
+  for (int e = tid; e < LH * LW; e += 256) {
+    const int ly = e / LW, lx = e - ly * LW, gy = y0 + ly, gx = x0 + lx;
+    buf[0][ly][lx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? d[gy * W + gx] : -INFINITY;
+  }
+  for (int lx = tid; lx < LW; lx += 256) {
+    const int gx = x0 + lx;
+    s_first[lx] = (gx >= 0 && gx < W) ? first_row(first, v * W + gx, H) : H;
+  }
+  __syncthreads();
+  int cur = 0;
+#pragma unroll 1
+  for (int it = 0; it < ITERS; ++it) {
+    const int m = 2 * (it + 1), rh = LH - 2 * m, rw = LW - 2 * m;
+    for (int e = tid; e < rh * rw; e += 256) {
+      const int ly = m + e / rw, lx = m + e % rw, gy = y0 + ly, gx = x0 + lx;
+      float o = -INFINITY;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const float c = buf[cur][ly][lx];
+        o = c;
+        if (c < 0.1f && gy >= s_first[lx]) {
+          float mx = -INFINITY;
+#pragma unroll
+          for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+            for (int dx = -2; dx <= 2; ++dx) mx = fmaxf(mx, buf[cur][ly + dy][lx + dx]);
+          o = mx;
+        }
+      }
+      buf[cur ^ 1][ly][lx] = o;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (int e = tid; e < kTH * kTW; e += 256) {
+    const int ly = HALO + e / kTW, lx = HALO + e % kTW, gy = y0 + ly, gx = x0 + lx;
+    if (gy < H && gx < W) out[(size_t)v * H * W + gy * W + gx] = buf[cur][ly][lx];
+  }
+}
+
 // ---- 5x5 median, BORDER_REPLICATE (cv2.medianBlur for CV_32F)
 __device__ __forceinline__ float median25(const float *__restrict__ d, int H, int W, int y, int x) {
   float a[25];
@@ -289,21 +379,19 @@ extern "C" int di_depth_complete(const float *sparse, float *dense, float *scrat
   float *A = scratch, *B = scratch + (size_t)n, *valid = scratch + 2 * (size_t)n;
   float *mm_part = scratch + 3 * (size_t)n;                  // per-block min / max partials: 2 * V * blocks-per-view
   int32_t *first_a = iscratch, *first_b = iscratch + (size_t)V * W;
-  // 15 launches, no global atomics: the per-column "first valid row" by a column scan, the per-view min / max as
+  // 9 launches (round 5: the close and the six filling passes are one launch each; rounds 2-4: 15), no global atomics: the per-column "first valid row" by a column scan, the per-view min / max as
   // per-block partials of the kernel that produces the map
   hipLaunchKernelGGL(dc_multiscale_kernel, g, b, 0, s, sparse, A, first_a, first_b, V, H, W);   // s2
-  hipLaunchKernelGGL((dc_box_kernel<2, true>), g, b, 0, s, A, B, V, H, W);               // close: dilate
-  hipLaunchKernelGGL((dc_box_kernel<2, false>), g, b, 0, s, B, A, V, H, W);              //        erode -> s3
+  const dim3 gt((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, V);
+  hipLaunchKernelGGL(dc_close_kernel, gt, b, 0, s, A, B, V, H, W);                       // close: dilate + erode -> s3
+  { float *t = A; A = B; B = t; }
   const dim3 gc((V * W + 63) / 64);
   hipLaunchKernelGGL(dc_median_valid_kernel, g, b, 0, s, A, B, first_a, V, H, W);        // s4
   hipLaunchKernelGGL(dc_col_first_kernel, gc, b, 0, s, B, first_a, V, H, W);             // its top rows
   hipLaunchKernelGGL((dc_fill_kernel<4, false>), g, b, 0, s, B, first_a, A, first_b, V, H, W);      // s5
   hipLaunchKernelGGL(dc_col_first_kernel, gc, b, 0, s, A, first_b, V, H, W);             // its top rows
-  float *src = A, *dst = B;
-  for (int it = 0; it < 6; ++it) {                                                       // s7
-    hipLaunchKernelGGL((dc_fill_kernel<2, true>), g, b, 0, s, src, first_b, dst, (int32_t *)nullptr, V, H, W);
-    float *t = src; src = dst; dst = t;
-  }
+  float *src = B, *dst = A;
+  hipLaunchKernelGGL((dc_fill_iter_kernel<6>), gt, b, 0, s, A, first_b, B, V, H, W);     // s7: the six filling passes
   const dim3 gv((H * W + 255) / 256, V);
   hipLaunchKernelGGL(dc_median_top_kernel, gv, b, 0, s, src, first_b, dst, valid, mm_part, V, H, W);
   hipLaunchKernelGGL(dc_bilateral_invert_kernel, gv, b, 0, s, dst, valid, mm_part, dense, V, H, W);
