@@ -424,9 +424,13 @@ def bench_forward(args, rank, world, device):
     n_img = 6 * args.batch
     es = 2 if dtype == torch.float16 else 4
     alg_bytes = 4 * n_img * 128 * Hi * Wi * es
-    def la_times(events):
-        return [s.elapsed_time(e) * 1e-3 for (name, n, s, e) in events if name == 'local_attn_fwd' and n == n_img]
-    durs, shared = la_times(prof), la_times(in_step)
+    def la_times(events, stream=False):
+        # dispatch-bound events (the kernel's own begin / end time stamps, as rocprofv3 reports them) when the launch site
+        # supports them; `stream`: the interval between two events recorded on the launch stream around the launch
+        return [(s.stream_ms(e) if stream else s.elapsed_time(e)) * 1e-3 for (name, n, s, e) in events
+                if name == 'local_attn_fwd' and n == n_img]
+    durs, shared, durs_stream = la_times(prof), la_times(in_step), la_times(prof, stream=True)
+    bound = all(s.dispatch_bound() for (name, n, s, e) in prof if name == 'local_attn_fwd' and n == n_img)
     avg = sum(durs) / max(len(durs), 1)
     achieved = alg_bytes / avg / 1e9 if durs else None
     # The streaming floor of THIS box for the launch's bytes: an element-wise kernel that reads three maps of the launch's size
@@ -465,11 +469,16 @@ def bench_forward(args, rank, world, device):
                     pmc_note='traffic / mfma_busy / lds_busy are read from the committed rocprofv3 --pmc session named in pmc_source '
                              '(profiles/pmc_local_attn.json), not measured by this run; achieved / frac / avg_launch_us are live',
                     avg_launch_us=round(avg * 1e6, 2), launches=len(durs), algorithmic_bytes=alg_bytes,
+                    stream_event_avg_us=round(sum(durs_stream) / max(len(durs_stream), 1) * 1e6, 2),
                     stream_floor_us=None if stream_floor_us is None else round(stream_floor_us, 2),
                     frac_of_stream_floor=None if not stream_floor_us or not durs else round(stream_floor_us / (avg * 1e6), 4),
                     in_step_avg_us=round(sum(shared) / max(len(shared), 1) * 1e6, 2),
-                    timed_in=f'{args.roofline_steps} eager single-stream forwards right after the timed region, HIP '
-                             'events on the launch stream; in_step_avg_us: the same with the two-stream schedule')
+                    timed_in=f'{args.roofline_steps} eager single-stream forwards right after the timed region; avg_launch_us: HIP events '
+                             + ('BOUND TO THE DISPATCH on the launch stream (hipExtLaunchKernelGGL start / stop events: the '
+                                'kernel\'s own begin / end time stamps, the figure rocprofv3 --kernel-trace reports; rounds 1-4 '
+                                'reported stream_event_avg_us)' if bound else 'recorded on the launch stream around the launch')
+                             + '; stream_event_avg_us: two events recorded on the stream around the launch (adds the 2-3 us of '
+                               'their own packets); in_step_avg_us: the same with the two-stream schedule')
     out = _line(args, 'samples/sec forward (Fusion_0075 synthetic)',
                 parallel.throughput(args.batch * max(1, args.inflight), args.steps, elapsed, world), elapsed,
                 'f16' if dtype == torch.float16 else 'f32',
@@ -623,8 +632,9 @@ def bench_forward_pp(args, rank, world, device):
     S = 6 * args.batch * (Hi * Wi + (Hi // 2) * (Wi // 2))
     alg = (S * 128 + nq * (8 * 2 * 4 * 3 + 128)) * es        # value + packed offsets/logits + output
     durs = [s.elapsed_time(e) * 1e-3 for (name, n, s, e) in prof if name == 'ms_deform_attn_fwd' and n == nq]
+    durs_stream = [s.stream_ms(e) * 1e-3 for (name, n, s, e) in prof if name == 'ms_deform_attn_fwd' and n == nq]
     # the image self-attention (2 levels) and the P2I cross attention (1 level) share nq: the 2-level one is slower
-    durs = sorted(durs)[len(durs) // 2:]
+    durs, durs_stream = sorted(durs)[len(durs) // 2:], sorted(durs_stream)[len(durs_stream) // 2:]
     avg = sum(durs) / max(len(durs), 1)
     out = _line(args, 'samples/sec forward (Fusion_0075_plusplus synthetic)',
                 parallel.throughput(args.batch * max(1, args.inflight), args.steps, elapsed, world), elapsed,
@@ -641,7 +651,11 @@ def bench_forward_pp(args, rank, world, device):
                            achieved=round(alg / avg / 1e9, 1) if durs else None, peak=HBM_PEAK_GBS, unit='GB/s',
                            frac=round(alg / avg / 1e9 / HBM_PEAK_GBS, 4) if durs else None,
                            traffic=pmc_file('pmc_ms_deform_attn.json').get('hbm_bytes_per_launch'),
-                           avg_launch_us=round(avg * 1e6, 2), launches=len(durs), algorithmic_bytes=alg)
+                           avg_launch_us=round(avg * 1e6, 2), launches=len(durs), algorithmic_bytes=alg,
+                           stream_event_avg_us=round(sum(durs_stream) / max(len(durs_stream), 1) * 1e6, 2),
+                           timed_in='eager forwards after the timed region; avg_launch_us from HIP events bound to the dispatch '
+                                    '(the kernel\'s own time stamps, as rocprofv3 reports them), stream_event_avg_us from events '
+                                    'recorded on the stream around the launch')
     if single is not None:
         out['single_sample'] = single
     if want_cpu:

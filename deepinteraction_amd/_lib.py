@@ -39,6 +39,8 @@ SIGNATURES = {
     'di_bevwarp_gather_fwd': [_c_p] * 8 + [_c_i] * 7 + [_c_p],
     'di_ms_deform_attn_fwd': [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_i, _c_p],
     'di_ms_deform_attn_hm_fwd': [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p],
+    'di_timed_begin': [_c_p, _c_p],
+    'di_timed_elapsed_us': [_c_p, _c_p, _c_i, _c_p],
     'di_v2_self_feature': [_c_p] * 9 + [_c_f, _c_f] + [_c_p] * 6 + [_c_f] + [_c_p] * 2 + [_c_i] * 6 + [_c_p],
     'di_pointwise_chain_hm_fwd': [_c_p, _c_p, _c_p, _c_p, ctypes.c_longlong, _c_i, _c_i, _c_p],
     'di_pointwise_multi_warp_hm_fwd': [_c_p] * 7 + [_c_i] * 6 + [_c_p] * 7,
@@ -83,7 +85,8 @@ SIGNATURES = {
 # helpers that return a value instead of an error code
 VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_i2p_key_table_bytes': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 3,
                'di_token_splitk_workspace_bytes': [_c_i] * 2, 'di_mha_decode_x_ranges': [_c_i] * 3,
-               'di_graph_node_count': [_c_p], 'di_local_attn_ring_timeouts': [_c_p], 'di_bn_workspace_floats': [_c_i]}
+               'di_graph_node_count': [_c_p], 'di_local_attn_ring_timeouts': [_c_p], 'di_bn_workspace_floats': [_c_i],
+               'di_timed_consumed': []}
 _LONGLONG = {'di_topk_workspace_bytes', 'di_i2p_key_table_bytes', 'di_graph_node_count', 'di_token_splitk_workspace_bytes'}
 
 # ---- the step program of di_token_program (structs of include/deepinteraction_hip.h)

@@ -24,6 +24,10 @@ struct LdsRaised {
   unsigned long long done = 0;
 };
 int ensure_lds(LdsRaised &state, const void *kernel, int bytes);
+// Measurement: events BOUND TO A DISPATCH (hipExtLaunchKernelGGL's start / stop events carry the kernel's own begin / end time
+// stamps, what rocprofv3 reports; events recorded on the stream around a launch add the 2-3 us of their own packets).
+// di_timed_begin arms the calling thread; the next launch site that supports it takes the pair (and clears the slot).
+bool take_launch_events(hipEvent_t &start, hipEvent_t &stop);
 
 #define DI_REQUIRE(cond, ...)            \
   do {                                   \

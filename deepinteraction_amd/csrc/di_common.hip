@@ -49,6 +49,58 @@ long long di_graph_node_count(void *graph) {
 
 namespace di {
 
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static thread_local int g_ev_consumed = 0;
+
+bool take_launch_events(hipEvent_t &start, hipEvent_t &stop) {
+  if (g_ev_start == nullptr) return false;
+  start = g_ev_start;
+  stop = g_ev_stop;
+  g_ev_start = g_ev_stop = nullptr;
+  g_ev_consumed = 1;
+  return true;
+}
+
+}  // namespace di
+
+extern "C" {
+int di_timed_begin(void **start_ev, void **stop_ev) {
+  hipEvent_t a = nullptr, b = nullptr;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+    di::set_error("hipEventCreate failed");
+    return DI_ERR_LAUNCH;
+  }
+  di::g_ev_start = a;
+  di::g_ev_stop = b;
+  di::g_ev_consumed = 0;
+  *start_ev = a;
+  *stop_ev = b;
+  return DI_OK;
+}
+// 1 when the launch issued since di_timed_begin took the events (else they were never recorded), and disarms the thread
+int di_timed_consumed(void) {
+  di::g_ev_start = di::g_ev_stop = nullptr;
+  return di::g_ev_consumed;
+}
+int di_timed_elapsed_us(void *start_ev, void *stop_ev, int recorded, float *us) {
+  int rc = DI_OK;
+  if (recorded) {
+    float ms = 0.f;
+    if (hipEventSynchronize((hipEvent_t)stop_ev) != hipSuccess ||
+        hipEventElapsedTime(&ms, (hipEvent_t)start_ev, (hipEvent_t)stop_ev) != hipSuccess) {
+      di::set_error("hipEventElapsedTime failed");
+      rc = DI_ERR_LAUNCH;
+    }
+    *us = ms * 1e3f;
+  }
+  (void)hipEventDestroy((hipEvent_t)start_ev);
+  (void)hipEventDestroy((hipEvent_t)stop_ev);
+  return rc;
+}
+}
+
+namespace di {
+
 int device_cus() {
   static int cus[64] = {0};
   int dev = 0;

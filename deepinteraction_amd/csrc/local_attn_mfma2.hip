@@ -30,6 +30,8 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "di_common.h"
 
 namespace di {
@@ -444,9 +446,15 @@ static int launch(const void *q, const void *k, const void *v, void *out, int n,
   if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
   static const int grid_env = getenv("DI_LA_GRID") ? atoi(getenv("DI_LA_GRID")) : 0;   // measurement: workgroups of the launch
   if (grid_env > 0 && grid_env < grid) grid = grid_env / 8 * 8;
-  hipLaunchKernelGGL(local_attn_m2_kernel<G>, dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, stream,
-                     (const __half *)q, (const __half *)k, (const __half *)v, (__half *)out, n, H, W, scale,
-                     tiles_x, tiles_y);
+  hipEvent_t ev0, ev1;
+  if (take_launch_events(ev0, ev1))                          // measurement: the dispatch's own begin / end time stamps
+    hipExtLaunchKernelGGL(local_attn_m2_kernel<G>, dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, stream, ev0, ev1, 0,
+                          (const __half *)q, (const __half *)k, (const __half *)v, (__half *)out, n, H, W, scale, tiles_x,
+                          tiles_y);
+  else
+    hipLaunchKernelGGL(local_attn_m2_kernel<G>, dim3((unsigned)grid), dim3(G::NT), G::LDS_BYTES, stream,
+                       (const __half *)q, (const __half *)k, (const __half *)v, (__half *)out, n, H, W, scale,
+                       tiles_x, tiles_y);
   return check_launch("local_attn_m2");
 }
 

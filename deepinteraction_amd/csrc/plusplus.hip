@@ -16,6 +16,8 @@
 // All are gather / HBM-bound: 16 lanes own one 128-channel texel row (16 B per lane), fp32 accumulation.
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "di_common.h"
 
 namespace di {
@@ -670,12 +672,22 @@ int di_ms_deform_attn_hm_fwd(const void *value_hm, const void *offsets, int off_
   const long long rows = (long long)bs * nq;
   const dim3 grid((unsigned)((rows + 7) / 8)), blk(256);
   hipStream_t s = (hipStream_t)stream;
-  if (n_levels == 1)
-    hipLaunchKernelGGL((di::pp::ms_deform_attn_hm_kernel<1, 4>), grid, blk, 0, s, (const __half *)value_hm, (const __half *)offsets,
-                       off_row_stride, (const __half *)logits, logit_row_stride, ref, ref_shared, (__half *)out, bs, nq, S, lv);
-  else
-    hipLaunchKernelGGL((di::pp::ms_deform_attn_hm_kernel<2, 4>), grid, blk, 0, s, (const __half *)value_hm, (const __half *)offsets,
-                       off_row_stride, (const __half *)logits, logit_row_stride, ref, ref_shared, (__half *)out, bs, nq, S, lv);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  const bool timed = di::take_launch_events(ev0, ev1);       // measurement: the dispatch's own begin / end time stamps
+#define DI_MSDA_HM(LL)                                                                                                         \
+  do {                                                                                                                         \
+    if (timed)                                                                                                                 \
+      hipExtLaunchKernelGGL((di::pp::ms_deform_attn_hm_kernel<LL, 4>), grid, blk, 0, s, ev0, ev1, 0, (const __half *)value_hm, \
+                            (const __half *)offsets, off_row_stride, (const __half *)logits, logit_row_stride, ref,           \
+                            ref_shared, (__half *)out, bs, nq, S, lv);                                                         \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((di::pp::ms_deform_attn_hm_kernel<LL, 4>), grid, blk, 0, s, (const __half *)value_hm,                 \
+                         (const __half *)offsets, off_row_stride, (const __half *)logits, logit_row_stride, ref, ref_shared,   \
+                         (__half *)out, bs, nq, S, lv);                                                                        \
+  } while (0)
+  if (n_levels == 1) DI_MSDA_HM(1);
+  else DI_MSDA_HM(2);
+#undef DI_MSDA_HM
   return di::check_launch("ms_deform_attn_hm_fwd");
 }
 

@@ -23,14 +23,47 @@ _DT = {torch.float32: _lib.DI_F32, torch.float16: _lib.DI_F16}
 PROFILE = None
 
 
+class _DispatchTimer:
+    """Start 'event' of a profiled launch: `elapsed_time(end)` (ms) is the kernel's OWN duration when the launch bound a pair of
+    events to its dispatch (`di_timed_begin`: the window-attention and deformable-attention kernels - what rocprofv3 reports),
+    else the interval between two events recorded on the stream around it; `stream_ms(end)` is always the latter."""
+
+    def __init__(self):
+        self.start = torch.cuda.Event(enable_timing=True)
+        self.handles = None
+        self.us = None
+
+    def stream_ms(self, end):
+        return self.start.elapsed_time(end)
+
+    def dispatch_bound(self):
+        return self.handles is not None
+
+    def elapsed_time(self, end):
+        if self.handles is None:
+            return self.start.elapsed_time(end)
+        if self.us is None:
+            out = ctypes.c_float(0.0)
+            _lib.call('di_timed_elapsed_us', self.handles[0], self.handles[1], 1, ctypes.byref(out))
+            self.us = float(out.value)
+        return self.us * 1e-3
+
+
 def _profiled(name, n, launch):
     if PROFILE is None:
         return launch()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
+    t, e = _DispatchTimer(), torch.cuda.Event(enable_timing=True)
+    a, b = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.call('di_timed_begin', ctypes.byref(a), ctypes.byref(b))
+    t.start.record()
     launch()
     e.record()
-    PROFILE.append((name, n, s, e))
+    if _lib.lib().di_timed_consumed():
+        t.handles = (a, b)
+    else:
+        out = ctypes.c_float(0.0)
+        _lib.call('di_timed_elapsed_us', a, b, 0, ctypes.byref(out))          # never recorded: just destroy them
+    PROFILE.append((name, n, t, e))
 
 
 def _code(t):

@@ -97,6 +97,15 @@ int di_local_attn_train_bwd(const void *q, const void *k, const void *v, const v
  * since the library was loaded (0 on a healthy run; synchronises `stream`), -1 on a HIP error.  Host code checks it where it
  * synchronises anyway (`GraphedHotPath.check_health()`, bench.py); environment DI_RING_DBG=32 injects the fault (tests). */
 int di_local_attn_ring_timeouts(void *stream);
+/* Measurement plumbing (bench.py's live roofline): the duration of ONE kernel as its dispatch reports it.  di_timed_begin
+ * creates two events and arms the calling thread: the next di_local_attn_fwd* (matrix-core kernels) or
+ * di_ms_deform_attn_hm_fwd launch issued by this thread binds them to its dispatch (hipExtLaunchKernelGGL: the kernel's own
+ * begin / end time stamps - what rocprofv3 reports; events recorded on the stream around a launch add the 2-3 us of their own
+ * packets).  di_timed_consumed: 1 when a launch took them (disarms the thread either way).  di_timed_elapsed_us waits for the
+ * stop event (`recorded` = the value of di_timed_consumed), writes microseconds and destroys both events. */
+int di_timed_begin(void **start_ev, void **stop_ev);
+int di_timed_consumed(void);
+int di_timed_elapsed_us(void *start_ev, void *stop_ev, int recorded, float *us);
 /* Measurement (environment DI_RING_DBG & 16): the phase time stamps of workgroup 0's wavefronts of the last DI_LA_RING launch,
  * 16 x 128 uint64 (tag << 56 | shader clock; entry 127 of a wave = its count) copied to `host_out`. */
 int di_local_attn_ring_stamps(void *host_out, void *stream);
