@@ -39,6 +39,7 @@ SIGNATURES = {
     'di_bevwarp_gather_fwd': [_c_p] * 8 + [_c_i] * 7 + [_c_p],
     'di_ms_deform_attn_fwd': [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_i, _c_p],
     'di_ms_deform_attn_hm_fwd': [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_i, _c_i, _c_i, _c_p, _c_p],
+    'di_local_attn_ring_timeouts_async': [_c_p, _c_p],
     'di_timed_begin': [_c_p, _c_p],
     'di_timed_elapsed_us': [_c_p, _c_p, _c_i, _c_p],
     'di_v2_self_feature': [_c_p] * 9 + [_c_f, _c_f] + [_c_p] * 6 + [_c_f] + [_c_p] * 2 + [_c_i] * 6 + [_c_p],

@@ -372,6 +372,7 @@ int launch_local_attn_mfma2(const void *q, const void *k, const void *v, void *o
 int launch_local_attn_ring(const void *q, const void *k, const void *v, void *out, int n, int H, int W,
                            float scale, int cfg, hipStream_t stream);    // local_attn_ring.hip
 int ring_timeouts(unsigned *host_out, hipStream_t stream);
+int ring_timeouts_async(unsigned *host_out, hipStream_t stream);
 int ring_stamps(unsigned long long *host_out, hipStream_t stream);
 
 static int run_la(LaOp op, int dtype, int kH, int kW, const LaArgs &A) {
@@ -427,6 +428,14 @@ int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out,
 
 int di_local_attn_ring_stamps(void *host_out, void *stream) {
   return di::ring_stamps((unsigned long long *)host_out, (hipStream_t)stream);
+}
+
+int di_local_attn_ring_timeouts_async(void *host_word, void *stream) {
+  if (host_word == nullptr) {
+    di::set_error("null host word");
+    return DI_ERR_ARG;
+  }
+  return di::ring_timeouts_async((unsigned *)host_word, (hipStream_t)stream);
 }
 
 int di_local_attn_ring_timeouts(void *stream) {

@@ -589,6 +589,14 @@ int ring_stamps(unsigned long long *host_out, hipStream_t stream) {
   return hipMemcpy(host_out, buf, 16 * 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? DI_OK : DI_ERR_LAUNCH;
 }
 
+// the same without a synchronisation: the counter is copied into the caller's (pinned) host word behind everything queued on
+// `stream`; the caller looks at it whenever it likes (the value is monotonic)
+int ring_timeouts_async(unsigned *host_out, hipStream_t stream) {
+  unsigned *dev = nullptr;
+  if (hipGetSymbolAddress((void **)&dev, HIP_SYMBOL(ring::timeouts)) != hipSuccess) return DI_ERR_LAUNCH;
+  return hipMemcpyAsync(host_out, dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream) == hipSuccess ? DI_OK : DI_ERR_LAUNCH;
+}
+
 // bounded spins that gave up since the library was loaded (tests: must stay 0)
 int ring_timeouts(unsigned *host_out, hipStream_t stream) {
   unsigned *dev = nullptr;

@@ -78,6 +78,7 @@ class GraphedHotPath:
         self.query_geom = QueryGeometry(self.img_metas, dev)
         self.graph = None
         self.out = None
+        self._health = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else None
         self._build_arena()
         self._capture(warmup)
 
@@ -189,7 +190,16 @@ class GraphedHotPath:
         return self._nodes
 
     def __call__(self):
+        # faults a captured kernel can only report through device memory (the ring window attention's bounded spins: the
+        # affected tiles are NaN): a pinned host word receives the device counter behind every replay, without a
+        # synchronisation; what an EARLIER replay reported is checked here
+        if self._health is not None and int(self._health[0]) != 0:
+            raise RuntimeError(f'local_attn_ring: {int(self._health[0])} bounded spins gave up in an earlier replay - the affected '
+                               'output tiles hold NaN (ops.check_ring_health)')
         self.graph.replay()
+        if self._health is not None:
+            from . import _lib, ops
+            _lib.call('di_local_attn_ring_timeouts_async', self._health.data_ptr(), ops._stream())
         return self.out
 
     # ------------------------------------------------------------------ per-sample inputs

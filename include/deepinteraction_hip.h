@@ -97,6 +97,10 @@ int di_local_attn_train_bwd(const void *q, const void *k, const void *v, const v
  * since the library was loaded (0 on a healthy run; synchronises `stream`), -1 on a HIP error.  Host code checks it where it
  * synchronises anyway (`GraphedHotPath.check_health()`, bench.py); environment DI_RING_DBG=32 injects the fault (tests). */
 int di_local_attn_ring_timeouts(void *stream);
+/* The same without a synchronisation: the counter is copied into the caller's PINNED host word (uint32) behind everything
+ * queued on `stream`; the value is monotonic, the caller looks at it whenever it likes (`GraphedHotPath.__call__` checks the
+ * word a previous replay filled and raises). */
+int di_local_attn_ring_timeouts_async(void *host_word, void *stream);
 /* Measurement plumbing (bench.py's live roofline): the duration of ONE kernel as its dispatch reports it.  di_timed_begin
  * creates two events and arms the calling thread: the next di_local_attn_fwd* (matrix-core kernels) or
  * di_ms_deform_attn_hm_fwd launch issued by this thread binds them to its dispatch (hipExtLaunchKernelGGL: the kernel's own
