@@ -665,12 +665,18 @@ struct FfnArgs {
 };
 
 __global__ __launch_bounds__(NT, 2) void ffn_ln_kernel(const __half *__restrict__ x, __half *__restrict__ y, FfnArgs A, long long M) {
+  // PERSISTENT since round 5: one workgroup per CU walks the token pairs in passes (pair = 2 groups of 16 tokens per wave;
+  // pass p gives wave w of workgroup b the pair p * waves + w * workgroups + b - wave-major, so a ragged last pass lands
+  // on wave 0 of many workgroups and costs a fraction of a pass).  Before: one workgroup per 256 tokens - 134 400 tokens
+  // = 525 workgroups = 2.05 rounds on 256 CUs ran as 3 (72 000 tokens: 1.1 as 2).  The chunk images are re-streamed per
+  // pass (they never fit: 4 x 66.5 KB); the double buffer runs straight through the pass boundaries.
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int Mi = (int)M;
-  const int ngroups = (Mi + 15) / 16;
-  const int g0 = (blockIdx.x * NW + wave) * 2;                // this wave's pair of token groups
+  const int ngroups = (Mi + 15) / 16, npairs = (ngroups + 1) / 2;
+  const int waves = (int)gridDim.x * NW, npass = (npairs + waves - 1) / waves;
+  const int nch = A.single ? 1 : A.n, total = npass * nch;
   auto dma_chunk = [&](const unsigned char *img, unsigned char *buf) {
     const unsigned char *src = img + lane * 16;
 #pragma unroll
@@ -681,139 +687,149 @@ __global__ __launch_bounds__(NT, 2) void ffn_ln_kernel(const __half *__restrict_
     if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(src + 64 * 1024), (lptr_t)(buf + 64 * 1024), 16, 0, 0);   // biases
   };
   dma_chunk(A.img[0], lds);
-  h8 xb[2][4];
-  int pix[2];
+  int cs = 0;                                                  // chunk images streamed so far (buffer = cs & 1)
+  for (int pass = 0; pass < npass; ++pass) {
+    const int pidx = pass * waves + wave * (int)gridDim.x + (int)blockIdx.x;
+    const bool active = pidx < npairs;                         // wave-uniform; idle waves still stream weights and meet the barriers
+    h8 xb[2][4];
+    int pix[2];
 #pragma unroll
-  for (int pg = 0; pg < 2; ++pg) {
-    const int grp = g0 + pg;
-    pix[pg] = grp < ngroups ? grp * 16 + i : Mi;
-    const int pc = pix[pg] < Mi ? pix[pg] : Mi - 1;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      xb[pg][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(x + (size_t)pc * 128 + kk * 32 + g * 8));
-  }
-  f4 out[2][8];
-#pragma unroll
-  for (int pg = 0; pg < 2; ++pg)
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) out[pg][nb] = f4{0.f, 0.f, 0.f, 0.f};
-
-  for (int c = 0; c < A.n; ++c) {
-    unsigned char *buf = lds + (c & 1) * kChainImage;
-    const unsigned char *lw1 = buf, *lw2 = buf + 128 * 128 * 2;
-    const float *lb = reinterpret_cast<const float *>(buf + 2 * 128 * 128 * 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // chunk c's image has landed (issued a whole chunk ago)
-    __syncthreads();
-    if (c + 1 < A.n) dma_chunk(A.img[c + 1], lds + ((c + 1) & 1) * kChainImage);
-    // ---- link 1: hidden chunk = relu(W1[c] . x + b1[c])
-    f4 acc[2][8];
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-#pragma unroll
-      for (int pg = 0; pg < 2; ++pg) acc[pg][nb] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(16 * nb + i, 4 * kk + g)));
-#pragma unroll
-        for (int pg = 0; pg < 2; ++pg) acc[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[pg][kk], acc[pg][nb], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (A.single) {                                            // the link's accumulators (+ bias) ARE the output
-#pragma unroll
-      for (int nb = 0; nb < 8; ++nb) {
-        const f4 bias = *reinterpret_cast<const f4 *>(lb + 16 * nb + 4 * g);
-#pragma unroll
-        for (int pg = 0; pg < 2; ++pg) out[pg][nb] = acc[pg][nb] + bias;
-      }
-      break;
-    }
-    h8 hb[2][4];
-#pragma unroll
-    for (int pg = 0; pg < 2; ++pg)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const f4 ba = *reinterpret_cast<const f4 *>(lb + 16 * (2 * kk) + 4 * g), bb = *reinterpret_cast<const f4 *>(lb + 16 * (2 * kk + 1) + 4 * g);
-        h8 t;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          t[r] = (_Float16)fmaxf(acc[pg][2 * kk][r] + ba[r], 0.f);
-          t[4 + r] = (_Float16)fmaxf(acc[pg][2 * kk + 1][r] + bb[r], 0.f);
-        }
-        hb[pg][kk] = t;
-      }
-    // ---- link 2: out += W2[:, chunk c] . hidden chunk  (+ the chunk image's b2: the real bias in chunk 0, zeros after)
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(16 * nb + i, 4 * kk + g)));
-#pragma unroll
-        for (int pg = 0; pg < 2; ++pg) out[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, hb[pg][kk], out[pg][nb], 0, 0, 0);
-      }
-      const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
-#pragma unroll
-      for (int pg = 0; pg < 2; ++pg) out[pg][nb] += bias;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // ---- epilogue: residual + LayerNorm over the 128 channels of a token (32 per lane, 4 lanes per token), 16-B stores.
-  // Image row 16nb + 4g + r of the last link is channel 32(nb/2) + 8g + 4(nb%2) + r = element 4(nb%2) + r of xb[.][nb/2].
-#pragma unroll
-  for (int pg = 0; pg < 2; ++pg) {
-    if (A.single) {                                            // residual from its own tensor, same channel layout
+    for (int pg = 0; pg < 2; ++pg) {
+      const int grp = 2 * pidx + pg;
+      pix[pg] = (active && grp < ngroups) ? grp * 16 + i : Mi;
       const int pc = pix[pg] < Mi ? pix[pg] : Mi - 1;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
-        xb[pg][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A.res + (size_t)pc * 128 + kk * 32 + g * 8));
+        xb[pg][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(x + (size_t)pc * 128 + kk * 32 + g * 8));
     }
-    float sum = 0.f;
+    f4 out[2][8];
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
+    for (int pg = 0; pg < 2; ++pg)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = out[pg][nb][r] + (float)xb[pg][nb >> 1][4 * (nb & 1) + r];
-        out[pg][nb][r] = v;
-        sum += v;
-      }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.f / 128.f);
-    float var = 0.f;
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = out[pg][nb][r] - mean;
-        var += d * d;
-      }
-    var += __shfl_xor(var, 16);
-    var += __shfl_xor(var, 32);
-    const float rstd = rsqrtf(var * (1.f / 128.f) + A.eps);
-    if (A.presum != nullptr && pix[pg] < Mi) {
+      for (int nb = 0; nb < 8; ++nb) out[pg][nb] = f4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < nch; ++c, ++cs) {
+      unsigned char *buf = lds + (cs & 1) * kChainImage;
+      const unsigned char *lw1 = buf, *lw2 = buf + 128 * 128 * 2;
+      const float *lb = reinterpret_cast<const float *>(buf + 2 * 128 * 128 * 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this chunk's image has landed (issued a whole chunk ago)
+      __syncthreads();
+      if (cs + 1 < total) dma_chunk(A.img[c + 1 < nch ? c + 1 : 0], lds + ((cs + 1) & 1) * kChainImage);
+      if (!active) continue;
+      // ---- link 1: hidden chunk = relu(W1[c] . x + b1[c]), one PAIR of row blocks at a time: the pair becomes k-step p2 of
+      // link 2's operand at once (or, single-link form, two blocks of the output), so only 2 x 2 accumulators are live
+      h8 hb[2][4];
 #pragma unroll
       for (int p2 = 0; p2 < 4; ++p2) {
-        h8 o;
+        f4 acc[2][2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[r] = (_Float16)out[pg][2 * p2][r];
-          o[4 + r] = (_Float16)out[pg][2 * p2 + 1][r];
+        for (int e = 0; e < 2; ++e) {
+          const int nb = 2 * p2 + e;
+#pragma unroll
+          for (int pg = 0; pg < 2; ++pg) acc[e][pg] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw1 + w_off<128>(16 * nb + i, 4 * kk + g)));
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg) acc[e][pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, xb[pg][kk], acc[e][pg], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        *reinterpret_cast<h8 *>(A.presum + (size_t)pix[pg] * 128 + 32 * p2 + 8 * g) = o;
+        const f4 ba = *reinterpret_cast<const f4 *>(lb + 16 * (2 * p2) + 4 * g), bb = *reinterpret_cast<const f4 *>(lb + 16 * (2 * p2 + 1) + 4 * g);
+        if (A.single) {                                        // the link's accumulators (+ bias) ARE the output
+#pragma unroll
+          for (int pg = 0; pg < 2; ++pg) {
+            out[pg][2 * p2] = acc[0][pg] + ba;
+            out[pg][2 * p2 + 1] = acc[1][pg] + bb;
+          }
+        } else {
+#pragma unroll
+          for (int pg = 0; pg < 2; ++pg) {
+            h8 t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              t[r] = (_Float16)fmaxf(acc[0][pg][r] + ba[r], 0.f);
+              t[4 + r] = (_Float16)fmaxf(acc[1][pg][r] + bb[r], 0.f);
+            }
+            hb[pg][p2] = t;
+          }
+        }
+      }
+      if (A.single) continue;
+      // ---- link 2: out += W2[:, chunk c] . hidden chunk  (+ the chunk image's b2: the real bias in chunk 0, zeros after)
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const h8 a = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(lw2 + w_off<128>(16 * nb + i, 4 * kk + g)));
+#pragma unroll
+          for (int pg = 0; pg < 2; ++pg) out[pg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, hb[pg][kk], out[pg][nb], 0, 0, 0);
+        }
+        const f4 bias = *reinterpret_cast<const f4 *>(lb + 128 + 16 * nb + 4 * g);
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) out[pg][nb] += bias;
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (pix[pg] < Mi) {
+    if (!active) continue;
+    // ---- epilogue: residual + LayerNorm over the 128 channels of a token (32 per lane, 4 lanes per token), 16-B stores.
+    // Image row 16nb + 4g + r of the last link is channel 32(nb/2) + 8g + 4(nb%2) + r = element 4(nb%2) + r of xb[.][nb/2].
 #pragma unroll
-      for (int p2 = 0; p2 < 4; ++p2) {
-        const h8 lw = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A.ln_w + 32 * p2 + 8 * g));
-        const h8 lbv = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A.ln_b + 32 * p2 + 8 * g));
-        h8 o;
+    for (int pg = 0; pg < 2; ++pg) {
+      if (A.single) {                                          // residual from its own tensor, same channel layout
+        const int pc = pix[pg] < Mi ? pix[pg] : Mi - 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          xb[pg][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A.res + (size_t)pc * 128 + kk * 32 + g * 8));
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          o[r] = (_Float16)((out[pg][2 * p2][r] - mean) * rstd * (float)lw[r] + (float)lbv[r]);
-          o[4 + r] = (_Float16)((out[pg][2 * p2 + 1][r] - mean) * rstd * (float)lw[4 + r] + (float)lbv[4 + r]);
+          const float v = out[pg][nb][r] + (float)xb[pg][nb >> 1][4 * (nb & 1) + r];
+          out[pg][nb][r] = v;
+          sum += v;
         }
-        *reinterpret_cast<h8 *>(y + (size_t)pix[pg] * 128 + 32 * p2 + 8 * g) = o;
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum * (1.f / 128.f);
+      float var = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = out[pg][nb][r] - mean;
+          var += d * d;
+        }
+      var += __shfl_xor(var, 16);
+      var += __shfl_xor(var, 32);
+      const float rstd = rsqrtf(var * (1.f / 128.f) + A.eps);
+      if (A.presum != nullptr && pix[pg] < Mi) {
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+          h8 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o[r] = (_Float16)out[pg][2 * p2][r];
+            o[4 + r] = (_Float16)out[pg][2 * p2 + 1][r];
+          }
+          *reinterpret_cast<h8 *>(A.presum + (size_t)pix[pg] * 128 + 32 * p2 + 8 * g) = o;
+        }
+      }
+      if (pix[pg] < Mi) {
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+          const h8 lw = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A.ln_w + 32 * p2 + 8 * g));
+          const h8 lbv = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(A.ln_b + 32 * p2 + 8 * g));
+          h8 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o[r] = (_Float16)((out[pg][2 * p2][r] - mean) * rstd * (float)lw[r] + (float)lbv[r]);
+            o[4 + r] = (_Float16)((out[pg][2 * p2 + 1][r] - mean) * rstd * (float)lw[4 + r] + (float)lbv[4 + r]);
+          }
+          *reinterpret_cast<h8 *>(y + (size_t)pix[pg] * 128 + 32 * p2 + 8 * g) = o;
+        }
       }
     }
   }
@@ -889,8 +905,11 @@ extern "C" int di_ffn_ln_fwd_ex(const void *x, int n_chunks, const void *const *
   constexpr int LDS = 2 * kChainImage;
   static di::LdsRaised raised;
   if (int rc = di::ensure_lds(raised, (const void *)ffn_ln_kernel, LDS)) return rc;
-  const long long groups = (n_tokens + 15) / 16;
-  const long long grid = (groups + 2 * NW - 1) / (2 * NW);
+  const long long groups = (n_tokens + 15) / 16, pairs = (groups + 1) / 2;
+  const int n_cu = di::device_cus();
+  if (n_cu <= 0) return DI_ERR_LAUNCH;
+  long long grid = (pairs + NW - 1) / NW;                      // persistent: at most one workgroup per CU
+  if (grid > n_cu) grid = n_cu;
   hipLaunchKernelGGL(ffn_ln_kernel, dim3((unsigned)grid), dim3(NT), LDS, (hipStream_t)stream, (const __half *)x, (__half *)y, A,
                      n_tokens);
   return di::check_launch("ffn_ln");
