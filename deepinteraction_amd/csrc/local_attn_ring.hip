@@ -45,8 +45,19 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 __device__ __attribute__((aligned(128))) unsigned int zero_line[32];   // what a texel outside the map reads (128 B)
 __device__ unsigned int timeouts;                                       // bounded spins that gave up (0 on a healthy run)
 
-template <int WX_, int WY_, int SCHED_ = 0, int NPW_ = 2, int POL_ = 0, int POISON_ = 3>
+template <int WX_, int WY_, int SCHED_ = 0, int NPW_ = 2, int POL_ = 0, int POISON_ = 3, int SUB_ = 0>
 struct Cfg {
+  // SUB > 0: the ragged LAST round of tiles of an XCD's range is cut into sub-tiles of SUB WAVE-ROWS (2 SUB query rows x TW:
+  // the halo rows 2 SUB s .. 2 SUB s + 2 SUB + 7 of the tile, multiplied by the consumer waves of those wave-rows) spread
+  // over all of the XCD's workgroups, when that makes it shorter: 1 092 tiles on 256 workgroups are 4 full rounds + 68
+  // tiles = 272 sub-tiles of one wave-row, one per workgroup, instead of a fifth round of full tiles on 68 of them.
+  // MEASURED AND NOT KEPT (round 5, profiles/r05r_ring_subtiles.txt): bit-identical, and 39.3 us (SUB 1) / 36.5 us (SUB 2)
+  // against 36.3 us - the launch is not quantised in rounds (the 68 workgroups of the fifth round have the L1 / L2 paths
+  // of their XCDs to themselves and finish it in a fraction of a round), while sub-tiles re-read their halos: 2.5 x / 1.5 x
+  // the bytes of the ragged round through the vector L1.  Default 0.
+  static constexpr int SUB = NPW_ == 2 ? SUB_ : 0;
+  static constexpr int NSUB = SUB > 0 ? WY_ / SUB : 1;   // sub-tiles of a tile
+  static constexpr int SUBROWS = 2 * SUB + 8;            // halo rows of a sub-tile
   static constexpr int WX = WX_, WY = WY_, POL = POL_;    // POL: cache policy of the halo DMA (measurement)
   static constexpr bool POISON = (POISON_ & 1) != 0;   // consumers poison their stores; 0: measurement only (round 4: a timed-out wait computes on)
   static constexpr bool PDEAD = (POISON_ & 2) != 0;    // producers stop issuing after a timeout
@@ -62,6 +73,7 @@ struct Cfg {
   static constexpr int TSB = 768;                      // measurement (dbg & 16): 96 time stamps per wavefront of workgroup 0
   static constexpr int LDS_BYTES = RING + 64 + (NCW + NPW_) * TSB;   // + landed[NPW <= 8] at RING, done[8] at RING + 32, the time stamps
   static constexpr int RPB = HR / NPW_, IPB = RPB * IPR;  // rows / DMA instructions of one producer per block
+  static constexpr int IPB2 = (SUBROWS / NPW_) * IPR;    // the same for a sub-tile block (NPW = 2: half of its rows per producer)
   static_assert(NCW == 8 && HR % NPW == 0 && (NPW == 2 || NPW == 4 || NPW == 8) && HC % 8 == 0 && LDS_BYTES <= 160 * 1024,
                 "ring geometry");
 };
@@ -126,6 +138,20 @@ __device__ __forceinline__ void wait_blocks(int n) {
   else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * IPB) : "memory");
 }
 
+// at most f full blocks' + s sub-tile blocks' worth of this wave's DMA still in flight (f + s <= 2)
+template <int IPB, int IPB2>
+__device__ __forceinline__ void wait_mix(int f, int s) {
+  static_assert(2 * IPB <= 63, "vmcnt is 6 bits");
+  switch (f * 3 + s) {
+    case 1: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(IPB2) : "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * IPB2) : "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(IPB) : "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(IPB + IPB2) : "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * IPB) : "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
 constexpr int SPIN_LIMIT = 1 << 20;
 
 template <class G>
@@ -171,9 +197,33 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
   const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
   const int gxw = ((int)gridDim.x - xcd + 7) >> 3;
   const int t_end = (int)(((long long)ntiles * (xcd + 1)) >> 3);
-  const int tile0 = (int)(((long long)ntiles * xcd) >> 3) + wl;
-  if (tile0 >= t_end) return;
-  const int ntl = (t_end - tile0 + gxw - 1) / gxw;            // tiles of this workgroup
+  const int t_beg = (int)(((long long)ntiles * xcd) >> 3);
+  const int tile0 = t_beg + wl;
+  // work items of this workgroup: `nfull` full tiles (tile0 + it * gxw), then either one more full tile (the ragged round as
+  // it is) or its share of the ragged round's tiles cut into wave-row sub-tiles (item = tile, wave-row q)
+  const int rounds = (t_end - t_beg) / gxw, left = (t_end - t_beg) - rounds * gxw;     // full rounds, tiles of the ragged one
+  const bool cut = G::SUB > 0 && left > 0 && G::NSUB * left <= 2 * gxw;
+  const int nsub = cut ? (G::NSUB * left - wl + gxw - 1) / gxw : 0;                      // sub-tiles wl, wl + gxw, ...
+  const int nfull = rounds + ((!cut && wl < left) ? 1 : 0);
+  const int ntl = nfull + (nsub > 0 ? nsub : 0);
+  if (ntl <= 0) return;
+  const int NF = nfull * G::BPT;                              // blocks of full tiles come first
+  struct Item {
+    TileCoord t;
+    int q;                                                    // sub-tile (wave-rows q SUB .. q SUB + SUB - 1), -1: the whole tile
+  };
+  auto item = [&](int it) {
+    Item w;
+    if (it < nfull) {
+      w.t = decode_tile(tile0 + it * gxw, tiles_x, per_img, G::TH, G::TW);
+      w.q = -1;
+    } else {
+      const int sidx = wl + (it - nfull) * gxw;               // sub-tile index inside the ragged round
+      w.t = decode_tile(t_beg + rounds * gxw + sidx / G::NSUB, tiles_x, per_img, G::TH, G::TW);
+      w.q = sidx % G::NSUB;
+    }
+    return w;
+  };
 
   if (tid < 16) lds_st32(f_landed + 4 * tid, 0);             // landed[0..1] (+ padding), done[0..7]
   __syncthreads();                                           // the only barrier of the kernel
@@ -201,8 +251,15 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
       const unsigned m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
       min_done = __builtin_amdgcn_readfirstlane((int)m);
     };
+    // the oldest unannounced block Bo has landed once at most its n younger blocks' instructions are in flight
+    auto wait_for = [&](int Bo, int nyoung) {
+      const int f = min(max(NF - (Bo + 1), 0), nyoung);
+      wait_mix<G::IPB, G::IPB2>(f, nyoung - f);
+    };
     for (int it = 0; it < ntl; ++it) {
-      const TileCoord t = decode_tile(tile0 + it * gxw, tiles_x, per_img, G::TH, G::TW);
+      const Item wi = item(it);
+      const TileCoord t = wi.t;
+      const int r_lo = wi.q < 0 ? 0 : 2 * G::SUB * wi.q, r_hi = wi.q < 0 ? HR : r_lo + G::SUBROWS;   // halo rows this item needs
       const bool interior = t.y0 >= 4 && t.x0 >= 4 && t.y0 - 4 + HR <= H && t.x0 - 4 + G::HC <= W;
       const long long tile_off = ((long long)(t.img * H + t.y0 - 4) * W + (t.x0 - 4)) * 256 + d_off;
       bool x_ok[G::IPR];
@@ -218,7 +275,7 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
         int spins = 0;
         while (B - G::NBLK >= min_done) {
           if (published < B) {                                // meanwhile: announce the oldest block of mine that is in flight
-            wait_blocks<G::IPB>(B - published - 1);
+            wait_for(published, B - published - 1);
             ++published;
             publish();
           } else {
@@ -244,6 +301,7 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
 #pragma unroll
         for (int rr = 0; rr < G::RPB; ++rr) {
           const int r = p + rr * G::NPW;
+          if (G::SUB > 0 && (r < r_lo || r >= r_hi)) continue;   // (wave-uniform) a sub-tile takes SUBROWS of the halo rows
           const unsigned char *row = src + (long long)r * W * 256;
           const int gy = t.y0 - 4 + r;
           const bool y_ok = gy >= 0 && gy < H;
@@ -258,7 +316,7 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
         stamp(2);                                             // issued
         issued = B + 1;
         if (B - published >= 2) {                             // never more than two blocks unannounced (vmcnt is 6 bits)
-          wait_blocks<G::IPB>(2);
+          wait_for(B - 2, 2);
           published = B - 1;
           publish();
         }
@@ -266,7 +324,7 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     }
   drain:
     while (published < issued) {                              // drain: no DMA may outlive the workgroup's LDS
-      wait_blocks<G::IPB>(issued - published - 1);
+      wait_for(published, issued - published - 1);
       ++published;
       publish();
     }
@@ -364,15 +422,24 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     for (int kk = 0; kk < 4; ++kk) qf[kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(qb + kk * 64));
   };
 
-  TileCoord cur = decode_tile(tile0, tiles_x, per_img, G::TH, G::TW);
+  Item wcur = item(0);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) qf[kk] = h8{1, 1, 1, 1, 1, 1, 1, 1};
-  if (!(dbg & 2)) load_q(cur);
+  int q_for = -1;                                            // the item qf holds the queries of
   for (int it = 0; it < ntl; ++it) {
     const bool has_next = it + 1 < ntl;
-    TileCoord nxt = cur;
-    if (has_next) nxt = decode_tile(tile0 + (it + 1) * gxw, tiles_x, per_img, G::TH, G::TW);
+    Item wnxt = wcur;
+    if (has_next) wnxt = item(it + 1);
+    const TileCoord cur = wcur.t, nxt = wnxt.t;
     const int B0 = it * G::BPT;
+    // a sub-tile belongs to the consumer waves of SUB wave-rows; the others are past its four blocks at once
+    if (G::SUB > 0 && wcur.q >= 0 && wcur.q != wy / (G::SUB > 0 ? G::SUB : 1)) {
+      release(B0 + G::BPT);
+      wcur = wnxt;
+      continue;
+    }
+    const bool next_mine = has_next && (wnxt.q < 0 || wnxt.q == wy / (G::SUB > 0 ? G::SUB : 1));
+    if (q_for != it && !(dbg & 2)) load_q(cur);
 
     // ---------------- S^T = K . Q^T over the two K blocks
     f4 s[10];
@@ -442,7 +509,10 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
     }
     // (requested a whole tile ahead into a second register set the launch is 1.5 us SLOWER, 37.0 against 35.5 us: the requests
     // then share the L1 queue with the producers' DMA for longer)
-    if (has_next && !(dbg & 2)) load_q(nxt);                               // qf is dead until the next tile's first block
+    if (next_mine && !(dbg & 2)) {                                         // qf is dead until the next tile's first block
+      load_q(nxt);
+      q_for = it + 1;
+    }
 
     // ---------------- O^T = V^T . P^T over the two V blocks, each block finishes 64 output channels
     const float inv = 1.f / sum;
@@ -517,7 +587,7 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
               make_uint4(wv[2 * pr][0], wv[2 * pr][1], wv[2 * pr + 1][0], wv[2 * pr + 1][1]);
       }
     });
-    cur = nxt;
+    wcur = wnxt;
   }
   dump_ts();
 }
@@ -574,9 +644,9 @@ int launch_local_attn_ring(const void *q, const void *k, const void *v, void *ou
     case 3: return ring::launch<ring::Cfg<2, 4, 0, 2, 2>>(q, k, v, out, n, H, W, scale, stream);   // the compiler's own schedule
     case 4: return ring::launch<ring::Cfg<2, 4, 2, 4, 2>>(q, k, v, out, n, H, W, scale, stream);   // four producer wavefronts
     case 5: return ring::launch<ring::Cfg<2, 4, 2, 2, 0>>(q, k, v, out, n, H, W, scale, stream);   // plain DMA loads
-    case 6: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 0>>(q, k, v, out, n, H, W, scale, stream);   // cfg 0 without the NaN poisoning (A/B)
-    case 7: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 1>>(q, k, v, out, n, H, W, scale, stream);   // consumer side only (A/B)
-    case 8: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 2>>(q, k, v, out, n, H, W, scale, stream);   // producer side only (A/B)
+    case 6: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 3, 1>>(q, k, v, out, n, H, W, scale, stream);   // cfg 0 with the ragged round cut into sub-tiles of one wave-row (A/B: slower)
+    case 7: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 3, 2>>(q, k, v, out, n, H, W, scale, stream);   // ... and as sub-tiles of two wave-rows
+    case 8: return ring::launch<ring::Cfg<1, 8, 2, 2, 2, 3, 1>>(q, k, v, out, n, H, W, scale, stream);   // cfg 1 with one-wave-row sub-tiles
   }
   set_error("unknown local_attn_ring configuration %d", cfg);
   return DI_ERR_ARG;

@@ -107,7 +107,7 @@ def _f32(t):
 # ------------------------------------------------------------------ local-window attention
 LA_AUTO, LA_VALU = 0, 1
 LA_MFMA = 3           # + configuration 0..4 of the persistent pipelined row-pair kernel (1 = 8x8 tiles)
-LA_RING = 24          # + 0 / 1: the ring generation (one workgroup per CU, LDS-DMA rows, flag-synchronised), 16x8 / 8x16 tiles; + 2..6: measurement variants (6 = without the NaN poisoning)
+LA_RING = 24          # + 0 / 1: the ring generation (one workgroup per CU, LDS-DMA rows, flag-synchronised), 16x8 / 8x16 tiles; + 2..8: measurement variants (6 / 7 / 8: the ragged last round cut into sub-tiles - measured, slower)
 
 
 def local_attention(q, k, v, kH, kW, scale, variant=LA_AUTO):
