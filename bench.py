@@ -2,10 +2,14 @@
 """bench.py - throughput of the interaction hot path on MI355X.
 
 Metric (BASELINE.json): samples/sec forward, Fusion_0075 synthetic.  A "step" is one pass of the hot path over one
-batch: the next device-resident synthetic sample of a small pool is made current (`GraphedHotPath.load`: features,
-points, pillars and geometry constants copied into the captured buffers) and the full MMRI encoder (2 layers) + MMPI
-decoder (1 decoder layer + 4 RoI layers, Q=200) forward runs on it.  Default workload = BASELINE.json configs[1]:
-Fusion_0075_refactor shapes (image features 6x256x112x200, BEV 512x180x180, 262 144 points), fp16.
+batch: the full MMRI encoder (2 layers) + MMPI decoder (1 decoder layer + 4 RoI layers, Q=200) forward on the next
+device-resident synthetic sample of a small pool.  Default workload = BASELINE.json configs[1]: Fusion_0075_refactor
+shapes (image features 6x256x112x200, BEV 512x180x180, 262 144 points), fp16.
+Hand-over of a sample to the captured forward (`--handover`): `resident` (default since round 5) = zero-copy, the
+sample lies in the static input buffers of the captured forward that is replayed (where its producer wrote it; one
+capture per pool sample stands for that), every replay reads it from HBM; `copy` (rounds 2-4) = the next pool sample is
+first copied into the static buffers (`GraphedHotPath.load`: features, points, pillars, geometry constants) - the line
+carries that figure too, as `copy_handover`.
 
     python bench.py --gpus N --steps K --warmup W           N > 1 without a torchrun environment re-launches itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
@@ -53,12 +57,17 @@ def parse():
     ap.add_argument('--shape', default='R', choices=['R', 'A', 'TINY'])
     ap.add_argument('--model', default='v1', choices=['v1', 'pp'], help='pp = DeepInteraction++ (configs[4])')
     ap.add_argument('--mode', default='forward', choices=['forward', 'train'], help='train = configs[2]/[3]')
-    ap.add_argument('--inflight', type=int, default=3,
-                    help='samples in flight per GPU: N independent captured forwards, each load()ed with its own sample and replayed '
-                         'on its own stream (a step = N x batch samples).  3 since round 5: the decoder half of a forward is a chain '
-                         'of launches that fill a fraction of the chip, a third sample fills more of it (same box: 924 / 957 / 939 '
-                         'samples/s at 2 / 3 / 4); 2 = the reference\'s samples_per_gpu (Fusion_0075_refactor.py:94), the default of '
-                         'rounds 2-4; 1 = one sample at a time (the latency figure, also reported as `single_sample`)')
+    ap.add_argument('--inflight', type=int, default=4,
+                    help='samples in flight per GPU: N lanes (HIP streams), each replaying captured forwards of its own samples one '
+                         'behind the other (a step = N x batch samples).  The decoder half of a forward is a chain of launches that '
+                         'fill a fraction of the chip; more samples in flight fill more of it.  4 since the lanes are launched from '
+                         'one host thread each (--launch-threads: 1 030 / 1 090 / 1 092 / 1 108 samples/s at 3 / 4 / 6 / 8 lanes, '
+                         'tools/launch_cost.py; behind ONE launching thread 957 / 939 at 3 / 4, the default 3 of the first half '
+                         'of round 5); 2 = the reference\'s samples_per_gpu (Fusion_0075_refactor.py:94), the default of rounds '
+                         '2-4; 1 = one sample at a time (the latency figure, also reported as `single_sample`)')
+    ap.add_argument('--launch-threads', type=int, default=1, choices=[0, 1],
+                    help='1: every lane is launched from its own host thread (graphed.LaneLaunchers) - a replay costs the launching '
+                         'thread 0.3-1.0 ms of hipGraphLaunch, of the order of the GPU time per sample; 0: one launching thread')
     ap.add_argument('--amp', action='store_true',
                     help='train mode: mixed precision - the hot path under torch.autocast(fp16) (fp16 activations, the fused '
                          'matrix-core window attention forward / backward of csrc/local_attn_train.hip), float32 master weights, '
@@ -78,7 +87,15 @@ def parse():
                          'reference boundary: frozen backbones emit NCHW), raw points / pillars and the metas - the channels-last '
                          'transposing copy, GraphedHotPath.prepare() (padding, host 4x4 inverses, H2D of the geometry constants) '
                          'and load() all run inside the timed region.  A secondary line; the headline hands prepared records')
-    ap.add_argument('--pool', type=int, default=4, help='distinct device-resident samples cycled through the steps')
+    ap.add_argument('--pool', type=int, default=8, help='distinct device-resident samples cycled through the steps')
+    ap.add_argument('--handover', default='resident', choices=['resident', 'copy'],
+                    help='graph-replayed forward modes: how a step\'s sample becomes the captured forward\'s input.  resident '
+                         '(default since round 5): zero-copy - the producer has written the sample into the static input buffers '
+                         'of its in-flight slot (one captured forward per pool sample stands for that here: a lane replays the '
+                         'forwards of ITS samples in turn, every replay reads its maps / points / pillars from HBM where they '
+                         'lie).  copy (rounds 2-4): one captured forward per lane, every step first copies the next pool sample '
+                         '(110 MB, ~40 us + 5 small geometry copies) into its static buffers - timed again after the headline and '
+                         'reported as `copy_handover`')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true',
                     help='launch every kernel from the host each step instead of replaying the captured hipGraph')
@@ -277,6 +294,105 @@ def settle(step, ms):
         torch.cuda.synchronize()
 
 
+def launch_text(resident):
+    if resident:
+        return ('per step and sample in flight: hipGraph replay of the captured forward whose static input buffers hold the '
+                'sample (zero-copy hand-over: one capture per pool sample, a lane replays the captures of its samples in turn)')
+    return ('per step and sample in flight: load() of the next pool sample into the captured buffers + hipGraph replay of the '
+            'captured forward')
+
+
+def graphed_steps(capture, pool, cap, n_lanes, resident, raw_pool=None, launch_threads=True):
+    """The graph-replayed step of both forward lines.  `capture(inputs)` -> GraphedHotPath.  Returns (step, step_copy, step1,
+    graphs, records, g): `step` = one step of `n_lanes` samples in flight under the chosen hand-over, `step_copy` = the same
+    with the copying hand-over of rounds 2-4 (on the first capture of every lane), `step1` = one sample at a time, `g` = the
+    LAST capture (the modules' output attributes point at its static outputs: the parity leg load()s pool[0] into it).
+
+    resident: one capture per pool sample, all with the layout and pillar capacity of the largest sample (captured from
+    `prepare()`d records, padded as load() pads); lane l owns samples l, l + n_lanes, ... and replays their captures in turn
+    on its stream - no capture is ever replayed on two streams."""
+    import torch
+    from deepinteraction_amd.graphed import LaneLaunchers
+    first = capture(pool[cap])                                     # the largest sample sets the capacity
+    records = [first.prepare(d) for d in pool]
+    if resident:
+        while len(records) < n_lanes:
+            records = records + records
+        graphs = [capture(first.record_inputs(r)) for r in records]
+        first = None
+        own = [graphs[l::n_lanes] for l in range(n_lanes)]
+    else:
+        own = [[first]] + [[capture(pool[cap])] for _ in range(n_lanes - 1)]
+        graphs = [o[0] for o in own]
+    g = graphs[-1]
+    lanes = [torch.cuda.Stream() for _ in own] if n_lanes > 1 else [None]
+    for lane in lanes:                                             # the lanes start after everything queued so far
+        if lane is not None:
+            lane.wait_stream(torch.cuda.current_stream())
+    it, turn, one = [0], [0], [0]
+    # one launching host thread per lane (graphed.LaneLaunchers: four lanes are host-bound behind one launching thread)
+    launchers = LaneLaunchers(lanes) if n_lanes > 1 and launch_threads else None
+
+    def issue(fns):
+        if launchers is not None:
+            launchers.run(fns)
+            return
+        for fn, lane in zip(fns, lanes):
+            with torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext():
+                fn()
+
+    def copy_then_replay(o, i):
+        def fn():
+            if raw_pool is not None:
+                o[0].load_raw(raw_pool[i % len(raw_pool)])           # NCHW -> channels-last inside the one copy
+            else:
+                o[0].load(records[i % len(records)])                 # per-sample: copies into the captured buffers ...
+            o[0]()                                                   # ... and one replay of the captured forward
+        return fn
+
+    def step_copy():
+        issue([copy_then_replay(o, it[0] + l) for l, o in enumerate(own)])
+        it[0] += len(own)
+
+    def step_resident():
+        issue([o[turn[0] % len(o)] for o in own])                    # the next of every lane's samples, where it lies
+        turn[0] += 1
+
+    def step1():
+        if resident:
+            graphs[one[0] % len(graphs)]()
+        else:
+            g.load(records[one[0] % len(records)])
+            g()
+        one[0] += 1
+    return (step_resident if resident else step_copy), step_copy, step1, graphs, records, g
+
+
+def secondary_lines(args, parallel, device, world, n_lanes, step1, step_copy):
+    """After the headline's timed region: the one-sample-at-a-time figure (when several are in flight) and, under the
+    resident hand-over, the same step with the copying hand-over of rounds 2-4."""
+    import torch
+    single = copy_handover = None
+    if n_lanes > 1:
+        torch.cuda.synchronize()
+        for _ in range(max(2, args.warmup // 2)):
+            step1()
+        e1 = parallel.timed_region(step1, args.steps, device)
+        single = dict(value=round(parallel.throughput(args.batch, args.steps, e1, world), 3), unit='samples/s',
+                      ms_per_step=round(e1 / args.steps * 1e3, 3), inflight=1)
+    if step_copy is not None:
+        torch.cuda.synchronize()
+        for _ in range(max(2, args.warmup)):
+            step_copy()
+        e2 = parallel.timed_region(step_copy, args.steps, device)
+        copy_handover = dict(value=round(parallel.throughput(args.batch * n_lanes, args.steps, e2, world), 3), unit='samples/s',
+                             ms_per_step=round(e2 / args.steps * 1e3, 3), inflight=n_lanes,
+                             note='the protocol of rounds 2-4: every step first copies the next pool sample into the static '
+                                  'buffers of one captured forward per lane (GraphedHotPath.load: one device-to-device copy of '
+                                  'all maps / points / pillars + the geometry constants)')
+    return single, copy_handover
+
+
 def _line(args, metric, value, elapsed, dtype, workload, extra_cfg):
     return dict(metric=metric, value=round(value, 3), unit='samples/s', n_gpus=args.gpus, steps=args.steps,
                 warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True,
@@ -336,47 +452,22 @@ def bench_forward(args, rank, world, device):
                 rng = list(synth.PC_RANGE)
                 glue = PointGlue(dict(max_num_points=20, max_voxels=(30000, 60000), point_cloud_range=rng,
                                       voxel_size=[(rng[3] - rng[0]) / Wb, (rng[4] - rng[1]) / Hb, rng[5] - rng[2]])).eval()
-            graphs = [GraphedHotPath(enc, dec, dev_pool[cap], glue=glue, image_net=image_net) for _ in range(max(1, args.inflight))]
-            g = graphs[-1]                                  # (the modules' output attributes point at the last capture)
-            records = [g.prepare(d) for d in dev_pool]
-            lanes = [torch.cuda.Stream() for _ in graphs] if len(graphs) > 1 else [None]
-            it = [0]
+            n_lanes = max(1, args.inflight)
+            resident = args.handover == 'resident' and not args.from_raw
             raw_pool = None
             if args.from_raw:          # NCHW-contiguous device maps, as a frozen backbone hands them over
                 raw_pool = [dict(d, img_feats=d['img_feats'].contiguous(), pts_feats=d['pts_feats'].contiguous()) for d in dev_pool]
-
-            def step():
-                for gi, lane in zip(graphs, lanes):
-                    with torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext():
-                        if raw_pool is not None:
-                            gi.load_raw(raw_pool[it[0] % len(raw_pool)])    # NCHW -> channels-last inside the one copy
-                        else:
-                            gi.load(records[it[0] % len(records)])  # per-sample: copies into the captured buffers ...
-                        it[0] += 1
-                        gi()                                         # ... and one replay of the captured forward
-        if not args.eager and len(graphs) > 1:
-            for lane in lanes:                             # the lanes start after everything queued so far
-                lane.wait_stream(torch.cuda.current_stream())
+            step, step_copy, step1, graphs, records, g = graphed_steps(
+                lambda inp: GraphedHotPath(enc, dec, inp, glue=glue, image_net=image_net), dev_pool, cap, n_lanes, resident, raw_pool, bool(args.launch_threads))
         settle(step, args.settle_ms)
         for _ in range(args.warmup):
             step()
         # barrier + synchronize | K steps | barrier + synchronize, MAX over ranks
         elapsed = parallel.timed_region(step, args.steps, device)
 
-        single = None
-        if not args.eager and len(graphs) > 1:             # the one-sample-at-a-time figure beside the headline
-            torch.cuda.synchronize()
-            one = [0]
-
-            def step1():
-                g.load(records[one[0] % len(records)])
-                one[0] += 1
-                g()
-            for _ in range(max(2, args.warmup // 2)):
-                step1()
-            e1 = parallel.timed_region(step1, args.steps, device)
-            single = dict(value=round(parallel.throughput(args.batch, args.steps, e1, world), 3), unit='samples/s',
-                          ms_per_step=round(e1 / args.steps * 1e3, 3), inflight=1)
+        single = copy_handover = None
+        if not args.eager:
+            single, copy_handover = secondary_lines(args, parallel, device, world, n_lanes, step1, step_copy if resident else None)
 
         # parity sample: the product's outputs on pool[0], in the benched launch mode
         product_out = None
@@ -487,8 +578,9 @@ def bench_forward(args, rank, world, device):
                 f'Fusion_0075_refactor shapes (shape {args.shape}), random-init weights',
                 dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(dev_pool), inflight=max(1, args.inflight),
                      from_points=bool(args.from_points), from_raw=bool(args.from_raw), from_images=bool(args.from_images),
-                     launch='eager' if args.eager else 'per step and sample in flight: load() of the next pool sample into the '
-                                                       'captured buffers + hipGraph replay of the captured forward',
+                     launch='eager' if args.eager else launch_text(resident),
+                     handover=None if args.eager else ('resident' if resident else 'copy'),
+                     launch_threads=None if args.eager else (n_lanes if args.launch_threads and n_lanes > 1 else 1),
                      graph_nodes=None if g is None else g.num_nodes()))
     from deepinteraction_amd import _lib
     roofline['ring_spin_timeouts'] = int(_lib.lib().di_local_attn_ring_timeouts(None))     # bounded flag spins that gave up: must be 0
@@ -496,6 +588,8 @@ def bench_forward(args, rank, world, device):
     out['roofline'] = roofline
     if single is not None:
         out['single_sample'] = single
+    if copy_handover is not None:
+        out['copy_handover'] = copy_handover
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         same = ({k: v.float().cpu() for k, v in enc.state_dict().items()},
                 {k: v.float().cpu() for k, v in dec.state_dict().items()})
@@ -567,39 +661,19 @@ def bench_forward_pp(args, rank, world, device):
                 eager(pool[it[0] % len(pool)])
                 it[0] += 1
         else:
-            cap = pool[max(range(len(pool)), key=lambda i: n_pillars[i])]
-            graphs = [GraphedHotPath(enc, dec, cap, image_net=image_net) for _ in range(max(1, args.inflight))]
-            g = graphs[-1]                                  # (the modules' output attributes point at the last capture)
-            records = [g.prepare(d) for d in pool]
-            lanes = [torch.cuda.Stream() for _ in graphs] if len(graphs) > 1 else [None]
-            for lane in lanes:
-                if lane is not None:
-                    lane.wait_stream(torch.cuda.current_stream())
-
-            def step():                                     # as the v1 line: N independent captured forwards, own sample each
-                for gi, lane in zip(graphs, lanes):
-                    with torch.cuda.stream(lane) if lane is not None else contextlib.nullcontext():
-                        gi.load(records[it[0] % len(records)])
-                        it[0] += 1
-                        gi()
+            cap = max(range(len(pool)), key=lambda i: n_pillars[i])
+            n_lanes = max(1, args.inflight)
+            resident = args.handover == 'resident'
+            # as the v1 line: N independent captured forwards in flight, own sample each
+            step, step_copy, step1, graphs, records, g = graphed_steps(
+                lambda inp: GraphedHotPath(enc, dec, inp, image_net=image_net), pool, cap, n_lanes, resident, None, bool(args.launch_threads))
         settle(step, args.settle_ms)
         for _ in range(args.warmup):
             step()
         elapsed = parallel.timed_region(step, args.steps, device)
-        single = None
-        if not args.eager and len(graphs) > 1:              # the one-sample-at-a-time figure beside the line's value
-            torch.cuda.synchronize()
-            one = [0]
-
-            def step1():
-                g.load(records[one[0] % len(records)])
-                one[0] += 1
-                g()
-            for _ in range(max(2, args.warmup // 2)):
-                step1()
-            e1 = parallel.timed_region(step1, args.steps, device)
-            single = dict(value=round(parallel.throughput(args.batch, args.steps, e1, world), 3), unit='samples/s',
-                          ms_per_step=round(e1 / args.steps * 1e3, 3), inflight=1)
+        single = copy_handover = None
+        if not args.eager:
+            single, copy_handover = secondary_lines(args, parallel, device, world, n_lanes, step1, step_copy if resident else None)
         product_out = graph_vs_eager = None
         want_cpu = rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and not args.from_images
         if want_cpu:               # the product's outputs on pool[0], in the benched launch mode
@@ -643,7 +717,9 @@ def bench_forward_pp(args, rank, world, device):
                 'Fusion_0075_plusplus shapes (2 image levels 112x200 / 56x100, BEV 180x180), random-init weights',
                 dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(pool), from_images=bool(args.from_images),
                      inflight=max(1, args.inflight),
-                     launch='eager' if args.eager else 'per step and sample in flight: load() + hipGraph replay',
+                     launch='eager' if args.eager else launch_text(resident),
+                     handover=None if args.eager else ('resident' if resident else 'copy'),
+                     launch_threads=None if args.eager else (n_lanes if args.launch_threads and n_lanes > 1 else 1),
                      graph_nodes=None if g is None else g.num_nodes()))
     out['roofline'] = dict(bound='hbm', kernel='pp::ms_deform_attn_hm_kernel<2, 4>, image self-attention (2 levels, 134 400 queries): '
                                                'head-major value map (bs, 8, S, 16), lanes = (query, head, corner column, channel half), '
@@ -658,6 +734,8 @@ def bench_forward_pp(args, rank, world, device):
                                     'recorded on the stream around the launch')
     if single is not None:
         out['single_sample'] = single
+    if copy_handover is not None:
+        out['copy_handover'] = copy_handover
     if want_cpu:
         e32, d32 = harness.build_models_pp(shape, nprop, torch.float32, 'cpu')      # same seed / init, before half_maps_
         base, par = cpu_baseline_pp(shape, nprop, (e32.state_dict(), d32.state_dict()), host_pool[0], product_out)

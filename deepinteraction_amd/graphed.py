@@ -9,6 +9,8 @@ kernels, profiles/r01c).  `GraphedHotPath` captures one forward into a hipGraph
     out = g()                                         # replay on the current inputs
     g.load(new_inputs)                                # copy a new sample into the static buffers
     out = g()
+    g.img_feats, g.pts_feats, g.pts, g.pillars ...    # or: the producer writes the next sample INTO the static buffers
+                                                      # (zero-copy hand-over; geometry through load_geometry())
 
 Everything that is shape-static is captured as is.  What varies per sample is handled outside the
 graph, in place:
@@ -23,6 +25,9 @@ graph, in place:
 No work is skipped on replay: depth scatter/completion, all gathers, attention and GEMM kernels
 are part of the graph.
 """
+import queue
+import threading
+
 import torch
 
 from .geometry import SampleGeometry
@@ -278,6 +283,16 @@ class GraphedHotPath:
                 r.extra.append((mod, [mod.static_geometry_record(g, m) for g, m in zip(self.sample_geom, r.img_metas)]))
         return r
 
+    def record_inputs(self, r):
+        """The input dict of a prepared record (points / pillars padded to the captured capacity).  A forward captured from
+        it - `GraphedHotPath(enc, dec, g.record_inputs(r))` - has this capture's layout and capacity and holds the record's
+        sample in its static buffers: the ZERO-COPY hand-over (one captured forward per in-flight slot whose producer writes
+        its feature maps, points and pillars straight into the slot's `img_feats` / `pts_feats` / `pts` / `pillars*` views;
+        `bench.py --handover resident` emulates that producer with one capture per pool sample)."""
+        return {self._img_key: r.img_feats, 'pts_feats': r.pts_feats, 'img_metas': [dict(m) for m in r.img_metas],
+                'pts_metas': {'pts': r.pts, 'pillars': r.pillars, 'pillar_coors': r.pillar_coors,
+                              'pillars_num_points': r.pillars_num_points}}
+
     def load_raw(self, inputs):
         """`load(prepare(inputs))` without the intermediate record: every input of a raw batch (dict as produced by
         `harness.to_device`; the maps in ANY dense memory format, e.g. the NCHW a backbone hands over) goes straight into
@@ -311,9 +326,15 @@ class GraphedHotPath:
             put(self.pillars, pm['pillars'], 0.0)
             put(self.pillar_coors, pm['pillar_coors'], 0)
             put(self.pillars_num_points, pm['pillars_num_points'], 0)
-        self.img_metas = [dict(m) for m in inputs['img_metas']]
+        self.load_geometry(inputs['img_metas'])                  # pageable host temporaries: blocking copies
+
+    def load_geometry(self, img_metas):
+        """The zero-copy hand-over's other half: the producer has written maps / points / pillars into the static buffers
+        (`img_feats`, `pts_feats`, `pts`, `pillars*`: padded as `prepare()` pads), this refreshes the per-sample geometry
+        constants from `img_metas` in place (host 4x4 inverses + a few small H2D copies)."""
+        self.img_metas = [dict(m) for m in img_metas]
         for g, m in zip(self.sample_geom, self.img_metas):
-            g._buf.copy_(SampleGeometry._pack(m, g.img_hw))      # pageable host temporaries: blocking copies
+            g._buf.copy_(SampleGeometry._pack(m, g.img_hw))
             g.forget()
         self.query_geom._buf.copy_(QueryGeometry._pack(self.img_metas)[0])
         for mod in self.enc.modules():
@@ -340,3 +361,61 @@ class GraphedHotPath:
         for mod, recs in r.extra:
             for g, rec in zip(self.sample_geom, recs):
                 mod.load_static_geometry(g, rec)
+
+
+class LaneLaunchers:
+    """One HOST THREAD per in-flight lane (a lane = a HIP stream on which captured forwards are replayed one behind the other).
+
+    Why: a replay of the 93-node forward costs the launching thread 0.3 ms of hipGraphLaunch into an idle queue and 0.7-1.0 ms
+    while the GPU is busy (tools/launch_cost.py, round 5) - of the same order as the 0.9-1.0 ms the GPU needs per sample when
+    several are in flight.  With ONE launching thread four lanes are host-bound (1 006 samples/s, the launches of a step take
+    2.98 of its 3.97 ms); with a thread per lane the launches of a step run side by side (CUDAGraph.replay and the ctypes calls
+    release the GIL) and the same four lanes reach 1 090.
+
+        pool = LaneLaunchers(streams)
+        pool.run([fn0, fn1, ...])      # fn_l runs on lane l's thread with lane l's stream current; returns when all have returned
+        pool.close()
+
+    `run` returns when every lane has ISSUED its work (nothing is synchronised with the GPU); an exception raised on a lane is
+    re-raised by `run`."""
+
+    def __init__(self, streams):
+        self.streams = list(streams)
+        self._device = torch.cuda.current_device()
+        self._jobs = [queue.SimpleQueue() for _ in self.streams]
+        self._done = queue.SimpleQueue()
+        self._threads = [threading.Thread(target=self._work, args=(l,), daemon=True, name=f'lane{l}')
+                         for l in range(len(self.streams))]
+        for t in self._threads:
+            t.start()
+
+    def _work(self, l):
+        torch.cuda.set_device(self._device)
+        with torch.no_grad(), torch.cuda.stream(self.streams[l]):
+            while True:
+                fn = self._jobs[l].get()
+                if fn is None:
+                    return
+                try:
+                    fn()
+                    self._done.put(None)
+                except BaseException as e:         # handed to the caller of run()
+                    self._done.put(e)
+
+    def run(self, fns):
+        assert len(fns) == len(self.streams)
+        for q, fn in zip(self._jobs, fns):
+            q.put(fn)
+        err = None
+        for _ in fns:
+            e = self._done.get()
+            err = err or e
+        if err is not None:
+            raise err
+
+    def close(self):
+        for q in self._jobs:
+            q.put(None)
+        for t in self._threads:
+            t.join()
+        self._threads = []

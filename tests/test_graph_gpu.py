@@ -280,3 +280,51 @@ def test_the_graph_can_start_from_the_camera_images():
             assert float((p.float() - wp.float()).abs().max()) <= 2e-3 * float(wp.float().abs().max())
         if torch.equal(img, wimg) and all(torch.equal(p, wp) for p, wp in zip(pts, wpts)):
             _same(out, wout)            # same kernels on the same maps: the head's outputs are then identical too
+
+
+def test_resident_handover_captures_match_eager_at_the_benched_shape():
+    """bench.py's default step since round 5 (`--handover resident`, `bench.graphed_steps`): one captured forward per pool
+    sample, captured from the prepared (padded) record, lane l replaying the captures of samples l, l + L, ... in turn on its
+    stream - every replay bit-identical to the eager forward of ITS sample; then the copying hand-over on the same captures
+    (`step_copy`, the `copy_handover` figure) and `load_geometry` after a producer-style in-place write of the inputs."""
+    import bench
+    from deepinteraction_amd import harness, parallel
+    shape = synth.SHAPE_R
+    enc, dec = harness.build_models(shape, 200, torch.float16, 'cuda')
+    pool = [harness.to_device(synth.make_inputs(1, shape, seed=parallel.sample_seed(i)), 'cuda', torch.float16)
+            for i in range(4)]
+    with torch.no_grad():
+        eager = []
+        for d in pool:
+            _, out = harness.forward(enc, dec, d)
+            torch.cuda.synchronize()
+            eager.append({k: v.clone() for k, v in out[0][0].items()})
+        assert not all(torch.equal(eager[0][k], eager[1][k]) for k in eager[0])
+        cap = max(range(4), key=lambda i: int(pool[i]['pts_metas']['pillars'].shape[0]))
+        step, step_copy, step1, graphs, records, g = bench.graphed_steps(
+            lambda inp: GraphedHotPath(enc, dec, inp), pool, cap, 2, True)
+        assert len(graphs) == 4 and g is graphs[-1]
+        for rnd in range(4):
+            step()
+        torch.cuda.synchronize()
+        for i, gi in enumerate(graphs):                      # every capture still holds (and has just recomputed) its sample
+            _same(gi.out[0][0], eager[i])
+        for i in range(5):
+            step1()
+        torch.cuda.synchronize()
+        _same(graphs[0].out[0][0], eager[0])
+        # zero-copy hand-over proper: a producer writes sample 1 INTO capture 3's static buffers, geometry refreshed in place
+        r, gi = records[1], graphs[3]
+        gi.img_feats.copy_(r.img_feats); gi.pts_feats.copy_(r.pts_feats)
+        for dst, src in zip(gi.pts, r.pts):
+            dst.copy_(src)
+        gi.pillars.copy_(r.pillars); gi.pillar_coors.copy_(r.pillar_coors); gi.pillars_num_points.copy_(r.pillars_num_points)
+        gi.load_geometry(pool[1]['img_metas'])
+        _same(gi()[0][0], eager[1])
+        torch.cuda.synchronize()
+        # the copying hand-over of rounds 2-4 on the lanes' first captures
+        for rnd in range(3):
+            step_copy()
+        torch.cuda.synchronize()
+        _same(graphs[0].out[0][0], eager[(2 * 2) % 4])       # lane 0 loaded records 0, 2, 4
+        _same(graphs[1].out[0][0], eager[(2 * 2 + 1) % 4])
