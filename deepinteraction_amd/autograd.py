@@ -14,6 +14,9 @@ from . import ops
 _fwd = custom_fwd(device_type='cuda')
 _bwd = custom_bwd(device_type='cuda')
 
+import os
+OWN_WGRAD = os.environ.get('DI_OWN_WGRAD', '1') != '0'       # float32 1x1 weight gradients through csrc/wgrad.hip (A/B switch)
+
 
 class BEVWarpGather(torch.autograd.Function):
     """warped = bilinear(bev, unproject(depth)) masked to pc_range  (encoder_utils.py:183-196)."""
@@ -55,8 +58,10 @@ class PixelLinear(torch.autograd.Function):
     """y = x @ W^T + b for x = the (pixels, C) view of a feature map (a 1x1 convolution), pixels >> C.
 
     The weight gradient  dW = dy^T @ x  reduces over 10^5 pixels into a 128 x 128 result: as ONE GEMM the library
-    launches 16 workgroups (no split-K: 370 us on 134 400 pixels); here the pixels are cut into S slabs, the slabs
-    are a BATCHED GEMM (S x 16 workgroups) and the S partial results are summed."""
+    launches 16 workgroups (no split-K: 370 us on 134 400 pixels).  float32 with channel counts that are multiples of 128:
+    the own kernel of csrc/wgrad.hip (float32 matrix cores over pixel slabs + a fixed-order sum, bias gradient included).
+    Otherwise (fp16 under autocast, other widths) the pixels are cut into S slabs, the slabs are a BATCHED GEMM (S x 16
+    workgroups) and the S partial results are summed."""
 
     @staticmethod
     @_fwd
@@ -84,13 +89,19 @@ class PixelLinear(torch.autograd.Function):
             x = x.to(gy.dtype)
         if ctx.needs_input_grad[0]:
             gx = gy @ weight
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             M, S = x.shape[0], PixelLinear._slabs(x.shape[0])
-            if S > 1:
-                gw = torch.bmm(gy.view(S, M // S, -1).transpose(1, 2), x.contiguous().view(S, M // S, -1)).sum(0)
+            xc = x.contiguous()
+            if OWN_WGRAD and M >= 4096 and ops.wgrad_supported(xc, gy):
+                # float32: own kernel on the float32 matrix cores (csrc/wgrad.hip), 418 -> ~40 us on the image maps
+                gw, gb = ops.wgrad(xc, gy, bias=want_b)
+                want_b = False
+            elif S > 1:
+                gw = torch.bmm(gy.view(S, M // S, -1).transpose(1, 2), xc.view(S, M // S, -1)).sum(0)
             else:
                 gw = gy.t() @ x
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_b:
             gb = gy.sum(0)
         return gx, gw, gb
 

@@ -482,6 +482,31 @@ def bn_train_fwd(x, weight, bias, running_mean, running_var, num_batches, eps, m
     return y, saved
 
 
+def wgrad_supported(x, grad_y):
+    """True when `wgrad` takes this pair: dense float32 (pixels, C) matrices on the device, channel counts multiples of 128."""
+    return (x.is_cuda and x.dtype == torch.float32 and grad_y.dtype == torch.float32 and x.dim() == 2 and grad_y.dim() == 2
+            and x.shape[0] == grad_y.shape[0] and x.shape[0] > 0 and x.shape[1] % 128 == 0 and grad_y.shape[1] % 128 == 0
+            and x.is_contiguous() and grad_y.is_contiguous())
+
+
+def wgrad(x, grad_y, bias=False):
+    """(grad_w (Cout, Cin), grad_b (Cout,) or None) of y = x @ W^T + b for x (pixels, Cin), grad_y (pixels, Cout), float32
+    (csrc/wgrad.hip: float32 matrix cores, pixel slabs summed in a fixed order)."""
+    _dev(x, grad_y)
+    assert wgrad_supported(x, grad_y), 'wgrad: dense float32 (pixels, C) operands with C % 128 == 0'
+    P, Cin = x.shape
+    Cout = grad_y.shape[1]
+    nws = int(_lib.lib().di_wgrad_workspace_floats(P, Cin, Cout))
+    if nws < 0:
+        raise _lib.HipLibraryError(_lib.lib().di_last_error().decode())
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    gw = torch.empty(Cout, Cin, dtype=torch.float32, device=x.device)
+    gb = torch.empty(Cout, dtype=torch.float32, device=x.device) if bias else None
+    _lib.call('di_wgrad_f32', x.data_ptr(), grad_y.data_ptr(), P, Cin, Cout, gw.data_ptr(), 0 if gb is None else gb.data_ptr(),
+              ws.data_ptr(), _stream())
+    return gw, gb
+
+
 def bn_train_bwd(x, grad_y, saved, relu, workspace, affine):
     """(grad_x, grad_gamma, grad_beta) of `bn_train_fwd`; the ReLU mask is recomputed from x."""
     _dev(x, grad_y, saved)

@@ -588,6 +588,16 @@ int di_bn_train_fwd(const void *x, long long npix, int C, int dtype, const float
 int di_bn_train_bwd(const void *x, const void *grad_y, long long npix, int C, int dtype, const float *saved, int relu,
                     void *grad_x, float *grad_gamma, float *grad_beta, float *workspace, void *stream);
 
+/* Weight (and bias) gradient of a 1x1 convolution / pixel-wise Linear of the training step (the backward of every
+ * kernel_size-1 `conv` of encoder_utils.py:11-34 ConvBNReLU, of the K/V projection of decoder_utils.py:91-95), float32:
+ *     grad_w[co][ci] = sum_p grad_y[p][co] * x[p][ci],   grad_b[co] = sum_p grad_y[p][co]   (grad_b may be NULL)
+ * x (npix, Cin), grad_y (npix, Cout) row-major and dense, Cin and Cout multiples of 128.  Float32 matrix cores
+ * (v_mfma_f32_16x16x4_f32), pixel slabs summed in a fixed order by a second launch: bit-reproducible.
+ * `workspace`: di_wgrad_workspace_floats(npix, Cin, Cout) floats (-1 + di_last_error() on unsupported shapes). */
+long long di_wgrad_workspace_floats(long long npix, int Cin, int Cout);
+int di_wgrad_f32(const float *x, const float *grad_y, long long npix, int Cin, int Cout, float *grad_w, float *grad_b,
+                 float *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

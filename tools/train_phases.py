@@ -13,7 +13,8 @@ acc = [[] for _ in names]
 
 
 def tick():
-    torch.cuda.synchronize()
+    if not os.environ.get('NOSYNC'):          # NOSYNC=1: the HOST's time per phase (where it blocks, how far it runs ahead)
+        torch.cuda.synchronize()
     return time.perf_counter()
 
 
@@ -53,19 +54,19 @@ def step_graphed(record):
     tr.h.load(tr.records[i])
     tr.seed_word.random_(0, 2 ** 62)
     outs = tr.graphed(tr.h.img_feats, tr.h.pts_feats)
+    tr.dec.prepare_targets([g[0] for g in gts], [g[1] for g in gts], outs[0].device)      # host work under the replay
     t.append(tick())
     t.append(t[-1])
     preds = [[dict(zip(tr.module.keys, outs))]]
     losses = tr.dec.loss([g[0] for g in gts], [g[1] for g in gts], preds)
     loss = sum(v for k, v in losses.items() if k != 'matched_ious')
     t.append(tick())
-    tr.opt.zero_grad(set_to_none=True)
+    tr._zero_grad()
     t.append(tick())
-    loss.backward()
+    tr._backward(loss)
     t.append(tick())
     tr.reducer.finish()
-    torch.nn.utils.clip_grad_norm_([p for p in tr.params if p.grad is not None], max_norm=0.1, norm_type=2)
-    tr.opt.step()
+    tr._update()
     t.append(tick())
     if record:
         for i in range(len(names)):
@@ -73,7 +74,7 @@ def step_graphed(record):
 
 
 if os.environ.get('DI_TRAIN_GRAPH', '0') == '1':        # forward graph (load + replay) | - | loss | zero_grad | backward graph | ...
-    tr = train_step.GraphedTrainer(harness.SHAPES['R'], 200, dev, 1)
+    tr = train_step.GraphedTrainer(harness.SHAPES['R'], 200, dev, 1, amp=bool(os.environ.get('AMP')) or None)
     names[0], names[1] = 'load + forward graph', '-'
     step = step_graphed
 for _ in range(3):
