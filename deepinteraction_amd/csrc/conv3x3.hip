@@ -151,6 +151,114 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const __half *__restric
 
 
 // ------------------------------------------------------------------------------------------------------------
+// The class head's last convolution (128 -> classes <= 16; dense_heads/deepinteraction_decoder.py:109-118), 180 x 180: 1.9 GFLOP
+// on 8.3 MB - a launch of `conv3x3_kernel<4, 1, 1>` took 17 us (0.5 TB/s): 540 tiles in 2.1 rounds, and per tile FOUR dependent
+// round trips to memory (one per 32-channel chunk, each with 9 MFMAs per wave behind it).  Here: 8-row tiles (276: one round
+// at two workgroups per CU) and the halo chunks fetched FOUR ahead - for Cin = 128 every load of the tile is issued before
+// the first LDS write: 17.2 -> 14.8 us.  Same arithmetic order as conv3x3_kernel.
+// ------------------------------------------------------------------------------------------------------------
+template <int TH>
+__global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const __half *__restrict__ x, const __half *__restrict__ w,
+                                                               const float *__restrict__ bias, __half *__restrict__ y,
+                                                               int H, int W, int Cin, int Cout, int relu, int nchw,
+                                                               int tiles_x, int tiles_y) {
+  constexpr int WM = 4, RW = TH / WM, PF = 4;
+  constexpr int HP = (TH + 2) * (TW + 2);
+  constexpr int NLD = (HP * 4 + 255) / 256;
+  __shared__ __align__(16) unsigned char lds[2][HP * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, img = t / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const __half *xi = x + (size_t)img * H * W * Cin;
+
+  // piece e = (halo pixel P, slot s) of this thread: its address (or none) is the same for every chunk
+  const __half *src[NLD];
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int e = tid + j * 256;
+    const int P = e >> 2, s4 = e & 3;
+    const int hy = P / (TW + 2), hx = P - hy * (TW + 2);
+    const int yy = y0 + hy - 1, xx = x0 + hx - 1;
+    src[j] = (e < HP * 4 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? xi + ((size_t)yy * W + xx) * Cin + s4 * 8 : nullptr;
+  }
+  uint4 stage[PF][NLD];
+  auto fetch = [&](uint4 (&st)[NLD], int c0) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j)
+      st[j] = src[j] != nullptr ? *reinterpret_cast<const uint4 *>(src[j] + c0) : make_uint4(0, 0, 0, 0);
+  };
+  auto commit = [&](const uint4 (&st)[NLD], int buf) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int e = tid + j * 256;
+      if (e < HP * 4) *reinterpret_cast<uint4 *>(&lds[buf][lds_off(e >> 2, e & 3)]) = st[j];
+    }
+  };
+
+  f4 acc[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) acc[r] = f4{0.f, 0.f, 0.f, 0.f};
+  const __half *wl = w + (size_t)i * 9 * Cin + g * 8;       // weight row i (rows >= Cout are zero in the packing)
+
+  const int nchunk = Cin / CK;                              // a multiple of PF (host)
+#pragma unroll
+  for (int q = 0; q < PF; ++q) fetch(stage[q], q * CK);
+  commit(stage[0], 0);
+  __syncthreads();
+  for (int c4 = 0; c4 < nchunk; c4 += PF) {
+    // (all 36 weight fragments of the group in flight at once instead of one tap ahead: 15.7 us, no gain - the launch is at its
+    // latency floor: one round of 276 workgroups = one memory round trip + ~2 us of products + the stores)
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int ch = c4 + q, buf = q & 1, c0 = ch * CK;      // (PF is even: chunk ch lives in buffer ch & 1)
+      // slot q has been committed: refill it with the chunk PF ahead
+      if (ch + PF < nchunk) fetch(stage[q], (ch + PF) * CK);
+      h8 a[2];
+      a[0] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(wl + c0));
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) a[(tap + 1) & 1] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(wl + (tap + 1) * Cin + c0));
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          const int P = (wm * RW + r + ky) * (TW + 2) + i + kx;
+          const h8 b = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(&lds[buf][lds_off(P, g)]));
+          acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[tap & 1], b, acc[r], 0, 0, 0);
+        }
+      }
+      if (ch + 1 < nchunk) commit(stage[(q + 1) % PF], buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  const int xx = x0 + i;
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int yy = y0 + wm * RW + r;
+    if (yy >= H || xx >= W) continue;
+    const int n0 = 4 * g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (n0 + q >= Cout) continue;
+      float v = acc[r][q] + bias[n0 + q];
+      if (relu) v = fmaxf(v, 0.f);
+      if (!nchw) {
+        y[(((size_t)img * H + yy) * W + xx) * Cout + n0 + q] = __float2half(v);
+      } else {
+        const size_t o = (((size_t)img * Cout + n0 + q) * H + yy) * W + xx;
+        if (nchw == 2) reinterpret_cast<float *>(y)[o] = v;      // float32 logits (heat-map heads)
+        else y[o] = __float2half(v);
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
 // Second kernel, for Cout == 128: the weights go through LDS as well.  The K loop runs in STAGES = (32-channel chunk,
 // kernel row ky): a stage multiplies the three taps of one kernel row.  Its weight tile (3 taps x 128 rows x 32
 // channels = 24 KB, contiguous in the (chunk, ky, kx, n, c) packing) and - once per chunk - the next halo chunk are
@@ -938,6 +1046,15 @@ extern "C" int di_conv3x3_fwd(const void *x, const void *w_packed, const void *w
   } else if (Cout == 128) {
     if ((long long)n * ((H + 7) / 8) * tiles_x >= 768) DI_CV(8, 2, 4);
     else DI_CV(4, 2, 4);
+  } else if (Cin % (4 * CK) == 0 && H >= 8) {
+    static const int small = getenv("DI_CONV_SMALL") ? atoi(getenv("DI_CONV_SMALL")) : 1;   // 0: conv3x3_kernel<4, 1, 1> (A/B)
+    if (small) {
+      const int tiles_y = (H + 7) / 8;
+      hipLaunchKernelGGL((conv3x3_small_kernel<8>), dim3(tiles_x * tiles_y * n), dim3(256), 0, s, (const __half *)x,
+                         (const __half *)w_packed, bias, (__half *)y, H, W, Cin, Cout, relu, out_nchw, tiles_x, tiles_y);
+    } else {
+      DI_CV(4, 1, 1);
+    }
   } else {
     DI_CV(4, 1, 1);
   }

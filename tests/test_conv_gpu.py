@@ -24,7 +24,8 @@ def _ref(x, w, b, bn=None, relu=False):
 @pytest.mark.parametrize('shape', [(6, 256, 112, 200, 128), (1, 512, 180, 180, 128), (2, 128, 36, 36, 128),
                                    (1, 32, 5, 7, 128), (1, 64, 9, 17, 128), (3, 96, 16, 33, 128), (1, 128, 180, 180, 10),
                                    (13, 32, 16, 256, 128), (1, 64, 41, 50, 128),      # 16-row tiles / ragged 12-row tiles
-                                   (2, 32, 6, 19, 4)])
+                                   (2, 32, 6, 19, 4),
+                                   (2, 256, 21, 50, 10), (1, 128, 8, 16, 16), (1, 384, 9, 33, 3)])   # the class-head kernel: chunk groups, ragged
 def test_conv3x3_matches_torch(shape):
     assert torch.cuda.is_available(), 'gpu tests need a HIP device'
     n, Cin, H, W, Cout = shape
