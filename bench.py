@@ -303,7 +303,7 @@ def launch_text(resident):
 
 
 def graphed_steps(capture, pool, cap, n_lanes, resident, raw_pool=None, launch_threads=True):
-    """The graph-replayed step of both forward lines.  `capture(inputs)` -> GraphedHotPath.  Returns (step, step_copy, step1,
+    """The graph-replayed step of both forward lines.  `capture(inputs, overlap)` -> GraphedHotPath.  Returns (step, step_copy, step1,
     graphs, records, g): `step` = one step of `n_lanes` samples in flight under the chosen hand-over, `step_copy` = the same
     with the copying hand-over of rounds 2-4 (on the first capture of every lane), `step1` = one sample at a time, `g` = the
     LAST capture (the modules' output attributes point at its static outputs: the parity leg load()s pool[0] into it).
@@ -313,16 +313,22 @@ def graphed_steps(capture, pool, cap, n_lanes, resident, raw_pool=None, launch_t
     on its stream - no capture is ever replayed on two streams."""
     import torch
     from deepinteraction_amd.graphed import LaneLaunchers
-    first = capture(pool[cap])                                     # the largest sample sets the capacity
+    # captures that run side by side are single-stream ones (GraphedHotPath `overlap`); the one-at-a-time figure uses
+    # captures with the forward's own fork / join branches.  DI_OVERLAP set: that value everywhere (A/B runs)
+    lane_overlap = 0 if n_lanes > 1 and 'DI_OVERLAP' not in os.environ else None
+    first = capture(pool[cap], None)                               # the largest sample sets the capacity
     records = [first.prepare(d) for d in pool]
+    solo = [first] if not resident or lane_overlap is not None else []
     if resident:
         while len(records) < n_lanes:
             records = records + records
-        graphs = [capture(first.record_inputs(r)) for r in records]
-        first = None
+        if lane_overlap is not None and len(records) > 1:
+            solo.append(capture(first.record_inputs(records[1]), None))
+        graphs = [capture(first.record_inputs(r), lane_overlap) for r in records]
         own = [graphs[l::n_lanes] for l in range(n_lanes)]
     else:
-        own = [[first]] + [[capture(pool[cap])] for _ in range(n_lanes - 1)]
+        own = [[first if lane_overlap is None else capture(pool[cap], lane_overlap)]] + \
+              [[capture(pool[cap], lane_overlap)] for _ in range(n_lanes - 1)]
         graphs = [o[0] for o in own]
     g = graphs[-1]
     lanes = [torch.cuda.Stream() for _ in own] if n_lanes > 1 else [None]
@@ -360,10 +366,11 @@ def graphed_steps(capture, pool, cap, n_lanes, resident, raw_pool=None, launch_t
 
     def step1():
         if resident:
-            graphs[one[0] % len(graphs)]()
+            seq = solo if solo else graphs
+            seq[one[0] % len(seq)]()
         else:
-            g.load(records[one[0] % len(records)])
-            g()
+            solo[0].load(records[one[0] % len(records)])
+            solo[0]()
         one[0] += 1
     return (step_resident if resident else step_copy), step_copy, step1, graphs, records, g
 
@@ -458,7 +465,7 @@ def bench_forward(args, rank, world, device):
             if args.from_raw:          # NCHW-contiguous device maps, as a frozen backbone hands them over
                 raw_pool = [dict(d, img_feats=d['img_feats'].contiguous(), pts_feats=d['pts_feats'].contiguous()) for d in dev_pool]
             step, step_copy, step1, graphs, records, g = graphed_steps(
-                lambda inp: GraphedHotPath(enc, dec, inp, glue=glue, image_net=image_net), dev_pool, cap, n_lanes, resident, raw_pool, bool(args.launch_threads))
+                lambda inp, ov: GraphedHotPath(enc, dec, inp, glue=glue, image_net=image_net, overlap=ov), dev_pool, cap, n_lanes, resident, raw_pool, bool(args.launch_threads))
         settle(step, args.settle_ms)
         for _ in range(args.warmup):
             step()
@@ -581,6 +588,8 @@ def bench_forward(args, rank, world, device):
                      launch='eager' if args.eager else launch_text(resident),
                      handover=None if args.eager else ('resident' if resident else 'copy'),
                      launch_threads=None if args.eager else (n_lanes if args.launch_threads and n_lanes > 1 else 1),
+                     lane_captures=None if args.eager else ('single-stream' if n_lanes > 1 and 'DI_OVERLAP' not in os.environ
+                                                            else 'with the forward\'s fork / join branches'),
                      graph_nodes=None if g is None else g.num_nodes()))
     from deepinteraction_amd import _lib
     roofline['ring_spin_timeouts'] = int(_lib.lib().di_local_attn_ring_timeouts(None))     # bounded flag spins that gave up: must be 0
@@ -666,7 +675,7 @@ def bench_forward_pp(args, rank, world, device):
             resident = args.handover == 'resident'
             # as the v1 line: N independent captured forwards in flight, own sample each
             step, step_copy, step1, graphs, records, g = graphed_steps(
-                lambda inp: GraphedHotPath(enc, dec, inp, image_net=image_net), pool, cap, n_lanes, resident, None, bool(args.launch_threads))
+                lambda inp, ov: GraphedHotPath(enc, dec, inp, image_net=image_net, overlap=ov), pool, cap, n_lanes, resident, None, bool(args.launch_threads))
         settle(step, args.settle_ms)
         for _ in range(args.warmup):
             step()
@@ -720,6 +729,8 @@ def bench_forward_pp(args, rank, world, device):
                      launch='eager' if args.eager else launch_text(resident),
                      handover=None if args.eager else ('resident' if resident else 'copy'),
                      launch_threads=None if args.eager else (n_lanes if args.launch_threads and n_lanes > 1 else 1),
+                     lane_captures=None if args.eager else ('single-stream' if n_lanes > 1 and 'DI_OVERLAP' not in os.environ
+                                                            else 'with the forward\'s fork / join branches'),
                      graph_nodes=None if g is None else g.num_nodes()))
     out['roofline'] = dict(bound='hbm', kernel='pp::ms_deform_attn_hm_kernel<2, 4>, image self-attention (2 levels, 134 400 queries): '
                                                'head-major value map (bs, 8, S, 16), lanes = (query, head, corner column, channel half), '

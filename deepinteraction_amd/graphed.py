@@ -36,8 +36,13 @@ from .mmdet3d_plugin.models.utils.encoder_utils import GEOM_KEY
 
 
 class GraphedHotPath:
-    def __init__(self, encoder, decoder, inputs, warmup=3, glue=None, image_net=None):
-        """image_net: a `FrozenResNetFPN` (mmdet3d_plugin/models/detectors/image_glue.py) - the captured forward then STARTS
+    def __init__(self, encoder, decoder, inputs, warmup=3, glue=None, image_net=None, overlap=None):
+        """overlap: the fork / join sites of the captured forward (`utils.OVERLAP` bits; None = the process default).  0 = a
+        single-stream capture: what several captures replayed side by side on their own streams should be - their
+        parallelism comes from the other samples in flight, and every extra branch stream competes for the process's four
+        hardware queues (four lanes: 1 108-1 125 samples/s with the forked captures, 1 188-1 213 with single-stream ones;
+        one sample at a time the forked capture is the faster one, 1.385 against 1.414 ms).
+        image_net: a `FrozenResNetFPN` (mmdet3d_plugin/models/detectors/image_glue.py) - the captured forward then STARTS
         FROM THE CAMERA IMAGES: `inputs['images']` ((B*N, 3, H, W), the network's dtype) takes the place of
         `inputs['img_feats']` as the static input of the image slot (`self.img_feats` holds the images), and the feature
         levels the neck reads are produced inside every replay.
@@ -85,7 +90,14 @@ class GraphedHotPath:
         self.out = None
         self._health = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else None
         self._build_arena()
-        self._capture(warmup)
+        from . import utils
+        saved = utils.OVERLAP
+        if overlap is not None:
+            utils.OVERLAP = int(overlap)
+        try:
+            self._capture(warmup)
+        finally:
+            utils.OVERLAP = saved
 
     @staticmethod
     def _clone(x):

@@ -302,7 +302,7 @@ def test_resident_handover_captures_match_eager_at_the_benched_shape():
         assert not all(torch.equal(eager[0][k], eager[1][k]) for k in eager[0])
         cap = max(range(4), key=lambda i: int(pool[i]['pts_metas']['pillars'].shape[0]))
         step, step_copy, step1, graphs, records, g = bench.graphed_steps(
-            lambda inp: GraphedHotPath(enc, dec, inp), pool, cap, 2, True)
+            lambda inp, ov: GraphedHotPath(enc, dec, inp, overlap=ov), pool, cap, 2, True)
         assert len(graphs) == 4 and g is graphs[-1]
         for rnd in range(4):
             step()
