@@ -392,8 +392,8 @@ class LaneLaunchers:
     re-raised by `run`."""
 
     def __init__(self, streams):
-        self.streams = list(streams)
-        self._device = torch.cuda.current_device()
+        self.streams = list(streams)                # (None entries: no stream switch - the host-logic tests run without a device)
+        self._device = torch.cuda.current_device() if torch.cuda.is_available() else None
         self._jobs = [queue.SimpleQueue() for _ in self.streams]
         self._done = queue.SimpleQueue()
         self._threads = [threading.Thread(target=self._work, args=(l,), daemon=True, name=f'lane{l}')
@@ -402,8 +402,11 @@ class LaneLaunchers:
             t.start()
 
     def _work(self, l):
-        torch.cuda.set_device(self._device)
-        with torch.no_grad(), torch.cuda.stream(self.streams[l]):
+        import contextlib
+        if self._device is not None:
+            torch.cuda.set_device(self._device)
+        on = torch.cuda.stream(self.streams[l]) if self.streams[l] is not None else contextlib.nullcontext()
+        with torch.no_grad(), on:
             while True:
                 fn = self._jobs[l].get()
                 if fn is None:

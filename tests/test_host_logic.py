@@ -127,3 +127,35 @@ def test_loss_scaler_skips_an_overflow_step_and_backs_off():
     assert float(sc.scale) == 8.0 and float(sc.skipped) == 1.0                # two clean steps: the scale grows
     step(torch.tensor([float('nan'), 0.0, 0.0, 0.0]))
     assert float(sc.scale) == 4.0 and float(sc.skipped) == 2.0 and torch.isfinite(p).all()
+
+
+def test_lane_launchers_run_one_callable_per_lane_thread_and_hand_exceptions_over():
+    """graphed.LaneLaunchers (one launching host thread per in-flight lane): every callable runs on ITS lane's thread, `run`
+    returns after all of them, an exception raised on a lane is re-raised by `run`, and the pool keeps working after it."""
+    import threading
+    import pytest
+    from deepinteraction_amd.graphed import LaneLaunchers
+    pool = LaneLaunchers([None, None, None])
+    seen = [[] for _ in range(3)]
+    main = threading.get_ident()
+
+    def job(l):
+        return lambda: seen[l].append(threading.get_ident())
+    for _ in range(5):
+        pool.run([job(0), job(1), job(2)])
+    assert all(len(s) == 5 and len(set(s)) == 1 and s[0] != main for s in seen)
+    assert len({s[0] for s in seen}) == 3                      # three different threads, the same one per lane every time
+
+    def boom():
+        raise ValueError('lane 1 failed')
+    with pytest.raises(ValueError, match='lane 1 failed'):
+        pool.run([job(0), boom, job(2)])
+    assert len(seen[0]) == 6 and len(seen[2]) == 6             # the other lanes still ran their callable
+    pool.run([job(0), job(1), job(2)])
+    assert [len(s) for s in seen] == [7, 6, 7]
+    grads = []
+    pool.run([lambda: grads.append(torch.is_grad_enabled())] * 3)
+    assert grads == [False, False, False]                      # the lanes issue inference work
+    pool.close()
+    with pytest.raises(AssertionError):
+        pool.run([job(0)])
