@@ -282,7 +282,8 @@ def test_the_graph_can_start_from_the_camera_images():
             _same(out, wout)            # same kernels on the same maps: the head's outputs are then identical too
 
 
-def test_resident_handover_captures_match_eager_at_the_benched_shape():
+@pytest.mark.parametrize('n_lanes', [2, 4])
+def test_resident_handover_captures_match_eager_at_the_benched_shape(n_lanes):
     """bench.py's default step since round 5 (`--handover resident`, `bench.graphed_steps`): one captured forward per pool
     sample, captured from the prepared (padded) record, lane l replaying the captures of samples l, l + L, ... in turn on its
     stream - every replay bit-identical to the eager forward of ITS sample; then the copying hand-over on the same captures
@@ -302,8 +303,20 @@ def test_resident_handover_captures_match_eager_at_the_benched_shape():
         assert not all(torch.equal(eager[0][k], eager[1][k]) for k in eager[0])
         cap = max(range(4), key=lambda i: int(pool[i]['pts_metas']['pillars'].shape[0]))
         step, step_copy, step1, graphs, records, g = bench.graphed_steps(
-            lambda inp, ov: GraphedHotPath(enc, dec, inp, overlap=ov), pool, cap, 2, True)
+            lambda inp, ov: GraphedHotPath(enc, dec, inp, overlap=ov), pool, cap, n_lanes, True)
         assert len(graphs) == 4 and g is graphs[-1]
+        if n_lanes == 4:
+            # the bench's default: four captures replayed side by side, 8 rounds of 3 steps; the outputs are wiped between the
+            # rounds, so every round's replays must have produced them again - under the others' traffic
+            for rnd in range(8):
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                for i, gi in enumerate(graphs):
+                    _same(gi.out[0][0], eager[i])
+                    for v in gi.out[0][0].values():
+                        v.zero_()
+            return
         for rnd in range(4):
             step()
         torch.cuda.synchronize()
