@@ -434,3 +434,60 @@ class LaneLaunchers:
         for t in self._threads:
             t.join()
         self._threads = []
+
+
+class InflightLanes:
+    """Several samples in flight on one GPU, the serving form of what `bench.py` times: `n_lanes` lanes, each a HIP stream with
+    its own SINGLE-STREAM capture of the forward (`GraphedHotPath(overlap=0)`: the lanes are each other's parallelism) and its own
+    launching host thread (`LaneLaunchers`).  Use four lanes, or a multiple: a process has four hardware queues, and a lane count
+    that is not a multiple of four puts two lanes on one queue (5 lanes: 1 053 samples/s against 1 202 with 4).
+
+        lanes = InflightLanes(encoder, decoder, example_inputs, n_lanes=4)
+        lanes[l].load(record)              # or: the producer writes into lanes[l].img_feats / .pts_feats / .pts / .pillars* and
+        lanes[l].load_geometry(img_metas)  #     the geometry constants are refreshed in place (zero-copy hand-over)
+        outs = lanes.replay()              # one replay per lane, issued side by side from the lanes' threads (no synchronisation)
+        lanes.synchronize()                # outs[l] are lane l's static output tensors: valid until its next replay
+
+    `example_inputs` sets the shapes and the point / pillar capacity of every lane (`prepare()` pads smaller samples)."""
+
+    def __init__(self, encoder, decoder, example_inputs, n_lanes=4, launch_threads=True, **capture_kwargs):
+        self.slots = [GraphedHotPath(encoder, decoder, example_inputs, overlap=0 if n_lanes > 1 else None, **capture_kwargs)
+                      for _ in range(n_lanes)]
+        self.streams = [torch.cuda.Stream() for _ in self.slots]
+        for s_ in self.streams:
+            s_.wait_stream(torch.cuda.current_stream())
+        self._launchers = LaneLaunchers(self.streams) if launch_threads and n_lanes > 1 else None
+
+    def __len__(self):
+        return len(self.slots)
+
+    def __getitem__(self, l):
+        return self.slots[l]
+
+    def prepare(self, inputs):
+        return self.slots[0].prepare(inputs)            # every lane has the same layout: a record loads into any of them
+
+    def load(self, l, record):
+        """`slots[l].load(record)` on lane l's stream (ordered behind the lane's previous replay)."""
+        with torch.cuda.stream(self.streams[l]):
+            self.slots[l].load(record)
+
+    def replay(self, which=None):
+        """One replay of every lane (or of the lanes listed in `which`), issued side by side; returns their static outputs."""
+        which = list(range(len(self.slots))) if which is None else list(which)
+        if self._launchers is not None and len(which) == len(self.slots):
+            self._launchers.run(self.slots)
+        else:
+            for l in which:
+                with torch.cuda.stream(self.streams[l]):
+                    self.slots[l]()
+        return [self.slots[l].out for l in which]
+
+    def synchronize(self):
+        for s_ in self.streams:
+            s_.synchronize()
+
+    def close(self):
+        if self._launchers is not None:
+            self._launchers.close()
+            self._launchers = None

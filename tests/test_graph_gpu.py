@@ -341,3 +341,36 @@ def test_resident_handover_captures_match_eager_at_the_benched_shape(n_lanes):
         torch.cuda.synchronize()
         _same(graphs[0].out[0][0], eager[(2 * 2) % 4])       # lane 0 loaded records 0, 2, 4
         _same(graphs[1].out[0][0], eager[(2 * 2 + 1) % 4])
+
+
+def test_inflight_lanes_serving_form():
+    """graphed.InflightLanes: four lanes (single-stream captures, own streams, own launching threads), records loaded per lane,
+    replays issued side by side - every lane's outputs bit-identical to the eager forward of the sample it was given, over
+    several rounds with the samples rotating through the lanes."""
+    from deepinteraction_amd import harness, parallel
+    from deepinteraction_amd.graphed import InflightLanes
+    shape = synth.SHAPE_R
+    enc, dec = harness.build_models(shape, 200, torch.float16, 'cuda')
+    pool = [harness.to_device(synth.make_inputs(1, shape, seed=parallel.sample_seed(i)), 'cuda', torch.float16)
+            for i in range(5)]
+    with torch.no_grad():
+        eager = []
+        for d in pool:
+            _, out = harness.forward(enc, dec, d)
+            torch.cuda.synchronize()
+            eager.append({k: v.clone() for k, v in out[0][0].items()})
+        cap = max(range(5), key=lambda i: int(pool[i]['pts_metas']['pillars'].shape[0]))
+        lanes = InflightLanes(enc, dec, pool[cap], n_lanes=4)
+        recs = [lanes.prepare(d) for d in pool]
+        for rnd in range(5):
+            given = [(rnd + l) % 5 for l in range(4)]
+            for l, i in enumerate(given):
+                lanes.load(l, recs[i])
+            outs = lanes.replay()
+            lanes.synchronize()
+            for l, i in enumerate(given):
+                _same(outs[l][0][0], eager[i])
+        outs = lanes.replay(which=[2])                       # a single lane, from the calling thread
+        lanes.synchronize()
+        _same(outs[0][0][0], eager[given[2]])
+        lanes.close()
