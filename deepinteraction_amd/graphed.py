@@ -89,15 +89,13 @@ class GraphedHotPath:
         self.graph = None
         self.out = None
         self._health = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else None
+        # the process-global, monotonic device counter as this capture has already reported it (construction: what earlier
+        # launches of the process left behind is not this capture's fault)
+        self._health_seen = [0]
         self._build_arena()
         from . import utils
-        saved = utils.OVERLAP
-        if overlap is not None:
-            utils.OVERLAP = int(overlap)
-        try:
+        with utils.overlap(overlap):          # this thread's forwards only: other threads keep their fork / join sites
             self._capture(warmup)
-        finally:
-            utils.OVERLAP = saved
 
     @staticmethod
     def _clone(x):
@@ -196,11 +194,14 @@ class GraphedHotPath:
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.out = self._forward()
 
-    def check_health(self):
-        """Synchronises and raises when a captured kernel reported a fault it could only report through device memory (the
-        ring window attention's bounded spins: affected tiles are NaN in the outputs).  Call it where the outputs are read."""
+    def check_health(self, stream=None):
+        """Synchronises `stream` (default: the current one; InflightLanes passes the lane's) and raises when a captured
+        kernel reported a fault it could only report through device memory since the last check (the ring window attention's
+        bounded spins: affected tiles are NaN in the outputs).  Call it where the outputs are read.  A fault is reported
+        ONCE: the baseline moves up, later replays with sound outputs do not raise again."""
         from . import ops
-        ops.check_ring_health()
+        with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
+            ops.check_ring_health(self._health_seen)
 
     def num_nodes(self):
         """Nodes (kernel launches, copies, memsets) of the captured forward, or None when torch does not expose it."""
@@ -210,9 +211,10 @@ class GraphedHotPath:
         # faults a captured kernel can only report through device memory (the ring window attention's bounded spins: the
         # affected tiles are NaN): a pinned host word receives the device counter behind every replay, without a
         # synchronisation; what an EARLIER replay reported is checked here
-        if self._health is not None and int(self._health[0]) != 0:
-            raise RuntimeError(f'local_attn_ring: {int(self._health[0])} bounded spins gave up in an earlier replay - the affected '
-                               'output tiles hold NaN (ops.check_ring_health)')
+        if self._health is not None and int(self._health[0]) > self._health_seen[0]:
+            new, self._health_seen[0] = int(self._health[0]) - self._health_seen[0], int(self._health[0])
+            raise RuntimeError(f'local_attn_ring: {new} bounded spins gave up in an earlier replay - the affected output tiles of '
+                               'THAT replay hold NaN (ops.check_ring_health); reported once, later replays are checked afresh')
         self.graph.replay()
         if self._health is not None:
             from . import _lib, ops
@@ -472,8 +474,11 @@ class InflightLanes:
         with torch.cuda.stream(self.streams[l]):
             self.slots[l].load(record)
 
-    def replay(self, which=None):
-        """One replay of every lane (or of the lanes listed in `which`), issued side by side; returns their static outputs."""
+    def replay(self, which=None, check_health=False):
+        """One replay of every lane (or of the lanes listed in `which`), issued side by side; returns their static outputs.
+        `check_health=True` (serving paths that must never hand out a poisoned tile): synchronises the replayed lanes and
+        raises BEFORE returning when a kernel of these replays reported a fault through device memory (the ring window
+        attention's bounded spins: NaN tiles).  Default False: no synchronisation, a fault is raised by the NEXT replay."""
         which = list(range(len(self.slots))) if which is None else list(which)
         if self._launchers is not None and len(which) == len(self.slots):
             self._launchers.run(self.slots)
@@ -481,7 +486,14 @@ class InflightLanes:
             for l in which:
                 with torch.cuda.stream(self.streams[l]):
                     self.slots[l]()
+        if check_health:
+            self.check_health(which)
         return [self.slots[l].out for l in which]
+
+    def check_health(self, which=None):
+        """Synchronous health check of the listed lanes (all by default), each under ITS stream."""
+        for l in (range(len(self.slots)) if which is None else which):
+            self.slots[l].check_health(self.streams[l])
 
     def synchronize(self):
         for s_ in self.streams:

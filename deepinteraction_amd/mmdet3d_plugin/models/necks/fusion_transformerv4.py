@@ -56,7 +56,7 @@ class MMRI_P2I(nn.Module):
         _, C, H, W = img_feats.shape
         q = _tokens(img_feats)
         lidar_feats = ops.cl(lidar_feats)
-        if C == 128 and fused_tokens_ok(q, self.Local) and lidar_feats.dtype == torch.float16:
+        if C == 128 and self.Local.can_fuse_tokens(q) and lidar_feats.dtype == torch.float16:      # the SAME predicate Local.forward tests
             # the value projection GATHERS its input: the warped map (34 MB per sample) is neither written nor read
             # (ops.warp_project, the launch the v1 P2I block uses for its key / value projections)
             vp = self.Local.value_proj

@@ -169,6 +169,13 @@ class MultiScaleDeformableAttention(nn.Module):
             return [ops.chain_image(*padded128(so.weight, so.bias)), ops.chain_image(*padded128(aw.weight, aw.bias))]
         return module_cache(self, '_proj_images', [self.sampling_offsets, self.attention_weights], build)
 
+    def can_fuse_tokens(self, query, key_padding_mask=None):
+        """The fused fp16 inference form (chain-kernel projections, head-major value map, `ms_deform_attn_hm_kernel`) covers
+        what its kernels cover - 128 channels in 8 heads of 16, 4 points on 1 or 2 levels, no padding mask; anything else
+        (mmcv's default num_levels=4, other num_points) takes the generic kernel path."""
+        return (self.embed_dims == 128 and self.num_heads == 8 and self.num_points == 4 and self.num_levels in (1, 2)
+                and key_padding_mask is None and fused_tokens_ok(query, self))
+
     def can_fuse_norm(self, query, norm):
         """LayerNorm(identity + output_proj(.)) as the epilogue of the output projection (ops.linear_ln)."""
         return (self.batch_first and self.embed_dims == 128 and fused_tokens_ok(query, self) and isinstance(norm, nn.LayerNorm)
@@ -180,7 +187,7 @@ class MultiScaleDeformableAttention(nn.Module):
         """`then_norm`: an nn.LayerNorm applied to the result (the layer's next 'norm' step) - the residual add is
         then folded into the normalisation kernel; `with_sum` (with `then_norm`, fused form only): also return the
         un-normalised result -> (normed, sum).  `projected_value`: value_proj(value) when the caller already has it - HEAD-MAJOR
-        (bs, 8, S, 16) for the fused fp16 inference form (`fused_tokens_ok`), (bs, S, C) otherwise."""
+        (bs, 8, S, 16) for the fused fp16 inference form (`can_fuse_tokens`), (bs, S, C) otherwise."""
         if value is None:
             value = query
         if identity is None:
@@ -191,7 +198,7 @@ class MultiScaleDeformableAttention(nn.Module):
             query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
         shapes = [(int(h), int(w)) for h, w in spatial_shapes]
         bs, nq, _ = query.shape
-        fused = self.embed_dims == 128 and self.num_heads == 8 and fused_tokens_ok(query, self) and key_padding_mask is None
+        fused = self.can_fuse_tokens(query, key_padding_mask)
         n_off = self.num_heads * self.num_levels * self.num_points * 2
         n_log = n_off // 2
         ref = reference_points.to(torch.float32).contiguous()

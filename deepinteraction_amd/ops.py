@@ -131,12 +131,22 @@ def ring_timeouts():
     return n
 
 
-def check_ring_health():
-    """Raise when a window-attention launch gave up on a flag spin (its output tiles are NaN-poisoned)."""
+_RING_SEEN = [0]        # the counter value the last health check (or GraphedHotPath replay check) has already reported
+
+
+def check_ring_health(seen=None):
+    """Raise when a window-attention launch gave up on a flag spin SINCE THE LAST CHECK (its output tiles are NaN-poisoned).
+    The device counter is process-global and monotonic: a fault is reported once - the baseline then moves up, so that later
+    launches / replays whose outputs are fine do not keep raising for an old transient.  `seen`: a caller's own baseline
+    (a one-element list, updated in place); default = the process-wide one."""
+    seen = _RING_SEEN if seen is None else seen
     n = ring_timeouts()
-    if n:
-        raise _lib.HipLibraryError(f'local_attn_ring: {n} bounded spins gave up - the affected output tiles hold NaN; '
-                                   'the device (or another process sharing it) stalled a workgroup for > 0.1 s')
+    if n > seen[0]:
+        new, seen[0] = n - seen[0], n
+        _RING_SEEN[0] = max(_RING_SEEN[0], n)
+        raise _lib.HipLibraryError(f'local_attn_ring: {new} bounded spins gave up since the last check ({n} since the library '
+                                   'was loaded) - the affected output tiles hold NaN; the device (or another process sharing '
+                                   'it) stalled a workgroup for > 0.1 s')
 
 
 def local_attention_train_usable(q, k, v, kH, kW):

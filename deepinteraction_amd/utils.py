@@ -15,8 +15,44 @@ _SIDE_STREAMS = {}
 # which fork/join sites are active (bit 0: encoder layer sides, 1: the two shared convs, 2: depth chain, 3: decoder
 # first map, 4: the BEV -> image warp opens the side stream, 5: RoI side of a decoder block beside its self attention - measured
 # slower, off); DI_OVERLAP overrides for A/B measurements
+import contextlib as _contextlib
 import os as _os
-OVERLAP = int(_os.environ.get('DI_OVERLAP', '29'))   # measured (tools/overlap_ab.sh), ms/step: 0: 1.848, 1: 1.800, 5: 1.750, 13: 1.726, 15 (three-way fork): 1.86; later build 13: 1.707, 29: 1.693
+import sys as _sys
+import threading as _threading
+import types as _types
+
+_OVERLAP_DEFAULT = int(_os.environ.get('DI_OVERLAP', '29'))   # measured (tools/overlap_ab.sh), ms/step: 0: 1.848, 1: 1.800, 5: 1.750, 13: 1.726, 15 (three-way fork): 1.86; later build 13: 1.707, 29: 1.693
+_OVERLAP_LOCAL = _threading.local()
+
+
+class _Module(_types.ModuleType):
+    """`utils.OVERLAP` is what every fork / join site reads.  Reading returns the calling THREAD's override (`overlap(mask)`
+    context: a lane capture, a measurement) or else the process default; assigning sets the process default.  A capture on
+    one host thread (GraphedHotPath(overlap=0)) therefore never changes what a forward on another thread sees."""
+
+    @property
+    def OVERLAP(self):
+        return getattr(_OVERLAP_LOCAL, 'mask', None) if getattr(_OVERLAP_LOCAL, 'mask', None) is not None else _OVERLAP_DEFAULT
+
+    @OVERLAP.setter
+    def OVERLAP(self, mask):
+        global _OVERLAP_DEFAULT
+        _OVERLAP_DEFAULT = int(mask)
+
+
+_sys.modules[__name__].__class__ = _Module
+
+
+@_contextlib.contextmanager
+def overlap(mask):
+    """The fork / join mask of the forwards THIS thread issues inside the context (None: leave it as it is)."""
+    saved = getattr(_OVERLAP_LOCAL, 'mask', None)
+    if mask is not None:
+        _OVERLAP_LOCAL.mask = int(mask)
+    try:
+        yield
+    finally:
+        _OVERLAP_LOCAL.mask = saved
 
 
 def side_stream(device, i=0):

@@ -123,6 +123,7 @@ except Exception as e:
     assert 'NaN' in str(e)
 else:
     raise AssertionError('check_ring_health did not raise')
+ops.check_ring_health()        # a fault is reported ONCE: the baseline has moved up, nothing new happened since (round-5 advice)
 print('POISON_OK', n, round(frac, 3))
 '''
 
