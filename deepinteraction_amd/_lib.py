@@ -28,6 +28,8 @@ SIGNATURES = {
     'di_pointwise_chain_fwd': [_c_p] * 8 + [ctypes.c_longlong] + [_c_i] * 4 + [_c_p],
     'di_pointwise_chain_masked_fwd': [_c_p] * 8 + [ctypes.c_longlong] + [_c_i] * 4 + [_c_p, _c_p, _c_p],
     'di_i2p_build_keys': [_c_p] * 6 + [_c_i] * 8 + [_c_f, _c_f, _c_p],
+    'di_i2p_compact_keys': [_c_p] * 3 + [_c_i] * 5 + [_c_p],
+    'di_i2p_attn_dense_fwd': [_c_p] * 7 + [_c_i] * 5 + [_c_p],
     'di_i2p_attn_fwd': [_c_p] * 6 + [_c_i] * 7 + [_c_f, ctypes.c_ulonglong, _c_i, _c_p],
     'di_i2p_attn_bwd': [_c_p] * 10 + [_c_i] * 9 + [_c_f, _c_f, _c_f, ctypes.c_ulonglong, _c_i, _c_p],
     'di_i2p_attn_fwd_mass': [_c_p] * 7 + [_c_i] * 7 + [_c_f, ctypes.c_ulonglong, _c_i, _c_p],
@@ -85,11 +87,11 @@ SIGNATURES = {
     'di_wgrad_f32': [_c_p, _c_p, ctypes.c_longlong, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p],
 }
 # helpers that return a value instead of an error code
-VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_i2p_key_table_bytes': [_c_i] * 4, 'di_topk_workspace_bytes': [_c_i] * 3,
+VALUE_FUNCS = {'di_mha_decode_scratch_floats': [_c_i] * 4, 'di_i2p_key_table_bytes': [_c_i] * 4, 'di_i2p_dense_bytes': [_c_i] * 5, 'di_topk_workspace_bytes': [_c_i] * 3,
                'di_token_splitk_workspace_bytes': [_c_i] * 2, 'di_mha_decode_x_ranges': [_c_i] * 3,
                'di_graph_node_count': [_c_p], 'di_local_attn_ring_timeouts': [_c_p], 'di_bn_workspace_floats': [_c_i],
                'di_timed_consumed': [], 'di_wgrad_workspace_floats': [ctypes.c_longlong, _c_i, _c_i]}
-_LONGLONG = {'di_wgrad_workspace_floats', 'di_topk_workspace_bytes', 'di_i2p_key_table_bytes', 'di_graph_node_count', 'di_token_splitk_workspace_bytes'}
+_LONGLONG = {'di_i2p_dense_bytes', 'di_wgrad_workspace_floats', 'di_topk_workspace_bytes', 'di_i2p_key_table_bytes', 'di_graph_node_count', 'di_token_splitk_workspace_bytes'}
 
 # ---- the step program of di_token_program (structs of include/deepinteraction_hip.h)
 TOK_LOAD, TOK_LOAD_PARTS, TOK_ATTN, TOK_COMBINE, TOK_LINEAR, TOK_ROWOP, TOK_STORE, TOK_HEADS = range(1, 9)

@@ -22,7 +22,9 @@ FLAGS = ['-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-cuda-compat', '-Wno-unus
 
 
 # per-file flags; DI_PACKED_FP32=1 (experiments only) compiles WITH the packed instructions
-EXTRA = {}
+# i2p_dense.hip: MFMA results in arch VGPRs (the accumulators are touched by a rare VALU rescale; with AGPR accumulators
+# the compiler moves all 32 of them to VGPRs and back around every block - 64 moves per 12 MFMAs)
+EXTRA = {'i2p_dense.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 if os.environ.get('DI_PACKED_FP32') == '1':
     FLAGS = [f for f in FLAGS if f not in ('-Xclang', '-target-feature', '-packed-fp32-ops')]
 

@@ -9,6 +9,7 @@
 // cheaper than caching it in HBM.
 #include "di_common.h"
 #include "warp_common.h"
+#include "i2p_common.h"
 
 namespace di {
 
@@ -50,14 +51,7 @@ __device__ __forceinline__ bool project_point(const float *__restrict__ M /*4x4 
 //      version (projection of all 120 slots per pillar and layer, fp32 blend after 32 conversions per key, 64-bit
 //      address arithmetic, per-group maxima) spent ~4x that.
 // ---------------------------------------------------------------------------------
-constexpr int kMaxSlots = 128;
-
-struct KeyEnt {      // 32 B
-  int pix;           // (camera * Hi + ya) * Wi + xa : the upper-left corner, clamped into the map
-  int info;          // bit 0: the right corners are one pixel further; bit 1: the lower corners one row; bits 8..: slot
-  float w00, w01, w10, w11;   // bilinear weights; 0 where grid_sample's zero padding applies
-  int pad0, pad1;
-};
+// kMaxSlots, KeyEnt: i2p_common.h (shared with the matrix-core attention pass, i2p_dense.hip)
 
 __global__ __launch_bounds__(256) void i2p_clear_kernel(int *__restrict__ cnt, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;

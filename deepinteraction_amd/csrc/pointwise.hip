@@ -18,6 +18,8 @@
 // hidden activations never leave registers, and W2's columns are permuted accordingly when it is staged.
 // Weights live in LDS (XOR-swizzled 16-B chunks: conflict-free ds_read_b128 fragments), staged once per
 // persistent workgroup.  fp32 accumulation, bias add in fp32.
+#include <hip/hip_ext.h>
+
 #include "di_common.h"
 #include "warp_common.h"
 #include <type_traits>
@@ -319,9 +321,15 @@ static int launch(const void *x1, const void *x2, const void *x3, const void *w1
   const int per_cu = LDS <= 80 * 1024 ? 2 : 1;
   long long grid = (long long)n_cu * per_cu;
   if (grid * NW > nchunk) grid = (nchunk + NW - 1) / NW;
-  hipLaunchKernelGGL((pointwise_chain_kernel<K1, K2>), dim3((unsigned)grid), dim3(NT), LDS, stream,
-                     (const __half *)x1, (const __half *)x2, (const __half *)x3, (const __half *)w1, b1,
-                     (const __half *)w2, b2, (__half *)y, M, relu1, relu2, (const __half *)mask, bm, hm_S);
+  hipEvent_t ev0, ev1;
+  if (take_launch_events(ev0, ev1))                          // measurement: the dispatch's own begin / end time stamps
+    hipExtLaunchKernelGGL((pointwise_chain_kernel<K1, K2>), dim3((unsigned)grid), dim3(NT), LDS, stream, ev0, ev1, 0,
+                          (const __half *)x1, (const __half *)x2, (const __half *)x3, (const __half *)w1, b1,
+                          (const __half *)w2, b2, (__half *)y, M, relu1, relu2, (const __half *)mask, bm, hm_S);
+  else
+    hipLaunchKernelGGL((pointwise_chain_kernel<K1, K2>), dim3((unsigned)grid), dim3(NT), LDS, stream,
+                       (const __half *)x1, (const __half *)x2, (const __half *)x3, (const __half *)w1, b1,
+                       (const __half *)w2, b2, (__half *)y, M, relu1, relu2, (const __half *)mask, bm, hm_S);
   return check_launch("pointwise_chain");
 }
 
@@ -841,7 +849,12 @@ static int launch_multi(const void *x, const MultiArgs &A, long long M, long lon
   constexpr int LDS = 2 * kChainImage;
   static LdsRaised lds_raised;
   if (int rc = ensure_lds(lds_raised, (const void *)pointwise_multi_kernel<NG, WARP>, LDS)) return rc;
-  hipLaunchKernelGGL((pointwise_multi_kernel<NG, WARP>), dim3((unsigned)grid), dim3(NT), LDS, stream, (const __half *)x, A, M, Wp);
+  hipEvent_t ev0, ev1;
+  if (take_launch_events(ev0, ev1))                          // measurement: the dispatch's own begin / end time stamps
+    hipExtLaunchKernelGGL((pointwise_multi_kernel<NG, WARP>), dim3((unsigned)grid), dim3(NT), LDS, stream, ev0, ev1, 0,
+                          (const __half *)x, A, M, Wp);
+  else
+    hipLaunchKernelGGL((pointwise_multi_kernel<NG, WARP>), dim3((unsigned)grid), dim3(NT), LDS, stream, (const __half *)x, A, M, Wp);
   return check_launch("pointwise_multi");
 }
 

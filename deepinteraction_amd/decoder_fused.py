@@ -44,6 +44,12 @@ def usable(dec, lidar_feat, img_feat):
             return False
         if pp and not (blk.ffn.num_fcs == 2 and blk.self_ffn.num_fcs == 2 and blk.ffn.add_identity and blk.self_ffn.add_identity):
             return False
+        # the one-launch self branch (csrc/v2_self.hip: hidden <= 1024 in multiples of 32, <= 8 views, <= 512 queries - the
+        # proposal bound above): anything wider takes the module path (torch) instead of failing in the kernel's argument check
+        if pp and not (blk.self_ffn.feedforward_channels <= 1024 and blk.self_ffn.feedforward_channels % 32 == 0):
+            return False
+    if pp and img_feat is not None and lidar_feat.shape[0] > 0 and img_feat.shape[0] // lidar_feat.shape[0] > 8:
+        return False
     layer = dec.decoder[0]
     if layer.cross_only or layer.self_posembed is None or layer.cross_posembed is None:
         return False

@@ -11,6 +11,7 @@ import ctypes
 
 import collections
 import math
+import os
 
 import torch
 
@@ -266,9 +267,10 @@ def pointwise_chain(x1, w1, b1, relu1, x2=None, w2=None, b2=None, relu2=False, x
         assert mask.dtype == torch.float16 and mask.numel() == n * H * W and mask.is_contiguous()
         assert bm.dtype == torch.float32 and bm.numel() == 128
     y = empty_cl(n, 128, H, W, x1)
-    _lib.call('di_pointwise_chain_masked_fwd', x1.data_ptr(), ptr(x2), ptr(x3), w1.data_ptr(), b1.data_ptr(), ptr(w2),
-              ptr(b2), y.data_ptr(), n * H * W, k1, k2, int(bool(relu1)), int(bool(relu2)), ptr(mask), ptr(bm),
-              _stream())
+    _profiled('pointwise_chain', n * (k1 + k2), lambda: _lib.call(
+        'di_pointwise_chain_masked_fwd', x1.data_ptr(), ptr(x2), ptr(x3), w1.data_ptr(), b1.data_ptr(), ptr(w2),
+        ptr(b2), y.data_ptr(), n * H * W, k1, k2, int(bool(relu1)), int(bool(relu2)), ptr(mask), ptr(bm),
+        _stream()))
     return y
 
 
@@ -410,13 +412,18 @@ def pointwise_multi(x, chains):
 
 
 # ------------------------------------------------------------------ image -> BEV
-I2PKeys = collections.namedtuple('I2PKeys', 'table T V bev_hw')
+I2PKeys = collections.namedtuple('I2PKeys', 'table T V bev_hw dense dense_order', defaults=(None, None))
 
 
-def i2p_key_table(pillars, coors, num_points, proj, aug_rev, ori_hw, img_hw, bev_hw):
+I2P_DENSE = int(os.environ.get('DI_I2P_DENSE', '0'))      # 0: never build / use the dense key stream (A/B measurements)
+
+
+def i2p_key_table(pillars, coors, num_points, proj, aug_rev, ori_hw, img_hw, bev_hw, dense=True, sector_order=True):
     """Geometry pass of the pillar attention for ONE sample: the per-cell key table (valid-key count, pillar id and the
     compacted sampling coordinates of every (point, camera) slot that lands in an image).  Depends on the points and the
-    metas only - build it once per sample and hand it to every `i2p_attention` call (all encoder layers)."""
+    metas only - build it once per sample and hand it to every `i2p_attention` call (all encoder layers).
+    dense: also pack the keys into the dense stream the matrix-core attention pass reads (`di_i2p_compact_keys`, two small
+    launches; groups of 8 cells of the walk order - `sector_order` must then match the `i2p_attention` calls)."""
     _dev(pillars, coors, num_points, proj, aug_rev)
     P, T, D = pillars.shape
     V = proj.shape[0]
@@ -429,7 +436,13 @@ def i2p_key_table(pillars, coors, num_points, proj, aug_rev, ori_hw, img_hw, bev
     _lib.call('di_i2p_build_keys', pillars.data_ptr(), coors.data_ptr(), num_points.data_ptr(), proj.data_ptr(),
               aug_rev.data_ptr(), table.data_ptr(), P, T, D, V, Hi, Wi, Hb, Wb, float(ori_hw[0]), float(ori_hw[1]),
               _stream())
-    return I2PKeys(table, T, V, (Hb, Wb))
+    if not (dense and I2P_DENSE):
+        return I2PKeys(table, T, V, (Hb, Wb))
+    order = bev_sector_order(Hb, Wb, pillars.device) if sector_order else None
+    dtab = torch.empty(int(_lib.lib().di_i2p_dense_bytes(Hb, Wb, T, V, P)), dtype=torch.uint8, device=pillars.device)
+    _lib.call('di_i2p_compact_keys', table.data_ptr(), None if order is None else order.data_ptr(), dtab.data_ptr(), T, V, Wi, Hb,
+              Wb, _stream())
+    return I2PKeys(table, T, V, (Hb, Wb), dtab, bool(sector_order))
 
 
 _CELL_ORDER = {}
@@ -560,6 +573,13 @@ def i2p_attention(img, qfold, pillars, coors, num_points, proj, aug_rev, ori_hw,
     ctx = empty_cl(1, C, Hb, Wb, img)          # (allocating NCHW and converting was a 16 us transposing copy of garbage)
     valid = torch.empty((1, 1, Hb, Wb), dtype=img.dtype, device=img.device)
     order = bev_sector_order(Hb, Wb, img.device).data_ptr() if sector_order else None
+    if (keys.dense is not None and keys.dense_order == bool(sector_order) and not with_mass and dropout_p == 0.0
+            and img.dtype == torch.float16 and C == 128):
+        # the matrix-core pass (csrc/i2p_dense.hip): fp16 maps, 128 channels, no attention dropout
+        _profiled('i2p_attn_fwd', V, lambda: _lib.call(
+            'di_i2p_attn_dense_fwd', img.data_ptr(), qfold.data_ptr(), keys.table.data_ptr(), keys.dense.data_ptr(), order,
+            ctx.data_ptr(), valid.data_ptr(), V, Hi, Wi, Hb, Wb, _stream()))
+        return ctx, valid
     if with_mass:
         mass = torch.empty_like(valid)
         _lib.call('di_i2p_attn_fwd_mass', img.data_ptr(), qfold.data_ptr(), keys.table.data_ptr(), order, ctx.data_ptr(),

@@ -189,6 +189,19 @@ int di_i2p_attn_fwd(const void *img, const void *qfold, const void *key_table, c
 int di_i2p_attn_fwd_mass(const void *img, const void *qfold, const void *key_table, const int32_t *cell_order, void *ctx,
                          void *valid, void *mass, int T, int n_views, int Hi, int Wi, int Hb, int Wb, int C, float dropout_p,
                          unsigned long long seed, int dtype, void *stream);
+/* The attention pass ON THE MATRIX CORES (round 6; csrc/i2p_dense.hip) for fp16 maps of C = 128 channels without attention
+ * dropout - the benched inference configuration; same inputs, same outputs (every cell of ctx / valid written) as
+ * di_i2p_attn_fwd within fp16 round-off (the probabilities times the bilinear weights enter the value product as fp16).
+ * It reads the keys from a DENSE STREAM: di_i2p_compact_keys (once per sample, after di_i2p_build_keys; shared by all
+ * encoder layers) packs the keys of every group of 8 consecutive cells of the walk order `cell_order` (NULL = row-major;
+ * the SAME order must be passed to both calls) one behind the other, with explicit corner offsets, into `dense_table`
+ * (di_i2p_dense_bytes bytes, caller-owned; P = the number of pillars the key table was built from, an upper bound is fine). */
+long long di_i2p_dense_bytes(int Hb, int Wb, int T, int n_views, int P);
+int di_i2p_compact_keys(const void *key_table, const int32_t *cell_order, void *dense_table, int T, int n_views, int Wi, int Hb,
+                        int Wb, void *stream);
+int di_i2p_attn_dense_fwd(const void *img, const void *qfold, const void *key_table, const void *dense_table,
+                          const int32_t *cell_order, void *ctx, void *valid, int n_views, int Hi, int Wi, int Hb, int Wb,
+                          void *stream);
 /* Backward of the above: grad_ctx (Hb,Wb,C) -> grad_img (n_views,Hi,Wi,C) and grad_qfold (Hb,Wb,C), both
  * float32, zero-filled by the caller (grad_img is accumulated with atomics).  The sampling coordinates carry
  * no gradient (points and metas are data). */

@@ -1,0 +1,106 @@
+"""The matrix-core pillar attention (csrc/i2p_dense.hip, round 6) against the wave-per-cell kernel it replaces in the fp16
+inference forward (csrc/cross_modal.hip; that one is checked against the oracle's MMRI_I2P - reference
+encoder_utils.py:226-320 - in tests/test_encoder_gpu.py::test_i2p_module, which now runs the dense kernel as well)."""
+import pytest
+import torch
+
+from deepinteraction_amd import ops, synth
+from deepinteraction_amd.geometry import SampleGeometry
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _sample(shape, seed):
+    inp = synth.make_inputs(1, shape, seed=seed)
+    Hi, Wi = shape['img_hw']
+    geom = SampleGeometry(inp['img_metas'][0], (Hi, Wi), DEV)
+    pm = inp['pts_metas']
+    args = (pm['pillars'].to(DEV), pm['pillar_coors'].to(DEV), pm['pillars_num_points'].to(DEV), geom.lidar2img, geom.aug_rev,
+            geom.ori_hw)
+    return args
+
+
+def _maps(shape, seed, qscale):
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    img = torch.randn(6, 128, Hi, Wi, device=DEV, generator=g).half().contiguous(memory_format=torch.channels_last)
+    qf = (torch.randn(1, 128, Hb, Wb, device=DEV, generator=g) * qscale).half().contiguous(memory_format=torch.channels_last)
+    return img, qf
+
+
+def _both(shape, args, img, qf, sector_order):
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    keys_d = ops.i2p_key_table(*args, (Hi, Wi), (Hb, Wb), dense=True, sector_order=sector_order)
+    keys_w = ops.i2p_key_table(*args, (Hi, Wi), (Hb, Wb), dense=False)
+    assert keys_d.dense is not None and keys_w.dense is None
+    got, gv = ops.i2p_attention(img, qf, *args, keys=keys_d, sector_order=sector_order)
+    ref, rv = ops.i2p_attention(img, qf, *args, keys=keys_w, sector_order=sector_order)
+    torch.cuda.synchronize()
+    return got.float(), gv.float(), ref.float(), rv.float(), keys_d
+
+
+@pytest.mark.parametrize('sector_order', [True, False])
+@pytest.mark.parametrize('shape_name,qscale', [('TINY', 0.1), ('R', 0.1), ('R', 1.0)])
+def test_dense_kernel_matches_the_wave_per_cell_kernel(shape_name, qscale, sector_order):
+    """Same inputs, same key table: every cell of ctx / valid.  qscale 1.0: logits of +-30 and more - one-hot soft-maxes and
+    the lazy reference maximum's rescale path (a later key beating the first by more than 2^8)."""
+    shape = synth.SHAPE_R if shape_name == 'R' else synth.SHAPE_TINY
+    args = _sample(shape, seed=3)
+    img, qf = _maps(shape, 5, qscale)
+    got, gv, ref, rv, keys = _both(shape, args, img, qf, sector_order)
+    assert torch.equal(gv, rv)
+    assert not torch.isnan(got).any()
+    empty = rv[0, 0] == 0
+    assert got[0][:, empty].abs().max().item() == 0
+    # fp16 outputs of a convex combination of fp16 rows: 1 ulp of the output + the fp16 rounding of the probabilities
+    scale = ref.abs().max().item()
+    err = (got - ref).abs()
+    assert err.max().item() <= 4e-3 * scale, (err.max().item(), scale)
+    assert err.mean().item() <= 2e-4 * scale
+    # the dense stream holds every key of the table exactly once
+    Hb, Wb = shape['bev_hw']
+    cnt = keys.table[:Hb * Wb * 4].view(torch.int32)
+    ngroups = (Hb * Wb + 7) // 8
+    gstart = keys.dense[:(ngroups + 1) * 4].view(torch.int32)
+    assert int(gstart[0]) == 0 and int(gstart[-1]) == int(cnt.sum())
+    assert bool((gstart[1:] >= gstart[:-1]).all())
+
+
+def test_dense_kernel_is_permutation_invariant_and_convex():
+    """Size-independent properties at the benched shape: a constant image gives that constant wherever a key exists (the
+    soft-max weights sum to one, bilinear footprints over the edge sample zero padding: <= the constant), and the walk
+    order of the cells does not change any value (the grouping does: other neighbours share an MFMA tile)."""
+    shape = synth.SHAPE_R
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    args = _sample(shape, seed=0)
+    img, qf = _maps(shape, 9, 0.3)
+    k1 = ops.i2p_key_table(*args, (Hi, Wi), (Hb, Wb), sector_order=True)
+    k2 = ops.i2p_key_table(*args, (Hi, Wi), (Hb, Wb), sector_order=False)
+    a, va = ops.i2p_attention(img, qf, *args, keys=k1, sector_order=True)
+    b, vb = ops.i2p_attention(img, qf, *args, keys=k2, sector_order=False)
+    assert torch.equal(va, vb)
+    assert (a.float() - b.float()).abs().max().item() <= 2e-3 * a.float().abs().max().item()
+    const = torch.full_like(img, 0.75)
+    c, vc = ops.i2p_attention(const, qf, *args, keys=k1, sector_order=True)
+    v = vc[0, 0] > 0
+    c = c[0].float()
+    assert c[:, v].max().item() <= 0.75 + 1e-3 and c[:, ~v].abs().max().item() == 0
+    assert (c[:, v] > 0.75 - 1e-3).float().mean().item() > 0.9
+
+
+def test_dense_kernel_replays_bit_identically():
+    """Two launches on the same inputs are bit-identical (no atomics, fixed summation order) - what graph replay relies on."""
+    shape = synth.SHAPE_R
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    args = _sample(shape, seed=1)
+    img, qf = _maps(shape, 2, 0.3)
+    outs = []
+    for _ in range(3):
+        k = ops.i2p_key_table(*args, (Hi, Wi), (Hb, Wb))
+        outs.append(ops.i2p_attention(img, qf, *args, keys=k)[0].clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

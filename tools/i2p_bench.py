@@ -32,8 +32,11 @@ keys = ops.i2p_key_table(*args, (Hi, Wi), (Hb, Wb))
 cnt = keys.table[:Hb * Wb * 4].view(torch.int32)
 nk = int(cnt.sum())
 so = not os.environ.get('DI_I2P_NO_ORDER')
-us = timeit(lambda: ops.i2p_attention(img, bev, *args, keys=keys, sector_order=so), iters=50)
 print('sector order' if so else 'row-major order (XCD stripes)')
 byt = 6 * C * Hi * Wi * 2 + nk * 16 + 2 * C * Hb * Wb * 2
-print(f'i2p_attention  ({nk} keys, {int((cnt > 0).sum())} cells): {us:7.1f} us   algorithmic {byt / 1e6:.1f} MB -> '
-      f'{byt / us / 1e6:.3f} TB/s; gathered rows {nk * 4 * 256 / 1e6:.0f} MB -> {nk * 4 * 256 / us / 1e6:.2f} TB/s')
+for name, k in (('matrix-core (dense stream)', keys), ('wave per cell', ops.i2p_key_table(*args, (Hi, Wi), (Hb, Wb), dense=False))):
+    if name.startswith('matrix') and k.dense is None:
+        continue
+    us = timeit(lambda: ops.i2p_attention(img, bev, *args, keys=k, sector_order=so), iters=50)
+    print(f'i2p_attention {name} ({nk} keys, {int((cnt > 0).sum())} cells): {us:7.1f} us   algorithmic {byt / 1e6:.1f} MB -> '
+          f'{byt / us / 1e6:.3f} TB/s; gathered rows {nk * 4 * 256 / 1e6:.0f} MB -> {nk * 4 * 256 / us / 1e6:.2f} TB/s')
