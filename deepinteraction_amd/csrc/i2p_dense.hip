@@ -47,50 +47,108 @@ typedef __fp16 hv4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
-constexpr int NC = 8;            // BEV cells per group (MFMA columns in use; 16 columns exist)
-constexpr int NW = 2;            // wavefronts per workgroup, one group per wavefront at a time
+constexpr int NC = 8;            // BEV cells per group at most (MFMA columns in use; 16 columns exist)
+constexpr int kKeyCap = 48;      // a group closes before it would exceed this many keys (a single cell may: <= 120 keys); DI_I2PD_KEYCAP
+constexpr int kWavesPerCU = 8;   // resident wavefronts per CU (LDS: 20 KB each); the stream is cut into CUs x 8 shares
+constexpr int kMaxWaves = 4096;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLazy = 8.f;     // log2 units: the reference maximum is kept until a score beats it by more than this
 
 struct DenseKey {                // 32 B
   unsigned off[4];               // byte offset of corner row r from the map base (a multiple of 256); off[0] bits 0..3: the column
-  float w[4];                    // bilinear weights (0 where grid_sample's zero padding applies)
+  float w[4];                    // bilinear weights (0 where grid_sample's zero padding applies, and for padding keys)
+};
+struct GroupHdr {                // 64 B
+  int cell[NC];                  // the group's BEV cells, column by column (-1: column not used)
+  int sb_begin, sb_end;          // its superblocks (8 keys each) in the stream; every group has at least one
+  int nk, pad[5];
 };
 
-__host__ __device__ inline int n_groups(int ncell) { return (ncell + NC - 1) / NC; }
-__host__ __device__ inline long long keys_offset(int ngroups) { return (((long long)(ngroups + 1) * 4 + 255) / 256) * 256; }
+// GROUPS.  The walk order of the cells is cut into CHUNKS of 8 positions; a chunk is cut greedily into groups of consecutive
+// cells: a group closes before it would exceed kKeyCap keys (so the largest group is one crowded cell or ~6 superblocks - a
+// group is the unit of load balance: the first version's fixed 8-cell groups had up to 30 superblocks, one wavefront ran
+// 2.5 x the average).  Layout of the dense table (bytes):
+//   group headers (<= one per cell) | per chunk: groups in front (nchunks + 1) | per chunk: superblocks in front (nchunks + 1) |
+//   first group of every share (kMaxWaves + 1) | keys
+__host__ __device__ inline int n_chunks(int ncell) { return (ncell + NC - 1) / NC; }
+__host__ __device__ inline long long al256(long long x) { return (x + 255) / 256 * 256; }
+__host__ __device__ inline long long off_csub(int ncell) { return al256((long long)ncell * (long long)sizeof(GroupHdr)); }
+__host__ __device__ inline long long off_csb(int ncell) { return off_csub(ncell) + al256((long long)(n_chunks(ncell) + 1) * 4); }
+__host__ __device__ inline long long off_wst(int ncell) { return off_csb(ncell) + al256((long long)(n_chunks(ncell) + 1) * 4); }
+__host__ __device__ inline long long off_keys(int ncell) { return off_wst(ncell) + al256((long long)(kMaxWaves + 1) * 4); }
 
-__device__ __forceinline__ int group_keys(const int *__restrict__ cnt, const int *__restrict__ order, int G, int ncell) {
-  int s = 0;
+struct Split {                   // the groups of one chunk
+  int nsub;
+  int sub[NC], col[NC];          // per cell: its group (within the chunk) and its column
+  int nk[NC], nc[NC], first[NC]; // per group: keys, cells, first cell
+  int nsb[NC];                   // per group: superblocks = max(1, ceil(keys / 8))
+};
+__device__ __forceinline__ Split split_chunk(const int (&cnt)[NC], int ncells, int key_cap) {
+  Split S;
+  S.nsub = 0;
+  int keys = 0, cells = 0;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) S.nk[k] = S.nc[k] = S.first[k] = S.nsb[k] = 0;
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
-    const int pos = G * NC + j;
-    if (pos < ncell) s += cnt[order != nullptr ? order[pos] : pos];
+    if (j < ncells) {
+      if (cells > 0 && keys + cnt[j] > key_cap) {
+        ++S.nsub;
+        keys = cells = 0;
+      }
+      S.sub[j] = S.nsub;
+      S.col[j] = cells;
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+        if (k == S.nsub) {
+          if (cells == 0) S.first[k] = j;
+          S.nk[k] += cnt[j];
+          S.nc[k] += 1;
+        }
+      keys += cnt[j];
+      ++cells;
+    } else {
+      S.sub[j] = S.col[j] = 0;
+    }
   }
-  return s;
+  if (ncells > 0) ++S.nsub;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) S.nsb[k] = k < S.nsub ? max((S.nk[k] + 7) >> 3, 1) : 0;
+  return S;
 }
 
-// gcount[G] = keys of group G (one thread per group; the first version did this inside the one-workgroup scan: 32 dependent
-// gathers per thread, 66 us)
-__global__ __launch_bounds__(256) void group_count_kernel(const int *__restrict__ cnt, const int *__restrict__ order,
-                                                          int *__restrict__ gcount, int ncell, int ngroups) {
-  const int G = blockIdx.x * 256 + threadIdx.x;
-  if (G < ngroups) gcount[G] = group_keys(cnt, order, G, ncell);
+// csub[c] / csb[c] = groups / superblocks of chunk c (one thread per chunk)
+__global__ __launch_bounds__(256) void chunk_count_kernel(const int *__restrict__ cnt, const int *__restrict__ order,
+                                                          int *__restrict__ csub, int *__restrict__ csb, int ncell, int nchunks, int key_cap) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= nchunks) return;
+  int k[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const int pos = c * NC + j;
+    k[j] = pos < ncell ? cnt[order != nullptr ? order[pos] : pos] : 0;
+  }
+  const Split S = split_chunk(k, min(NC, ncell - c * NC), key_cap);
+  int nsb = 0;
+#pragma unroll
+  for (int q = 0; q < NC; ++q) nsb += S.nsb[q];
+  csub[c] = S.nsub;
+  csb[c] = nsb;
 }
 
-// gstart[G] = number of keys in front of group G in the dense stream (exclusive prefix sum of the groups' key counts, IN
-// PLACE over gcount); gstart[ngroups] = all keys.  ONE workgroup, plain stores only (a captured graph replays this: no
-// atomics, no memset).  A thread owns `per` consecutive groups (ngroups <= 8 * 1024).
-__global__ __launch_bounds__(1024) void group_scan_kernel(int *__restrict__ gstart, int ngroups) {
+// exclusive prefix sum IN PLACE of blockIdx.x-th array (a[n] = the total).  ONE workgroup per array, plain stores only (a
+// captured graph replays this: no atomics, no memset).  A thread owns `per` consecutive entries (n <= 8 * 1024).
+__global__ __launch_bounds__(1024) void scan_kernel(int *__restrict__ a0, int *__restrict__ a1, int n) {
   __shared__ int wsum[16];
+  int *a = blockIdx.x == 0 ? a0 : a1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (ngroups + 1023) / 1024;
+  const int per = (n + 1023) / 1024;
   int v[8];
   int mine = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int G = tid * per + k;
-    v[k] = (k < per && G < ngroups) ? gstart[G] : 0;
+    const int e = tid * per + k;
+    v[k] = (k < per && e < n) ? a[e] : 0;
     mine += v[k];
   }
   int inc = mine;                                  // inclusive scan over the wave
@@ -106,44 +164,149 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(int *__restrict__ gsta
   int run = base + inc - mine;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int G = tid * per + k;
-    if (k < per && G < ngroups) gstart[G] = run;
+    const int e = tid * per + k;
+    if (k < per && e < n) a[e] = run;
     run += v[k];
   }
-  if (tid == 1023) gstart[ngroups] = run;
+  if (tid == 1023) a[n] = run;
 }
 
-// One wavefront per group: the keys of its cells, cell after cell, into the dense stream - ready to fetch (explicit corner
-// offsets) and tagged with the cell's column.
+__device__ __forceinline__ uint4 key_addr(const float4 &k0, unsigned stepy) {
+  const int pix = __float_as_int(k0.x), info = __float_as_int(k0.y);
+  const unsigned o00 = (unsigned)pix * 256u, dx = (info & 1) ? 256u : 0u, dy = (info & 2) ? stepy : 0u;
+  return make_uint4(o00, o00 + dx, o00 + dy, o00 + dx + dy);
+}
+
+// One wavefront per chunk: the headers of its groups, their keys - cell after cell, ready to fetch (explicit corner offsets),
+// tagged with the cell's column, padded to whole superblocks (padding: weight 0, column 15, the address of the group's last
+// real key) - and the share table: share w of W starts at the first group whose first superblock is >= t(w) = w * all / W,
+// i.e. behind the group that holds superblock t(w) - 1 (every group writes the shares that start right behind it).
 __global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ cnt, const KeyEnt *__restrict__ keys,
-                                                      const int *__restrict__ order, const int *__restrict__ gstart,
-                                                      DenseKey *__restrict__ dense, int ncell, int ngroups, int nslots, int Wi) {
+                                                      const int *__restrict__ order, const int *__restrict__ csub,
+                                                      const int *__restrict__ csb, GroupHdr *__restrict__ hdr,
+                                                      int *__restrict__ wst, DenseKey *__restrict__ dense, int ncell, int nchunks,
+                                                      int nslots, int Wi, int W, int key_cap) {
   const int lane = threadIdx.x & 63;
-  const int G = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (G >= ngroups) return;
-  int mycell = 0, mycnt = 0;
-  if (lane < NC && G * NC + lane < ncell) {
-    mycell = order != nullptr ? order[G * NC + lane] : G * NC + lane;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= nchunks) return;
+  int mycell = -1, mycnt = 0;
+  if (lane < NC && c * NC + lane < ncell) {
+    mycell = order != nullptr ? order[c * NC + lane] : c * NC + lane;
     mycnt = cnt[mycell];
   }
-  int run = gstart[G];
-  const unsigned stepy = (unsigned)Wi * 256u;
+  int k[NC], cells[NC];
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
-    const int c = __builtin_amdgcn_readlane(mycnt, j), cell = __builtin_amdgcn_readlane(mycell, j);
-    for (int e = lane; e < c; e += 64) {
+    k[j] = __builtin_amdgcn_readlane(mycnt, j);
+    cells[j] = __builtin_amdgcn_readlane(mycell, j);
+  }
+  const Split S = split_chunk(k, min(NC, ncell - c * NC), key_cap);
+  const int G0 = csub[c], ngroups = csub[nchunks], nsb_all = csb[nchunks];
+  int sbb[NC + 1];                                    // first superblock of every group of the chunk
+  sbb[0] = csb[c];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) sbb[q + 1] = sbb[q] + S.nsb[q];
+  // headers
+#pragma unroll
+  for (int q = 0; q < NC; ++q)
+    if (q < S.nsub) {
+      GroupHdr *H = hdr + G0 + q;
+      if (lane < NC) {
+        int v = -1;
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+          if (S.sub[j] == q && S.col[j] == lane && j < ncell - c * NC) v = cells[j];
+        H->cell[lane] = v;
+      }
+      if (lane == 0) {
+        H->sb_begin = sbb[q];
+        H->sb_end = sbb[q + 1];
+        H->nk = S.nk[q];
+        // shares that start right behind this group: sb_begin < t(w) <= sb_end (and, for the very first group, t(w) = 0)
+        // (32-bit arithmetic: superblocks < 2^18, W <= 2^12 - the 64-bit divisions of the first version were most of this
+        //  kernel's 14 us)
+        const unsigned ua = (unsigned)nsb_all, uw = (unsigned)W;
+        unsigned w = ((unsigned)(sbb[q] + 1) * uw + ua - 1u) / ua;
+        if (G0 + q == 0) {
+          for (unsigned w0 = 0; w0 < uw && (w0 * ua) / uw == 0u; ++w0) wst[w0] = 0;
+        }
+        for (; w < uw && (w * ua) / uw <= (unsigned)sbb[q + 1]; ++w) wst[w] = G0 + q + 1;
+        if (G0 + q == ngroups - 1) wst[W] = ngroups;
+      }
+    }
+  // keys: lane j < 8 holds cell j's destination and column, lane q < 8 group q's padding; then every lane copies ONE key per
+  // pass (a chunk has ~40) and one padding key - two independent load -> store round trips instead of the first version's
+  // cell-after-cell loop (14 us for the 4 050 chunks)
+  const unsigned stepy = (unsigned)Wi * 256u;
+  int my_dst = 0, my_col = 0, my_pre = 0;           // per cell (lane j): first key's slot in the stream, column, keys in front (chunk)
+  int pad_dst = 0, pad_n = 0, pad_cell = -1, pad_cnt = 0;   // per group (lane q)
+  {
+    int pre = 0, in_group = 0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      if (S.col[j] == 0) in_group = 0;
+      int base = 0;
+#pragma unroll
+      for (int qq = 0; qq < NC; ++qq)
+        if (qq == S.sub[j]) base = sbb[qq] * 8;
+      if (lane == j) {
+        my_dst = base + in_group;
+        my_col = S.col[j];
+        my_pre = pre;
+      }
+      if (j < ncell - c * NC) {
+        pre += k[j];
+        in_group += k[j];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      int lc = -1, ln = 0;                          // the group's last cell that has keys
+#pragma unroll
+      for (int j = 0; j < NC; ++j)
+        if (j < ncell - c * NC && S.sub[j] == q && k[j] > 0) {
+          lc = cells[j];
+          ln = k[j];
+        }
+      if (lane == q && q < S.nsub) {
+        pad_dst = sbb[q] * 8 + S.nk[q];
+        pad_n = S.nsb[q] * 8 - S.nk[q];             // < 8, or 8 for a group without keys
+        pad_cell = lc;
+        pad_cnt = ln;
+      }
+    }
+  }
+  int total = 0;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) total += j < ncell - c * NC ? k[j] : 0;
+  for (int L0 = 0; L0 < total; L0 += 64) {           // a UNIFORM loop: the lane shuffles below read lanes 0 .. 7, which must be active
+    const int L = L0 + lane;
+    int j = 0;
+#pragma unroll
+    for (int jj = 1; jj < NC; ++jj) j += L >= __builtin_amdgcn_readlane(my_pre, jj) && jj < ncell - c * NC ? 1 : 0;
+    // (cells without keys share their `pre` with the next cell: the LAST cell with pre <= L is the one that owns key L)
+    const int e = L - __shfl(my_pre, j), cell = __shfl(mycell, j), col = __shfl(my_col, j), d0 = __shfl(my_dst, j);
+    if (L < total) {
       const float4 *kp = reinterpret_cast<const float4 *>(keys + (size_t)cell * nslots + e);
       const float4 k0 = kp[0];
       const float2 k1 = *reinterpret_cast<const float2 *>(kp + 1);
-      const int pix = __float_as_int(k0.x), info = __float_as_int(k0.y);
-      const unsigned o00 = (unsigned)pix * 256u, dx = (info & 1) ? 256u : 0u, dy = (info & 2) ? stepy : 0u;
-      uint4 a = make_uint4(o00 | (unsigned)j, o00 + dx, o00 + dy, o00 + dx + dy);
-      float4 b = make_float4(k0.z, k0.w, k1.x, k1.y);
-      uint4 *dst = reinterpret_cast<uint4 *>(dense + run + e);
+      uint4 a = key_addr(k0, stepy);
+      a.x |= (unsigned)col;
+      uint4 *dst = reinterpret_cast<uint4 *>(dense + d0 + e);
       dst[0] = a;
-      dst[1] = __builtin_bit_cast(uint4, b);
+      dst[1] = __builtin_bit_cast(uint4, make_float4(k0.z, k0.w, k1.x, k1.y));
     }
-    run += c;
+  }
+  {
+    const int q = lane >> 3, pi = lane & 7;
+    const int n = __shfl(pad_n, q), cell = __shfl(pad_cell, q), cn = __shfl(pad_cnt, q), d0 = __shfl(pad_dst, q);
+    if (q < S.nsub && pi < n) {
+      uint4 last = make_uint4(0u, 0u, 0u, 0u);      // the address part of the group's last real key (padding re-reads it)
+      if (cell >= 0) last = key_addr(*reinterpret_cast<const float4 *>(keys + (size_t)cell * nslots + (cn - 1)), stepy);
+      uint4 *dst = reinterpret_cast<uint4 *>(dense + d0 + pi);
+      dst[0] = make_uint4(last.x | 15u, last.y, last.z, last.w);
+      dst[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
 }
 
@@ -157,6 +320,36 @@ __device__ __forceinline__ void dma16_flat(const void *gp, unsigned lds_addr) { 
 }
 __device__ __forceinline__ void dma16_base(unsigned voff, const void *sbase, unsigned lds_addr) {   // uniform base + 32-bit lane offset
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+// A group header (64 B) through the SCALAR cache: lgkmcnt, not vmcnt - a vector load here would make the compiler put a
+// vmcnt(0) into the superblock loop at every group boundary, with the next superblocks' row DMAs in flight.  (Written as
+// assembly because the compiler turns `lane-dependent choice among H.cell[..]` into per-lane vector loads.)
+typedef int i16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ i16v load_hdr(const void *p) {
+  i16v v;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+// cell of column j (0..7) out of a header's eight
+__device__ __forceinline__ int pick_cell(const i16v &h, int j) {
+  const int c01 = j & 1 ? h[1] : h[0], c23 = j & 1 ? h[3] : h[2], c45 = j & 1 ? h[5] : h[4], c67 = j & 1 ? h[7] : h[6];
+  const int c03 = j & 2 ? c23 : c01, c47 = j & 2 ? c67 : c45;
+  return j & 4 ? c47 : c03;
+}
+// Four instructions behind ONE M0: an instruction offset applies to BOTH addresses (global and LDS), so instruction t uses
+// the base `sbase - 1024 t` and offset:1024 t - its data lands at M0 + 1024 t + 16 lane.  One statement: M0 must not change
+// in between.
+__device__ __forceinline__ void dma16_x4(unsigned v0, unsigned v1, unsigned v2, unsigned v3, const void *b0, const void *b1,
+                                         const void *b2, const void *b3, unsigned lds_addr) {
+  asm volatile(
+      "s_mov_b32 m0, %8\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %4\n\t"
+      "global_load_lds_dwordx4 %1, %5 offset:1024\n\t"
+      "global_load_lds_dwordx4 %2, %6 offset:2048\n\t"
+      "global_load_lds_dwordx4 %3, %7 offset:3072"
+      :
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(lds_addr)
+      : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -174,12 +367,17 @@ __device__ __forceinline__ void xpair(float x, float &lo, float &hi, bool half32
   lo = __builtin_bit_cast(float, a);
   hi = __builtin_bit_cast(float, b);
 }
+__device__ __forceinline__ float max_raw(float a, float b) {      // v_max_f32 without fmaxf's canonicalising v_max x, x
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float xmax(float x) {         // over the four 16-lane rows (lanes with equal lane % 16)
   float a, b;
   xpair(x, a, b, false);
-  x = fmaxf(a, b);
+  x = max_raw(a, b);
   xpair(x, a, b, true);
-  return fmaxf(a, b);
+  return max_raw(a, b);
 }
 __device__ __forceinline__ float xsum(float x) {
   float a, b;
@@ -188,23 +386,39 @@ __device__ __forceinline__ float xsum(float x) {
   xpair(x, a, b, true);
   return a + b;
 }
-__device__ __forceinline__ int slot_rot(int R) { return (2 * R + (R >> 3)) & 15; }   // f(row): distinct for rows 0..15
+// f(row): the 16-B slots of raw row R are stored rotated (XOR) by f(R % 16).  ds_read_b128 serves a wavefront in the lane
+// groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32): with A = rows {0-3, 12-15}, B = rows {4-11}, the score reads of
+// a group are slot (4 s) ^ f(A-rows) and (4 s + 1) ^ f(B-rows) - conflict free when f(A) and f(B) are each closed under ^ 1;
+// the transposed 8-B reads take 32 lanes = 8 rows x 32 B: conflict free when f(R) >> 1 is a bijection on rows 0-7 and on
+// rows 8-15.  (The first version, f = 2 R + R / 8, assumed 16 CONSECUTIVE lanes per group: 35 % of the LDS cycles were
+// bank-conflict cycles.)
+__device__ __forceinline__ int slot_rot(int R) {
+  R &= 15;
+  return R < 8 ? 2 * R : R < 12 ? 2 * (R - 4) + 1 : 2 * (R - 12) + 1;
+}
 
+
+// One wavefront = one SHARE of the stream: the consecutive groups [wst[w], wst[w + 1]), processed as one pipelined sequence of
+// superblocks (8 keys = 32 raw rows = 8 KB): the rows of superblock b + NB - 1, the keys 4 superblocks ahead and the next
+// group's queries are in flight (LDS-DMA) while superblock b is multiplied; a group boundary costs the flush of 8 output rows
+// and four LDS reads - no memory latency.  Headers come through the scalar cache (lgkmcnt, not vmcnt).
 template <int NB>
-__global__ __launch_bounds__(NW * 64) void attn_dense_kernel(
-    const unsigned char *__restrict__ img, const __half *__restrict__ qfold, const int *__restrict__ cnt_tab,
-    const int *__restrict__ order, const int *__restrict__ gstart, const DenseKey *__restrict__ dense,
-    __half *__restrict__ ctx, __half *__restrict__ valid_out, int ncell, int ngroups) {
-  // A SUPERBLOCK = 8 keys = 32 raw rows (8 KB): two score tiles of 16 rows, ONE value product with k = 32 rows.
-  constexpr int SBYTES = 8192, FEAT = NB * SBYTES, WBYTES = FEAT + 2048;   // per wavefront: NB row buffers + two key slots
-  __shared__ __align__(1024) unsigned char smem[NW * WBYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(64) void attn_dense_kernel(
+    const unsigned char *__restrict__ img, const unsigned char *__restrict__ qfold, const GroupHdr *__restrict__ hdr,
+    const int *__restrict__ wst, const DenseKey *__restrict__ dense, __half *__restrict__ ctx, __half *__restrict__ valid_out,
+    int W) {
+  constexpr int SBYTES = 8192, FEAT = NB * SBYTES, KEYS = FEAT, QBUF = FEAT + 2048, WBYTES = QBUF + 2048;
+  __shared__ __align__(1024) unsigned char smem[WBYTES];
+  const int lane = threadIdx.x & 63;
   const int i = lane & 15, g = lane >> 4;
-  // XCD x (blocks with blockIdx % 8 == x) takes the x-th eighth of the groups = one sector of the scene (a band of columns
-  // in one or two cameras); its wavefronts sweep it together
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nbx = gridDim.x >> 3;
-  const int gp = (ngroups + 7) >> 3, glo = xcd * gp, ghi = min(glo + gp, ngroups);
-  unsigned char *wbase = smem + wave * WBYTES;
+  // XCD x (blocks with blockIdx % 8 == x) takes the x-th eighth of the shares = one sector of the scene (a band of columns
+  // in one or two cameras)
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, wx = W >> 3;
+  const int w = xcd * wx + lb;
+  if (lb >= wx) return;
+  const int G0 = __builtin_amdgcn_readfirstlane(wst[w]), G1 = __builtin_amdgcn_readfirstlane(wst[w + 1]);
+  if (G0 >= G1) return;
+  unsigned char *wbase = smem;
   const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr_of(wbase));
 
   // lane constants.  Raw row R = 4 key + corner (key 0..7 of the superblock), 256 B per row, 16-B slots rotated by f(R % 16).
@@ -222,161 +436,220 @@ __global__ __launch_bounds__(NW * 64) void attn_dense_kernel(
 #pragma unroll
   for (int t = 0; t < 4; ++t) dma_slot[t] = (unsigned)((i ^ slot_rot(4 * t + g)) << 4);
 
-  for (int G = glo + lb * NW + wave; G < ghi; G += nbx * NW) {
-    int mycell = -1, mycnt = 0;
-    if (lane < NC && G * NC + lane < ncell) {
-      mycell = order != nullptr ? order[G * NC + lane] : G * NC + lane;
-      mycnt = cnt_tab[mycell];
+  i16v hc = load_hdr(hdr + G0);            // the current group's header: cells 0..7, sb_begin 8, sb_end 9
+  i16v hn = hc;                            // the next group's
+  const int sb0 = hc[8], sb1 = load_hdr(hdr + (G1 - 1))[9];          // the share's superblocks
+  const int nkeys = (sb1 - sb0) * 8;
+  const DenseKey *dk = dense + (size_t)sb0 * 8;
+  auto dma_keys = [&](int j) {             // 32 keys = 1 KB: lane -> key lane / 2, half lane % 2 (past the end: the last key again)
+    const int k = min(32 * j + (lane >> 1), nkeys - 1);
+    dma16_flat(reinterpret_cast<const unsigned char *>(dk + k) + (lane & 1) * 16, lds_w + KEYS + (j & 1) * 1024);
+  };
+  // the queries of group G (header H): 8 rows of 256 B -> the query buffer (two instructions: lane (g, i) fetches 16 B of the row
+  // of cell 4 t + g)
+  auto dma_q = [&](int G, const i16v &H) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // ONE query buffer: the reads of the previous group's rows are done
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int cell = max(pick_cell(H, 4 * t + g), 0);
+      dma16_base((unsigned)cell * 256u + (unsigned)((i ^ (2 * ((4 * t + g) & 7))) & 15) * 16u, qfold, lds_w + QBUF + t * 1024);
     }
-    const int kbeg = __builtin_amdgcn_readfirstlane(gstart[G]);
-    const int nk = __builtin_amdgcn_readfirstlane(gstart[G + 1]) - kbeg;
-    const int nsb = (nk + 7) >> 3;
-    if (lane < NC && mycell >= 0) valid_out[mycell] = (__half)(mycnt > 0 ? 1.f : 0.f);
-    const int ci = __shfl(mycell, i & (NC - 1));
-    h8 qt[4];
-    {
-      const __half *qp = qfold + (size_t)max(ci, 0) * 128 + 8 * g;
+  };
+  struct KeyData {                         // lane (i, g): keys g and 4 + g of a superblock
+    f4 w[2];
+    int col[2];
+  };
+  KeyData kn;
+  // everything superblock nb (relative to the share) needs from the key ring: its 8 x 4 row fetches, and the weights and
+  // columns of a lane's two keys
+  auto issue = [&](int nb, int slot) {
+    if ((nb & 3) == 0 && 32 * ((nb >> 2) + 1) < nkeys) dma_keys((nb >> 2) + 1);     // the next 32 keys, 4 superblocks ahead
+    const unsigned char *kr = wbase + KEYS + ((nb >> 2) & 1) * 1024 + (nb & 3) * 256;
+    unsigned off[8];                       // all LDS reads first: every DMA statement is a fence for the compiler's LDS accesses
 #pragma unroll
-      for (int s = 0; s < 4; ++s) qt[s] = *reinterpret_cast<const h8 *>(qp + 32 * s);
-      // the compiler's wait for these loads must sit HERE: placed at their first use it would be a vmcnt(0) inside the
-      // block loop, in front of the first MFMA of every block - with the row DMAs of the next block in flight
+    for (int t = 0; t < 8; ++t) off[t] = *reinterpret_cast<const unsigned *>(kr + t * 32 + g * 4);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qt[s]));
+    for (int h = 0; h < 2; ++h) {
+      kn.w[h] = *reinterpret_cast<const f4 *>(kr + (4 * h + g) * 32 + 16);
+      kn.col[h] = (int)(*reinterpret_cast<const unsigned *>(kr + (4 * h + g) * 32) & 15u);
     }
-    f4 acc[8];
 #pragma unroll
-    for (int blk = 0; blk < 8; ++blk) acc[blk] = f4{0.f, 0.f, 0.f, 0.f};
-    float mref = -INFINITY, l = 0.f;
+    for (int h = 0; h < 2; ++h)
+      dma16_x4((off[4 * h] & ~255u) | dma_slot[0], (off[4 * h + 1] & ~255u) | dma_slot[1], (off[4 * h + 2] & ~255u) | dma_slot[2],
+               (off[4 * h + 3] & ~255u) | dma_slot[3], img, img - 1024, img - 2048, img - 3072, lds_w + slot * SBYTES + h * 4096);
+  };
+  const int nsb = sb1 - sb0;
 
-    if (nsb > 0) {
-      const DenseKey *dk = dense + kbeg;
-      auto dma_keys = [&](int j) {           // 32 keys = 1 KB: lane -> key lane / 2, half lane % 2 (past the end: the last key again)
-        const int k = min(32 * j + (lane >> 1), nk - 1);
-        dma16_flat(reinterpret_cast<const unsigned char *>(dk + k) + (lane & 1) * 16, lds_w + FEAT + (j & 1) * 1024);
-      };
-      struct KeyData {                       // lane (i, g): keys g and 4 + g of a superblock
-        f4 w[2];
-        int col[2];
-      };
-      KeyData kn;
-      // everything superblock nb needs from the key ring: its 8 x 4 row fetches, and the weights and columns of a lane's keys
-      auto issue = [&](int nb, int slot) {
-        if ((nb & 3) == 0 && 32 * ((nb >> 2) + 1) < nk) dma_keys((nb >> 2) + 1);     // the next 32 keys, 4 superblocks ahead
-        const unsigned char *kr = wbase + FEAT + ((nb >> 2) & 1) * 1024 + (nb & 3) * 256;
-        unsigned off[8];                     // all LDS reads first: every DMA statement is a fence for the compiler's LDS accesses
+  dma_keys(0);
+  dma_q(G0, hc);
+  wait_vm<0>();
+  KeyData kq[NB - 1];                      // key data of the superblocks in flight (their ring slot may be overwritten before they run)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) off[t] = *reinterpret_cast<const unsigned *>(kr + t * 32 + g * 4);
+  for (int pb = 0; pb < NB - 1; ++pb) {
+    if (pb < nsb) issue(pb, pb);
+    kq[pb] = kn;
+  }
+  int G = G0;
+  int g_end = hc[9] - sb0;                 // first superblock (relative) behind the current group
+  h8 qt[4];
+  auto read_q = [&](int Gq) {              // lane (i, g): 16 B of the query of column i % 8 per k-step
+    // (the 16-B slots of row r are stored rotated by 2 r: the 16 lanes of a ds_read_b128 group - 8 rows x 2 k-groups - hit 16
+    //  different slots; unrotated, the 8 rows of a group shared 4 banks: 8-way conflicts at every group boundary were 23 % of
+    //  the kernel's LDS cycles)
+    const int j = i & (NC - 1);
+    const unsigned char *qb = wbase + QBUF + j * 256;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          kn.w[h] = *reinterpret_cast<const f4 *>(kr + (4 * h + g) * 32 + 16);
-          kn.col[h] = (int)(*reinterpret_cast<const unsigned *>(kr + (4 * h + g) * 32) & 15u);
-        }
+    for (int s = 0; s < 4; ++s) qt[s] = *reinterpret_cast<const h8 *>(qb + (((4 * s + g) ^ (2 * j)) << 4));
+  };
+  read_q(G0);
+  if (G0 + 1 < G1) {                       // the ONE query buffer is free again
+    hn = load_hdr(hdr + (G0 + 1));
+    dma_q(G0 + 1, hn);
+  }
+  f4 acc[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-          dma16_base((off[t] & ~255u) | dma_slot[t & 3], img, lds_w + slot * SBYTES + t * 1024);
-      };
-      dma_keys(0);
+  for (int blk = 0; blk < 8; ++blk) acc[blk] = f4{0.f, 0.f, 0.f, 0.f};
+  float mref = -INFINITY, l = 0.f;
+
+  int slot = 0;
+  for (int b = 0; b < nsb; ++b) {
+    const int nb = b + NB - 1;
+    int snext = slot + NB - 1;
+    if (snext >= NB) snext -= NB;
+    if (nb < nsb) {
+      issue(nb, snext);
+      wait_vm<8 * (NB - 1)>();             // superblock b has landed (younger: the NB - 1 superblocks behind it)
+    } else {
       wait_vm<0>();
-      KeyData kq[NB - 1];                    // key data of the superblocks in flight (their ring slot may be overwritten before they run)
+    }
+    const unsigned char *fb = wbase + slot * SBYTES;
+    const KeyData kc = kq[0];
 #pragma unroll
-      for (int pb = 0; pb < NB - 1; ++pb) {
-        if (pb < nsb) issue(pb, pb);
-        kq[pb] = kn;
-      }
-      int slot = 0;
-      for (int b = 0; b < nsb; ++b) {
-        const int nb = b + NB - 1;
-        int snext = slot + NB - 1;
-        if (snext >= NB) snext -= NB;
-        if (nb < nsb) {
-          issue(nb, snext);
-          wait_vm<8 * (NB - 1)>();           // superblock b has landed (younger: the NB - 1 superblocks behind it)
-        } else if (NB > 2 && nb - 1 < nsb) {
-          wait_vm<8 * (NB > 2 ? NB - 2 : 0)>();
-        } else {
-          wait_vm<0>();
-        }
-        const unsigned char *fb = wbase + slot * SBYTES;
-        const KeyData kc = kq[0];
-#pragma unroll
-        for (int q = 0; q + 1 < NB - 1; ++q) kq[q] = kq[q + 1];
-        kq[NB - 2] = kn;
+    for (int q = 0; q + 1 < NB - 1; ++q) kq[q] = kq[q + 1];
+    kq[NB - 2] = kn;
 
-        f4 D[2];
+    f4 D[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          D[h] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < 2; ++h) {
+      D[h] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const h8 a = *reinterpret_cast<const h8 *>(fb + h * 4096 + sc_off[s]);
-            D[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qt[s], D[h], 0, 0, 0);
-          }
-        }
-        bool ok[2];
-        float sc[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          ok[h] = (8 * b + 4 * h + g < nk) && (kc.col[h] == i);
-          const float v = (D[h][0] * kc.w[h][0] + D[h][1] * kc.w[h][1] + D[h][2] * kc.w[h][2] + D[h][3] * kc.w[h][3]) * kLog2e;
-          sc[h] = ok[h] ? v : -INFINITY;
-        }
-        const float mx = xmax(fmaxf(sc[0], sc[1]));
-        const bool beat = mx > mref + kLazy;             // also the first key of a column (mref = -inf)
-        const float mnew = beat ? mx : mref;
-        if (__any(beat && mref > -INFINITY)) {           // rare: a later key beats the reference by more than 2^kLazy
-          const float a = mnew == mref ? 1.f : __builtin_amdgcn_exp2f(mref - mnew);
-#pragma unroll
-          for (int blk = 0; blk < 8; ++blk) acc[blk] *= a;
-          l *= a;
-        }
-        mref = mnew;
-        h8 bc;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float p = ok[h] ? __builtin_amdgcn_exp2f(sc[h] - mref) : 0.f;
-          l += p;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) bc[4 * h + r] = (_Float16)(p * kc.w[h][r]);
-        }
-#pragma unroll
-        for (int blk = 0; blk < 8; ++blk) {
-          const hv4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(fb + tr_off[blk]));
-          const hv4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(fb + 4096 + tr_off[blk]));
-          h8 at;
-          at[0] = v0[0]; at[1] = v0[1]; at[2] = v0[2]; at[3] = v0[3];
-          at[4] = v1[0]; at[5] = v1[1]; at[6] = v1[2]; at[7] = v1[3];
-          acc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at, bc, acc[blk], 0, 0, 0);
-        }
-        slot = slot + 1 == NB ? 0 : slot + 1;
+      for (int s = 0; s < 4; ++s) {
+        const h8 a = *reinterpret_cast<const h8 *>(fb + h * 4096 + sc_off[s]);
+        D[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qt[s], D[h], 0, 0, 0);
       }
     }
-    // every cell of the group is written: cells without a key get their zero row (l = 0, acc = 0)
-    const float lt = xsum(l);
-    const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    if (i < NC && ci >= 0) {
-      __half *dst = ctx + (size_t)ci * 128 + 4 * g;
+    bool ok[2];
+    float sc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      ok[h] = kc.col[h] == i;              // padding keys carry column 15 (never a cell: their weights are 0)
+      const float v = (D[h][0] * kc.w[h][0] + D[h][1] * kc.w[h][1] + D[h][2] * kc.w[h][2] + D[h][3] * kc.w[h][3]) * kLog2e;
+      sc[h] = ok[h] ? v : -INFINITY;
+    }
+    const float mx = xmax(max_raw(sc[0], sc[1]));
+    const bool beat = mx > mref + kLazy;               // also the first key of a column (mref = -inf)
+    const float mnew = beat ? mx : mref;
+    if (__any(beat && mref > -INFINITY)) {             // rare: a later key beats the reference by more than 2^kLazy
+      const float a = mnew == mref ? 1.f : __builtin_amdgcn_exp2f(mref - mnew);
+#pragma unroll
+      for (int blk = 0; blk < 8; ++blk) acc[blk] *= a;
+      l *= a;
+    }
+    mref = mnew;
+    h8 bc;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float p = ok[h] ? __builtin_amdgcn_exp2f(sc[h] - mref) : 0.f;
+      l += p;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bc[4 * h + r] = (_Float16)(p * kc.w[h][r]);
+    }
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+      const hv4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(fb + tr_off[blk]));
+      const hv4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((hv4 __attribute__((address_space(3))) *)(fb + 4096 + tr_off[blk]));
+      h8 at;
+      at[0] = v0[0]; at[1] = v0[1]; at[2] = v0[2]; at[3] = v0[3];
+      at[4] = v1[0]; at[5] = v1[1]; at[6] = v1[2]; at[7] = v1[3];
+      acc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at, bc, acc[blk], 0, 0, 0);
+    }
+    slot = slot + 1 == NB ? 0 : slot + 1;
+
+    if (b + 1 == g_end) {
+      // the group is complete: every one of its cells is written - cells without a key get their zero row (l = 0, acc = 0) -
+      // and the padding column (15) is dropped
+      const int ci = pick_cell(hc, i & (NC - 1));
+      const float lt = xsum(l);
+      const float inv = lt > 0.f ? 1.f / lt : 0.f;
+      // a lane holds channels 16 blk + 4 g .. + 3 of its column; v_permlane16_swap between the blocks of a pair hands it 8
+      // consecutive channels (g even: block 2 pr, channels 4 g .. 4 g + 7; g odd: block 2 pr + 1, channels 4 (g - 1) .. + 7):
+      // four 16-byte stores per group instead of eight 8-byte ones (the stores share the texture path with the row fetches)
+      unsigned wv[8][2];
 #pragma unroll
       for (int blk = 0; blk < 8; ++blk) {
         h4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc[blk][r] * inv);
-        *reinterpret_cast<h4 *>(dst + 16 * blk) = o;
+        const uint2 raw = __builtin_bit_cast(uint2, o);
+        wv[blk][0] = raw.x;
+        wv[blk][1] = raw.y;
+      }
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const u2v sw = __builtin_amdgcn_permlane16_swap(wv[2 * pr][d], wv[2 * pr + 1][d], false, false);
+          wv[2 * pr][d] = sw[0];
+          wv[2 * pr + 1][d] = sw[1];
+        }
+      if (i < NC && ci >= 0) {
+        __half *dst = ctx + (size_t)ci * 128 + ((g & 1) ? 16 + 4 * (g - 1) : 4 * g);
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr)
+          *reinterpret_cast<uint4 *>(dst + 32 * pr) = make_uint4(wv[2 * pr][0], wv[2 * pr][1], wv[2 * pr + 1][0], wv[2 * pr + 1][1]);
+        if (g == 0) valid_out[ci] = (__half)(lt > 0.f ? 1.f : 0.f);
+      }
+#pragma unroll
+      for (int blk = 0; blk < 8; ++blk) acc[blk] = f4{0.f, 0.f, 0.f, 0.f};
+      mref = -INFINITY;
+      l = 0.f;
+      ++G;
+      if (G < G1) {
+        hc = hn;
+        g_end = hc[9] - sb0;
+        // the queries were issued one boundary ago, behind superblock b + NB - 2's rows and in front of b + NB - 1's: the wait
+        // of this iteration covered them for NB = 2; deeper rings leave NB - 2 younger superblocks in flight
+        if (NB > 2) wait_vm<8 * (NB > 2 ? NB - 2 : 0)>();
+        read_q(G);
+        if (G + 1 < G1) {                  // the buffer is free: this group's queries are in registers
+          hn = load_hdr(hdr + (G + 1));
+          dma_q(G + 1, hn);
+        }
       }
     }
   }
 }
 
 template <int NB>
-static int launch_attn(const void *img, const void *qfold, const int *cnt, const int32_t *order, const int *gstart,
-                       const DenseKey *dense, void *ctx, void *valid, int ncell, int ngroups, int blocks, hipStream_t s) {
+static int launch_attn(const void *img, const void *qfold, const GroupHdr *hdr, const int *wst, const DenseKey *dense, void *ctx,
+                       void *valid, int W, hipStream_t s) {
+  const int blocks = W;                                      // one wavefront per workgroup; W is a multiple of 8
   hipEvent_t ev0, ev1;
   if (take_launch_events(ev0, ev1))                          // measurement: the dispatch's own begin / end time stamps
-    hipExtLaunchKernelGGL((attn_dense_kernel<NB>), dim3(blocks), dim3(NW * 64), 0, s, ev0, ev1, 0, (const unsigned char *)img,
-                          (const __half *)qfold, cnt, order, gstart, dense, (__half *)ctx, (__half *)valid, ncell, ngroups);
+    hipExtLaunchKernelGGL((attn_dense_kernel<NB>), dim3(blocks), dim3(64), 0, s, ev0, ev1, 0, (const unsigned char *)img,
+                          (const unsigned char *)qfold, hdr, wst, dense, (__half *)ctx, (__half *)valid, W);
   else
-    hipLaunchKernelGGL((attn_dense_kernel<NB>), dim3(blocks), dim3(NW * 64), 0, s, (const unsigned char *)img,
-                       (const __half *)qfold, cnt, order, gstart, dense, (__half *)ctx, (__half *)valid, ncell, ngroups);
+    hipLaunchKernelGGL((attn_dense_kernel<NB>), dim3(blocks), dim3(64), 0, s, (const unsigned char *)img,
+                       (const unsigned char *)qfold, hdr, wst, dense, (__half *)ctx, (__half *)valid, W);
   return check_launch("i2p_attn_dense_fwd");
+}
+
+// shares of the stream = resident wavefronts of the device (a multiple of 8: one eighth per XCD)
+static int n_shares() {
+  static const int per_cu = getenv("DI_I2PD_WAVES") ? atoi(getenv("DI_I2PD_WAVES")) : kWavesPerCU;
+  const int cus = device_cus();
+  if (cus <= 0) return 0;
+  return std::min(kMaxWaves, std::max(8, cus * per_cu / 8 * 8));
 }
 
 }  // namespace i2pd
@@ -386,8 +659,9 @@ extern "C" {
 
 long long di_i2p_dense_bytes(int Hb, int Wb, int T, int n_views, int P) {
   const long long ncell = (long long)Hb * Wb;
-  const long long cap = std::min<long long>(ncell, std::max(P, 0)) * T * n_views;
-  return di::i2pd::keys_offset(di::i2pd::n_groups((int)ncell)) + std::max<long long>(cap, 1) * (long long)sizeof(di::i2pd::DenseKey);
+  // real keys + padding to whole superblocks (< 8 per group, 8 for a group without keys; at most one group per cell)
+  const long long cap = std::min<long long>(ncell, std::max(P, 0)) * T * n_views + 8ll * ncell;
+  return di::i2pd::off_keys((int)ncell) + cap * (long long)sizeof(di::i2pd::DenseKey);
 }
 
 int di_i2p_compact_keys(const void *key_table, const int32_t *cell_order, void *dense_table, int T, int n_views, int Wi, int Hb,
@@ -395,41 +669,49 @@ int di_i2p_compact_keys(const void *key_table, const int32_t *cell_order, void *
   DI_REQUIRE(key_table && dense_table, "null table");
   DI_REQUIRE(T > 0 && n_views > 0 && T * n_views <= di::kMaxSlots, "T*n_views=%d exceeds %d key slots", T * n_views, di::kMaxSlots);
   DI_REQUIRE(Hb > 0 && Wb > 0 && Wi > 0, "bad map shape");
-  const int ncell = Hb * Wb, ngroups = di::i2pd::n_groups(ncell);
-  DI_REQUIRE(ngroups <= 8 * 1024, "%d cell groups exceed the scan kernel's 8192", ngroups);
+  const int ncell = Hb * Wb, nchunks = di::i2pd::n_chunks(ncell);
+  DI_REQUIRE(nchunks <= 8 * 1024, "%d cell chunks exceed the scan kernel's 8192", nchunks);
+  DI_REQUIRE((long long)ncell * (T * n_views / 8 + 2) < (1ll << 20), "map too large for the share table's 32-bit arithmetic");
+  const int W = di::i2pd::n_shares();
+  if (W <= 0) return DI_ERR_LAUNCH;
+  static const int key_cap = getenv("DI_I2PD_KEYCAP") ? atoi(getenv("DI_I2PD_KEYCAP")) : di::i2pd::kKeyCap;
   const int *cnt = reinterpret_cast<const int *>(key_table);
   const di::KeyEnt *keys = reinterpret_cast<const di::KeyEnt *>(cnt + 2 * (size_t)ncell);
-  int *gstart = reinterpret_cast<int *>(dense_table);
-  di::i2pd::DenseKey *dense = reinterpret_cast<di::i2pd::DenseKey *>((char *)dense_table + di::i2pd::keys_offset(ngroups));
+  char *base = reinterpret_cast<char *>(dense_table);
+  di::i2pd::GroupHdr *hdr = reinterpret_cast<di::i2pd::GroupHdr *>(base);
+  int *csub = reinterpret_cast<int *>(base + di::i2pd::off_csub(ncell));
+  int *csb = reinterpret_cast<int *>(base + di::i2pd::off_csb(ncell));
+  int *wst = reinterpret_cast<int *>(base + di::i2pd::off_wst(ncell));
+  di::i2pd::DenseKey *dense = reinterpret_cast<di::i2pd::DenseKey *>(base + di::i2pd::off_keys(ncell));
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(di::i2pd::group_count_kernel, dim3((ngroups + 255) / 256), dim3(256), 0, s, cnt, cell_order, gstart, ncell, ngroups);
-  hipLaunchKernelGGL(di::i2pd::group_scan_kernel, dim3(1), dim3(1024), 0, s, gstart, ngroups);
-  hipLaunchKernelGGL(di::i2pd::compact_kernel, dim3((ngroups + 3) / 4), dim3(256), 0, s, cnt, keys, cell_order, gstart, dense, ncell,
-                     ngroups, T * n_views, Wi);
+  hipLaunchKernelGGL(di::i2pd::chunk_count_kernel, dim3((nchunks + 255) / 256), dim3(256), 0, s, cnt, cell_order, csub, csb, ncell,
+                     nchunks, key_cap);
+  hipLaunchKernelGGL(di::i2pd::scan_kernel, dim3(2), dim3(1024), 0, s, csub, csb, nchunks);
+  hipLaunchKernelGGL(di::i2pd::compact_kernel, dim3((nchunks + 3) / 4), dim3(256), 0, s, cnt, keys, cell_order, csub, csb, hdr, wst,
+                     dense, ncell, nchunks, T * n_views, Wi, W, key_cap);
   return di::check_launch("i2p_compact_keys");
 }
 
 int di_i2p_attn_dense_fwd(const void *img, const void *qfold, const void *key_table, const void *dense_table,
                           const int32_t *cell_order, void *ctx, void *valid, int n_views, int Hi, int Wi, int Hb, int Wb,
                           void *stream) {
-  DI_REQUIRE(img && qfold && key_table && dense_table && ctx && valid, "null argument");
+  (void)key_table;
+  (void)cell_order;                                           // the walk order is baked into the dense table's group headers
+  DI_REQUIRE(img && qfold && dense_table && ctx && valid, "null argument");
   DI_REQUIRE(n_views > 0 && Hi > 0 && Wi > 0 && Hb > 0 && Wb > 0, "bad map shape");
   DI_REQUIRE((long long)n_views * Hi * Wi * 256 < (1ll << 32), "image map too large for 32-bit byte offsets");
-  const int ncell = Hb * Wb, ngroups = di::i2pd::n_groups(ncell);
-  const int *cnt = reinterpret_cast<const int *>(key_table);
-  const int *gstart = reinterpret_cast<const int *>(dense_table);
-  const di::i2pd::DenseKey *dense =
-      reinterpret_cast<const di::i2pd::DenseKey *>((const char *)dense_table + di::i2pd::keys_offset(ngroups));
-  // one group per wavefront by default (a multiple of 8 blocks: one share of the groups per XCD); DI_I2PD_BLOCKS: fewer,
-  // persistent workgroups (measurement)
-  static const int want_blocks = getenv("DI_I2PD_BLOCKS") ? atoi(getenv("DI_I2PD_BLOCKS")) : 0;
+  DI_REQUIRE((long long)Hb * Wb * 256 < (1ll << 32), "BEV map too large for 32-bit byte offsets");
+  const int ncell = Hb * Wb;
+  const int W = di::i2pd::n_shares();
+  if (W <= 0) return DI_ERR_LAUNCH;
+  const char *base = reinterpret_cast<const char *>(dense_table);
+  const di::i2pd::GroupHdr *hdr = reinterpret_cast<const di::i2pd::GroupHdr *>(base);
+  const int *wst = reinterpret_cast<const int *>(base + di::i2pd::off_wst(ncell));
+  const di::i2pd::DenseKey *dense = reinterpret_cast<const di::i2pd::DenseKey *>(base + di::i2pd::off_keys(ncell));
   static const int nb_env = getenv("DI_I2PD_NB") ? atoi(getenv("DI_I2PD_NB")) : 2;
-  const int gp = (ngroups + 7) / 8;
-  int blocks = 8 * ((gp + di::i2pd::NW - 1) / di::i2pd::NW);
-  if (want_blocks > 0) blocks = std::min(blocks, (want_blocks + 7) / 8 * 8);
   hipStream_t s = (hipStream_t)stream;
-  if (nb_env == 3) return di::i2pd::launch_attn<3>(img, qfold, cnt, cell_order, gstart, dense, ctx, valid, ncell, ngroups, blocks, s);
-  return di::i2pd::launch_attn<2>(img, qfold, cnt, cell_order, gstart, dense, ctx, valid, ncell, ngroups, blocks, s);
+  if (nb_env == 3) return di::i2pd::launch_attn<3>(img, qfold, hdr, wst, dense, ctx, valid, W, s);
+  return di::i2pd::launch_attn<2>(img, qfold, hdr, wst, dense, ctx, valid, W, s);
 }
 
 }  // extern "C"

@@ -415,7 +415,7 @@ def pointwise_multi(x, chains):
 I2PKeys = collections.namedtuple('I2PKeys', 'table T V bev_hw dense dense_order', defaults=(None, None))
 
 
-I2P_DENSE = int(os.environ.get('DI_I2P_DENSE', '0'))      # 0: never build / use the dense key stream (A/B measurements)
+I2P_DENSE = int(os.environ.get('DI_I2P_DENSE', '1'))      # 0: never build / use the dense key stream (A/B measurements)
 
 
 def i2p_key_table(pillars, coors, num_points, proj, aug_rev, ori_hw, img_hw, bev_hw, dense=True, sector_order=True):

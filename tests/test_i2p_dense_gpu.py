@@ -60,13 +60,29 @@ def test_dense_kernel_matches_the_wave_per_cell_kernel(shape_name, qscale, secto
     err = (got - ref).abs()
     assert err.max().item() <= 4e-3 * scale, (err.max().item(), scale)
     assert err.mean().item() <= 2e-4 * scale
-    # the dense stream holds every key of the table exactly once
+    # the dense stream: every group owns whole superblocks (8 keys), at least one, enough for its keys; the groups cover
+    # every cell once; no group exceeds the key cap unless it is a single cell
     Hb, Wb = shape['bev_hw']
-    cnt = keys.table[:Hb * Wb * 4].view(torch.int32)
-    ngroups = (Hb * Wb + 7) // 8
-    gstart = keys.dense[:(ngroups + 1) * 4].view(torch.int32)
-    assert int(gstart[0]) == 0 and int(gstart[-1]) == int(cnt.sum())
-    assert bool((gstart[1:] >= gstart[:-1]).all())
+    ncell = Hb * Wb
+    cnt = keys.table[:ncell * 4].view(torch.int32).cpu()
+    nchunks = (ncell + 7) // 8
+    al = lambda x: (x + 255) // 256 * 256
+    off_csub = al(ncell * 64)
+    ngroups = int(keys.dense[off_csub + nchunks * 4:off_csub + nchunks * 4 + 4].view(torch.int32)[0])
+    assert nchunks <= ngroups <= ncell
+    hdr = keys.dense[:ngroups * 64].view(torch.int32).view(ngroups, 16).cpu()
+    cells, sb_begin, sb_end, nk = hdr[:, :8], hdr[:, 8], hdr[:, 9], hdr[:, 10]
+    assert int(sb_begin[0]) == 0 and bool((sb_begin[1:] == sb_end[:-1]).all())
+    span = (sb_end - sb_begin) * 8
+    assert bool((span >= 8).all()) and bool((span >= nk).all())
+    assert bool(((span < nk + 8) | ((nk == 0) & (span == 8))).all())
+    assert int(nk.sum()) == int(cnt.sum())
+    seen = cells[cells >= 0]
+    assert seen.numel() == ncell and seen.unique().numel() == ncell
+    single = (cells >= 0).sum(1) == 1
+    assert bool(((nk <= 48) | single).all())
+    per_group = torch.where(cells >= 0, cnt[cells.clamp(min=0).long()], torch.zeros_like(cells)).sum(1)
+    assert torch.equal(per_group.to(torch.int32), nk)
 
 
 def test_dense_kernel_is_permutation_invariant_and_convex():

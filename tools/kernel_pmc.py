@@ -58,6 +58,7 @@ with torch.no_grad():
         for _ in range(3):
             keys = ops.i2p_key_table(*a, (Hi, Wi), (Hb, Wb))
             ops.i2p_attention(img, bev, *a, keys=keys)
+            ops.i2p_attention(img, bev, *a, keys=keys._replace(dense=None))       # the wave-per-cell kernel beside it
     if 'bw' in which:
         pts = pm['pts'][0].cuda()
         dense = ops.depth_complete(ops.depth_scatter(pts, geom.lidar2img, geom.aug_rev, Hi, Wi, geom.ori_hw))

@@ -10,7 +10,7 @@ for f in sorted(glob.glob(os.path.join(out, 'p*.csv'))):
             agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
 res = {}
 for key, cs in sorted(agg.items()):
-    if not any(k in key[0] for k in ('conv3x3', 'local_attn', 'pointwise', 'i2p', 'mha_decode', 'tl_', 'dynconv', 'bevwarp')):
+    if not any(k in key[0] for k in ('conv3x3', 'local_attn', 'pointwise', 'i2p', 'mha_decode', 'tl_', 'dynconv', 'bevwarp', 'attn_dense')):
         continue
     d = {c: sum(v) / len(v) for c, v in cs.items()}
     res[f'{key[0]} grid={key[1]}'] = d
