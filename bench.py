@@ -191,6 +191,9 @@ def cpu_baseline(shape, num_proposals, state, sample, product_out, budget_s=60.0
         dt, sh = probe(div) if div != 4 else (t16, sh)
     frac = 1.0 / (div * div)
     base = dict(value=round(frac / dt, 5), unit='samples/s', cores=cores, kind='port',
+                protocol='ONE timed oracle forward after a 1/16-area probe (bounded: the full-size forward takes ~17 s; BASELINE.md 3 '
+                         'names 2 warm-up + 5 timed iterations, which would be two minutes of CPU work inside a bench run that must '
+                         'finish within minutes) - a baseline figure, not a benchmark of the oracle',
                 sample=(f'oracle MMRI+MMPI forward, fp32, {cores} threads, on a 1/{div * div}-area sample '
                         f'(image feats 6x{sh["c_img"]}x{sh["img_hw"][0]}x{sh["img_hw"][1]}, BEV {sh["bev_hw"][0]}^2, '
                         f'{sh["n_points"]} points) in {dt:.1f} s; value = area fraction / time'))
@@ -227,6 +230,51 @@ def cpu_baseline_pp(shape, num_proposals, state, sample, product_out):
     return base, par
 
 
+def cpu_baseline_train(args):
+    """The training line's CPU figure: the oracle (kind "port") forward + BACKWARD on this box's host cores, bounded - the
+    1/4-area sample of the workload (the full-size forward alone is 17 s; with the backward it would be a minute), scaled by
+    the area.  The scalar that is differentiated is the sum of the head's outputs (the loss itself is the product's own code -
+    the reference's loss functions live in mmdet / mmdet3d, absent here); the backward of the whole MMRI + MMPI graph is what
+    costs the time either way.  --model pp: the ++ oracle at the full shape is ~40 s forward; a 1/4-area ++ shape is used."""
+    import torch
+    from deepinteraction_amd import harness, synth
+    from oracle import parity
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    pp = args.model == 'pp'
+    shape = (harness.SHAPES_PP if pp else harness.SHAPES)[args.shape]
+    div = 2 if shape['bev_hw'][0] >= 100 else 1
+    Hi, Wi = shape['img_hw'][0] // div, shape['img_hw'][1] // div
+    if pp:
+        Hi, Wi = Hi // 2 * 2, Wi // 2 * 2
+    Hb = shape['bev_hw'][0] // div
+    sh = dict(shape, img_hw=(Hi, Wi), input_shape=(Hi * 4, Wi * 4), bev_hw=(Hb, Hb), n_points=shape['n_points'] // (div * div))
+    nprop = args.proposals if Hb >= 50 else 24
+    if pp:
+        inp = synth.make_inputs_pp(1, sh, seed=0)
+        e32, d32 = harness.build_models_pp(sh, nprop, torch.float32, 'cpu')
+        E, D = parity.build_oracle_pp(sh, nprop, (e32.state_dict(), d32.state_dict()))
+        feats = ([f.float() for f in inp['img_feats']], [f.float() for f in inp['pts_feats']])
+    else:
+        inp = synth.make_inputs(1, sh, seed=0)
+        E, D = parity.build_oracle(sh, nprop)
+        feats = (inp['img_feats'].float(), inp['pts_feats'].float())
+    for p_ in [p for m in (E, D) for p in m.parameters()]:
+        p_.requires_grad_(True)
+    t0 = time.time()
+    with torch.enable_grad():
+        img, (p0, p1) = E(feats[0], feats[1], inp['img_metas'], inp['pts_metas'])
+        out = D([p0, p1], img, inp['img_metas'])[0][0]
+        scalar = sum(v.float().sum() for v in out.values() if torch.is_tensor(v) and v.is_floating_point() and v.requires_grad)
+        scalar.backward()
+    dt = time.time() - t0
+    frac = 1.0 / (div * div)
+    return dict(value=round(frac / dt, 5), unit='samples/s', cores=cores, kind='port',
+                sample=(f'oracle {"FusionTransformerv4 + ++ head" if pp else "MMRI + MMPI"} forward + backward (sum of the head outputs), '
+                        f'fp32, {cores} threads, ONE step on a 1/{div * div}-area sample (image feats {Hi}x{Wi}, BEV {Hb}^2, '
+                        f'{sh["n_points"]} points) in {dt:.1f} s; value = area fraction / time'))
+
+
 def pmc_file(name):
     p = os.path.join(ROOT, 'profiles', name)
     return json.load(open(p)) if os.path.exists(p) else {}
@@ -234,16 +282,58 @@ def pmc_file(name):
 
 # ------------------------------------------------------------------------------------------------ workloads
 def run_dry(args, parallel, rank, world):
-    """No GPU: exercises launcher, rank environment, barrier / max-over-ranks timing on gloo."""
+    """No GPU: exercises launcher, rank environment, core binding, barrier / max-over-ranks timing on gloo.  --mode train: also
+    the training step's gradient-reducer wiring on the REAL parameter list (the two modules built on the CPU, a synthetic
+    backward of the real shapes - `train_step.synthetic_backward` - with the image RoI blocks unused on odd ranks, as when
+    every view of a rank's sample holds <= 1 query: reference decoder_utils.py:726, find_unused_parameters=True)."""
     parallel.init('gloo')
-    el = parallel.timed_region(lambda: time.sleep(0.002 * (rank + 1)), args.steps)
+    binding = parallel.bind_rank_threads(int(os.environ.get('LOCAL_RANK', rank)), world)
+    extra = {}
+    if args.mode == 'train':
+        import torch
+        from deepinteraction_amd import harness, synth, train_step
+        enc, dec = harness.build_models(synth.SHAPE_TINY, args.proposals, torch.float32, 'cpu')
+        enc.train(), dec.train()
+        named = [(('enc.' if m is enc else 'dec.') + n, p) for m in (enc, dec) for n, p in m.named_parameters()]
+        params = train_step.trainable_parameters(enc, dec)
+        red = parallel.GradientReducer(params, world)
+        unused = ('dec.decode_head.0.', 'dec.decode_head.2.') if rank % 2 == 1 else ()
+        worst = [0.0]
+
+        def step():
+            for p in params:
+                p.grad = None
+            ws = train_step.synthetic_backward(named, rank, step.i, unused=unused + ('dec.heatmap_head.',))
+            red.finish()
+            # every rank knows every rank's weights: the averaged gradient must be the mean over ALL ranks (zeros where unused)
+            for i, (n, p) in enumerate(named):
+                if n.startswith('dec.heatmap_head.'):
+                    assert p.grad is None, n                      # unused everywhere: stays frozen
+                    continue
+                want = 0.0
+                for r in range(world):
+                    image_block = n.startswith('dec.decode_head.0.') or n.startswith('dec.decode_head.2.')
+                    if not (r % 2 == 1 and image_block):
+                        want += (r + 1) * 0.5 + (step.i + 1) * 0.125 + (i % 7) * 0.03125
+                worst[0] = max(worst[0], float((p.grad - want / world).abs().max()))
+            step.i += 1
+        step.i = 0
+        el = parallel.timed_region(step, args.steps)
+        worst_all = parallel.max_over_ranks(worst[0])
+        assert worst_all < 1e-5, worst_all
+        extra = dict(parameters=len(params), gradient_bytes=sum(p.numel() for p in params) * 4, buckets=len(red.buckets),
+                     unused_on_odd_ranks='decode_head.0 / decode_head.2 (image RoI blocks)', max_abs_error=worst_all)
+        workload = 'dry-run train: gradient reducer on the real parameter list, synthetic backward'
+    else:
+        el = parallel.timed_region(lambda: time.sleep(0.002 * (rank + 1)), args.steps)
+        workload = 'dry-run'
     seen = parallel.sum_over_ranks(1)
     if rank == 0:
         print(json.dumps(dict(metric='dry-run (launcher + timing protocol only)', value=round(
             parallel.throughput(args.batch, args.steps, el, world), 3), unit='samples/s', n_gpus=args.gpus,
             steps=args.steps, warmup=args.warmup, ms_per_step=round(el / args.steps * 1e3, 3), higher_is_better=True,
             scaling='weak', vs_baseline=None, dtype='none', data='none',
-            config=dict(workload='dry-run', ranks_seen=int(seen), backend='gloo'))))
+            config=dict(workload=workload, ranks_seen=int(seen), backend='gloo', cpu_binding=binding, **extra))))
 
 
 def main():
@@ -267,18 +357,20 @@ def main():
     device = torch.device('cuda', local)
     parallel.init('nccl', device)                 # RCCL over xGMI
     ranks_seen = int(parallel.sum_over_ranks(1, device))
+    # one node, N ranks: every rank's host threads (lane launchers, the training step's Hungarian assignment) on its own cores
+    binding = parallel.bind_rank_threads(local, world)
     if args.mode == 'train':
-        if args.model != 'v1':
-            sys.exit('--mode train runs the Fusion_0075_refactor model (BASELINE configs[2] / [3]); the DeepInteraction++ training '
-                     'forward / backward is timed by tools/pp_train_bench.py')
         from deepinteraction_amd import train_step
-        out = train_step.bench(args, rank, world, device)
+        out = train_step.bench(args, rank, world, device)       # --model pp: the DeepInteraction++ step (configs[4]), eager launches
+        if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline_train(args)
     elif args.model == 'pp':
         out = bench_forward_pp(args, rank, world, device)
     else:
         out = bench_forward(args, rank, world, device)
     if rank == 0:
         out['config']['ranks_seen'] = ranks_seen
+        out['config']['cpu_binding'] = binding
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
@@ -503,8 +595,7 @@ def bench_forward(args, rank, world, device):
         from deepinteraction_amd import utils as di_utils
 
         def kernel_times(overlap):
-            saved, di_utils.OVERLAP = di_utils.OVERLAP, overlap
-            try:
+            with di_utils.overlap(overlap):          # this thread's forwards only (utils.OVERLAP is thread-aware since round 6)
                 harness.forward(enc, dec, dev_pool[0])
                 torch.cuda.synchronize()
                 ops.PROFILE = []
@@ -513,22 +604,23 @@ def bench_forward(args, rank, world, device):
                 torch.cuda.synchronize()
                 got, ops.PROFILE = ops.PROFILE, None
                 return got
-            finally:
-                di_utils.OVERLAP = saved
         in_step = kernel_times(di_utils.OVERLAP)
         ops.PROFILE = kernel_times(0)
         prof, ops.PROFILE = ops.PROFILE, None
     Hi, Wi = shape['img_hw']
     n_img = 6 * args.batch
     es = 2 if dtype == torch.float16 else 4
-    alg_bytes = 4 * n_img * 128 * Hi * Wi * es
+    # round 6: both image-side attentions of a layer are ONE launch over 2 x n_img images (pair buffers, DI_PAIR_ATTN=0: two)
+    pair = any(name == 'local_attn_fwd' and n == 2 * n_img for (name, n, s, e) in prof)
+    n_la = 2 * n_img if pair else n_img
+    alg_bytes = 4 * n_la * 128 * Hi * Wi * es
     def la_times(events, stream=False):
         # dispatch-bound events (the kernel's own begin / end time stamps, as rocprofv3 reports them) when the launch site
         # supports them; `stream`: the interval between two events recorded on the launch stream around the launch
         return [(s.stream_ms(e) if stream else s.elapsed_time(e)) * 1e-3 for (name, n, s, e) in events
-                if name == 'local_attn_fwd' and n == n_img]
+                if name == 'local_attn_fwd' and n == n_la]
     durs, shared, durs_stream = la_times(prof), la_times(in_step), la_times(prof, stream=True)
-    bound = all(s.dispatch_bound() for (name, n, s, e) in prof if name == 'local_attn_fwd' and n == n_img)
+    bound = all(s.dispatch_bound() for (name, n, s, e) in prof if name == 'local_attn_fwd' and n == n_la)
     avg = sum(durs) / max(len(durs), 1)
     achieved = alg_bytes / avg / 1e9 if durs else None
     # The streaming floor of THIS box for the launch's bytes: an element-wise kernel that reads three maps of the launch's size
@@ -538,7 +630,7 @@ def bench_forward(args, rank, world, device):
     stream_floor_us = None
     if durs and device.type == 'cuda' and dtype == torch.float16:
         gq = torch.Generator(device=device).manual_seed(0)
-        mk = lambda: torch.randn(n_img, 128, Hi, Wi, device=device, generator=gq).half().contiguous(memory_format=torch.channels_last)
+        mk = lambda: torch.randn(n_la, 128, Hi, Wi, device=device, generator=gq).half().contiguous(memory_format=torch.channels_last)
         sets = [(mk(), mk(), mk()) for _ in range(3)]
         outs = [torch.empty_like(sets[0][0]) for _ in range(3)]
         f3 = lambda i: torch.addcmul(sets[i][0], sets[i][1], sets[i][2], out=outs[i])
@@ -558,7 +650,7 @@ def bench_forward(args, rank, world, device):
         stream_floor_us = ev0.elapsed_time(ev1) / 45 * 1e3
         del gr, sets, outs
     pmc = pmc_file('pmc_local_attn.json')
-    roofline = dict(bound='hbm', kernel=f'di_local_attn_fwd, image side {n_img}x{Hi}x{Wi}, 9x9, C=128 '
+    roofline = dict(bound='hbm', kernel=f'di_local_attn_fwd, image side {n_la}x{Hi}x{Wi}' + (' (I_IML and P2I of a layer in ONE launch)' if pair else '') + ', 9x9, C=128 '
                                         f'({ops.local_attention_kernel_name()})',
                     achieved=None if achieved is None else round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
@@ -591,6 +683,55 @@ def bench_forward(args, rank, world, device):
                      lane_captures=None if args.eager else ('single-stream' if n_lanes > 1 and 'DI_OVERLAP' not in os.environ
                                                             else 'with the forward\'s fork / join branches'),
                      graph_nodes=None if g is None else g.num_nodes()))
+    # the cross-attention kernels BASELINE names, each against its own byte roofline: live timing of
+    # the same profiled forwards (both timers), the counters from the committed rocprofv3 --pmc passes of the same forward
+    from deepinteraction_amd import measure
+    if durs and dtype == torch.float16 and args.shape != 'TINY':
+        pm0 = dev_pool[0]['pts_metas']
+        b0, b1 = (0, pm0['pillars'].shape[0]) if args.batch == 1 else (0, int((pm0['pillar_coors'][:, 0] == 0).sum()))
+        from deepinteraction_amd.geometry import SampleGeometry
+        Hb, Wb = shape['bev_hw']
+        g0 = SampleGeometry(dev_pool[0]['img_metas'][0], (Hi, Wi), device)
+        kt = ops.i2p_key_table(pm0['pillars'][b0:b1], pm0['pillar_coors'][b0:b1], pm0['pillars_num_points'][b0:b1], g0.lidar2img,
+                               g0.aug_rev, g0.ori_hw, (Hi, Wi), (Hb, Wb), dense=False)
+        n_keys = int(kt.table[:Hb * Wb * 4].view(torch.int32).sum())
+        alg = measure.algorithmic_bytes(shape, 1, es, n_keys)      # per launch: the encoder launches these per SAMPLE, except ...
+        alg_b = measure.algorithmic_bytes(shape, args.batch, es, n_keys)   # ... the window attentions and 1x1 chains (whole batch)
+        summ = measure.committed()
+        ks = [
+            measure.kernel_row('window attention, image side (I_IML + P2I' + (' in one launch: 2' if pair else ': 4') + ' launches / forward)',
+                               roofline['kernel'], prof, 'local_attn_fwd', n_la, (2 if pair else 1) * alg_b['local_attn_img'],
+                               measure.pmc_row(summ, 'local_attn_ring_kernel')),
+            measure.kernel_row('window attention, BEV side (P_IML: 2 launches / forward)', 'di_local_attn_fwd, 180x180 (m2 generation)',
+                               prof, 'local_attn_fwd', args.batch, alg_b['local_attn_bev'], measure.pmc_row(summ, 'local_attn_m2_kernel')),
+            measure.kernel_row('pillar attention image -> BEV (MMRI_I2P: 2 launches / forward and sample)',
+                               'di_i2p_attn_dense_fwd (matrix-core stream kernel, csrc/i2p_dense.hip)' if ops.I2P_DENSE else
+                               'di_i2p_attn_fwd (wave per cell, csrc/cross_modal.hip)', prof, 'i2p_attn_fwd', 6, alg['i2p_attn'],
+                               measure.pmc_row(summ, 'attn_dense_kernel') or measure.pmc_row(summ, 'i2p_attn_kernel')),
+            measure.kernel_row('BEV -> image warp + K / V projection (BEVWarp + P2I keys / values: 2 launches / forward and sample)',
+                               'di_pointwise_multi_warp_fwd', prof, 'pointwise_multi_warp', 6, alg['warp_project_kv'],
+                               measure.pmc_row(summ, 'pointwise_multi_kernel<5, true>')),
+            measure.kernel_row('q / k / v / P2I-query projections of the image map (2 launches / forward)', 'di_pointwise_multi_fwd, 4 chains',
+                               prof, 'pointwise_multi', (n_img, 4), alg_b['pointwise_multi_img'],
+                               measure.pmc_row(summ, 'pointwise_multi_kernel<5, false>')),
+            measure.kernel_row('out_proj + integration chain, image side (2 launches / forward)', 'di_pointwise_chain_masked_fwd <256, 256>',
+                               prof, 'pointwise_chain', n_img * 512, alg_b['pointwise_chain_img'],
+                               measure.pmc_row(summ, 'pointwise_chain_kernel<256, 256>'), size='large'),
+        ]
+        for k in ks:
+            k['key_count'] = n_keys if 'pillar' in k['name'] else None
+        roofline['kernels'] = ks
+        ring = measure.pmc_row(summ, 'local_attn_ring_kernel')
+        if ring is not None and ring.get('hbm_bytes_per_launch'):
+            # the committed counters of THIS round's launch shape (one launch for both image-side attentions of a layer)
+            roofline.update(traffic=ring['hbm_bytes_per_launch'], mfma_busy=ring.get('mfma_busy'), lds_busy=ring.get('lds_busy'),
+                            valu_busy=ring.get('valu_busy'), pmc_source=summ.get('source'),
+                            pmc_note='traffic / mfma_busy / valu_busy / lds_busy are read from the committed rocprofv3 --pmc passes named '
+                                     'in pmc_source (profiles/forward_roofline.json), not measured by this run; achieved / frac / '
+                                     'avg_launch_us are live')
+        per_fwd = (4 * alg_b['local_attn_img'] + 2 * alg_b['local_attn_bev'] + 2 * args.batch * alg['i2p_attn']
+                   + 2 * args.batch * alg['warp_project_kv'] + 2 * alg_b['pointwise_multi_img'] + 2 * alg_b['pointwise_chain_img'])
+        roofline['forward'] = measure.forward_block(summ, per_fwd)
     from deepinteraction_amd import _lib
     roofline['ring_spin_timeouts'] = int(_lib.lib().di_local_attn_ring_timeouts(None))     # bounded flag spins that gave up: must be 0
     assert roofline['ring_spin_timeouts'] == 0, 'the ring window-attention kernel gave up on a flag spin: results are invalid'

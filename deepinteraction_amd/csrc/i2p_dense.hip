@@ -77,62 +77,35 @@ __host__ __device__ inline long long off_csb(int ncell) { return off_csub(ncell)
 __host__ __device__ inline long long off_wst(int ncell) { return off_csb(ncell) + al256((long long)(n_chunks(ncell) + 1) * 4); }
 __host__ __device__ inline long long off_keys(int ncell) { return off_wst(ncell) + al256((long long)(kMaxWaves + 1) * 4); }
 
-struct Split {                   // the groups of one chunk
-  int nsub;
-  int sub[NC], col[NC];          // per cell: its group (within the chunk) and its column
-  int nk[NC], nc[NC], first[NC]; // per group: keys, cells, first cell
-  int nsb[NC];                   // per group: superblocks = max(1, ceil(keys / 8))
-};
-__device__ __forceinline__ Split split_chunk(const int (&cnt)[NC], int ncells, int key_cap) {
-  Split S;
-  S.nsub = 0;
-  int keys = 0, cells = 0;
-#pragma unroll
-  for (int k = 0; k < NC; ++k) S.nk[k] = S.nc[k] = S.first[k] = S.nsb[k] = 0;
-#pragma unroll
-  for (int j = 0; j < NC; ++j) {
-    if (j < ncells) {
-      if (cells > 0 && keys + cnt[j] > key_cap) {
-        ++S.nsub;
-        keys = cells = 0;
-      }
-      S.sub[j] = S.nsub;
-      S.col[j] = cells;
-#pragma unroll
-      for (int k = 0; k < NC; ++k)
-        if (k == S.nsub) {
-          if (cells == 0) S.first[k] = j;
-          S.nk[k] += cnt[j];
-          S.nc[k] += 1;
-        }
-      keys += cnt[j];
-      ++cells;
-    } else {
-      S.sub[j] = S.col[j] = 0;
-    }
-  }
-  if (ncells > 0) ++S.nsub;
-#pragma unroll
-  for (int k = 0; k < NC; ++k) S.nsb[k] = k < S.nsub ? max((S.nk[k] + 7) >> 3, 1) : 0;
-  return S;
-}
-
-// csub[c] / csb[c] = groups / superblocks of chunk c (one thread per chunk)
+// csub[c] / csb[c] = groups / superblocks of chunk c (one thread per chunk): the greedy cut, serially over the 8 cells
 __global__ __launch_bounds__(256) void chunk_count_kernel(const int *__restrict__ cnt, const int *__restrict__ order,
-                                                          int *__restrict__ csub, int *__restrict__ csb, int ncell, int nchunks, int key_cap) {
+                                                          int *__restrict__ csub, int *__restrict__ csb, int ncell, int nchunks,
+                                                          int key_cap) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= nchunks) return;
   int k[NC];
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     const int pos = c * NC + j;
-    k[j] = pos < ncell ? cnt[order != nullptr ? order[pos] : pos] : 0;
+    k[j] = pos < ncell ? cnt[order != nullptr ? order[pos] : pos] : -1;
   }
-  const Split S = split_chunk(k, min(NC, ncell - c * NC), key_cap);
-  int nsb = 0;
+  int keys = 0, cells = 0, nsub = 0, nsb = 0;
 #pragma unroll
-  for (int q = 0; q < NC; ++q) nsb += S.nsb[q];
-  csub[c] = S.nsub;
+  for (int j = 0; j < NC; ++j)
+    if (k[j] >= 0) {
+      if (cells > 0 && keys + k[j] > key_cap) {
+        nsb += max((keys + 7) >> 3, 1);
+        ++nsub;
+        keys = cells = 0;
+      }
+      keys += k[j];
+      ++cells;
+    }
+  if (cells > 0) {
+    nsb += max((keys + 7) >> 3, 1);
+    ++nsub;
+  }
+  csub[c] = nsub;
   csb[c] = nsb;
 }
 
@@ -181,6 +154,9 @@ __device__ __forceinline__ uint4 key_addr(const float4 &k0, unsigned stepy) {
 // tagged with the cell's column, padded to whole superblocks (padding: weight 0, column 15, the address of the group's last
 // real key) - and the share table: share w of W starts at the first group whose first superblock is >= t(w) = w * all / W,
 // i.e. behind the group that holds superblock t(w) - 1 (every group writes the shares that start right behind it).
+// Lane j < 8 owns CELL j of the chunk, lane q < 8 owns GROUP q: the greedy cut is one serial pass over the 8 counts (wave
+// uniform), whose results land in the owning lanes by compare-with-lane-id; everything after it is lane-parallel.  (The first
+// version kept the cut in uniform arrays indexed by compile-time loops: 2 700 instructions, 13 us for the 4 050 chunks.)
 __global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ cnt, const KeyEnt *__restrict__ keys,
                                                       const int *__restrict__ order, const int *__restrict__ csub,
                                                       const int *__restrict__ csb, GroupHdr *__restrict__ hdr,
@@ -189,121 +165,110 @@ __global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ cn
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= nchunks) return;
+  const int ncells = min(NC, ncell - c * NC);
   int mycell = -1, mycnt = 0;
-  if (lane < NC && c * NC + lane < ncell) {
+  if (lane < ncells) {
     mycell = order != nullptr ? order[c * NC + lane] : c * NC + lane;
     mycnt = cnt[mycell];
   }
-  int k[NC], cells[NC];
+  const int G0 = csub[c], ngroups = csub[nchunks], nsb_all = csb[nchunks], sb_first = csb[c];
+  // the cut
+  int gkeys = 0, cells = 0, nsub = 0;
+  int my_sub = 0, my_col = 0, my_in = 0;                 // lane j: its cell's group, column, keys in front of it in the group
+  int g_nk = 0, g_nc = 0, g_lastcell = -1, g_lastcnt = 0;   // lane q: its group's keys, cells, last cell that has keys
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
-    k[j] = __builtin_amdgcn_readlane(mycnt, j);
-    cells[j] = __builtin_amdgcn_readlane(mycell, j);
-  }
-  const Split S = split_chunk(k, min(NC, ncell - c * NC), key_cap);
-  const int G0 = csub[c], ngroups = csub[nchunks], nsb_all = csb[nchunks];
-  int sbb[NC + 1];                                    // first superblock of every group of the chunk
-  sbb[0] = csb[c];
-#pragma unroll
-  for (int q = 0; q < NC; ++q) sbb[q + 1] = sbb[q] + S.nsb[q];
-  // headers
-#pragma unroll
-  for (int q = 0; q < NC; ++q)
-    if (q < S.nsub) {
-      GroupHdr *H = hdr + G0 + q;
-      if (lane < NC) {
-        int v = -1;
-#pragma unroll
-        for (int j = 0; j < NC; ++j)
-          if (S.sub[j] == q && S.col[j] == lane && j < ncell - c * NC) v = cells[j];
-        H->cell[lane] = v;
+    const int cj = __builtin_amdgcn_readlane(mycnt, j), cellj = __builtin_amdgcn_readlane(mycell, j);
+    if (j < ncells) {
+      if (cells > 0 && gkeys + cj > key_cap) {
+        ++nsub;
+        gkeys = cells = 0;
       }
-      if (lane == 0) {
-        H->sb_begin = sbb[q];
-        H->sb_end = sbb[q + 1];
-        H->nk = S.nk[q];
-        // shares that start right behind this group: sb_begin < t(w) <= sb_end (and, for the very first group, t(w) = 0)
-        // (32-bit arithmetic: superblocks < 2^18, W <= 2^12 - the 64-bit divisions of the first version were most of this
-        //  kernel's 14 us)
-        const unsigned ua = (unsigned)nsb_all, uw = (unsigned)W;
-        unsigned w = ((unsigned)(sbb[q] + 1) * uw + ua - 1u) / ua;
-        if (G0 + q == 0) {
-          for (unsigned w0 = 0; w0 < uw && (w0 * ua) / uw == 0u; ++w0) wst[w0] = 0;
-        }
-        for (; w < uw && (w * ua) / uw <= (unsigned)sbb[q + 1]; ++w) wst[w] = G0 + q + 1;
-        if (G0 + q == ngroups - 1) wst[W] = ngroups;
-      }
-    }
-  // keys: lane j < 8 holds cell j's destination and column, lane q < 8 group q's padding; then every lane copies ONE key per
-  // pass (a chunk has ~40) and one padding key - two independent load -> store round trips instead of the first version's
-  // cell-after-cell loop (14 us for the 4 050 chunks)
-  const unsigned stepy = (unsigned)Wi * 256u;
-  int my_dst = 0, my_col = 0, my_pre = 0;           // per cell (lane j): first key's slot in the stream, column, keys in front (chunk)
-  int pad_dst = 0, pad_n = 0, pad_cell = -1, pad_cnt = 0;   // per group (lane q)
-  {
-    int pre = 0, in_group = 0;
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-      if (S.col[j] == 0) in_group = 0;
-      int base = 0;
-#pragma unroll
-      for (int qq = 0; qq < NC; ++qq)
-        if (qq == S.sub[j]) base = sbb[qq] * 8;
       if (lane == j) {
-        my_dst = base + in_group;
-        my_col = S.col[j];
-        my_pre = pre;
+        my_sub = nsub;
+        my_col = cells;
+        my_in = gkeys;
       }
-      if (j < ncell - c * NC) {
-        pre += k[j];
-        in_group += k[j];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NC; ++q) {
-      int lc = -1, ln = 0;                          // the group's last cell that has keys
-#pragma unroll
-      for (int j = 0; j < NC; ++j)
-        if (j < ncell - c * NC && S.sub[j] == q && k[j] > 0) {
-          lc = cells[j];
-          ln = k[j];
+      if (lane == nsub) {
+        g_nk += cj;
+        g_nc += 1;
+        if (cj > 0) {
+          g_lastcell = cellj;
+          g_lastcnt = cj;
         }
-      if (lane == q && q < S.nsub) {
-        pad_dst = sbb[q] * 8 + S.nk[q];
-        pad_n = S.nsb[q] * 8 - S.nk[q];             // < 8, or 8 for a group without keys
-        pad_cell = lc;
-        pad_cnt = ln;
+      }
+      gkeys += cj;
+      ++cells;
+    }
+  }
+  nsub += ncells > 0 ? 1 : 0;
+  // superblocks of the groups: lane q
+  const int g_nsb = lane < nsub ? max((g_nk + 7) >> 3, 1) : 0;
+  int inc = g_nsb;                                        // inclusive prefix over lanes 0 .. 7
+#pragma unroll
+  for (int d = 1; d < NC; d <<= 1) {
+    const int t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  const int g_sb0 = sb_first + inc - g_nsb, g_sb1 = sb_first + inc;
+  // headers: cells into their columns, -1 into the unused ones; the rest by the group's lane
+  {
+    const int sb_of_mine = __shfl(g_sb0, my_sub);
+    if (lane < ncells) hdr[G0 + my_sub].cell[my_col] = mycell;
+    const int q = lane >> 3, col = lane & 7;
+    const int nc_q = __shfl(g_nc, q);
+    if (q < nsub && col >= nc_q) hdr[G0 + q].cell[col] = -1;
+    if (lane < nsub) {
+      GroupHdr *H = hdr + G0 + lane;
+      H->sb_begin = g_sb0;
+      H->sb_end = g_sb1;
+      H->nk = g_nk;
+      // shares that start right behind this group: sb_begin < t(w) <= sb_end (and, for the very first group, t(w) = 0).
+      // 32-bit arithmetic: superblocks < 2^19, W <= 2^12.
+      const unsigned ua = (unsigned)nsb_all, uw = (unsigned)W;
+      unsigned w = ((unsigned)(g_sb0 + 1) * uw + ua - 1u) / ua;
+      if (G0 + lane == 0)
+        for (unsigned w0 = 0; w0 < uw && (w0 * ua) / uw == 0u; ++w0) wst[w0] = 0;
+      for (; w < uw && (w * ua) / uw <= (unsigned)g_sb1; ++w) wst[w] = G0 + lane + 1;
+      if (G0 + lane == ngroups - 1) wst[W] = ngroups;
+    }
+    // keys: every lane copies ONE key per pass (a chunk has ~40) and one padding key: two independent load -> store
+    // round trips
+    const unsigned stepy = (unsigned)Wi * 256u;
+    const int my_dst = sb_of_mine * 8 + my_in;
+    int pre = mycnt;                                      // keys in front of cell j in the CHUNK: exclusive prefix over lanes 0 .. 7
+#pragma unroll
+    for (int d = 1; d < NC; d <<= 1) {
+      const int t = __shfl_up(pre, d);
+      if (lane >= d) pre += t;
+    }
+    const int total = __builtin_amdgcn_readlane(pre, NC - 1);
+    pre -= mycnt;
+    for (int L0 = 0; L0 < total; L0 += 64) {              // a UNIFORM loop: the lane shuffles below read lanes 0 .. 7, which must be active
+      const int L = L0 + lane;
+      int j = 0;
+#pragma unroll
+      for (int jj = 1; jj < NC; ++jj) j += (jj < ncells && L >= __builtin_amdgcn_readlane(pre, jj)) ? 1 : 0;
+      // (cells without keys share their `pre` with the next cell: the LAST cell with pre <= L is the one that owns key L)
+      const int e = L - __shfl(pre, j), cell = __shfl(mycell, j), colj = __shfl(my_col, j), d0 = __shfl(my_dst, j);
+      if (L < total) {
+        const float4 *kp = reinterpret_cast<const float4 *>(keys + (size_t)cell * nslots + e);
+        const float4 k0 = kp[0];
+        const float2 k1 = *reinterpret_cast<const float2 *>(kp + 1);
+        uint4 a = key_addr(k0, stepy);
+        a.x |= (unsigned)colj;
+        uint4 *dst = reinterpret_cast<uint4 *>(dense + d0 + e);
+        dst[0] = a;
+        dst[1] = __builtin_bit_cast(uint4, make_float4(k0.z, k0.w, k1.x, k1.y));
       }
     }
-  }
-  int total = 0;
-#pragma unroll
-  for (int j = 0; j < NC; ++j) total += j < ncell - c * NC ? k[j] : 0;
-  for (int L0 = 0; L0 < total; L0 += 64) {           // a UNIFORM loop: the lane shuffles below read lanes 0 .. 7, which must be active
-    const int L = L0 + lane;
-    int j = 0;
-#pragma unroll
-    for (int jj = 1; jj < NC; ++jj) j += L >= __builtin_amdgcn_readlane(my_pre, jj) && jj < ncell - c * NC ? 1 : 0;
-    // (cells without keys share their `pre` with the next cell: the LAST cell with pre <= L is the one that owns key L)
-    const int e = L - __shfl(my_pre, j), cell = __shfl(mycell, j), col = __shfl(my_col, j), d0 = __shfl(my_dst, j);
-    if (L < total) {
-      const float4 *kp = reinterpret_cast<const float4 *>(keys + (size_t)cell * nslots + e);
-      const float4 k0 = kp[0];
-      const float2 k1 = *reinterpret_cast<const float2 *>(kp + 1);
-      uint4 a = key_addr(k0, stepy);
-      a.x |= (unsigned)col;
-      uint4 *dst = reinterpret_cast<uint4 *>(dense + d0 + e);
-      dst[0] = a;
-      dst[1] = __builtin_bit_cast(uint4, make_float4(k0.z, k0.w, k1.x, k1.y));
-    }
-  }
-  {
-    const int q = lane >> 3, pi = lane & 7;
-    const int n = __shfl(pad_n, q), cell = __shfl(pad_cell, q), cn = __shfl(pad_cnt, q), d0 = __shfl(pad_dst, q);
-    if (q < S.nsub && pi < n) {
-      uint4 last = make_uint4(0u, 0u, 0u, 0u);      // the address part of the group's last real key (padding re-reads it)
-      if (cell >= 0) last = key_addr(*reinterpret_cast<const float4 *>(keys + (size_t)cell * nslots + (cn - 1)), stepy);
-      uint4 *dst = reinterpret_cast<uint4 *>(dense + d0 + pi);
+    const int pi = lane & 7;
+    const int n = __shfl(g_nsb * 8 - g_nk, q), pc = __shfl(g_lastcell, q), pn = __shfl(g_lastcnt, q);
+    const int pd = __shfl(g_sb0 * 8 + g_nk, q);
+    if (q < nsub && pi < n) {                             // < 8 padding keys, or 8 for a group without keys
+      uint4 last = make_uint4(0u, 0u, 0u, 0u);            // the address part of the group's last real key (padding re-reads it)
+      if (pc >= 0) last = key_addr(*reinterpret_cast<const float4 *>(keys + (size_t)pc * nslots + (pn - 1)), stepy);
+      uint4 *dst = reinterpret_cast<uint4 *>(dense + pd + pi);
       dst[0] = make_uint4(last.x | 15u, last.y, last.z, last.w);
       dst[1] = make_uint4(0u, 0u, 0u, 0u);
     }

@@ -85,7 +85,7 @@ def forward(enc, dec, d):
     return (img, pts), dec(pts, img, d['img_metas'])
 
 
-def build_models_pp(shape, num_proposals, dtype, device, seed=0, num_layers=2):
+def build_models_pp(shape, num_proposals, dtype, device, seed=0, num_layers=2, train_cfg=None):
     """(FusionTransformerv4, DeepInteractionPlusPlusDecoder) of Fusion_0075_plusplus.py:210-303 (BASELINE.json configs[4])
     at `shape`, eval mode, random init - with the sampling-offset / attention-weight Linears moved off mmcv's zero init so
     that the deformable samples are spread.  dtype float16 = the mixed mode of `precision.half_maps_`: fp16 neck and
@@ -94,7 +94,10 @@ def build_models_pp(shape, num_proposals, dtype, device, seed=0, num_layers=2):
     from .mmdet3d_plugin import DeepInteractionPlusPlusDecoder, FusionTransformerv4
     torch.manual_seed(seed)
     enc = FusionTransformerv4(**encoder_pp_cfg(shape['c_img'], shape['c_pts'], num_layers))
-    dec = DeepInteractionPlusPlusDecoder(**decoder_cfg(bev=shape['bev_hw'][0], num_proposals=num_proposals))
+    cfg = decoder_cfg(bev=shape['bev_hw'][0], num_proposals=num_proposals)
+    if train_cfg is not None:
+        cfg['train_cfg'] = train_cfg
+    dec = DeepInteractionPlusPlusDecoder(**cfg)
     randomize_bn([enc, dec])
     gen = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():

@@ -68,11 +68,40 @@ class DeepInteractionEncoderLayer(nn.Module):
         # P_integration(cat(P_out_proj(cat(I2P, P2P)), lidar)) (:26-27): one fused kernel at inference
         return mix2(self.P_out_proj, I2P_feat, P2P_feat, self.P_integration, lidar_feat)
 
-    def _image_side(self, img_feat, img5, lidar_feat, img_metas, pts_metas, warped=None, warped_ready=None, kv=None):
+    # ONE window-attention launch for BOTH image-side attentions of the layer (round 6): I_IML (keys / values = the image map)
+    # and P2I (keys / values = the warped BEV map) have the same query pixels, window and scale, so their maps are laid out as
+    # the two halves of three PAIR BUFFERS (2 BN images each: [I_IML | P2I] queries, keys, values) - written in place by the
+    # image map's projection launch and by the warp-project launch - and the attention kernel, which works image by image,
+    # walks 2 BN images: 2 x 1 092 tiles = 8.5 rounds of the 256 workgroups instead of 2 x 4.27 (two ragged last rounds, two
+    # prologues), no kernel change.  DI_PAIR_ATTN=0 restores the two launches.
+    PAIR = __import__('os').environ.get('DI_PAIR_ATTN', '1') != '0'
+
+    def _pair_buffers(self, img_feat, lidar_feat):
+        I, PL = self.I_IML, self.P2I_block.Local
+        if not (self.PAIR and not torch.is_grad_enabled() and self.P2I_block.warp_kv_fusable(lidar_feat)
+                and I.kernel_size == PL.kernel_size
+                and fusable_projections(img_feat, I.query_project, I.key_project, I.value_project, PL.query_project)):
+            return None
+        BN, _, H, W = img_feat.shape
+        return tuple(ops.empty_cl(2 * BN, 128, H, W, img_feat) for _ in range(3))
+
+    def _image_side(self, img_feat, img5, lidar_feat, img_metas, pts_metas, warped=None, warped_ready=None, kv=None, pair=None):
         BN, I_C, I_H, I_W = img_feat.shape
         # fp16 inference: the four projections of the image map (query / key / value of I_IML and the query of P2I)
         # are ONE launch that reads it once.
         I, PL = self.I_IML, self.P2I_block.Local
+        if pair is None and kv is None and warped is None:
+            pair = self._pair_buffers(img_feat, lidar_feat)
+        if pair is not None:
+            q2, k2, v2 = pair
+            project_many([I.query_project, I.key_project, I.value_project, PL.query_project], img_feat,
+                         outs=[q2[:BN], k2[:BN], v2[:BN], q2[BN:]])
+            if kv is None:
+                self.P2I_block.warp_kv(lidar_feat, img5, img_metas, pts_metas, out=(k2[BN:], v2[BN:]))
+            if warped_ready is not None:
+                torch.cuda.current_stream().wait_event(warped_ready)
+            both = ops.local_attention(q2, k2, v2, I.kernel_size, I.kernel_size, 1.0 / math.sqrt(128))
+            return mix2(self.I_out_proj, both[BN:], both[:BN], self.I_integration, img_feat)
         if fusable_projections(img_feat, I.query_project, I.key_project, I.value_project, PL.query_project):
             q_i, k_i, v_i, q_p = project_many([I.query_project, I.key_project, I.value_project, PL.query_project], img_feat)
             if warped_ready is not None:
@@ -103,11 +132,14 @@ class DeepInteractionEncoderLayer(nn.Module):
             # by the image side after its own projections.  `warped` stays referenced until after the join (allocator
             # contract of fork_join).
             main, side = torch.cuda.current_stream(lidar_feat.device), utils.side_stream(lidar_feat.device, 0)
+            pair = self._pair_buffers(img_feat, lidar_feat)       # allocated in front of the fork: both streams write into them
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 # fp16 inference: the warp is gathered inside the key / value projection launch (no warped map in memory)
                 warped = kv = None
-                if self.P2I_block.warp_kv_fusable(lidar_feat) and fusable_projections(
+                if pair is not None:
+                    kv = self.P2I_block.warp_kv(lidar_feat, img5, img_metas, pts_metas, out=(pair[1][BN:], pair[2][BN:]))
+                elif self.P2I_block.warp_kv_fusable(lidar_feat) and fusable_projections(
                         img_feat, self.I_IML.query_project, self.I_IML.key_project, self.I_IML.value_project,
                         self.P2I_block.Local.query_project):
                     kv = self.P2I_block.warp_kv(lidar_feat, img5, img_metas, pts_metas)
@@ -116,9 +148,9 @@ class DeepInteractionEncoderLayer(nn.Module):
                 ready = torch.cuda.Event()
                 ready.record(side)
                 new_lidar_feat = self._bev_side(lidar_feat, img5, img_metas, pts_metas)
-            new_img_feat = self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas, warped, ready, kv)
+            new_img_feat = self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas, warped, ready, kv, pair)
             main.wait_stream(side)
-            del warped, kv
+            del warped, kv, pair
             return new_img_feat, new_lidar_feat
         new_lidar_feat = self._bev_side(lidar_feat, img5, img_metas, pts_metas)
         new_img_feat = self._image_side(img_feat, img5, lidar_feat, img_metas, pts_metas)

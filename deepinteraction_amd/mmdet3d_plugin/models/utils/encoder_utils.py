@@ -217,9 +217,10 @@ def fusable_projections(x, *seqs):
     return len(seqs) <= 4
 
 
-def project_many(seqs, x):
+def project_many(seqs, x, outs=None):
     """Several projections of the SAME map (e.g. query / key / value of a self-attention block): one launch that reads
-    x once (ops.pointwise_multi) for 128-channel fp16 inference chains, else one after the other."""
+    x once (ops.pointwise_multi) for 128-channel fp16 inference chains, else one after the other.  outs (fused form only):
+    the maps to write into."""
     ok = 1 <= len(seqs) <= 4
     for seq in seqs:
         if isinstance(seq, tuple):
@@ -227,7 +228,8 @@ def project_many(seqs, x):
         mods = list(seq) if isinstance(seq, nn.Sequential) else [seq]
         ok = ok and len(mods) in (1, 2) and _fusable(x, *mods) and all(m.conv.in_channels == 128 for m in mods)
     if ok and len(seqs) > 1:
-        return ops.pointwise_multi(x, [seq if isinstance(seq, tuple) else _chain_consts(seq, x.dtype) for seq in seqs])
+        return ops.pointwise_multi(x, [seq if isinstance(seq, tuple) else _chain_consts(seq, x.dtype) for seq in seqs], outs=outs)
+    assert outs is None, 'caller-provided outputs need the fused path (check fusable_projections first)'
     assert not any(isinstance(seq, tuple) for seq in seqs), 'packed chains need the fused path'
     return [project(seq, x) for seq in seqs]
 
@@ -434,9 +436,10 @@ class MMRI_P2I(nn.Module):
         return (lidar_feats.is_cuda and lidar_feats.dtype == torch.float16 and lidar_feats.shape[1] == 128
                 and not torch.is_grad_enabled() and fusable_projections(lidar_feats, L.key_project, L.value_project))
 
-    def warp_kv(self, lidar_feats, img_feats, img_metas, pts_metas):
+    def warp_kv(self, lidar_feats, img_feats, img_metas, pts_metas, out=None):
         """key / value maps (B*N,C,H,W) of the local attention over the warped BEV map, WITHOUT the warped map in memory:
-        `ops.warp_project` gathers the BEV samples inside the projection launch (one launch per sample)."""
+        `ops.warp_project` gathers the BEV samples inside the projection launch (one launch per sample).  out: (k, v) maps
+        of that shape to write into (the second halves of the encoder layer's pair buffers)."""
         B, V, C, I_H, I_W = img_feats.shape
         L = self.Local
         chains = [_chain_consts(L.key_project, lidar_feats.dtype), _chain_consts(L.value_project, lidar_feats.dtype)]
@@ -444,10 +447,13 @@ class MMRI_P2I(nn.Module):
         for b in range(B):
             geom = sample_geometry(img_metas, pts_metas, b, (I_H, I_W), lidar_feats.device)
             depth = self.Warp.dense_depth(geom, pts_metas['pts'][b], I_H, I_W)
+            outs = None if out is None else [out[0][b * V:(b + 1) * V], out[1][b * V:(b + 1) * V]]
             k, v = ops.warp_project(lidar_feats[b:b + 1], depth, geom.img2lidar, geom.aug_fwd, geom.xs, geom.ys,
-                                    geom.pc_range, chains)
+                                    geom.pc_range, chains, outs=outs)
             ks.append(k)
             vs.append(v)
+        if out is not None:
+            return out
         return (ks[0], vs[0]) if B == 1 else (torch.cat(ks, 0), torch.cat(vs, 0))
 
     def forward(self, lidar_feats, img_feats, img_metas, pts_metas, query=None, warped=None, kv=None, **kwargs):

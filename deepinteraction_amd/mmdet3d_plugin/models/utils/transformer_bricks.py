@@ -173,8 +173,35 @@ class MultiScaleDeformableAttention(nn.Module):
         """The fused fp16 inference form (chain-kernel projections, head-major value map, `ms_deform_attn_hm_kernel`) covers
         what its kernels cover - 128 channels in 8 heads of 16, 4 points on 1 or 2 levels, no padding mask; anything else
         (mmcv's default num_levels=4, other num_points) takes the generic kernel path."""
-        return (self.embed_dims == 128 and self.num_heads == 8 and self.num_points == 4 and self.num_levels in (1, 2)
-                and key_padding_mask is None and fused_tokens_ok(query, self))
+        return self.kernels_cover() and key_padding_mask is None and fused_tokens_ok(query, self)
+
+    def kernels_cover(self):
+        """The deformable-attention kernels (csrc/plusplus.hip, forward and backward) cover the reference configurations: 128
+        channels in 8 heads, 4 points on 1 or 2 levels.  Anything else (mmcv's default num_levels=4, other point counts)
+        runs `_core_torch` - mmcv's own `multi_scale_deformable_attn_pytorch` formulation on torch ops."""
+        return self.embed_dims == 128 and self.num_heads == 8 and self.num_points == 4 and self.num_levels in (1, 2)
+
+    def _core_torch(self, v, offsets, logits, ref, shapes):
+        """mmcv `multi_scale_deformable_attn_pytorch` (mmcv/ops/multi_scale_deform_attn.py): per level F.grid_sample
+        (bilinear, zero padding, align_corners=False) of the head-split value map at reference + offset / (W, H), weighted
+        by the soft-max over levels x points.  v (bs,S,C), offsets (bs,nq,heads*L*P*2), logits (bs,nq,heads*L*P)."""
+        bs, S, C = v.shape
+        nq, Hh, L, P = offsets.shape[1], self.num_heads, self.num_levels, self.num_points
+        d = C // Hh
+        w = logits.float().view(bs, nq, Hh, L * P).softmax(-1).view(bs, nq, Hh, L, P)
+        norm = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float32, device=v.device)
+        refb = ref.float().expand(bs, -1, -1, -1) if ref.shape[0] == 1 else ref.float()
+        loc = refb[:, :, None, :, None, :] + offsets.float().view(bs, nq, Hh, L, P, 2) / norm[None, None, None, :, None, :]
+        grids = 2 * loc - 1
+        vals = v.float().view(bs, S, Hh, d).split([h_ * w_ for h_, w_ in shapes], dim=1)
+        acc = []
+        for l, (h_, w_) in enumerate(shapes):
+            vl = vals[l].flatten(2).transpose(1, 2).reshape(bs * Hh, d, h_, w_)
+            gl = grids[:, :, :, l].transpose(1, 2).flatten(0, 1)                      # (bs*heads, nq, P, 2)
+            acc.append(F.grid_sample(vl, gl, mode='bilinear', padding_mode='zeros', align_corners=False))
+        att = w.transpose(1, 2).reshape(bs * Hh, 1, nq, L * P)
+        out = (torch.stack(acc, dim=-2).flatten(-2) * att).sum(-1).view(bs, Hh * d, nq)
+        return out.transpose(1, 2).contiguous().to(v.dtype)
 
     def can_fuse_norm(self, query, norm):
         """LayerNorm(identity + output_proj(.)) as the epilogue of the output projection (ops.linear_ln)."""
@@ -226,7 +253,9 @@ class MultiScaleDeformableAttention(nn.Module):
                 v = v.masked_fill(key_padding_mask[..., None], 0.0)
             w, b = self.packed()
             proj = F.linear(query, w, b)                                           # (bs, nq, heads*L*P*3)
-            if torch.is_grad_enabled() and (v.requires_grad or proj.requires_grad):
+            if not (self.kernels_cover() and v.is_cuda):
+                out = self._core_torch(v, proj[..., :n_off], proj[..., n_off:], ref, shapes)
+            elif torch.is_grad_enabled() and (v.requires_grad or proj.requires_grad):
                 out = MSDeformAttn.apply(v.contiguous(), proj, ref, shapes, self.num_points)
             else:
                 out = ops.ms_deform_attn(v.contiguous(), proj[..., :n_off], proj[..., n_off:], ref, shapes, self.num_points)

@@ -194,8 +194,8 @@ def similar_forward(x_ori, x_loc, kH, kW):
     x_ori, x_loc = cl(x_ori), cl(x_loc)
     n, C, H, W = x_ori.shape
     out = torch.empty((n, H, W, kH * kW), dtype=torch.float32, device=x_ori.device)
-    _lib.call('di_locatt_similar_fwd', x_ori.data_ptr(), x_loc.data_ptr(), out.data_ptr(), n, H, W, C, kH,
-              kW, _code(x_ori), _stream())
+    _profiled('locatt_similar_fwd', n, lambda: _lib.call('di_locatt_similar_fwd', x_ori.data_ptr(), x_loc.data_ptr(), out.data_ptr(), n, H, W, C, kH,
+              kW, _code(x_ori), _stream()))
     return out
 
 
@@ -204,8 +204,8 @@ def similar_backward(x, grad_out, kH, kW, is_ori):
     x, grad_out = cl(x), _f32(grad_out)
     n, C, H, W = x.shape
     out = empty_cl(n, C, H, W, x)
-    _lib.call('di_locatt_similar_bwd', x.data_ptr(), grad_out.data_ptr(), out.data_ptr(), n, H, W, C, kH,
-              kW, int(bool(is_ori)), _code(x), _stream())
+    _profiled('locatt_similar_bwd', n, lambda: _lib.call('di_locatt_similar_bwd', x.data_ptr(), grad_out.data_ptr(), out.data_ptr(), n, H, W, C, kH,
+              kW, int(bool(is_ori)), _code(x), _stream()))
     return out
 
 
@@ -214,8 +214,8 @@ def weighting_forward(x_ori, x_weight, kH, kW):
     x_ori, x_weight = cl(x_ori), _f32(x_weight)
     n, C, H, W = x_ori.shape
     out = empty_cl(n, C, H, W, x_ori)
-    _lib.call('di_locatt_weighting_fwd', x_ori.data_ptr(), x_weight.data_ptr(), out.data_ptr(), n, H, W, C,
-              kH, kW, _code(x_ori), _stream())
+    _profiled('locatt_weighting_fwd', n, lambda: _lib.call('di_locatt_weighting_fwd', x_ori.data_ptr(), x_weight.data_ptr(), out.data_ptr(), n, H, W, C,
+              kH, kW, _code(x_ori), _stream()))
     return out
 
 
@@ -224,8 +224,8 @@ def weighting_backward_ori(x_weight, grad_out, kH, kW):
     x_weight, grad_out = _f32(x_weight), cl(grad_out)
     n, C, H, W = grad_out.shape
     out = empty_cl(n, C, H, W, grad_out)
-    _lib.call('di_locatt_weighting_bwd_ori', x_weight.data_ptr(), grad_out.data_ptr(), out.data_ptr(), n, H,
-              W, C, kH, kW, _code(grad_out), _stream())
+    _profiled('locatt_weighting_bwd_ori', n, lambda: _lib.call('di_locatt_weighting_bwd_ori', x_weight.data_ptr(), grad_out.data_ptr(), out.data_ptr(), n, H,
+              W, C, kH, kW, _code(grad_out), _stream()))
     return out
 
 
@@ -235,8 +235,8 @@ def weighting_backward_weight(x_ori, grad_out, kH, kW):
     grad_out = cl(grad_out.to(x_ori.dtype))
     n, C, H, W = x_ori.shape
     out = torch.empty((n, H, W, kH * kW), dtype=torch.float32, device=x_ori.device)
-    _lib.call('di_locatt_weighting_bwd_weight', x_ori.data_ptr(), grad_out.data_ptr(), out.data_ptr(), n, H,
-              W, C, kH, kW, _code(x_ori), _stream())
+    _profiled('locatt_weighting_bwd_weight', n, lambda: _lib.call('di_locatt_weighting_bwd_weight', x_ori.data_ptr(), grad_out.data_ptr(), out.data_ptr(), n, H,
+              W, C, kH, kW, _code(x_ori), _stream()))
     return out
 
 
@@ -390,22 +390,31 @@ def token_linear_multi(x, images):
     return ys
 
 
-def pointwise_multi(x, chains):
+def _check_outs(outs, nc, n, H, W, like):
+    assert len(outs) == nc
+    for y in outs:
+        assert y.shape == (n, 128, H, W) and y.dtype == like.dtype and y.device == like.device and _is_cl(y), \
+            'caller-provided outputs must be channels-last maps of the result shape'
+    return list(outs)
+
+
+def pointwise_multi(x, chains, outs=None):
     """Several chains over one fp16 channels-last map (C = 128) in ONE launch, x read once.  chains: list of
-    (image, relu1, relu2, two_links) with image = chain_image(...).  Returns one map per chain."""
+    (image, relu1, relu2, two_links) with image = chain_image(...).  Returns one map per chain.  outs: write into these
+    (e.g. halves of a pair buffer that ONE window-attention launch then reads) instead of allocating."""
     _dev(x)
     x = cl(x)
     n, C, H, W = x.shape
     assert C == 128 and x.dtype == torch.float16 and 1 <= len(chains) <= 4
     nc = len(chains)
-    ys = [empty_cl(n, 128, H, W, x) for _ in chains]
+    ys = [empty_cl(n, 128, H, W, x) for _ in chains] if outs is None else _check_outs(outs, nc, n, H, W, x)
     P, I = ctypes.c_void_p * nc, ctypes.c_int * nc
     for (im, r1, r2, two) in chains:
         assert im.dtype == torch.uint8 and im.numel() == 2 * 128 * 128 * 2 + 1024 and im.is_cuda
     a_im, a_y = P(*[c[0].data_ptr() for c in chains]), P(*[y.data_ptr() for y in ys])
     a_r1, a_r2 = I(*[int(bool(c[1])) for c in chains]), I(*[int(bool(c[2])) for c in chains])
     a_two = I(*[int(bool(c[3])) for c in chains])
-    _profiled('pointwise_multi', n, lambda: _lib.call(
+    _profiled('pointwise_multi', (n, nc), lambda: _lib.call(
         'di_pointwise_multi_fwd', x.data_ptr(), nc, ctypes.addressof(a_im), ctypes.addressof(a_y), ctypes.addressof(a_r1),
         ctypes.addressof(a_r2), ctypes.addressof(a_two), n * H * W, _stream()))
     return ys
@@ -653,7 +662,7 @@ def bevwarp_gather(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range):
     return out
 
 
-def warp_project(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range, chains, head_major=False):
+def warp_project(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range, chains, head_major=False, outs=None):
     """`pointwise_multi(bevwarp_gather(bev, depth, ...), chains)` in one launch: the warped map is gathered into the
     projection kernel's registers and never written (bit-identical outputs).  At most two chains (the P2I block's key / value
     projections): both weight images stay resident in LDS.  bev (1,128,Hb,Wb) fp16 channels-last.
@@ -676,7 +685,7 @@ def warp_project(bev, depth, img2lidar, aug_fwd, xs, ys, pc_range, chains, head_
                   ctypes.addressof(a_y), ctypes.addressof(a_r1), ctypes.addressof(zero), ctypes.addressof(zero),
                   ctypes.addressof(a_hm), _stream())
         return ys_
-    ys_ = [empty_cl(V, 128, Hi, Wi, bev) for _ in chains]
+    ys_ = [empty_cl(V, 128, Hi, Wi, bev) for _ in chains] if outs is None else _check_outs(outs, nc, V, Hi, Wi, bev)
     P, I = ctypes.c_void_p * nc, ctypes.c_int * nc
     for (im, r1, r2, two) in chains:
         assert im.dtype == torch.uint8 and im.numel() == 2 * 128 * 128 * 2 + 1024 and im.is_cuda

@@ -35,6 +35,29 @@ def init(backend, device=None):
     return True
 
 
+def bind_rank_threads(local_rank, ranks_on_node):
+    """One node, N ranks: give every rank its own contiguous slice of the host cores this process may run on
+    (`sched_setaffinity`) and size torch's intra-op pool to it.  A rank of the forward bench runs up to five host threads
+    that matter (four lane launchers + the main thread) and the training step a scipy Hungarian assignment per sample: with
+    8 ranks sharing one socket unpinned, the launchers of one rank migrate onto cores another rank's assignment is using.
+    Returns a description for the bench line (`config.cpu_binding`); a no-op description when the platform has no affinity
+    call or a rank's slice would be empty."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return dict(bound=False, reason='no sched_getaffinity on this platform')
+    n = max(1, int(ranks_on_node))
+    per = len(cores) // n
+    if n == 1 or per < 1:
+        return dict(bound=False, cores_visible=len(cores), ranks_on_node=n,
+                    reason='single rank' if n == 1 else 'fewer cores than ranks')
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(per, 16)))
+    return dict(bound=True, cores_visible=len(cores), ranks_on_node=n, cores_per_rank=per, first_core=mine[0], last_core=mine[-1],
+                torch_threads=torch.get_num_threads())
+
+
 def sample_ids(step, batch_per_rank, rank, world):
     """Global sample indices rank `rank` owns at `step` (weak scaling: the global batch is
     world * batch_per_rank consecutive samples, dealt to ranks in contiguous blocks)."""

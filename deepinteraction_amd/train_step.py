@@ -78,16 +78,44 @@ class LossScaler:
                                  self.growth_interval)
 
 
+def trainable_parameters(enc, dec):
+    """The parameter list the step optimises and the gradient reducer buckets: every parameter of neck and head, in
+    registration order (the reducer buckets them in reverse: the order backward produces their gradients)."""
+    return [p for m in (enc, dec) for p in m.parameters()]
+
+
+def synthetic_backward(named_params, rank, step, unused=()):
+    """Host-only stand-in for a backward pass (bench.py --dry-run --mode train, tests/test_parallel.py): every parameter
+    whose name does not start with a prefix in `unused` receives the gradient w * ones through autograd - so the reducer's
+    post-accumulate hooks fire as in a real step - with w = a number that depends on (rank, step, parameter index).
+    Returns {name: w} of the parameters this rank touched."""
+    loss, ws = 0.0, {}
+    for i, (n, p) in enumerate(named_params):
+        if not p.requires_grad or any(n.startswith(u) for u in unused):
+            continue
+        w = float((rank + 1) * 0.5 + (step + 1) * 0.125 + (i % 7) * 0.03125)      # exact in float32
+        ws[n] = w
+        loss = loss + (p * w).sum()
+    loss.backward()
+    return ws
+
+
 class Trainer:
-    def __init__(self, shape, num_proposals, device, world, batch=1, pool=2, rank=0, seed=0, amp=None):
+    def __init__(self, shape, num_proposals, device, world, batch=1, pool=2, rank=0, seed=0, amp=None, model='v1'):
+        """model: 'v1' = Fusion_0075_refactor (BASELINE configs[2] / [3]); 'pp' = DeepInteraction++ (configs[4]:
+        FusionTransformerv4 neck + DeepInteractionPlusPlusDecoder, `shape` a SHAPE_PP dict) - the same step, eager launches."""
         import os
+        self.model = model
         # mixed precision (opt-in; the reference trains this configuration in float32): the hot path under torch.autocast(fp16)
         self.amp = os.environ.get('DI_TRAIN_AMP', '0') == '1' if amp is None else bool(amp)
         bev = shape['bev_hw'][0]
         tc = dict(TRAIN_CFG, grid_size=[bev * 8, bev * 8, 40], voxel_size=[108.0 / (bev * 8)] * 2 + [0.2])
-        self.enc, self.dec = harness.build_models(shape, num_proposals, torch.float32, device, seed=seed, train_cfg=tc)
+        if model == 'pp':
+            self.enc, self.dec = harness.build_models_pp(shape, num_proposals, torch.float32, device, seed=seed, train_cfg=tc)
+        else:
+            self.enc, self.dec = harness.build_models(shape, num_proposals, torch.float32, device, seed=seed, train_cfg=tc)
         self.enc.train(), self.dec.train()                            # identical initial weights on every rank
-        self.params = [p for m in (self.enc, self.dec) for p in m.parameters()]
+        self.params = trainable_parameters(self.enc, self.dec)
         # Mixed precision keeps the convolution / linear / attention-projection parameters of the MODEL in fp16 and their
         # float32 MASTER copies in the optimizer (the values autocast would produce by casting the float32 weight in every
         # step - 216 cast launches forward and as many backward, 2 ms of a captured step - are the fp16 rounding of the
@@ -111,8 +139,10 @@ class Trainer:
         self.pool = []
         for i in range(pool):
             ids = parallel.sample_ids(i, batch, rank, world)
-            inp = synth.make_inputs(batch, shape, seed=parallel.sample_seed(ids[0]))
-            d = harness.to_device(inp, device, torch.float32)
+            if model == 'pp':
+                d = harness.to_device_pp(synth.make_inputs_pp(batch, shape, seed=parallel.sample_seed(ids[0])), device, torch.float32)
+            else:
+                d = harness.to_device(synth.make_inputs(batch, shape, seed=parallel.sample_seed(ids[0])), device, torch.float32)
             self.pool.append((d, [synth_gt(parallel.sample_seed(s)) for s in ids]))
         self.i = 0
 
@@ -293,18 +323,20 @@ class GraphedTrainer(Trainer):
 
 def bench(args, rank, world, device):
     """`bench.py --mode train`: returns rank 0's JSON line (a dict)."""
-    shape = harness.SHAPES[args.shape]
+    pp = getattr(args, 'model', 'v1') == 'pp'
+    shape = (harness.SHAPES_PP if pp else harness.SHAPES)[args.shape]
     import os
     # --amp / --train-eager of bench.py; the environment switches of round 4's first measurements still work
     amp = bool(getattr(args, 'amp', False)) or os.environ.get('DI_TRAIN_AMP', '0') == '1'
-    eager = bool(getattr(args, 'train_eager', False)) or os.environ.get('DI_TRAIN_GRAPH', '1') == '0'
+    eager = bool(getattr(args, 'train_eager', False)) or os.environ.get('DI_TRAIN_GRAPH', '1') == '0' or pp
     cls = Trainer if eager else GraphedTrainer
+    extra = dict(model='pp') if pp else {}
     if rank == 0:
         import sys
         print(f'[train] {cls.__name__}, {args.batch} sample(s) per rank'
               f'{" (the reference configuration: samples_per_gpu=2)" if args.batch == 2 else ""}, '
               f'{"mixed precision" if amp else "float32"}', file=sys.stderr)
-    tr = cls(shape, args.proposals, device, world, batch=args.batch, pool=max(2, min(args.pool, 2)), rank=rank, amp=amp)
+    tr = cls(shape, args.proposals, device, world, batch=args.batch, pool=max(2, min(args.pool, 2)), rank=rank, amp=amp, **extra)
     losses = []
     calibration = 0
     if tr.scaler is not None:
@@ -320,11 +352,14 @@ def bench(args, rank, world, device):
         tr.step()
     elapsed = parallel.timed_region(lambda: losses.append(tr.step()), args.steps, device)
     losses = [float(l) for l in losses]
-    return dict(metric='samples/sec training step (forward + loss + backward + gradient all-reduce + AdamW)',
+    roofline = None
+    if rank == 0 and args.gpus == 1 and getattr(args, 'roofline_steps', 0) > 0:
+        roofline = train_roofline(tr if eager else None, shape, args, device, world, amp, pp)
+    out = dict(metric='samples/sec training step (forward + loss + backward + gradient all-reduce + AdamW)',
                 value=round(parallel.throughput(args.batch, args.steps, elapsed, world), 3), unit='samples/s',
                 n_gpus=args.gpus, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 2),
                 higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f16' if amp else 'f32', data='synthetic',
-                config=dict(workload=f'Fusion_0075_refactor training step (shape {args.shape}): MMRI encoder + MMPI '
+                config=dict(workload=f'{"Fusion_0075_plusplus (DeepInteraction++)" if pp else "Fusion_0075_refactor"} training step (shape {args.shape}): {"FusionTransformerv4 neck + ++" if pp else "MMRI encoder + MMPI"} '
                                      'decoder forward, head loss (Hungarian assignment on the host), backward, '
                                      'bucketed gradient all-reduce launched from backward hooks, AdamW + grad clip',
                             batch_per_gpu=args.batch, global_batch=args.batch * args.gpus, trainer=cls.__name__,
@@ -339,3 +374,68 @@ def bench(args, rank, world, device):
                 first_loss=round(losses[0], 4), last_loss=round(losses[-1], 4),
                 **({} if tr.scaler is None else {'loss_scale': float(tr.scaler.scale), 'skipped_steps': int(tr.scaler.skipped),
                                                   'loss_scale_calibration_steps': calibration}))
+    if roofline is not None:
+        out['roofline'] = roofline
+    return out
+
+
+# (kernel name of ops.PROFILE, maps of n*C*H*W elements read + written per call, what it is)
+_TRAIN_KERNELS = {
+    'local_attn_train_bwd': (19, 'fused window-attention backward (csrc/local_attn_train.hip: row-dot + BWD_Q | BWD_V | BWD_K programs)'),
+    'local_attn_train_fwd': (4, 'fused window-attention forward with the saved log-sum-exp'),
+    'locatt_similar_fwd': (2, 'locatt_ops similar forward (float32, unfused: + the (n,H,W,81) weight tensor)'),
+    'locatt_similar_bwd': (2, 'locatt_ops similar backward'),
+    'locatt_weighting_fwd': (2, 'locatt_ops weighting forward'),
+    'locatt_weighting_bwd_ori': (2, 'locatt_ops weighting backward w.r.t. the values'),
+    'locatt_weighting_bwd_weight': (2, 'locatt_ops weighting backward w.r.t. the weights'),
+    'ms_deform_attn_bwd': (None, 'multi-scale deformable attention backward (DeepInteraction++)'),
+}
+
+
+def train_roofline(eager_trainer, shape, args, device, world, amp, pp):
+    """The training line's `roofline`: the window-attention kernels of the step (its largest own kernels by bytes), timed
+    live with HIP events in EAGER steps of the same model and data after the timed region (events cannot bracket a kernel
+    inside a graph replay): every profiled launch of the image-side maps, the dominant one (largest total time) on top."""
+    from . import measure, ops
+    tr = eager_trainer
+    if tr is None:
+        tr = Trainer(shape, args.proposals, device, world, batch=args.batch, pool=2, rank=0, amp=amp, **(dict(model='pp') if pp else {}))
+    tr.step()
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    for _ in range(max(1, min(args.roofline_steps, 2))):
+        tr.step()
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    Hi, Wi = shape['img_hw']
+    n_img = 6 * args.batch
+    rows = []
+    steps_p = max(1, min(args.roofline_steps, 2))
+    if pp:      # the ++ neck has no window attention: its byte-bound kernel is the deformable attention (forward launches, 2 levels)
+        es = 2 if amp else 4
+        nq = n_img * Hi * Wi
+        S = n_img * (Hi * Wi + (Hi // 2) * (Wi // 2))
+        alg = (S * 128 + nq * (8 * 2 * 4 * 3 + 128)) * es
+        ev = [(n, s_, e) for (nm, n, s_, e) in prof if nm == 'ms_deform_attn_fwd' and n == nq]
+        if ev:
+            r = measure.kernel_row('ms_deform_attn_fwd', 'multi-scale deformable attention forward of the image tokens (csrc/plusplus.hip), '
+                                   'self attention (2 levels) and P2I (1 level) launches together', prof, 'ms_deform_attn_fwd', nq, alg)
+            r['total_us_per_step'] = round(sum(s_.stream_ms(e) for _, s_, e in ev) * 1e3 / steps_p, 1)
+            rows.append(r)
+    for name, (maps, what) in _TRAIN_KERNELS.items():
+        ev = [(n, s, e) for (nm, n, s, e) in prof if nm == name and n == n_img]
+        if not ev or maps is None:
+            continue
+        es = 2 if name.startswith('local_attn_train') else 4
+        alg = maps * n_img * 128 * Hi * Wi * es + (n_img * Hi * Wi * 81 * 4 if name.startswith('locatt') else 0)
+        r = measure.kernel_row(name, what, prof, name, n_img, alg)
+        r['total_us_per_step'] = round(sum(s.stream_ms(e) for _, s, e in ev) * 1e3 / steps_p, 1)
+        rows.append(r)
+    if not rows:
+        return None
+    rows.sort(key=lambda r: -r['total_us_per_step'])
+    top = dict(rows[0])
+    top.update(bound='hbm', traffic=None, kernels=rows,
+               timed_in='eager training steps right after the timed region, HIP events on the launch stream around each call '
+                        '(a call of the fused backward is four launches); image-side maps only')
+    return top

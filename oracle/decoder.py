@@ -363,6 +363,10 @@ class DeepInteractionDecoder(nn.Module):
         ones = {'nuScenes': (8, 9), 'Waymo': (1, 2)}[self.test_cfg['dataset']]
         for c in ones:                                                                        # :232-237
             local_max[:, c] = heat[:, c]
+        # (test infrastructure: how far every cell is from being the maximum of its 3x3 neighbourhood - 0 for the survivors of
+        #  the NMS; the tie-aware comparison of `query_heatmap_score` reads it, oracle/parity.py::heatmap_score_ties)
+        self.nms_margin = (local_max - heat).view(B, heat.shape[1], -1)
+        self.nms_heat = heat.view(B, heat.shape[1], -1).clone()
         heat = heat * (heat == local_max)
         heat = heat.view(B, heat.shape[1], -1)
         top = heat.view(B, -1).argsort(dim=-1, descending=True)[..., :self.num_proposals]     # :242

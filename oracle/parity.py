@@ -96,7 +96,32 @@ def oracle_decoder(D, enc, img_metas, top_override=None):
     with torch.no_grad():
         out = D([enc['pts_conv'], enc['pts']], enc['img'], img_metas, top_override=top_override)[0][0]
     return dict(out=out, labels=D.query_labels.clone(), masks=[m.clone() for m in D.on_the_image_mask],
-                top=D.top_proposals.clone(), seconds=time.time() - t0)
+                top=D.top_proposals.clone(), seconds=time.time() - t0,
+                nms_margin=D.nms_margin.clone(), nms_heat=D.nms_heat.clone())
+
+
+def heatmap_score_ties(prod_score, ref, tol=2e-3):
+    """TIE-AWARE comparison of `query_heatmap_score` (B, classes, Q) against an oracle run `ref` on the SAME proposals
+    (reference deepinteraction_decoder.py:225-253: an entry is the heat value of (class, cell) when that cell is the maximum of
+    its 3x3 neighbourhood - `heat * (heat == local_max)` - and 0 otherwise).  Two fp16 heat-map heads may decide a near-tie the
+    other way: the entry then differs by its WHOLE value (0 <-> heat).  Every entry must either agree within `tol`, or be such a
+    flip - one side 0, the other the cell's heat value within `tol` - of a cell whose heat value is within `tol` of its 3x3
+    maximum in the oracle.  Returns (entries, flips, worst error of the agreeing entries, worst margin of a flip)."""
+    got, want = prod_score.detach().float().cpu(), ref['out']['query_heatmap_score'].float()
+    B, C, Q = want.shape
+    cell = (ref['top'] % ref['nms_margin'].shape[-1])[:, None, :].expand(-1, C, -1)
+    margin = ref['nms_margin'].gather(-1, cell)              # 0 where the oracle's cell survives the NMS
+    heat = ref['nms_heat'].gather(-1, cell)
+    err = (got - want).abs()
+    agree = err <= tol
+    flip = ~agree & (((got == 0) & ((want - heat).abs() <= tol)) | ((want == 0) & ((got - heat).abs() <= tol)))
+    bad = ~agree & ~flip
+    assert not bool(bad.any()), ('query_heatmap_score differs without being an NMS flip', int(bad.sum()),
+                                 float(err[bad].max()))
+    worst_margin = float(margin[flip].max()) if bool(flip.any()) else 0.0
+    assert worst_margin <= tol, ('an NMS flip of a cell that is NOT a near-tie', worst_margin)
+    return dict(entries=int(want.numel()), flips=int(flip.sum()), max_err_agreeing=float(err[agree].max()),
+                worst_flip_margin=worst_margin)
 
 
 def rel_stats(got, ref):

@@ -159,3 +159,27 @@ def test_lane_launchers_run_one_callable_per_lane_thread_and_hand_exceptions_ove
     pool.close()
     with pytest.raises(AssertionError):
         pool.run([job(0)])
+
+
+def test_msda_torch_formulation_matches_mmcv_core():
+    """`MultiScaleDeformableAttention._core_torch` (the path of configurations the kernels do not cover: mmcv's default
+    num_levels=4, other point counts) against the oracle's restatement of mmcv's `multi_scale_deformable_attn_pytorch`."""
+    import torch
+    from deepinteraction_amd.mmdet3d_plugin.models.utils.transformer_bricks import MultiScaleDeformableAttention
+    from oracle import thirdparty as tp
+    torch.manual_seed(0)
+    for L, P in ((4, 4), (2, 8), (1, 2)):
+        m = MultiScaleDeformableAttention(128, num_heads=8, num_levels=L, num_points=P, batch_first=True).eval()
+        assert not m.kernels_cover()
+        shapes = [(12, 20), (6, 10), (3, 5), (2, 3)][:L]
+        S = sum(h * w for h, w in shapes)
+        bs, nq = 2, 50
+        v, off, lg = torch.randn(bs, S, 128), torch.randn(bs, nq, 8 * L * P * 2) * 2, torch.randn(bs, nq, 8 * L * P)
+        ref = torch.rand(bs, nq, L, 2)
+        got = m._core_torch(v, off, lg, ref, shapes)
+        w = lg.view(bs, nq, 8, L * P).softmax(-1).view(bs, nq, 8, L, P)
+        norm = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float32)
+        loc = ref[:, :, None, :, None, :] + off.view(bs, nq, 8, L, P, 2) / norm[None, None, None, :, None, :]
+        want = tp.ms_deform_attn_core(v.view(bs, S, 8, 16), shapes, loc, w)
+        assert (got - want).abs().max().item() <= 1e-5
+    assert MultiScaleDeformableAttention(128, num_heads=8, num_levels=2, num_points=4).kernels_cover()

@@ -190,3 +190,23 @@ def test_bench_self_launches_n_ranks():
     assert rec['n_gpus'] == 2 and rec['config']['ranks_seen'] == 2 and rec['steps'] == 4
     # the slowest rank (rank 1 sleeps 4 ms per step) sets the time
     assert rec['ms_per_step'] >= 3.9
+
+
+def test_bench_dry_run_train_wires_the_reducer_on_the_real_parameter_list():
+    """`bench.py --gpus 2 --mode train --dry-run`: two gloo ranks, the two hot-path modules built on
+    the CPU, the gradient reducer bucketed over their REAL parameter list (414 tensors, 91.6 MB: two 64-MB buckets), hooks
+    fired by a synthetic backward of the real shapes; the image RoI blocks are unused on rank 1 (a sample whose views hold
+    <= 1 query each: reference decoder_utils.py:726 under find_unused_parameters=True, Fusion_0075_refactor.py:277), the
+    detached heat-map head on every rank.  The ranks agree exactly; every rank is pinned to its own slice of the cores."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--mode', 'train', '--dry-run', '--steps', '2'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    cfg = rec['config']
+    assert cfg['ranks_seen'] == 2 and cfg['parameters'] > 400 and cfg['gradient_bytes'] > 80e6 and cfg['buckets'] >= 2
+    assert cfg['max_abs_error'] < 1e-5
+    b = cfg['cpu_binding']
+    assert b['ranks_on_node'] == 2 and (not b['bound'] or b['cores_per_rank'] * 2 <= b['cores_visible'])

@@ -348,3 +348,32 @@ def test_fused_linear_layernorm():
                                          lb.double(), 1e-5)
     err = (got - ref).abs().max().item()
     assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize('num_levels,num_points', [(4, 4), (2, 8), (1, 2)])
+def test_msda_module_outside_the_fused_form_takes_the_generic_kernels(num_levels, num_points):
+    """the deformable-attention kernels - fused fp16 form AND the generic one, as this test found -
+    cover 4 points on 1 or 2 levels (`kernels_cover` / `can_fuse_tokens`); mmcv's default num_levels=4, or other point
+    counts, must not raise: they run mmcv's grid_sample formulation on torch ops (`_core_torch`, checked on the CPU against
+    the oracle's restatement of mmcv's core), fp16 inference agreeing with the float32 run of the same module."""
+    from deepinteraction_amd.mmdet3d_plugin.models.utils.transformer_bricks import MultiScaleDeformableAttention
+    torch.manual_seed(3)
+    m = MultiScaleDeformableAttention(128, num_heads=8, num_levels=num_levels, num_points=num_points, batch_first=True).to(DEV).eval()
+    with torch.no_grad():
+        m.sampling_offsets.weight.add_(torch.randn_like(m.sampling_offsets.weight) * 0.05)
+        m.attention_weights.weight.add_(torch.randn_like(m.attention_weights.weight) * 0.05)
+    shapes = [(12, 20), (6, 10), (3, 5), (2, 3)][:num_levels]
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(2, 240, 128, generator=g).to(DEV)
+    v = torch.randn(2, S, 128, generator=g).to(DEV)
+    ref = torch.rand(2, 240, num_levels, 2, generator=g).to(DEV)
+    with torch.no_grad():
+        want = m(q, value=v, reference_points=ref, spatial_shapes=shapes)
+        mh = MultiScaleDeformableAttention(128, num_heads=8, num_levels=num_levels, num_points=num_points, batch_first=True)
+        mh.load_state_dict(m.state_dict())
+        mh = mh.to(DEV).half().eval()
+        assert not mh.can_fuse_tokens(q.half()) and not mh.kernels_cover()
+        got = mh(q.half(), value=v.half(), reference_points=ref, spatial_shapes=shapes)
+    assert got.dtype == torch.float16
+    assert (got.float() - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())

@@ -128,7 +128,11 @@ def test_fp16_eager(ctx):
     own = dict(img=nchw(got_enc[0]), pts_conv=nchw(got_enc[1][0]), pts=nchw(got_enc[1][1]))
     forced_own = parity.oracle_decoder(ctx['D'], own, ctx['inp']['img_metas'], top_override=top.cpu())
     hs = parity.compare_decoder(out, labels, masks, top, forced_own, forced_own)
-    _report('fp16_eager_B1_Q200', dict(encoder=es, decoder=ds, head_on_product_maps=hs))
+    # query_heatmap_score entry by entry, tie-aware (no exemption by name): against the oracle head on the product's OWN maps -
+    # the heat-map heads' arithmetic alone decides which cell of a near-tie survives the NMS
+    ties = parity.heatmap_score_ties(out['query_heatmap_score'], forced_own, tol=3e-3)
+    assert ties['flips'] <= 0.01 * ties['entries'], ties
+    _report('fp16_eager_B1_Q200', dict(encoder=es, decoder=ds, head_on_product_maps=hs, heatmap_score_ties=ties))
     _check_fp16('fp16', es, ds)
     for k, s in hs['keys'].items():              # the mixed-mode head itself is float32-accurate
         if k != 'query_heatmap_score':
@@ -146,7 +150,9 @@ def test_fp16_identical_parameters(ctx):
     free = parity.oracle_decoder(D, ref, ctx['inp']['img_metas'])
     forced = parity.oracle_decoder(D, ref, ctx['inp']['img_metas'], top_override=top.cpu())
     ds = parity.compare_decoder(out, labels, masks, top, free, forced)
-    _report('fp16_identical_parameters_B1_Q200', dict(encoder=es, decoder=ds))
+    ties = parity.heatmap_score_ties(out['query_heatmap_score'], forced, tol=3e-3)
+    assert ties['flips'] <= 0.01 * ties['entries'], ties
+    _report('fp16_identical_parameters_B1_Q200', dict(encoder=es, decoder=ds, heatmap_score_ties=ties))
     _check_fp16('fp16_same_params', es, ds)
 
 

@@ -7,7 +7,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 top = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 40
 ring = [int(r['Calls']) for r in rows if 'local_attn_ring' in r['Name']]
 msda = [int(r['Calls']) for r in rows if 'ms_deform_attn' in r['Name'] and 'bwd' not in r['Name']]
-n_fwd = ring[0] / 4 if ring else (sum(msda) / 6 if msda else 1)
+conv = [int(r['Calls']) for r in rows if 'conv3x3_pc_kernel<20' in r['Name']]      # once per v1 forward (the image conv)
+n_fwd = conv[0] if conv else (ring[0] / 4 if ring else (sum(msda) / 6 if msda else 1))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print(f'forwards {n_fwd:.1f}   kernel us / forward {tot / n_fwd / 1e3:.1f}   launches / forward {sum(int(r["Calls"]) for r in rows) / n_fwd:.1f}')
 for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs']))[:top]:

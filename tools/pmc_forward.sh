@@ -7,7 +7,7 @@ ARGS="--eager --steps 6 --warmup 2 --inflight 1 --no-cpu-baseline --roofline-ste
 [ -n "$MODEL" ] && ARGS="$ARGS --model $MODEL"
 cd /tmp
 i=0
-for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"; do
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU"; do
   i=$((i+1))
   DI_OVERLAP=0 timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/p$i.log 2>&1
   f=$(find $OUT/p$i -name '*counter_collection.csv' | head -1)

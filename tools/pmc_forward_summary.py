@@ -39,6 +39,8 @@ def merge(path, tag):
                 e['mfma_busy'] = d['SQ_VALU_MFMA_BUSY_CYCLES']['mean'] / (4 * b)
             if 'SQ_LDS_IDX_ACTIVE' in d:
                 e['lds_busy'] = d['SQ_LDS_IDX_ACTIVE']['mean'] / b
+            if 'SQ_ACTIVE_INST_VALU' in d:          # as DESIGN section 3 quotes it since round 2: VALU-active cycles / busy CU cycles
+                e['valu_busy'] = d['SQ_ACTIVE_INST_VALU']['mean'] / b
         out[k] = e
     print(json.dumps(dict(source=tag, formula='(2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch, eager forward, one stream', kernels=out), indent=1))
 
