@@ -406,7 +406,7 @@ int di_local_attn_fwd_ex(const void *q, const void *k, const void *v, void *out,
     }
     return di::launch_local_attn_mfma2(q, k, v, out, n, H, W, scale, variant - DI_LA_MFMA, (hipStream_t)stream);
   }
-  if (variant >= DI_LA_RING && variant < DI_LA_RING + 9) {
+  if (variant >= DI_LA_RING && variant < DI_LA_RING + 12) {
     if (!mfma_ok) {
       di::set_error("MFMA local attention needs fp16, C=128, 9x9, < 2^23 pixels (got dtype=%d C=%d %dx%d)", dtype, C, kH, kW);
       return DI_ERR_ARG;

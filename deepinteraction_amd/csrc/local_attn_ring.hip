@@ -273,6 +273,7 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
         const int B = it * G::BPT + b;
         // the buffer of block B held block B - 3: free once every consumer is past it
         int spins = 0;
+        if (B - G::NBLK >= min_done) {                        // (scalar: the buffer is usually free - skip the wait AND its give-up test)
         while (B - G::NBLK >= min_done) {
           if (published < B) {                                // meanwhile: announce the oldest block of mine that is in flight
             wait_for(published, B - published - 1);
@@ -292,7 +293,10 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
         // a producer that gave up issues nothing more: it never writes into a block a consumer may still be reading.
         // ((dbg & 32): fault injection - the consumers' waits then give up and count)
         if constexpr (G::PDEAD)
-          if (__builtin_amdgcn_readfirstlane((int)(spins > spin_limit)) != 0 || ((dbg & 32) && it >= 1)) goto drain;
+          if (__builtin_amdgcn_readfirstlane((int)(spins > spin_limit)) != 0) goto drain;
+        }
+        if constexpr (G::PDEAD)
+          if ((dbg & 32) && it >= 1) goto drain;             // fault injection (tests)
         stamp(1);                                             // buffer free
         const unsigned dst = lds0 + (B % G::NBLK) * G::BLKB;
         {
@@ -366,6 +370,9 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
   auto wait_landed = [&](int B) {
     int spins = 0;
     stamp(4);                                                 // starts waiting for a block
+    // (round 6: the whole wait - and its give-up bookkeeping - behind ONE scalar test: with the flags read ahead the block has
+    //  usually landed, and the three scalar selects of the fault model ran 20 times per 5 tiles for nothing: 37.0 -> us)
+    if (seen <= B) {
     while (seen <= B) {
       unsigned m;
       if constexpr (G::NPW == 2) {
@@ -391,6 +398,7 @@ __global__ __launch_bounds__(G::NT, 1) void local_attn_ring_kernel(
       const bool gave_up = __builtin_amdgcn_readfirstlane((int)(spins > spin_limit)) != 0;
       poison = gave_up ? 0x7FFF7FFFu : poison;
       seen = gave_up ? 0x3FFFFFFF : seen;
+    }
     }
     stamp(5);                                                 // has it
   };
@@ -647,6 +655,10 @@ int launch_local_attn_ring(const void *q, const void *k, const void *v, void *ou
     case 6: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 3, 1>>(q, k, v, out, n, H, W, scale, stream);   // cfg 0 with the ragged round cut into sub-tiles of one wave-row (A/B: slower)
     case 7: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 3, 2>>(q, k, v, out, n, H, W, scale, stream);   // ... and as sub-tiles of two wave-rows
     case 8: return ring::launch<ring::Cfg<1, 8, 2, 2, 2, 3, 1>>(q, k, v, out, n, H, W, scale, stream);   // cfg 1 with one-wave-row sub-tiles
+    // round 6 (36.1 us in r04zl, 37.9-38.0 us in r05 - the fault model?): cfg 0 without it, piece by piece
+    case 9: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 0>>(q, k, v, out, n, H, W, scale, stream);    // no poisoning, producers keep issuing (round 4's behaviour)
+    case 10: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 1>>(q, k, v, out, n, H, W, scale, stream);   // consumers poison, producers keep issuing
+    case 11: return ring::launch<ring::Cfg<2, 4, 2, 2, 2, 2>>(q, k, v, out, n, H, W, scale, stream);   // producers stop, consumers do not poison
   }
   set_error("unknown local_attn_ring configuration %d", cfg);
   return DI_ERR_ARG;

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepinteraction_amd import ops
 
 variants = [int(a) for a in sys.argv[1:]] or [5, 3, 4, 6]
-n, C, H, W = (6, 128, 112, 200) if os.environ.get('LA_SHAPE', 'img') == 'img' else (1, 128, 180, 180)
+n, C, H, W = (int(os.environ.get('LA_N', '6')), 128, 112, 200) if os.environ.get('LA_SHAPE', 'img') == 'img' else (1, 128, 180, 180)
 g = torch.Generator(device='cuda').manual_seed(0)
 mk = lambda: torch.randn(n, C, H, W, device='cuda', generator=g).relu().half().contiguous(memory_format=torch.channels_last)
 sets = [(mk(), mk(), mk()) for _ in range(3)]          # rotate inputs: 3 x 138 MB > the 256 MB Infinity Cache
