@@ -557,6 +557,8 @@ __global__ __launch_bounds__(NTH) void program_kernel(Program prog, Heads heads,
   __shared__ Program lp;
   __shared__ Heads lh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (round 6, measured and not kept: role r on XCD r % 8, so that a role's 13 token groups share one L2 for its <= 128 KB of
+  //  weights - HBM traffic per launch 6.62 -> 6.56 MB, time unchanged: the weights are not what this kernel fetches from HBM)
   const int b = blockIdx.y, q0 = blockIdx.x * TM;
   const int rows = min(TM, Q - q0);
   const long long m0 = (long long)b * Q + q0;
@@ -822,9 +824,17 @@ __global__ __launch_bounds__(256) void splitk_kernel(const __half *__restrict__ 
                                                      float *__restrict__ part, int M, int nks, int ks_per_slice) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * 16;
+  // XCD-aware (round 6): consecutive block ids go round-robin over the 8 XCDs, each with its own L2.  With a (row block,
+  // slice) grid the 13 row blocks of ONE slice landed on all 8 XCDs and every XCD fetched that slice's weights for itself:
+  // 32 MB of HBM traffic per launch for 8.4 MB of operands (profiles/r06_pmc_forward.json).  Now slice s belongs to XCD s % 8:
+  // its row blocks share one L2, the weights cross the fabric once.
+  const int nrb = (M + 15) >> 4, nsl = (nks + ks_per_slice - 1) / ks_per_slice;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int slice = xcd + 8 * (j / nrb), rb = j % nrb;
+  if (slice >= nsl) return;
+  const int m0 = rb * 16;
   const int mr = min(m0 + i, M - 1);
-  const int kb = blockIdx.y * ks_per_slice, ke = min(kb + ks_per_slice, nks);
+  const int kb = slice * ks_per_slice, ke = min(kb + ks_per_slice, nks);
   f4 ah[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}}, al[2] = {f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
   const __half *w0 = wp + (size_t)(2 * wave) * nks * 1024 + lane * 8, *w1 = w0 + (size_t)nks * 1024;
   for (int k0 = kb; k0 < ke; k0 += 7) {                    // 7 k-steps in flight (42 x 16 B per lane)
@@ -849,7 +859,7 @@ __global__ __launch_bounds__(256) void splitk_kernel(const __half *__restrict__ 
       }
   }
   if (m0 + i < M) {
-    float *dst = part + ((size_t)blockIdx.y * M + m0 + i) * 128 + wave * 32 + 4 * g;
+    float *dst = part + ((size_t)slice * M + m0 + i) * 128 + wave * 32 + 4 * g;
     *reinterpret_cast<f4 *>(dst) = ah[0] + al[0] * kLoInv;
     *reinterpret_cast<f4 *>(dst + 16) = ah[1] + al[1] * kLoInv;
   }
@@ -1042,7 +1052,7 @@ int di_token_splitk(const void *f2p, const void *w_packed, float *workspace, int
   DI_REQUIRE(f2p && w_packed && workspace && M > 0 && K >= 32 && K % 32 == 0,
              "bad split-K shape M=%d K=%d (N = 128, K multiple of 32)", M, K);
   const int nks = K / 32, per = 14, ns = (nks + per - 1) / per;
-  hipLaunchKernelGGL(di::t32::splitk_kernel, dim3((M + 15) / 16, ns), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(di::t32::splitk_kernel, dim3(8 * ((M + 15) / 16) * ((ns + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
                      (const __half *)f2p, (const __half *)w_packed, workspace, M, nks, per);
   if (nslices) *nslices = ns;
   return di::check_launch("token_splitk");
