@@ -194,13 +194,20 @@ class DeepInteractionEncoder(nn.Module):
             pts_metas[GEOM_KEY] = [None] * len(img_metas)
         geoms = [sample_geometry(img_metas, pts_metas, b, (I_H, I_W), dev) for b in range(len(img_metas))]
 
+        def depth_only():
+            for b, g in enumerate(geoms):
+                BEVWarp.dense_depth(g, pts_metas['pts'][b], I_H, I_W)
+
+        def keys_only():
+            bounds = pillar_batch_bounds(pts_metas, len(img_metas))
+            for b, g in enumerate(geoms):
+                MMRI_I2P.pillar_keys(g, pts_metas, bounds[b], bounds[b + 1], (I_H, I_W), tuple(pts_feats.shape[-2:]))
+
         def depth_maps():
             # what depends on the points and the metas only: sparse depth + completion (~15 tiny launches per sample)
             # and the key table of the pillar attention
-            bounds = pillar_batch_bounds(pts_metas, len(img_metas))
-            for b, g in enumerate(geoms):
-                BEVWarp.dense_depth(g, pts_metas['pts'][b], I_H, I_W)
-                MMRI_I2P.pillar_keys(g, pts_metas, bounds[b], bounds[b + 1], (I_H, I_W), tuple(pts_feats.shape[-2:]))
+            depth_only()
+            keys_only()
 
         def pts_conv():
             y = self._shared_conv(self.shared_conv_pts, pts_feats)
@@ -216,7 +223,13 @@ class DeepInteractionEncoder(nn.Module):
             else:
                 def convs():
                     return self._shared_conv(self.shared_conv_img, img_feats), pts_conv()
-                (new_img_feat, (new_pts_feat, pts_feat_conv)), _ = fork_join(dev, convs, depth_maps)
+                if utils.OVERLAP & 64:
+                    # round 6: the key table (projection + the dense stream of the matrix-core pillar attention: 5 launches,
+                    # ~36 us) on a branch of its own beside the depth chain (~90 us) - together they had become longer than
+                    # the two convolutions they hide under
+                    (new_img_feat, (new_pts_feat, pts_feat_conv)) = fork_join(dev, convs, depth_only, keys_only)[0]
+                else:
+                    (new_img_feat, (new_pts_feat, pts_feat_conv)), _ = fork_join(dev, convs, depth_maps)
         else:
             new_img_feat = self._shared_conv(self.shared_conv_img, img_feats)
             new_pts_feat, pts_feat_conv = pts_conv()
