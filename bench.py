@@ -82,6 +82,12 @@ def parse():
     ap.add_argument('--from-points', action='store_true',
                     help='start every step from the raw points: the pillars of pts_metas are rebuilt by the voxeliser inside '
                          'the captured forward (detector glue, detectors/deepinteraction.py:120-171) instead of being loaded')
+    ap.add_argument('--from-lidar', action='store_true',
+                    help='forward mode: the frozen LiDAR branch (hard voxelisation at 0.075 m, HardSimpleVFE, the sparse 3-D encoder '
+                         'without spconv, SECOND, SECONDFPN: FrozenLidarBackbone, torch ops + MIOpen, random init) runs EAGERLY in front '
+                         'of every replay and writes the BEV map into the captured forward\'s static input (its shapes depend on the '
+                         'number of active voxels: not capturable); one sample at a time.  Combine with --from-images --from-points for '
+                         'the forward from raw sensor tensors')
     ap.add_argument('--from-raw', action='store_true',
                     help='the per-sample host work INSIDE the step: every step starts from NCHW device feature maps (the '
                          'reference boundary: frozen backbones emit NCHW), raw points / pillars and the metas - the channels-last '
@@ -338,7 +344,7 @@ def run_dry(args, parallel, rank, world):
 
 def main():
     args = parse()
-    if args.eager or args.dry_run or args.mode != 'forward' or (args.model == 'pp' and args.from_images):
+    if args.eager or args.dry_run or args.mode != 'forward' or (args.model == 'pp' and args.from_images) or args.from_lidar:
         args.inflight = 1          # several samples in flight exist for the graph-replayed forwards only
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(args))
@@ -558,6 +564,31 @@ def bench_forward(args, rank, world, device):
                 raw_pool = [dict(d, img_feats=d['img_feats'].contiguous(), pts_feats=d['pts_feats'].contiguous()) for d in dev_pool]
             step, step_copy, step1, graphs, records, g = graphed_steps(
                 lambda inp, ov: GraphedHotPath(enc, dec, inp, glue=glue, image_net=image_net, overlap=ov), dev_pool, cap, n_lanes, resident, raw_pool, bool(args.launch_threads))
+        lidar_ms = None
+        if args.from_lidar:
+            assert not args.eager and shape['c_pts'] == 512, '--from-lidar feeds the 512-channel BEV input of the reference configuration'
+            from deepinteraction_amd.mmdet3d_plugin import FrozenLidarBackbone
+            rng = list(synth.PC_RANGE)
+            grid = shape['bev_hw'][0] * 8                               # 1440 at shape R: voxels of 0.075 m
+            lidar = FrozenLidarBackbone.synthetic(
+                dict(max_num_points=10, max_voxels=(120000, 160000), point_cloud_range=rng,
+                     voxel_size=[(rng[3] - rng[0]) / grid, (rng[4] - rng[1]) / grid, (rng[5] - rng[2]) / 41.0]),
+                (41, grid, grid), device, dtype=dtype).eval()
+            turn = [0]
+
+            def step():       # noqa: F811  one sample at a time: LiDAR branch (eager) -> the capture's static BEV input -> replay
+                gg = graphs[turn[0] % len(graphs)]
+                turn[0] += 1
+                gg.pts_feats.copy_(lidar(gg.pts)[0])
+                gg()
+            step1, step_copy = step, None
+            lidar(graphs[0].pts)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i_ in range(5):
+                lidar(graphs[i_ % len(graphs)].pts)
+            torch.cuda.synchronize()
+            lidar_ms = (time.perf_counter() - t0) / 5 * 1e3
         settle(step, args.settle_ms)
         for _ in range(args.warmup):
             step()
@@ -565,7 +596,7 @@ def bench_forward(args, rank, world, device):
         elapsed = parallel.timed_region(step, args.steps, device)
 
         single = copy_handover = None
-        if not args.eager:
+        if not args.eager and not args.from_lidar:
             single, copy_handover = secondary_lines(args, parallel, device, world, n_lanes, step1, step_copy if resident else None)
 
         # parity sample: the product's outputs on pool[0], in the benched launch mode
@@ -672,11 +703,13 @@ def bench_forward(args, rank, world, device):
     out = _line(args, 'samples/sec forward (Fusion_0075 synthetic)',
                 parallel.throughput(args.batch * max(1, args.inflight), args.steps, elapsed, world), elapsed,
                 'f16' if dtype == torch.float16 else 'f32',
+                ('frozen LiDAR branch (voxelisation + sparse 3-D encoder + SECOND + SECONDFPN, eager torch ops) + ' if args.from_lidar else '') +
                 ('frozen ResNet-50 + FPN image network (torch / MIOpen) + ' if args.from_images else '') +
                 'Full MMRI encoder (2 layers) + MMPI decoder forward, '
                 f'Fusion_0075_refactor shapes (shape {args.shape}), random-init weights',
                 dict(num_proposals=args.proposals, pillars=n_pillars, pool=len(dev_pool), inflight=max(1, args.inflight),
                      from_points=bool(args.from_points), from_raw=bool(args.from_raw), from_images=bool(args.from_images),
+                     from_lidar=bool(args.from_lidar), lidar_branch_ms=None if lidar_ms is None else round(lidar_ms, 3),
                      launch='eager' if args.eager else launch_text(resident),
                      handover=None if args.eager else ('resident' if resident else 'copy'),
                      launch_threads=None if args.eager else (n_lanes if args.launch_threads and n_lanes > 1 else 1),

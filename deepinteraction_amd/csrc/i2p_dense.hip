@@ -32,6 +32,7 @@
 // round before).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include <hip/hip_ext.h>
 
@@ -420,24 +421,16 @@ __global__ __launch_bounds__(64) void attn_dense_kernel(
       dma16_base((unsigned)cell * 256u + (unsigned)((i ^ (2 * ((4 * t + g) & 7))) & 15) * 16u, qfold, lds_w + QBUF + t * 1024);
     }
   };
-  struct KeyData {                         // lane (i, g): keys g and 4 + g of a superblock
-    f4 w[2];
-    int col[2];
-  };
-  KeyData kn;
-  // everything superblock nb (relative to the share) needs from the key ring: its 8 x 4 row fetches, and the weights and
-  // columns of a lane's two keys
+  // everything superblock nb (relative to the share) needs from the key ring for its 8 x 4 row fetches.  `slot`: a compile-time
+  // buffer index (the superblock loop is unrolled by NB: every LDS address is lane constant + immediate)
   auto issue = [&](int nb, int slot) {
-    if ((nb & 3) == 0 && 32 * ((nb >> 2) + 1) < nkeys) dma_keys((nb >> 2) + 1);     // the next 32 keys, 4 superblocks ahead
+    // the next 32 keys, while superblock nb - (NB - 1) = 4 c is multiplied: the slot they overwrite held chunk c - 1, whose last
+    // superblock (4 c - 1) is done (the weights / columns of a superblock are read from the ring when it is multiplied)
+    if ((nb & 3) == NB - 1 && 32 * ((nb >> 2) + 1) < nkeys) dma_keys((nb >> 2) + 1);
     const unsigned char *kr = wbase + KEYS + ((nb >> 2) & 1) * 1024 + (nb & 3) * 256;
     unsigned off[8];                       // all LDS reads first: every DMA statement is a fence for the compiler's LDS accesses
 #pragma unroll
     for (int t = 0; t < 8; ++t) off[t] = *reinterpret_cast<const unsigned *>(kr + t * 32 + g * 4);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      kn.w[h] = *reinterpret_cast<const f4 *>(kr + (4 * h + g) * 32 + 16);
-      kn.col[h] = (int)(*reinterpret_cast<const unsigned *>(kr + (4 * h + g) * 32) & 15u);
-    }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
       dma16_x4((off[4 * h] & ~255u) | dma_slot[0], (off[4 * h + 1] & ~255u) | dma_slot[1], (off[4 * h + 2] & ~255u) | dma_slot[2],
@@ -448,12 +441,9 @@ __global__ __launch_bounds__(64) void attn_dense_kernel(
   dma_keys(0);
   dma_q(G0, hc);
   wait_vm<0>();
-  KeyData kq[NB - 1];                      // key data of the superblocks in flight (their ring slot may be overwritten before they run)
 #pragma unroll
-  for (int pb = 0; pb < NB - 1; ++pb) {
+  for (int pb = 0; pb < NB - 1; ++pb)
     if (pb < nsb) issue(pb, pb);
-    kq[pb] = kn;
-  }
   int G = G0;
   int g_end = hc[9] - sb0;                 // first superblock (relative) behind the current group
   h8 qt[4];
@@ -476,11 +466,10 @@ __global__ __launch_bounds__(64) void attn_dense_kernel(
   for (int blk = 0; blk < 8; ++blk) acc[blk] = f4{0.f, 0.f, 0.f, 0.f};
   float mref = -INFINITY, l = 0.f;
 
-  int slot = 0;
-  for (int b = 0; b < nsb; ++b) {
+  // one superblock; SLOT = its row buffer (compile time)
+  auto body = [&](auto SLOT, int b) {
+    constexpr int slot = decltype(SLOT)::value, snext = (slot + NB - 1) % NB;
     const int nb = b + NB - 1;
-    int snext = slot + NB - 1;
-    if (snext >= NB) snext -= NB;
     if (nb < nsb) {
       issue(nb, snext);
       wait_vm<8 * (NB - 1)>();             // superblock b has landed (younger: the NB - 1 superblocks behind it)
@@ -488,10 +477,17 @@ __global__ __launch_bounds__(64) void attn_dense_kernel(
       wait_vm<0>();
     }
     const unsigned char *fb = wbase + slot * SBYTES;
-    const KeyData kc = kq[0];
+    // lane (i, g): the weights and columns of keys g and 4 + g, from the key ring
+    const unsigned char *kc_ = wbase + KEYS + ((b >> 2) & 1) * 1024 + (b & 3) * 256 + g * 32;
+    struct {
+      f4 w[2];
+      int col[2];
+    } kc;
 #pragma unroll
-    for (int q = 0; q + 1 < NB - 1; ++q) kq[q] = kq[q + 1];
-    kq[NB - 2] = kn;
+    for (int h = 0; h < 2; ++h) {
+      kc.w[h] = *reinterpret_cast<const f4 *>(kc_ + h * 128 + 16);
+      kc.col[h] = (int)(*reinterpret_cast<const unsigned *>(kc_ + h * 128) & 15u);
+    }
 
     f4 D[2];
 #pragma unroll
@@ -538,8 +534,6 @@ __global__ __launch_bounds__(64) void attn_dense_kernel(
       at[4] = v1[0]; at[5] = v1[1]; at[6] = v1[2]; at[7] = v1[3];
       acc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at, bc, acc[blk], 0, 0, 0);
     }
-    slot = slot + 1 == NB ? 0 : slot + 1;
-
     if (b + 1 == g_end) {
       // the group is complete: every one of its cells is written - cells without a key get their zero row (l = 0, acc = 0) -
       // and the padding column (15) is dropped
@@ -592,6 +586,12 @@ __global__ __launch_bounds__(64) void attn_dense_kernel(
         }
       }
     }
+  };
+  for (int b0 = 0; b0 < nsb; b0 += NB) {
+    body(std::integral_constant<int, 0>(), b0);
+    if (b0 + 1 < nsb) body(std::integral_constant<int, 1>(), b0 + 1);
+    if constexpr (NB > 2)
+      if (b0 + 2 < nsb) body(std::integral_constant<int, 2>(), b0 + 2);
   }
 }
 

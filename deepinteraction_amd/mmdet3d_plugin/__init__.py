@@ -8,10 +8,10 @@ from .models.dense_heads.deepinteractionplusplus_decoder import DeepInteractionP
 from .models.necks.deepinteraction_encoder import DeepInteractionEncoder  # noqa: F401
 from .models.necks.fusion_transformerv4 import (MMRI_I2P, MMRI_P2I, DeepInteractionLayer, FusionTransformerv4,  # noqa: F401
                                                 MMRI_I2P_Polar)
-from .models.detectors import (DeepInteractionInference, FrozenResNetFPN, FrozenSwinFPN, ImageGlue, PointGlue,  # noqa: F401
-                               bbox3d2result)
+from .models.detectors import (DeepInteractionInference, FrozenLidarBackbone, FrozenResNetFPN, FrozenSECOND,  # noqa: F401
+                               FrozenSECONDFPN, FrozenSparseEncoder, FrozenSwinFPN, ImageGlue, PointGlue, bbox3d2result)
 from .models.updated_modules import SPConvVoxelization  # noqa: F401
 
 __all__ = ['DeepInteractionEncoder', 'DeepInteractionDecoder', 'FusionTransformerv4', 'DeepInteractionLayer',
-           'MMRI_P2I', 'MMRI_I2P', 'MMRI_I2P_Polar', 'DeepInteractionPlusPlusDecoder', 'SPConvVoxelization', 'PointGlue', 'ImageGlue', 'FrozenResNetFPN', 'FrozenSwinFPN', 'DeepInteractionInference', 'bbox3d2result', 'TransFusionBBoxCoder', 'HungarianAssigner3D',
+           'MMRI_P2I', 'MMRI_I2P', 'MMRI_I2P_Polar', 'DeepInteractionPlusPlusDecoder', 'SPConvVoxelization', 'PointGlue', 'ImageGlue', 'FrozenResNetFPN', 'FrozenSwinFPN', 'FrozenLidarBackbone', 'FrozenSparseEncoder', 'FrozenSECOND', 'FrozenSECONDFPN', 'DeepInteractionInference', 'bbox3d2result', 'TransFusionBBoxCoder', 'HungarianAssigner3D',
            'HeuristicAssigner3D', 'BBox3DL1Cost', 'BBoxBEVL1Cost', 'IoU3DCost']

@@ -120,3 +120,66 @@ def test_dense_kernel_replays_bit_identically():
         k = ops.i2p_key_table(*args, (Hi, Wi), (Hb, Wb))
         outs.append(ops.i2p_attention(img, qf, *args, keys=k)[0].clone())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_dense_kernel_without_any_pillar():
+    """Edge case: a sample without pillars (P = 0) - every group of the stream is one padding superblock; every cell of ctx and
+    valid is written with zeros (the caller allocates them uninitialised)."""
+    shape = synth.SHAPE_TINY
+    Hi, Wi = shape['img_hw']
+    Hb, Wb = shape['bev_hw']
+    args = list(_sample(shape, seed=3))
+    args[0], args[1], args[2] = args[0][:0].contiguous(), args[1][:0].contiguous(), args[2][:0].contiguous()
+    img, qf = _maps(shape, 5, 0.3)
+    k = ops.i2p_key_table(*args, (Hi, Wi), (Hb, Wb))
+    assert k.dense is not None
+    ctx, valid = ops.i2p_attention(img, qf, *args, keys=k)
+    torch.cuda.synchronize()
+    assert float(ctx.float().abs().max()) == 0.0 and float(valid.float().abs().max()) == 0.0
+
+
+_TUNED_SCRIPT = r'''
+import torch
+from deepinteraction_amd import ops, synth
+from deepinteraction_amd.geometry import SampleGeometry
+shape = synth.SHAPE_R
+Hi, Wi = shape['img_hw']; Hb, Wb = shape['bev_hw']
+inp = synth.make_inputs(1, shape, seed=7)
+geom = SampleGeometry(inp['img_metas'][0], (Hi, Wi), 'cuda')
+pm = inp['pts_metas']
+args = (pm['pillars'].cuda(), pm['pillar_coors'].cuda(), pm['pillars_num_points'].cuda(), geom.lidar2img, geom.aug_rev, geom.ori_hw)
+g = torch.Generator(device='cuda').manual_seed(1)
+img = torch.randn(6, 128, Hi, Wi, device='cuda', generator=g).half().contiguous(memory_format=torch.channels_last)
+qf = (torch.randn(1, 128, Hb, Wb, device='cuda', generator=g) * 0.5).half().contiguous(memory_format=torch.channels_last)
+kd = ops.i2p_key_table(*args, (Hi, Wi), (Hb, Wb))
+kw = ops.i2p_key_table(*args, (Hi, Wi), (Hb, Wb), dense=False)
+a, va = ops.i2p_attention(img, qf, *args, keys=kd)
+b, vb = ops.i2p_attention(img, qf, *args, keys=kw)
+torch.cuda.synchronize()
+assert torch.equal(va, vb) and not torch.isnan(a.float()).any()
+sc = b.float().abs().max().item()
+assert (a.float() - b.float()).abs().max().item() <= 4e-3 * sc
+ncell = Hb * Wb
+al = lambda x: (x + 255) // 256 * 256
+nchunks = (ncell + 7) // 8
+off = al(ncell * 64) + nchunks * 4
+ngroups = int(kd.dense[off:off + 4].view(torch.int32)[0])
+print('TUNED_OK', ngroups)
+'''
+
+
+@pytest.mark.parametrize('env', [dict(DI_I2PD_KEYCAP='6', DI_I2PD_WAVES='3'), dict(DI_I2PD_KEYCAP='400', DI_I2PD_NB='3', DI_I2PD_WAVES='5')])
+def test_dense_kernel_with_other_group_and_share_sizes(env):
+    """The stream's cut is a tuning choice, not part of the result: a key cap of 6 (almost every cell its own group, single
+    cells far over the cap, ~4x the groups) with 3 shares per CU, and no cap at all (always 8 cells per group: groups of up to
+    ~25 superblocks) with the three-buffer pipeline - same outputs as the wave-per-cell kernel.  (Own process: the switches are
+    read at the first launch.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get('PYTHONPATH', ''), **env)
+    r = subprocess.run([sys.executable, '-c', _TUNED_SCRIPT], env=e, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'TUNED_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    ngroups = int(r.stdout.split('TUNED_OK')[1].split()[0])
+    assert (ngroups > 12000) if env['DI_I2PD_KEYCAP'] == '6' else (ngroups == (180 * 180 + 7) // 8)

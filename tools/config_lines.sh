@@ -24,4 +24,6 @@ run cfg5_pp_forward --steps 20 --warmup 5 --model pp                      # conf
 run sec_from_raw --steps 20 --warmup 5 --from-raw --no-cpu-baseline
 run sec_from_points --steps 20 --warmup 5 --from-points --no-cpu-baseline
 run sec_from_images --steps 20 --warmup 5 --from-images --no-cpu-baseline
+run sec_from_sensors --steps 10 --warmup 3 --from-lidar --from-images --from-points --no-cpu-baseline   # raw points + camera images -> boxes' inputs
+run sec_from_lidar --steps 10 --warmup 3 --from-lidar --no-cpu-baseline
 echo done
