@@ -514,3 +514,38 @@ def test_warp_project_equals_gather_then_project(shape_name):
     got = ops.warp_project(bev, *args, packed)
     for a, b in zip(got, ref):
         assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize('overlap', [0, 29])
+def test_one_window_attention_launch_per_layer_equals_two(overlap):
+    """Round 6: I_IML and P2I of a layer as ONE launch over pair buffers (`DeepInteractionEncoderLayer._pair_buffers`) against
+    the two launches of rounds 1-5 (`PAIR = False`): bit-identical encoder outputs, with and without the fork / join sites, and
+    twice as many image-side window-attention launches without the pairing."""
+    _require_gpu()
+    from deepinteraction_amd import utils
+    from deepinteraction_amd.mmdet3d_plugin.models.necks import deepinteraction_encoder as de
+    shape, inp = _tiny(seed=8)
+    torch.manual_seed(3)
+    M = de.DeepInteractionEncoder(2, shape['c_img'], shape['c_pts'], 128).eval().to(DEV, torch.float16)
+    pm = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in inp['pts_metas'].items()}
+    pm['pts'] = [p.to(DEV) for p in inp['pts_metas']['pts']]
+    img = inp['img_feats'].to(DEV, torch.float16).contiguous(memory_format=torch.channels_last)
+    pts = inp['pts_feats'].to(DEV, torch.float16).contiguous(memory_format=torch.channels_last)
+    outs, launches = [], []
+    saved = de.DeepInteractionEncoderLayer.PAIR
+    try:
+        for pair in (True, False):
+            de.DeepInteractionEncoderLayer.PAIR = pair
+            ops.PROFILE = []
+            with torch.no_grad(), utils.overlap(overlap):
+                gi, (g0, g1) = M(img, pts, inp['img_metas'], dict(pm))
+            torch.cuda.synchronize()
+            prof, ops.PROFILE = ops.PROFILE, None
+            launches.append(sorted(n for (name, n, s, e) in prof if name == 'local_attn_fwd'))
+            outs.append((gi.clone(), g0.clone(), g1.clone()))
+    finally:
+        de.DeepInteractionEncoderLayer.PAIR = saved
+        ops.PROFILE = None
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert launches[0] == [1, 1, 12, 12] and launches[1] == [1, 1, 6, 6, 6, 6], launches
