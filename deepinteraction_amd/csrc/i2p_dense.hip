@@ -50,7 +50,9 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 
 constexpr int NC = 8;            // BEV cells per group at most (MFMA columns in use; 16 columns exist)
 constexpr int kKeyCap = 48;      // a group closes before it would exceed this many keys (a single cell may: <= 120 keys); DI_I2PD_KEYCAP
-constexpr int kWavesPerCU = 8;   // resident wavefronts per CU (LDS: 20 KB each); the stream is cut into CUs x 8 shares
+constexpr int kResident = 8;      // resident wavefronts per CU (LDS: 20 KB each)
+constexpr int kWavesPerCU = 16;  // shares per CU (DI_I2PD_WAVES): twice the resident wavefronts - guided shares, see share_t
+constexpr int kBigSixteenths = 13;   // (DI_I2PD_BIG) measured: uniform 8 per CU 20.0 us; 16 per CU with 11 / 12 / 13 / 14 sixteenths: 20.5 / 19.4 / 18.8 / 18.9 us
 constexpr int kMaxWaves = 4096;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLazy = 8.f;     // log2 units: the reference maximum is kept until a score beats it by more than this
@@ -77,6 +79,22 @@ __host__ __device__ inline long long off_csub(int ncell) { return al256((long lo
 __host__ __device__ inline long long off_csb(int ncell) { return off_csub(ncell) + al256((long long)(n_chunks(ncell) + 1) * 4); }
 __host__ __device__ inline long long off_wst(int ncell) { return off_csb(ncell) + al256((long long)(n_chunks(ncell) + 1) * 4); }
 __host__ __device__ inline long long off_keys(int ncell) { return off_wst(ncell) + al256((long long)(kMaxWaves + 1) * 4); }
+
+// SHARES.  Share w of W (W / 8 per XCD, in stream order inside the XCD's eighth of the stream) starts at the first group whose
+// first superblock is >= t(w).  The first half of an XCD's shares (the workgroups that are dispatched first and fill every
+// resident slot) take `big` sixteenths of its superblocks, the second half - dispatched as slots free up - the rest in small
+// pieces: the small shares fill the tail that one share per resident wavefront leaves (the average wavefront lived 12.4 us of a
+// 20.4 us launch: a share is cut at group boundaries, +- one group of up to 6 superblocks around a mean of 13).  big = 8:
+// uniform shares.
+__host__ __device__ inline unsigned share_t(unsigned w, unsigned nsb, unsigned W, unsigned big) {
+  const unsigned wx = W >> 3, x = w / wx, j = w - x * wx, half = wx >> 1;
+  if (x >= 8u) return nsb;
+  const unsigned X0 = (unsigned)(((unsigned long long)x * nsb) >> 3), X1 = (unsigned)(((unsigned long long)(x + 1u) * nsb) >> 3);
+  const unsigned len = X1 - X0, bigpart = (len * big) >> 4;
+  if (half == 0u) return X0;
+  return j < half ? X0 + (unsigned)(((unsigned long long)j * bigpart) / half)
+                  : X0 + bigpart + (unsigned)(((unsigned long long)(j - half) * (len - bigpart)) / half);
+}
 
 // csub[c] / csb[c] = groups / superblocks of chunk c (one thread per chunk): the greedy cut, serially over the 8 cells
 __global__ __launch_bounds__(256) void chunk_count_kernel(const int *__restrict__ cnt, const int *__restrict__ order,
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ cn
                                                       const int *__restrict__ order, const int *__restrict__ csub,
                                                       const int *__restrict__ csb, GroupHdr *__restrict__ hdr,
                                                       int *__restrict__ wst, DenseKey *__restrict__ dense, int ncell, int nchunks,
-                                                      int nslots, int Wi, int W, int key_cap) {
+                                                      int nslots, int Wi, int W, int key_cap, int big) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= nchunks) return;
@@ -224,13 +242,18 @@ __global__ __launch_bounds__(256) void compact_kernel(const int *__restrict__ cn
       H->sb_begin = g_sb0;
       H->sb_end = g_sb1;
       H->nk = g_nk;
-      // shares that start right behind this group: sb_begin < t(w) <= sb_end (and, for the very first group, t(w) = 0).
-      // 32-bit arithmetic: superblocks < 2^19, W <= 2^12.
-      const unsigned ua = (unsigned)nsb_all, uw = (unsigned)W;
-      unsigned w = ((unsigned)(g_sb0 + 1) * uw + ua - 1u) / ua;
+      // shares that start right behind this group: sb_begin < t(w) <= sb_end (and, for the very first group, t(w) = 0);
+      // t is monotone: the first such share by bisection
+      const unsigned ua = (unsigned)nsb_all, uw = (unsigned)W, ub = (unsigned)big;
+      unsigned lo = 0u, hi = uw;                            // smallest w in [0, W] with t(w) > sb_begin (t(W) = all > sb_begin)
+      while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (share_t(mid, ua, uw, ub) > (unsigned)g_sb0) hi = mid; else lo = mid + 1u;
+      }
+      unsigned w = lo;
       if (G0 + lane == 0)
-        for (unsigned w0 = 0; w0 < uw && (w0 * ua) / uw == 0u; ++w0) wst[w0] = 0;
-      for (; w < uw && (w * ua) / uw <= (unsigned)g_sb1; ++w) wst[w] = G0 + lane + 1;
+        for (unsigned w0 = 0; w0 < uw && share_t(w0, ua, uw, ub) == 0u; ++w0) wst[w0] = 0;
+      for (; w < uw && share_t(w, ua, uw, ub) <= (unsigned)g_sb1; ++w) wst[w] = G0 + lane + 1;
       if (G0 + lane == ngroups - 1) wst[W] = ngroups;
     }
     // keys: every lane copies ONE key per pass (a chunk has ~40) and one padding key: two independent load -> store
@@ -640,6 +663,7 @@ int di_i2p_compact_keys(const void *key_table, const int32_t *cell_order, void *
   const int W = di::i2pd::n_shares();
   if (W <= 0) return DI_ERR_LAUNCH;
   static const int key_cap = getenv("DI_I2PD_KEYCAP") ? atoi(getenv("DI_I2PD_KEYCAP")) : di::i2pd::kKeyCap;
+  static const int big = getenv("DI_I2PD_BIG") ? std::min(15, std::max(1, atoi(getenv("DI_I2PD_BIG")))) : di::i2pd::kBigSixteenths;
   const int *cnt = reinterpret_cast<const int *>(key_table);
   const di::KeyEnt *keys = reinterpret_cast<const di::KeyEnt *>(cnt + 2 * (size_t)ncell);
   char *base = reinterpret_cast<char *>(dense_table);
@@ -653,7 +677,7 @@ int di_i2p_compact_keys(const void *key_table, const int32_t *cell_order, void *
                      nchunks, key_cap);
   hipLaunchKernelGGL(di::i2pd::scan_kernel, dim3(2), dim3(1024), 0, s, csub, csb, nchunks);
   hipLaunchKernelGGL(di::i2pd::compact_kernel, dim3((nchunks + 3) / 4), dim3(256), 0, s, cnt, keys, cell_order, csub, csb, hdr, wst,
-                     dense, ncell, nchunks, T * n_views, Wi, W, key_cap);
+                     dense, ncell, nchunks, T * n_views, Wi, W, key_cap, big);
   return di::check_launch("i2p_compact_keys");
 }
 
