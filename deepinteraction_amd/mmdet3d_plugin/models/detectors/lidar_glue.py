@@ -22,6 +22,8 @@ State-dict keys mirror mmdet3d's modules (`conv_input.0.weight`, `encoder_layers
 Parity: against `oracle/sparse_encoder.py` (dense restatement of the published spconv semantics) - UNPINNED: spconv / mmdet3d
 are not in this image.  Shapes depend on the data (the number of active voxels): this part runs eagerly, in front of the
 captured forward."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -138,7 +140,9 @@ class FrozenSparseEncoder(nn.Module):
         self.in_channels, self.sparse_shape, self.output_channels = in_channels, tuple(sparse_shape), output_channels
         self.base_channels, self.encoder_channels, self.encoder_paddings = base_channels, encoder_channels, encoder_paddings
         self.dtype = dtype
-        self._p = {}
+        self._p, self._h = {}, {}
+
+    HIP = os.environ.get('DI_SPARSE_HIP', '1') != '0'       # 0: the torch formulation (gather matrix + GEMM) on the device too
 
     # ---- the module tree as (kind, key prefix, geometry) in execution order
     def plan(self):
@@ -195,23 +199,68 @@ class FrozenSparseEncoder(nn.Module):
     def load_mmdet_state(self, sd):
         missing = [k for k in self.state_keys() if k not in sd]
         assert not missing, f'missing SparseEncoder entries: {missing[:4]}'
-        self._p = {}
+        self._p, self._geom = {}, {}
         for st in self.plan():
             if st[0] == 'block':
                 for n in (1, 2):
                     self._p[f'{st[1]}.{n}'] = _fold(f'{st[1]}.conv{n}.weight', f'{st[1]}.bn{n}', st[1], sd)
+                    self._geom[f'{st[1]}.{n}'] = (27, st[2])
             else:
                 self._p[st[1]] = _fold(f'{st[1]}.0.weight', f'{st[1]}.1', st[1], sd)
+                ks = (3, 3, 3) if st[0] == 'subm' else st[4]
+                self._geom[st[1]] = (ks[0] * ks[1] * ks[2], st[2])
+        self._master = dict(self._p)                          # float32, where load_mmdet_state ran
         return self
 
     def to(self, *a, **k):
         dev = a[0] if a else k.get('device')
-        self._p = {n: (w.to(dev, self.dtype), b.to(dev, self.dtype)) for n, (w, b) in self._p.items()}
+        self._p = {n: (w.to(dev, self.dtype), b.to(dev, self.dtype)) for n, (w, b) in self._master.items()}
+        self._h = {}
+        if torch.device(dev).type == 'cuda' and self.dtype == torch.float16:
+            # the HIP kernels' form: weights as MFMA operand fragments (csrc/sparse_conv.hip), float32 bias
+            from .... import ops
+            for n, (w, b) in self._master.items():
+                K, cin = self._geom[n]
+                frag, cin_pad = ops.sparse_weight_fragments(w, K, cin)
+                self._h[n] = (frag.to(dev), b.float().to(dev), cin_pad, w.shape[1])
         return self
+
+    @torch.no_grad()
+    def _forward_hip(self, voxel_features, coors, batch_size):
+        """The same layers on `csrc/sparse_conv.hip`: a level = its sorted int32 keys + one fp16 feature row per key; rulebooks by
+        `di_sparse_mark` / `di_sparse_nbr`, every convolution ONE launch (gather, MFMA product, bias / residual / ReLU)."""
+        from .... import ops
+        shape = self.sparse_shape
+        D, H, W = shape
+        assert batch_size * D * H * W < 2 ** 31, 'linear voxel keys are 32-bit'
+        c = coors.long()
+        keys, order = torch.sort((((c[:, 0] * D + c[:, 1]) * H + c[:, 2]) * W + c[:, 3]).to(torch.int32))
+        cin8 = (self.in_channels + 7) // 8 * 8
+        feats = F.pad(voxel_features[order].to(torch.float16), (0, cin8 - self.in_channels)).contiguous()
+        nbr = None
+        for st in self.plan():
+            if st[0] in ('subm', 'block') and nbr is None:
+                nbr = ops.sparse_neighbours(keys, keys, batch_size, shape, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+            if st[0] == 'subm':
+                feats = ops.sparse_conv(feats, nbr, *self._h[st[1]], relu=True)
+            elif st[0] == 'block':
+                h = ops.sparse_conv(feats, nbr, *self._h[f'{st[1]}.1'], relu=True)
+                feats = ops.sparse_conv(h, nbr, *self._h[f'{st[1]}.2'], relu=True, residual=feats)
+            else:
+                okeys, oshape = ops.sparse_output_keys(keys, batch_size, shape, st[4], st[5], st[6])
+                onbr = ops.sparse_neighbours(keys, okeys, batch_size, shape, oshape, st[4], st[5], st[6])
+                feats = ops.sparse_conv(feats, onbr, *self._h[st[1]], relu=True)
+                keys, shape, nbr = okeys, oshape, None
+        D, H, W = shape
+        d = feats.new_zeros((batch_size * D * H * W, feats.shape[1]))
+        d[keys.long()] = feats
+        return d.view(batch_size, D, H, W, -1).permute(0, 4, 1, 2, 3).reshape(batch_size, -1, H, W)
 
     @torch.no_grad()
     def forward(self, voxel_features, coors, batch_size):
         """voxel_features (M, in_channels), coors (M, 4) int [b, z, y, x] -> dense BEV map (B, C * D_out, H / 8, W / 8)."""
+        if voxel_features.is_cuda and getattr(self, '_h', None) and self.HIP:
+            return self._forward_hip(voxel_features, coors, batch_size)
         coords = coors.long()
         x = SparseTensor(coords, voxel_features.to(self.dtype), self.sparse_shape, batch_size)
         order = torch.argsort(x.keys())

@@ -855,6 +855,71 @@ def voxelize(points, voxel_size, pc_range, max_points, max_voxels, n_feat=None):
     return voxels, coords, num, n_vox
 
 
+# ------------------------------------------------------------------ sparse 3-D convolutions of the frozen LiDAR encoder
+def _geo16(batch, in_shape, out_shape, ksize, stride, padding):
+    return (ctypes.c_int32 * 16)(int(batch), *map(int, in_shape), *map(int, out_shape), *map(int, ksize), *map(int, stride),
+                                 *map(int, padding))
+
+
+def sparse_out_shape(in_shape, ksize, stride, padding):
+    return tuple((n + 2 * p - k) // s + 1 for n, k, s, p in zip(in_shape, ksize, stride, padding))
+
+
+def sparse_output_keys(in_keys, batch, in_shape, ksize, stride, padding):
+    """spconv `SparseConv3d`'s output set: the SORTED int32 keys ((b * D + z) * H + y) * W + x of the output cells whose window
+    holds an active input voxel (a byte map of the output grid, marked by one launch; its non-zero scan is the key list - this
+    synchronises, the count decides the shapes that follow) and the output shape."""
+    _dev(in_keys)
+    assert in_keys.dtype == torch.int32 and in_keys.is_contiguous()
+    out_shape = sparse_out_shape(in_shape, ksize, stride, padding)
+    occ = torch.zeros(int(batch) * out_shape[0] * out_shape[1] * out_shape[2], dtype=torch.uint8, device=in_keys.device)
+    geo = _geo16(batch, in_shape, out_shape, ksize, stride, padding)
+    _lib.call('di_sparse_mark', in_keys.data_ptr(), in_keys.numel(), ctypes.addressof(geo), occ.data_ptr(), _stream())
+    return torch.nonzero(occ).squeeze(1).to(torch.int32), out_shape
+
+
+def sparse_neighbours(in_keys, out_keys, batch, in_shape, out_shape, ksize, stride, padding):
+    """The rulebook of a sparse convolution as a neighbour table (K, M_out) int32: row of `in_keys` (sorted) that kernel offset o
+    (index order kd, kh, kw) of output voxel m reads, or -1."""
+    _dev(in_keys, out_keys)
+    assert in_keys.dtype == out_keys.dtype == torch.int32 and in_keys.is_contiguous() and out_keys.is_contiguous()
+    K = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
+    nbr = torch.empty((K, out_keys.numel()), dtype=torch.int32, device=in_keys.device)
+    geo = _geo16(batch, in_shape, out_shape, ksize, stride, padding)
+    _lib.call('di_sparse_nbr', in_keys.data_ptr(), out_keys.data_ptr(), in_keys.numel(), out_keys.numel(), ctypes.addressof(geo),
+              nbr.data_ptr(), _stream())
+    return nbr
+
+
+def sparse_weight_fragments(weight, K, cin):
+    """(K * cin, cout) float weights (offsets in kernel index order, then input channels) -> (fp16 fragments in the MFMA operand
+    order of di_sparse_conv_fwd, cin_pad)."""
+    cout = weight.shape[1]
+    cin_pad = (cin + 31) // 32 * 32
+    w = weight.new_zeros((K, cin_pad, cout))
+    w[:, :cin] = weight.reshape(K, cin, cout)
+    w = w.view(K, cin_pad // 32, 4, 8, cout // 16, 16).permute(0, 1, 4, 2, 5, 3)        # K, kk, mt, g, i, e
+    return w.contiguous().to(torch.float16), cin_pad
+
+
+def sparse_conv(feats, nbr, wfrag, bias, cin_pad, cout, relu=True, residual=None):
+    """out[m] = act(sum_o feats[nbr[o, m]] W[o] + bias (+ residual[m])): gather, product and epilogue in one launch."""
+    _dev(feats, nbr, wfrag)
+    assert feats.dtype == torch.float16 and feats.is_contiguous() and nbr.dtype == torch.int32 and nbr.is_contiguous()
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == cout)
+    K, M_out = nbr.shape
+    M_in, cin = feats.shape
+    assert wfrag.dtype == torch.float16 and wfrag.numel() == K * cin_pad * cout
+    out = torch.empty((M_out, cout), dtype=torch.float16, device=feats.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == torch.float16 and residual.is_contiguous()
+    _profiled('sparse_conv_fwd', M_out, lambda: _lib.call(
+        'di_sparse_conv_fwd', feats.data_ptr(), nbr.data_ptr(), wfrag.data_ptr(), bias.data_ptr() if bias is not None else None,
+        residual.data_ptr() if residual is not None else None, out.data_ptr(), M_in, M_out, K, cin, cin_pad, cout, int(bool(relu)),
+        _stream()))
+    return out
+
+
 # ------------------------------------------------------------------ DeepInteraction++ operators
 def _rows(t):
     """(rows.., cols) view with unit column stride and uniform row stride -> (data_ptr, row stride in elements)."""

@@ -611,6 +611,28 @@ long long di_wgrad_workspace_floats(long long npix, int Cin, int Cout);
 int di_wgrad_f32(const float *x, const float *grad_y, long long npix, int Cin, int Cout, float *grad_w, float *grad_b,
                  float *workspace, void *stream);
 
+/* Sparse 3-D convolutions of the frozen LiDAR middle encoder (csrc/sparse_conv.hip; mmdet3d 0.17.1 `SparseEncoder` over spconv
+ * `SubMConv3d` / `SparseConv3d`, called by models/detectors/deepinteraction.py:127 with Fusion_0075_refactor.py:160-171 -
+ * spconv is a CUDA-only third-party dependency: these replace its rulebook + gather-GEMM-scatter ops).  A level of the sparse
+ * tensor is its SORTED list of linear voxel keys ((b * D + z) * H + y) * W + x (int32: B * D * H * W < 2^31) and a feature matrix
+ * with one row per key.  `geo16` (host memory) = [B, inD, inH, inW, outD, outH, outW, kD, kH, kW, sD, sH, sW, pD, pH, pW].
+ *   di_sparse_mark      SparseConv3d output set: occ[out key] = 1 (bytes, B*outD*outH*outW, zeroed by the caller) wherever an
+ *                       active input voxel lies in the window; the caller's non-zero scan of `occ` is the sorted output key list.
+ *   di_sparse_nbr       the rulebook as a neighbour table nbr (K = kD*kH*kW, M_out): row of `in_keys` holding the voxel at
+ *                       out * stride - pad + offset (kernel index order kd, kh, kw), or -1.  Submanifold layers pass
+ *                       out_keys = in_keys, stride 1, pad (k - 1) / 2 and share the table among the layers of a resolution.
+ *   di_sparse_conv_fwd  out[m, :] = act(sum_o feats[nbr[o, m], :] . W[o] + bias (+ residual[m, :])), fp16 rows, float32
+ *                       accumulation on the matrix cores.  feats (M_in, cin), cin a multiple of 8; `wfrag` = the (K, cin_pad,
+ *                       cout) weights, cin zero-padded to cin_pad (a multiple of 32), in MFMA operand order
+ *                       [K][cin_pad / 32][cout / 16][lane = 16 g + i][8]: element e = W[o][32 kk + 8 g + e][16 mt + i]
+ *                       (ops.sparse_weight_fragments); bias (cout) float32 or NULL, residual (M_out, cout) or NULL, relu 0 / 1.
+ *                       Shapes: (cin_pad, cout) in {32} x {16, 32, 64}, {64} x {64, 128}, {128} x {128}; K <= 27. */
+int di_sparse_mark(const int32_t *in_keys, int M_in, const int32_t *geo16, void *occ, void *stream);
+int di_sparse_nbr(const int32_t *in_keys, const int32_t *out_keys, int M_in, int M_out, const int32_t *geo16, int32_t *nbr,
+                  void *stream);
+int di_sparse_conv_fwd(const void *feats, const int32_t *nbr, const void *wfrag, const float *bias, const void *residual,
+                       void *out, int M_in, int M_out, int K, int cin, int cin_pad, int cout, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

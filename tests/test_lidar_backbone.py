@@ -127,3 +127,99 @@ def test_lidar_backbone_from_raw_points_on_the_device():
                                      lg.FrozenSECOND().synthetic_state(1)), lg.FrozenSECONDFPN().synthetic_state(2))[0]
     err = (out.float().cpu() - want).abs()
     assert err.max().item() <= 3e-2 * max(1.0, want.abs().max().item()) and err.mean().item() <= 2e-3 * max(1.0, want.abs().max().item())
+
+
+# ---------------------------------------------------------------- csrc/sparse_conv.hip (the device path of FrozenSparseEncoder)
+def _sorted_level(shape, batch, n, seed, dev):
+    _, coors = _voxels(shape, batch, n, seed)
+    x = lg.SparseTensor(coors.long().to(dev), torch.zeros(coors.shape[0], 1, device=dev), shape, batch)
+    order = torch.argsort(x.keys())
+    x.coords = x.coords[order]
+    return x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,batch', [((9, 40, 36), 2), ((41, 64, 72), 1)])
+def test_device_rulebooks_equal_the_searchsorted_rulebooks(shape, batch):
+    """`di_sparse_nbr` / `di_sparse_mark` against the torch rulebooks (which tests above pin to brute force): integer work, equal."""
+    from deepinteraction_amd import ops
+    dev = 'cuda'
+    x = _sorted_level(shape, batch, 600, 5, dev)
+    keys = x.keys().to(torch.int32)
+    nbr = ops.sparse_neighbours(keys, keys, batch, shape, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    assert torch.equal(nbr.t().long(), lg.subm_rulebook(x))
+    for ks, st, pd in (((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))):
+        ocoords, onbr, oshape = lg.strided_rulebook(x, ks, st, pd)
+        okeys, oshape2 = ops.sparse_output_keys(keys, batch, shape, ks, st, pd)
+        assert oshape2 == oshape
+        want_keys = ((ocoords[:, 0] * oshape[0] + ocoords[:, 1]) * oshape[1] + ocoords[:, 2]) * oshape[2] + ocoords[:, 3]
+        assert torch.equal(okeys.long(), want_keys)
+        got = ops.sparse_neighbours(keys, okeys, batch, shape, oshape, ks, st, pd)
+        assert torch.equal(got.t().long(), onbr)
+    # an empty level
+    e = torch.empty(0, dtype=torch.int32, device=dev)
+    ok, osh = ops.sparse_output_keys(e, 1, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    assert ok.numel() == 0 and ops.sparse_neighbours(e, ok, 1, shape, osh, (3, 3, 3), (2, 2, 2), (1, 1, 1)).shape == (27, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cin,cout,K', [(8, 16, 27), (16, 16, 27), (16, 32, 27), (32, 32, 27), (32, 64, 27), (64, 64, 27),
+                                        (64, 128, 27), (128, 128, 27), (128, 128, 3)])
+def test_sparse_conv_kernel_equals_gather_and_product(cin, cout, K):
+    """One launch (gather, MFMA product, bias / residual / ReLU) against the float64 gather + product of the same fp16 numbers:
+    ragged row counts, rows without any neighbour, offsets nobody has, with and without residual / bias / ReLU."""
+    from deepinteraction_amd import ops
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(cin * 1000 + cout + K)
+    for M_in, M_out, fill in ((1000, 777, 0.3), (5, 128, 0.05), (300, 1, 1.0), (4000, 4099, 0.6)):
+        feats = torch.randn(M_in, cin, generator=g).half()
+        real = 5 if cin == 8 else cin                       # conv_input: 5 real channels, rows padded to 8
+        feats[:, real:] = 0
+        nbr = torch.randint(0, M_in, (K, M_out), generator=g, dtype=torch.int32)
+        nbr[torch.rand(K, M_out, generator=g) > fill] = -1
+        nbr[K // 2] = -1                                     # an offset no voxel has
+        nbr[:, M_out // 2] = -1                              # a voxel without neighbours
+        w = torch.randn(K * real, cout, generator=g) * (2.0 / (K * real * fill + 1)) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        res = torch.randn(M_out, cout, generator=g).half()
+        frag, cin_pad = ops.sparse_weight_fragments(w, K, real)
+        w16 = w.half().double().view(K, real, cout)
+        X = torch.cat([feats[:, :real].double(), torch.zeros(1, real, dtype=torch.float64)], 0)[nbr.long()]      # (K, M_out, real)
+        base = torch.einsum('kmc,kcd->md', X, w16)
+        for use_bias, use_res, relu in ((True, False, True), (True, True, True), (False, False, False)):
+            want = base + (bias.double() if use_bias else 0) + (res.double() if use_res else 0)
+            want = want.relu() if relu else want
+            got = ops.sparse_conv(feats.to(dev), nbr.to(dev), frag.to(dev), bias.to(dev) if use_bias else None, cin_pad, cout,
+                                  relu=relu, residual=res.to(dev) if use_res else None)
+            err = (got.double().cpu() - want).abs()
+            tol = 2e-3 * max(1.0, want.abs().max().item())                       # fp16 output rounding
+            assert err.max().item() <= tol, (cin, cout, K, M_out, use_bias, use_res, relu, err.max().item(), tol)
+    out = ops.sparse_conv(feats.to(dev), torch.empty((K, 0), dtype=torch.int32, device=dev), frag.to(dev), None, cin_pad, cout)
+    assert out.shape == (0, cout)
+
+
+@pytest.mark.gpu
+def test_sparse_encoder_device_kernels_against_the_torch_formulation_and_the_oracle():
+    """The whole `FrozenSparseEncoder` on `csrc/sparse_conv.hip` (fp16) == its torch formulation on the device (fp16, same
+    weights) within fp16 round-off, and the float32 dense oracle within the fp16 budget; two samples, one of them nearly empty."""
+    dev = 'cuda'
+    shape = (41, 64, 72)
+    feats, coors = _voxels(shape, 1, 900, 11)
+    f2, c2 = _voxels(shape, 1, 3, 12)
+    c2[:, 0] = 1
+    feats, coors = torch.cat([feats, f2], 0), torch.cat([coors, c2], 0)
+    mid = lg.FrozenSparseEncoder(sparse_shape=shape, dtype=torch.float16)
+    sd = mid.synthetic_state(3)
+    mid.load_mmdet_state(sd).to(dev)
+    assert mid._h and mid.HIP
+    got = mid(feats.to(dev), coors.to(dev), 2)
+    mid.HIP = False
+    ref16 = mid(feats.to(dev), coors.to(dev), 2)
+    mid.HIP = True
+    want = osp.sparse_encoder(feats, coors, 2, sd, shape)
+    assert got.shape == want.shape == ref16.shape
+    scale = max(1.0, want.abs().max().item())
+    assert (got.float() - ref16.float()).abs().max().item() <= 1e-2 * scale
+    err = (got.float().cpu() - want).abs()
+    assert err.max().item() <= 3e-2 * scale and err.mean().item() <= 2e-3 * scale
+    assert bool(((got != 0).any(1) == (ref16 != 0).any(1)).all())                    # the same active cells

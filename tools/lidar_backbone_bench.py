@@ -31,6 +31,33 @@ coors = torch.nn.functional.pad(c.long(), (1, 0))
 ms_mid, x = timed(lambda: net.middle(feats, coors, 1))
 ms_bb, y = timed(lambda: net.neck(net.backbone(x)))
 print(f'voxels {v.shape[0]}; whole branch {ms_all:.2f} ms = voxelise {ms_vox:.2f} + sparse encoder {ms_mid:.2f} + SECOND / FPN {ms_bb:.2f}')
+if net.middle._h:
+    net.middle.HIP = False
+    ms_t, xt = timed(lambda: net.middle(feats, coors, 1))
+    net.middle.HIP = True
+    print(f'sparse encoder: csrc/sparse_conv.hip {ms_mid:.2f} ms, torch formulation (gather matrix + GEMM) {ms_t:.2f} ms; '
+          f'max |diff| {(x.float() - xt.float()).abs().max().item():.3e} of {xt.float().abs().max().item():.3f}')
+    # the device path level by level
+    from deepinteraction_amd import ops
+    import torch.nn.functional as F
+    shape = (41, grid, grid)
+    c = coors.long()
+    keys = torch.sort((((c[:, 0] * 41 + c[:, 1]) * grid + c[:, 2]) * grid + c[:, 3]).to(torch.int32)).values
+    for st in net.middle.plan():
+        if st[0] != 'down':
+            continue
+        ms_n, nbr = timed(lambda: ops.sparse_neighbours(keys, keys, 1, shape, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1)))
+        fill = (nbr >= 0).float().mean().item() * 27
+        cin = st[2]
+        f = torch.randn(keys.numel(), cin, device=dev).half()
+        h = net.middle._h[st[1].rsplit('.', 1)[0] + '.0.1'] if st[1] != 'conv_out' else net.middle._h['encoder_layers.encoder_layer4.0.1']
+        ms_c, _ = timed(lambda: ops.sparse_conv(f, nbr, *h, relu=True), n=10)
+        ms_o, (okeys, oshape) = timed(lambda: ops.sparse_output_keys(keys, 1, shape, st[4], st[5], st[6]))
+        ms_on, onbr = timed(lambda: ops.sparse_neighbours(keys, okeys, 1, shape, oshape, st[4], st[5], st[6]))
+        flop = 2.0 * (nbr >= 0).sum().item() * cin * h[3]
+        print(f'level {shape}: {keys.numel()} voxels, {fill:.1f} neighbours each; submanifold table {ms_n:.3f} ms, one {cin} -> {h[3]} '
+              f'product {ms_c:.3f} ms ({flop / ms_c / 1e9:.1f} TFLOP/s useful); output set {ms_o:.3f} ms -> {okeys.numel()} voxels, its table {ms_on:.3f} ms')
+        keys, shape = okeys, oshape
 # rulebooks vs products of the sparse encoder
 xs = lg.SparseTensor(coors, feats.half(), (41, grid, grid), 1)
 o = torch.argsort(xs.keys()); xs.coords, xs.feats = xs.coords[o], xs.feats[o]
