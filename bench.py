@@ -84,9 +84,9 @@ def parse():
                          'the captured forward (detector glue, detectors/deepinteraction.py:120-171) instead of being loaded')
     ap.add_argument('--from-lidar', action='store_true',
                     help='forward mode: the frozen LiDAR branch (hard voxelisation at 0.075 m, HardSimpleVFE, the sparse 3-D encoder '
-                         'without spconv, SECOND, SECONDFPN: FrozenLidarBackbone, torch ops + MIOpen, random init) runs EAGERLY in front '
-                         'of every replay and writes the BEV map into the captured forward\'s static input (its shapes depend on the '
-                         'number of active voxels: not capturable); one sample at a time.  Combine with --from-images --from-points for '
+                         'without spconv - csrc/sparse_conv.hip -, SECOND, SECONDFPN: FrozenLidarBackbone, random init) runs EAGERLY on the '
+                         'lane\'s stream in front of every replay and writes the BEV map into the captured forward\'s static input (its '
+                         'shapes depend on the number of active voxels: not capturable).  Combine with --from-images --from-points for '
                          'the forward from raw sensor tensors')
     ap.add_argument('--from-raw', action='store_true',
                     help='the per-sample host work INSIDE the step: every step starts from NCHW device feature maps (the '
@@ -344,7 +344,7 @@ def run_dry(args, parallel, rank, world):
 
 def main():
     args = parse()
-    if args.eager or args.dry_run or args.mode != 'forward' or (args.model == 'pp' and args.from_images) or args.from_lidar:
+    if args.eager or args.dry_run or args.mode != 'forward' or (args.model == 'pp' and args.from_images):
         args.inflight = 1          # several samples in flight exist for the graph-replayed forwards only
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(args))
@@ -400,7 +400,7 @@ def launch_text(resident):
             'captured forward')
 
 
-def graphed_steps(capture, pool, cap, n_lanes, resident, raw_pool=None, launch_threads=True):
+def graphed_steps(capture, pool, cap, n_lanes, resident, raw_pool=None, launch_threads=True, before=None):
     """The graph-replayed step of both forward lines.  `capture(inputs, overlap)` -> GraphedHotPath.  Returns (step, step_copy, step1,
     graphs, records, g): `step` = one step of `n_lanes` samples in flight under the chosen hand-over, `step_copy` = the same
     with the copying hand-over of rounds 2-4 (on the first capture of every lane), `step1` = one sample at a time, `g` = the
@@ -408,7 +408,8 @@ def graphed_steps(capture, pool, cap, n_lanes, resident, raw_pool=None, launch_t
 
     resident: one capture per pool sample, all with the layout and pillar capacity of the largest sample (captured from
     `prepare()`d records, padded as load() pads); lane l owns samples l, l + n_lanes, ... and replays their captures in turn
-    on its stream - no capture is ever replayed on two streams."""
+    on its stream - no capture is ever replayed on two streams.  `before`: a one-element list holding a callable(capture) that the
+    lane runs on its stream right before the replay (the eager LiDAR branch of --from-lidar), or None."""
     import torch
     from deepinteraction_amd.graphed import LaneLaunchers
     # captures that run side by side are single-stream ones (GraphedHotPath `overlap`); the one-at-a-time figure uses
@@ -458,14 +459,20 @@ def graphed_steps(capture, pool, cap, n_lanes, resident, raw_pool=None, launch_t
         issue([copy_then_replay(o, it[0] + l) for l, o in enumerate(own)])
         it[0] += len(own)
 
+    def fed(gg):
+        def fn():
+            before[0](gg)
+            gg()
+        return fn if before is not None and before[0] is not None else gg
+
     def step_resident():
-        issue([o[turn[0] % len(o)] for o in own])                    # the next of every lane's samples, where it lies
+        issue([fed(o[turn[0] % len(o)]) for o in own])               # the next of every lane's samples, where it lies
         turn[0] += 1
 
     def step1():
         if resident:
             seq = solo if solo else graphs
-            seq[one[0] % len(seq)]()
+            fed(seq[one[0] % len(seq)])()
         else:
             solo[0].load(records[one[0] % len(records)])
             solo[0]()
@@ -562,8 +569,9 @@ def bench_forward(args, rank, world, device):
             raw_pool = None
             if args.from_raw:          # NCHW-contiguous device maps, as a frozen backbone hands them over
                 raw_pool = [dict(d, img_feats=d['img_feats'].contiguous(), pts_feats=d['pts_feats'].contiguous()) for d in dev_pool]
+            before = [None]
             step, step_copy, step1, graphs, records, g = graphed_steps(
-                lambda inp, ov: GraphedHotPath(enc, dec, inp, glue=glue, image_net=image_net, overlap=ov), dev_pool, cap, n_lanes, resident, raw_pool, bool(args.launch_threads))
+                lambda inp, ov: GraphedHotPath(enc, dec, inp, glue=glue, image_net=image_net, overlap=ov), dev_pool, cap, n_lanes, resident, raw_pool, bool(args.launch_threads), before)
         lidar_ms = None
         if args.from_lidar:
             assert not args.eager and shape['c_pts'] == 512, '--from-lidar feeds the 512-channel BEV input of the reference configuration'
@@ -574,14 +582,12 @@ def bench_forward(args, rank, world, device):
                 dict(max_num_points=10, max_voxels=(120000, 160000), point_cloud_range=rng,
                      voxel_size=[(rng[3] - rng[0]) / grid, (rng[4] - rng[1]) / grid, (rng[5] - rng[2]) / 41.0]),
                 (41, grid, grid), device, dtype=dtype).eval()
-            turn = [0]
+            assert resident, '--from-lidar needs the resident hand-over (every capture keeps its own points)'
 
-            def step():       # noqa: F811  one sample at a time: LiDAR branch (eager) -> the capture's static BEV input -> replay
-                gg = graphs[turn[0] % len(graphs)]
-                turn[0] += 1
+            def feed(gg):     # on the lane's stream, from the lane's thread: LiDAR branch (eager) -> the capture's static BEV input
                 gg.pts_feats.copy_(lidar(gg.pts)[0])
-                gg()
-            step1, step_copy = step, None
+            before[0] = feed
+            step_copy = None
             lidar(graphs[0].pts)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -596,7 +602,7 @@ def bench_forward(args, rank, world, device):
         elapsed = parallel.timed_region(step, args.steps, device)
 
         single = copy_handover = None
-        if not args.eager and not args.from_lidar:
+        if not args.eager:
             single, copy_handover = secondary_lines(args, parallel, device, world, n_lanes, step1, step_copy if resident else None)
 
         # parity sample: the product's outputs on pool[0], in the benched launch mode
@@ -703,7 +709,7 @@ def bench_forward(args, rank, world, device):
     out = _line(args, 'samples/sec forward (Fusion_0075 synthetic)',
                 parallel.throughput(args.batch * max(1, args.inflight), args.steps, elapsed, world), elapsed,
                 'f16' if dtype == torch.float16 else 'f32',
-                ('frozen LiDAR branch (voxelisation + sparse 3-D encoder + SECOND + SECONDFPN, eager torch ops) + ' if args.from_lidar else '') +
+                ('frozen LiDAR branch run eagerly on the lane\'s stream before every replay (HIP voxeliser, sparse 3-D encoder on csrc/sparse_conv.hip, SECOND + SECONDFPN through torch / MIOpen) + ' if args.from_lidar else '') +
                 ('frozen ResNet-50 + FPN image network (torch / MIOpen) + ' if args.from_images else '') +
                 'Full MMRI encoder (2 layers) + MMPI decoder forward, '
                 f'Fusion_0075_refactor shapes (shape {args.shape}), random-init weights',
