@@ -10,8 +10,9 @@
 // Three kernels, none of them a translation of spconv's hash-table pipeline:
 //   * `mark_kernel`   strided layers: every active input voxel marks the output cells whose window contains it in a byte map of
 //                     the OUTPUT grid (<= 11 MB at half resolution); the sorted output keys are the map's non-zero positions.
-//   * `nbr_kernel`    the rulebook as a dense neighbour table (K, M_out): one thread per (offset, output voxel), binary search of
-//                     the neighbour's linear key in the SORTED key list of the input level (no hash table, no atomics).
+//   * `nbr_kernel`    the rulebook as a dense neighbour table (K, M_out): one thread per (kernel row, output voxel), ONE binary
+//                     search per row in the SORTED key list of the input level - the kW neighbours of a row are consecutive
+//                     keys (no hash table, no atomics).
 //   * `conv_kernel`   gather + product + epilogue in one launch: a workgroup owns 128 output voxels (4 wavefronts x 2 tiles of 16)
 //                     and ALL output channels; Y^T = W^T . X^T on 16x16x32 MFMAs - the weight fragments of one kernel offset
 //                     (host-prepared in operand order: a fragment is one contiguous 1 KB read) are staged in LDS one offset
@@ -62,32 +63,42 @@ __global__ __launch_bounds__(256) void mark_kernel(const int *__restrict__ in_ke
   occ[((long long)(b * g.oD + oz) * g.oH + oy) * g.oW + ox] = 1;
 }
 
+// one thread per (kernel row (kd, kh), output voxel): ONE binary search for the row's first in-range x, then the kW neighbours are
+// consecutive keys of the sorted list (keys are unique: the next neighbour is at the same position or the next one)
 __global__ __launch_bounds__(256) void nbr_kernel(const int *__restrict__ in_keys, const int *__restrict__ out_keys, int M_in,
                                                    int M_out, Geo g, int *__restrict__ nbr) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int K = g.kD * g.kH * g.kW;
-  if (t >= (long long)M_out * K) return;
-  const int o = (int)(t / M_out), m = (int)(t - (long long)o * M_out);
-  const int kd = o / (g.kH * g.kW), kh = (o / g.kW) % g.kH, kw = o % g.kW;
+  const int KR = g.kD * g.kH;
+  if (t >= (long long)M_out * KR) return;
+  const int kr = (int)(t / M_out), m = (int)(t - (long long)kr * M_out);
+  const int kd = kr / g.kH, kh = kr - kd * g.kH;
   int key = out_keys[m];
   const int x = key % g.oW;
   key /= g.oW;
   const int y = key % g.oH;
   key /= g.oH;
   const int z = key % g.oD, b = key / g.oD;
-  const int iz = z * g.sD - g.pD + kd, iy = y * g.sH - g.pH + kh, ix = x * g.sW - g.pW + kw;
-  int res = -1;
-  if (iz >= 0 && iz < g.iD && iy >= 0 && iy < g.iH && ix >= 0 && ix < g.iW) {
-    const int want = ((b * g.iD + iz) * g.iH + iy) * g.iW + ix;
+  const int iz = z * g.sD - g.pD + kd, iy = y * g.sH - g.pH + kh, ix0 = x * g.sW - g.pW;
+  int *dst = nbr + (long long)kr * g.kW * M_out + m;
+  const bool row_ok = iz >= 0 && iz < g.iD && iy >= 0 && iy < g.iH;
+  const int kw_lo = max(0, -ix0), kw_hi = min(g.kW, g.iW - ix0);       // offsets with 0 <= ix0 + kw < iW
+  int pos = 0;
+  if (row_ok && kw_lo < kw_hi) {
+    const int want = ((b * g.iD + iz) * g.iH + iy) * g.iW + ix0 + kw_lo;
     int lo = 0, hi = M_in;                           // first position with in_keys[pos] >= want
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
       if (in_keys[mid] < want) lo = mid + 1;
       else hi = mid;
     }
-    if (lo < M_in && in_keys[lo] == want) res = lo;
+    pos = lo;
   }
-  nbr[t] = res;
+  const int base = ((b * g.iD + iz) * g.iH + iy) * g.iW + ix0;
+  for (int kw = 0; kw < g.kW; ++kw) {
+    int res = -1;
+    if (row_ok && kw >= kw_lo && kw < kw_hi && pos < M_in && in_keys[pos] == base + kw) res = pos++;
+    dst[(long long)kw * M_out] = res;
+  }
 }
 
 template <int KK, int MT>
@@ -264,8 +275,9 @@ int di_sparse_nbr(const int32_t *in_keys, const int32_t *out_keys, int M_in, int
   if (int rc = di::sp::check_geo(g)) return rc;
   DI_REQUIRE(M_in >= 0 && M_out >= 0, "M_in = %d, M_out = %d", M_in, M_out);
   if (M_out == 0) return DI_OK;
-  const long long n = (long long)M_out * g.kD * g.kH * g.kW;
-  DI_REQUIRE(n < (1ll << 31), "neighbour table of %lld entries", n);
+  DI_REQUIRE((long long)M_out * g.kD * g.kH * g.kW < (1ll << 31), "neighbour table of %lld entries",
+             (long long)M_out * g.kD * g.kH * g.kW);
+  const long long n = (long long)M_out * g.kD * g.kH;
   hipLaunchKernelGGL(di::sp::nbr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in_keys, out_keys,
                      M_in, M_out, g, nbr);
   return di::check_launch("sparse_nbr");

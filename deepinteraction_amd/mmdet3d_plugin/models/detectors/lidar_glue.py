@@ -335,10 +335,27 @@ class FrozenSECOND(_FrozenConvStack):
         return sd
 
     def load_mmdet_state(self, sd):
-        self._p = {}
+        self._p, self._master = {}, {}
         for i, k, ci, co, s in self.plan():
             w, b = self._fold2d(sd[f'blocks.{i}.{3 * k}.weight'], sd, f'blocks.{i}.{3 * k + 1}', False, self.eps)
             self._p[(i, k)] = (w.contiguous(memory_format=torch.channels_last), b, s)
+            self._master[(i, k)] = (w, b, s, ci, co)
+        return self
+
+    HIP = os.environ.get('DI_SPARSE_HIP', '1') != '0'
+
+    def to(self, *a, **k):
+        super().to(*a, **k)
+        dev = a[0] if a else k.get('device')
+        self._h = {}
+        if torch.device(dev).type == 'cuda' and self.dtype == torch.float16:
+            # stride-1 layers of 128 output channels (the whole first stage of the reference configuration) run on the hot
+            # path's own 3x3 kernel (csrc/conv3x3.hip, BatchNorm folded, ReLU in the epilogue); the rest through MIOpen
+            from .... import ops
+            for key, (w, b, s, ci, co) in self._master.items():
+                if s == 1 and co == 128 and ci % 32 == 0:
+                    wp, ws, bias = ops.pack_conv3x3(w, b)
+                    self._h[key] = (wp.to(dev), ws.to(dev), bias.to(dev))
         return self
 
     @torch.no_grad()
@@ -347,8 +364,13 @@ class FrozenSECOND(_FrozenConvStack):
         outs = []
         for i in range(len(self.out_channels)):
             for k in range(self.layer_nums[i] + 1):
-                w, b, s = self._p[(i, k)]
-                x = torch.relu_(F.conv2d(x, w, b, stride=s, padding=1))
+                h = getattr(self, '_h', {}).get((i, k)) if (x.is_cuda and self.HIP) else None
+                if h is not None and x.shape[2] >= 12:
+                    from .... import ops
+                    x = ops.conv3x3(x, h[0], h[1], h[2], relu=True)
+                else:
+                    w, b, s = self._p[(i, k)]
+                    x = torch.relu_(F.conv2d(x, w, b, stride=s, padding=1))
             outs.append(x)
         return tuple(outs)
 

@@ -119,6 +119,11 @@ def test_lidar_backbone_from_raw_points_on_the_device():
     pts = [p.to(dev) for p in inp['pts_metas']['pts']]
     out = net(pts)[0]
     assert out.shape == (1, 512, grid // 8, grid // 8) and out.dtype == torch.float16 and bool(torch.isfinite(out).all())
+    assert net.middle._h and net.backbone._h               # the device kernels ran: sparse_conv.hip and the own 3x3 kernel
+    net.middle.HIP = net.backbone.HIP = False
+    ref16 = net(pts)[0]                                     # the torch formulation of both, same fp16 weights
+    net.middle.HIP = net.backbone.HIP = True
+    assert (out.float() - ref16.float()).abs().max().item() <= 2e-2 * max(1.0, ref16.float().abs().max().item())
     v, c, n = net.pts_voxel_layer(pts[0])
     feats = osp.hard_simple_vfe(v.cpu(), n.cpu())
     mid = lg.FrozenSparseEncoder(sparse_shape=(41, grid, grid), dtype=torch.float32)

@@ -24,7 +24,9 @@ def timed(fn, n=5):
     return (time.perf_counter() - t0) / n * 1e3, out
 
 
-ms_all, _ = timed(lambda: net([pts[0]]))
+ms_all, _ = timed(lambda: net([pts[0]]), n=20)
+if os.environ.get('LIDAR_ONLY') == '1':          # under rocprofv3: the branch alone, 21 forwards
+    print(f'whole branch {ms_all:.2f} ms'); sys.exit(0)
 ms_vox, (v, c, n) = timed(lambda: net.pts_voxel_layer(pts[0]))
 feats = v[:, :, :5].sum(1) / n.clamp(min=1).to(v.dtype).unsqueeze(-1)
 coors = torch.nn.functional.pad(c.long(), (1, 0))
