@@ -24,6 +24,8 @@
 //                     Epilogue: + bias, + residual (SparseBasicBlock's identity), ReLU, 8-byte stores.
 #include <string.h>
 
+#include <type_traits>
+
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
@@ -39,6 +41,15 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxK = 27;      // kernel offsets of a layer
 constexpr int kVT = 2;         // voxel tiles of 16 per wavefront
 constexpr int kRows = 4 * kVT * 16;
+constexpr int kStages = 3;     // register stages of gathered rows: loads run kStages - 1 offsets ahead of the products
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 
 struct Geo {
   int B, iD, iH, iW, oD, oH, oW, kD, kH, kW, sD, sH, sW, pD, pH, pW;
@@ -102,10 +113,10 @@ __global__ __launch_bounds__(256) void nbr_kernel(const int *__restrict__ in_key
 }
 
 template <int KK, int MT>
-__global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__ feats, const int *__restrict__ nbr,
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_kernel(const __half *__restrict__ feats, const int *__restrict__ nbr,
                                                       const __half *__restrict__ wfrag, const float *__restrict__ bias,
-                                                      const __half *__restrict__ residual, __half *__restrict__ out, int M_out,
-                                                      int K, int cin, int relu) {
+                                                      const __half *__restrict__ residual, __half *__restrict__ out, int M_in,
+                                                      int M_out, int K, int cin, int relu) {
   constexpr int FRAG = KK * MT * 64;                 // 16-byte pieces of one offset's weight fragments
   extern __shared__ __align__(16) unsigned char lds[];
   uint4(*wbuf)[FRAG] = reinterpret_cast<uint4(*)[FRAG]>(lds);
@@ -114,7 +125,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__
   __shared__ int act[kMaxK + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int row0 = blockIdx.x * kRows;
+  // XCD-contiguous tiles: workgroups are dealt round-robin to the 8 XCDs; neighbouring tiles (which gather the same input rows:
+  // the active set is sorted z, y, x) should share an L2, so XCD x takes the x-th eighth of the tiles
+  const int nblk = (int)gridDim.x, per = (nblk + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (tile >= nblk) return;
+  const int row0 = tile * kRows;
   const int cout = MT * 16;
 
   if (tid < kMaxK) anyo[tid] = 0;
@@ -141,71 +157,88 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__
 #pragma unroll
     for (int vt = 0; vt < kVT; ++vt) acc[mt][vt] = f4{0.f, 0.f, 0.f, 0.f};
 
-  auto stage = [&](int o, int buf) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(wfrag) + (long long)o * FRAG;
-    for (int c = tid; c < FRAG; c += 256) wbuf[buf][c] = src[c];
+  // weights of one offset: L2 -> LDS by LDS-DMA (no registers; inline assembly: the compiler's own wait counting then sees only
+  // the gathers).  FRAG / 64 wave instructions of 1 KB, dealt to the four wavefronts; a wavefront waits for its own pieces
+  // (`wait_vm<gathers behind them>`) before the barrier that publishes the buffer.
+  constexpr int NDMA = FRAG / 64;                    // = KK * MT
+  const unsigned wbuf_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)lds;
+  auto stage_dma = [&](int o, int buf) __attribute__((always_inline)) {
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(wfrag) + (long long)__builtin_amdgcn_readfirstlane(o) * (FRAG * 16);
+#pragma unroll
+    for (int c = 0; c < (NDMA + 3) / 4; ++c) {
+      const int piece = c * 4 + wave;                // wave-uniform
+      if (NDMA % 4 == 0 || piece < NDMA) {
+        const unsigned voff = (unsigned)(piece * 1024 + lane * 16);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(wbuf_lds + (unsigned)(buf * FRAG * 16 + piece * 1024));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(dst) : "memory", "m0");
+      }
+    }
   };
-  auto gather = [&](int o, h8 (&xf)[kVT][KK]) -> bool {
+  // branch-free: a missing neighbour reads the ZERO ROW the caller keeps behind the last voxel (row M_in), lanes beyond a short
+  // row (cin 8 / 16) re-read its first channels - their weights are the zero padding of the fragments
+  auto gather = [&](int o, h8 (&xf)[kVT][KK]) __attribute__((always_inline)) -> bool {
     bool any = false;
 #pragma unroll
     for (int vt = 0; vt < kVT; ++vt) {
       const int idx = nb[o][wave * (kVT * 16) + vt * 16 + i];
       any |= idx >= 0;
+      const __half *row = feats + (long long)(idx >= 0 ? idx : M_in) * cin;
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
         const int ch = 32 * kk + 8 * g;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (idx >= 0 && ch < cin) v = *reinterpret_cast<const uint4 *>(feats + (long long)idx * cin + ch);
-        xf[vt][kk] = __builtin_bit_cast(h8, v);
+        xf[vt][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(row + (ch < cin ? ch : 0)));
       }
     }
     return __ballot(any) != 0ull;
   };
 
-  h8 xa[kVT][KK], xb[kVT][KK];
-  bool live_a = false, live_b = false;
+  // offset list position p: weights in LDS buffer p & 1 (staged during p - 1), gathered rows in register stage p % NS (loads
+  // issued during p - (NS - 1): a gather is an L2 / Infinity Cache miss more often than not, one offset of products hides none of it)
+  constexpr int NS = kStages;
+  static_assert(NS == 3, "three named register stages");
+  h8 x0[kVT][KK], x1[kVT][KK], x2[kVT][KK];          // (one 3-D array is demoted to scratch by hipcc)
+  unsigned live = 0;                                  // bit s: register stage s holds at least one real neighbour row of this wave
+  // No conditional loads (hipcc answers a conditionally loaded register array with scratch and vmcnt(0)): positions behind the
+  // end of the list re-load the last offset and are not multiplied, the list is walked in whole rounds of NS.
+  const int last = nact - 1;
   if (nact > 0) {
-    stage(act[1], 0);
-    live_a = gather(act[1], xa);
+    stage_dma(act[1], 0);
+    static_for<0, NS - 1>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      const bool l = gather(act[1 + min(s, last)], s == 0 ? x0 : x1);
+      live |= (unsigned)(l && s < nact) << s;
+    });
   }
-  __syncthreads();
-  for (int a = 0; a < nact; a += 2) {
-    // offset a from (buffer 0, xa), offset a + 1 from (buffer 1, xb)
-    if (a + 1 < nact) {
-      stage(act[2 + a], 1);
-      live_b = gather(act[2 + a], xb);
-    }
-    if (live_a) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  const int npos = (nact + NS - 1) / NS * NS;
+  for (int a = 0; a < npos; a += NS) {
+    static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      constexpr int sn = (s + NS - 1) % NS;
+      const int p = a + s;
+      stage_dma(act[1 + min(p + 1, last)], (p + 1) & 1);
+      h8(&xn)[kVT][KK] = sn == 0 ? x0 : (sn == 1 ? x1 : x2);
+      h8(&xc)[kVT][KK] = s == 0 ? x0 : (s == 1 ? x1 : x2);
+      const bool l = gather(act[1 + min(p + NS - 1, last)], xn);
+      live = (live & ~(1u << sn)) | ((unsigned)(l && p + NS - 1 < nact) << sn);
+      if (live & (1u << s)) {
+        const uint4 *wb = wbuf[p & 1];
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
+        for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const h8 w = __builtin_bit_cast(h8, wbuf[0][(kk * MT + mt) * 64 + lane]);
+          for (int mt = 0; mt < MT; ++mt) {
+            const h8 w = __builtin_bit_cast(h8, wb[(kk * MT + mt) * 64 + lane]);
 #pragma unroll
-          for (int vt = 0; vt < kVT; ++vt)
-            acc[mt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xa[vt][kk], acc[mt][vt], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    if (a + 1 >= nact) break;
-    if (a + 2 < nact) {
-      stage(act[3 + a], 0);
-      live_a = gather(act[3 + a], xa);
-    }
-    if (live_b) {
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const h8 w = __builtin_bit_cast(h8, wbuf[1][(kk * MT + mt) * 64 + lane]);
-#pragma unroll
-          for (int vt = 0; vt < kVT; ++vt)
-            acc[mt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xb[vt][kk], acc[mt][vt], 0, 0, 0);
-        }
-    }
-    __syncthreads();
+            for (int vt = 0; vt < kVT; ++vt)
+              acc[mt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xc[vt][kk], acc[mt][vt], 0, 0, 0);
+          }
+      }
+      // this wavefront's weight pieces have landed (younger: the kVT * KK row loads of the gather above), then publish
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(kVT * KK) : "memory");
+    });
   }
 
+  if (tile == 0 && tid < cout / 4) *reinterpret_cast<uint2 *>(out + (long long)M_out * cout + 4 * tid) = make_uint2(0, 0);   // the zero row
   // ---- epilogue: lane (i, g) holds output channels 16 mt + 4 g .. + 3 of voxel i
 #pragma unroll
   for (int vt = 0; vt < kVT; ++vt) {
@@ -231,13 +264,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__
 
 template <int KK, int MT>
 static int launch(const void *feats, const int *nbr, const void *wfrag, const float *bias, const void *residual, void *out,
-                  int M_out, int K, int cin, int relu, hipStream_t stream) {
-  const unsigned grid = (unsigned)((M_out + kRows - 1) / kRows);
+                  int M_in, int M_out, int K, int cin, int relu, hipStream_t stream) {
+  const unsigned grid = max(8u, (unsigned)((M_out + kRows - 1) / kRows + 7) / 8 * 8);   // a multiple of 8: see the tile mapping
   constexpr int lds_bytes = 2 * KK * MT * 64 * 16 + kMaxK * kRows * 4;
   static LdsRaised lds_raised;
   if (int rc = ensure_lds(lds_raised, (const void *)conv_kernel<KK, MT>, lds_bytes)) return rc;
   hipLaunchKernelGGL((conv_kernel<KK, MT>), dim3(grid), dim3(256), lds_bytes, stream, (const __half *)feats, nbr,
-                     (const __half *)wfrag, bias, (const __half *)residual, (__half *)out, M_out, K, cin, relu);
+                     (const __half *)wfrag, bias, (const __half *)residual, (__half *)out, M_in, M_out, K, cin, relu);
   return check_launch("sparse_conv_fwd");
 }
 
@@ -288,12 +321,11 @@ int di_sparse_conv_fwd(const void *feats, const int32_t *nbr, const void *wfrag,
   DI_REQUIRE(M_in >= 0 && M_out >= 0 && K > 0 && K <= di::sp::kMaxK, "M_in = %d, M_out = %d, K = %d", M_in, M_out, K);
   DI_REQUIRE(cin > 0 && cin % 8 == 0 && cin <= cin_pad && cin_pad % 32 == 0, "input rows of %d channels (padded %d)", cin, cin_pad);
   DI_REQUIRE((long long)M_in * cin < (1ll << 31) && (long long)M_out * cout < (1ll << 31), "feature matrix beyond 2^31 elements");
-  if (M_out == 0) return DI_OK;
   hipStream_t s = (hipStream_t)stream;
   const int kk = cin_pad / 32, mt = cout / 16;
   DI_REQUIRE(cout % 16 == 0, "cout = %d", cout);
 #define DI_SP(KKv, MTv) \
-  if (kk == KKv && mt == MTv) return di::sp::launch<KKv, MTv>(feats, nbr, wfrag, bias, residual, out, M_out, K, cin, relu, s)
+  if (kk == KKv && mt == MTv) return di::sp::launch<KKv, MTv>(feats, nbr, wfrag, bias, residual, out, M_in, M_out, K, cin, relu, s)
   DI_SP(1, 1);
   DI_SP(1, 2);
   DI_SP(1, 4);

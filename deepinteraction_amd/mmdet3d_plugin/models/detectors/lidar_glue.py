@@ -235,8 +235,7 @@ class FrozenSparseEncoder(nn.Module):
         assert batch_size * D * H * W < 2 ** 31, 'linear voxel keys are 32-bit'
         c = coors.long()
         keys, order = torch.sort((((c[:, 0] * D + c[:, 1]) * H + c[:, 2]) * W + c[:, 3]).to(torch.int32))
-        cin8 = (self.in_channels + 7) // 8 * 8
-        feats = F.pad(voxel_features[order].to(torch.float16), (0, cin8 - self.in_channels)).contiguous()
+        feats = ops.sparse_rows(voxel_features[order])       # (M + 1, 8): channels padded, the zero row missing neighbours read
         nbr = None
         for st in self.plan():
             if st[0] in ('subm', 'block') and nbr is None:
@@ -253,7 +252,7 @@ class FrozenSparseEncoder(nn.Module):
                 keys, shape, nbr = okeys, oshape, None
         D, H, W = shape
         d = feats.new_zeros((batch_size * D * H * W, feats.shape[1]))
-        d[keys.long()] = feats
+        d[keys.long()] = feats[:-1]
         return d.view(batch_size, D, H, W, -1).permute(0, 4, 1, 2, 3).reshape(batch_size, -1, H, W)
 
     @torch.no_grad()

@@ -903,14 +903,15 @@ def sparse_weight_fragments(weight, K, cin):
 
 
 def sparse_conv(feats, nbr, wfrag, bias, cin_pad, cout, relu=True, residual=None):
-    """out[m] = act(sum_o feats[nbr[o, m]] W[o] + bias (+ residual[m])): gather, product and epilogue in one launch."""
+    """out[m] = act(sum_o feats[nbr[o, m]] W[o] + bias (+ residual[m])): gather, product and epilogue in one launch.  feats
+    (M_in + 1, cin) with a ZERO LAST ROW (`sparse_rows`), the result has the same form: (M_out + 1, cout), last row zero."""
     _dev(feats, nbr, wfrag)
     assert feats.dtype == torch.float16 and feats.is_contiguous() and nbr.dtype == torch.int32 and nbr.is_contiguous()
     assert bias is None or (bias.dtype == torch.float32 and bias.numel() == cout)
     K, M_out = nbr.shape
-    M_in, cin = feats.shape
-    assert wfrag.dtype == torch.float16 and wfrag.numel() == K * cin_pad * cout
-    out = torch.empty((M_out, cout), dtype=torch.float16, device=feats.device)
+    M_in, cin = feats.shape[0] - 1, feats.shape[1]
+    assert M_in >= 0 and wfrag.dtype == torch.float16 and wfrag.numel() == K * cin_pad * cout
+    out = torch.empty((M_out + 1, cout), dtype=torch.float16, device=feats.device)
     if residual is not None:
         assert residual.shape == out.shape and residual.dtype == torch.float16 and residual.is_contiguous()
     _profiled('sparse_conv_fwd', M_out, lambda: _lib.call(
@@ -918,6 +919,14 @@ def sparse_conv(feats, nbr, wfrag, bias, cin_pad, cout, relu=True, residual=None
         residual.data_ptr() if residual is not None else None, out.data_ptr(), M_in, M_out, K, cin, cin_pad, cout, int(bool(relu)),
         _stream()))
     return out
+
+
+def sparse_rows(feats, cin=None):
+    """(M, C) features -> the kernels' form: fp16 (M + 1, cin) rows, channels zero-padded to `cin` (default: the next multiple of
+    8), one zero row behind the last voxel."""
+    M, C = feats.shape
+    cin = (C + 7) // 8 * 8 if cin is None else cin
+    return torch.nn.functional.pad(feats.to(torch.float16), (0, cin - C, 0, 1)).contiguous()
 
 
 # ------------------------------------------------------------------ DeepInteraction++ operators

@@ -622,10 +622,12 @@ int di_wgrad_f32(const float *x, const float *grad_y, long long npix, int Cin, i
  *                       out * stride - pad + offset (kernel index order kd, kh, kw), or -1.  Submanifold layers pass
  *                       out_keys = in_keys, stride 1, pad (k - 1) / 2 and share the table among the layers of a resolution.
  *   di_sparse_conv_fwd  out[m, :] = act(sum_o feats[nbr[o, m], :] . W[o] + bias (+ residual[m, :])), fp16 rows, float32
- *                       accumulation on the matrix cores.  feats (M_in, cin), cin a multiple of 8; `wfrag` = the (K, cin_pad,
+ *                       accumulation on the matrix cores.  feats (M_in + 1, cin), cin a multiple of 8, ROW M_in ALL ZERO (what a
+ *                       missing neighbour reads); out (M_out + 1, cout): the kernel writes the zero row M_out, so an output is the
+ *                       next layer's input as it is.  `wfrag` = the (K, cin_pad,
  *                       cout) weights, cin zero-padded to cin_pad (a multiple of 32), in MFMA operand order
  *                       [K][cin_pad / 32][cout / 16][lane = 16 g + i][8]: element e = W[o][32 kk + 8 g + e][16 mt + i]
- *                       (ops.sparse_weight_fragments); bias (cout) float32 or NULL, residual (M_out, cout) or NULL, relu 0 / 1.
+ *                       (ops.sparse_weight_fragments); bias (cout) float32 or NULL, residual (>= M_out rows of cout) or NULL, relu 0 / 1.
  *                       Shapes: (cin_pad, cout) in {32} x {16, 32, 64}, {64} x {64, 128}, {128} x {128}; K <= 27. */
 int di_sparse_mark(const int32_t *in_keys, int M_in, const int32_t *geo16, void *occ, void *stream);
 int di_sparse_nbr(const int32_t *in_keys, const int32_t *out_keys, int M_in, int M_out, const int32_t *geo16, int32_t *nbr,

@@ -194,13 +194,14 @@ def test_sparse_conv_kernel_equals_gather_and_product(cin, cout, K):
         for use_bias, use_res, relu in ((True, False, True), (True, True, True), (False, False, False)):
             want = base + (bias.double() if use_bias else 0) + (res.double() if use_res else 0)
             want = want.relu() if relu else want
-            got = ops.sparse_conv(feats.to(dev), nbr.to(dev), frag.to(dev), bias.to(dev) if use_bias else None, cin_pad, cout,
-                                  relu=relu, residual=res.to(dev) if use_res else None)
-            err = (got.double().cpu() - want).abs()
+            got = ops.sparse_conv(ops.sparse_rows(feats.to(dev), cin), nbr.to(dev), frag.to(dev), bias.to(dev) if use_bias else None, cin_pad,
+                                  cout, relu=relu, residual=ops.sparse_rows(res.to(dev), cout) if use_res else None)
+            assert got.shape == (M_out + 1, cout) and not bool(got[-1].any())                       # the zero row travels with the rows
+            err = (got[:-1].double().cpu() - want).abs()
             tol = 2e-3 * max(1.0, want.abs().max().item())                       # fp16 output rounding
             assert err.max().item() <= tol, (cin, cout, K, M_out, use_bias, use_res, relu, err.max().item(), tol)
-    out = ops.sparse_conv(feats.to(dev), torch.empty((K, 0), dtype=torch.int32, device=dev), frag.to(dev), None, cin_pad, cout)
-    assert out.shape == (0, cout)
+    out = ops.sparse_conv(ops.sparse_rows(feats.to(dev), cin), torch.empty((K, 0), dtype=torch.int32, device=dev), frag.to(dev), None, cin_pad, cout)
+    assert out.shape == (1, cout) and not bool(out.any())
 
 
 @pytest.mark.gpu

@@ -51,7 +51,7 @@ if net.middle._h:
         ms_n, nbr = timed(lambda: ops.sparse_neighbours(keys, keys, 1, shape, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1)))
         fill = (nbr >= 0).float().mean().item() * 27
         cin = st[2]
-        f = torch.randn(keys.numel(), cin, device=dev).half()
+        f = ops.sparse_rows(torch.randn(keys.numel(), cin, device=dev))
         h = net.middle._h[st[1].rsplit('.', 1)[0] + '.0.1'] if st[1] != 'conv_out' else net.middle._h['encoder_layers.encoder_layer4.0.1']
         ms_c, _ = timed(lambda: ops.sparse_conv(f, nbr, *h, relu=True), n=10)
         ms_o, (okeys, oshape) = timed(lambda: ops.sparse_output_keys(keys, 1, shape, st[4], st[5], st[6]))
