@@ -39,8 +39,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxK = 27;      // kernel offsets of a layer
-constexpr int kVT = 2;         // voxel tiles of 16 per wavefront
-constexpr int kRows = 4 * kVT * 16;
+constexpr int kMaxVT = 4;      // voxel tiles of 16 per wavefront: 2 or 4
 constexpr int kStages = 3;     // register stages of gathered rows: loads run kStages - 1 offsets ahead of the products
 
 template <int B, int E, class F>
@@ -112,12 +111,13 @@ __global__ __launch_bounds__(256) void nbr_kernel(const int *__restrict__ in_key
   }
 }
 
-template <int KK, int MT>
+template <int KK, int MT, int kVT>
 __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_kernel(const __half *__restrict__ feats, const int *__restrict__ nbr,
                                                       const __half *__restrict__ wfrag, const float *__restrict__ bias,
                                                       const __half *__restrict__ residual, __half *__restrict__ out, int M_in,
                                                       int M_out, int K, int cin, int relu) {
   constexpr int FRAG = KK * MT * 64;                 // 16-byte pieces of one offset's weight fragments
+  constexpr int kRows = 4 * kVT * 16;                // output voxels of a workgroup
   extern __shared__ __align__(16) unsigned char lds[];
   uint4(*wbuf)[FRAG] = reinterpret_cast<uint4(*)[FRAG]>(lds);
   int(*nb)[kRows] = reinterpret_cast<int(*)[kRows]>(lds + 2 * FRAG * 16);
@@ -262,14 +262,15 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
 }
 
-template <int KK, int MT>
+template <int KK, int MT, int kVT>
 static int launch(const void *feats, const int *nbr, const void *wfrag, const float *bias, const void *residual, void *out,
                   int M_in, int M_out, int K, int cin, int relu, hipStream_t stream) {
+  constexpr int kRows = 4 * kVT * 16;
   const unsigned grid = max(8u, (unsigned)((M_out + kRows - 1) / kRows + 7) / 8 * 8);   // a multiple of 8: see the tile mapping
   constexpr int lds_bytes = 2 * KK * MT * 64 * 16 + kMaxK * kRows * 4;
   static LdsRaised lds_raised;
-  if (int rc = ensure_lds(lds_raised, (const void *)conv_kernel<KK, MT>, lds_bytes)) return rc;
-  hipLaunchKernelGGL((conv_kernel<KK, MT>), dim3(grid), dim3(256), lds_bytes, stream, (const __half *)feats, nbr,
+  if (int rc = ensure_lds(lds_raised, (const void *)conv_kernel<KK, MT, kVT>, lds_bytes)) return rc;
+  hipLaunchKernelGGL((conv_kernel<KK, MT, kVT>), dim3(grid), dim3(256), lds_bytes, stream, (const __half *)feats, nbr,
                      (const __half *)wfrag, bias, (const __half *)residual, (__half *)out, M_in, M_out, K, cin, relu);
   return check_launch("sparse_conv_fwd");
 }
@@ -324,14 +325,16 @@ int di_sparse_conv_fwd(const void *feats, const int32_t *nbr, const void *wfrag,
   hipStream_t s = (hipStream_t)stream;
   const int kk = cin_pad / 32, mt = cout / 16;
   DI_REQUIRE(cout % 16 == 0, "cout = %d", cout);
-#define DI_SP(KKv, MTv) \
-  if (kk == KKv && mt == MTv) return di::sp::launch<KKv, MTv>(feats, nbr, wfrag, bias, residual, out, M_in, M_out, K, cin, relu, s)
-  DI_SP(1, 1);
-  DI_SP(1, 2);
-  DI_SP(1, 4);
-  DI_SP(2, 4);
-  DI_SP(2, 8);
-  DI_SP(4, 8);
+  // voxel tiles of 16 per wavefront: 4 for 64 -> 128 (measured 73.7 against 82.5 us), 2 everywhere else - whole wavefronts skip
+  // offsets on the sparse fine levels, 64 -> 64 is slower with 4 (190.6 against 164.5 us), 128 -> 128 needs the registers
+#define DI_SP(KKv, MTv, VTv) \
+  if (kk == KKv && mt == MTv) return di::sp::launch<KKv, MTv, VTv>(feats, nbr, wfrag, bias, residual, out, M_in, M_out, K, cin, relu, s)
+  DI_SP(1, 1, 2);
+  DI_SP(1, 2, 2);
+  DI_SP(1, 4, 2);
+  DI_SP(2, 4, 2);
+  DI_SP(2, 8, 4);
+  DI_SP(4, 8, 2);
 #undef DI_SP
   DI_REQUIRE(false, "sparse convolution %d -> %d channels is not one of the SparseEncoder's shapes (16|32 -> 16|32|64, 64 -> 64|128, 128 -> 128)",
              cin_pad, cout);
