@@ -8,7 +8,7 @@
 // with BatchNorm folded into W, b (frozen backbone), nbr = -1 where no active input voxel sits.
 //
 // Three kernels, none of them a translation of spconv's hash-table pipeline:
-//   * `mark_kernel`   strided layers: every active input voxel marks the output cells whose window contains it in a byte map of
+//   * `mark_kernel`   strided layers: every active input voxel marks the (<= 8) output cells whose window contains it in a byte map of
 //                     the OUTPUT grid (<= 11 MB at half resolution); the sorted output keys are the map's non-zero positions.
 //   * `nbr_kernel`    the rulebook as a dense neighbour table (K, M_out): one thread per (kernel row, output voxel), ONE binary
 //                     search per row in the SORTED key list of the input level - the kW neighbours of a row are consecutive
@@ -54,23 +54,30 @@ struct Geo {
   int B, iD, iH, iW, oD, oH, oW, kD, kH, kW, sD, sH, sW, pD, pH, pW;
 };
 
+// one thread per input voxel: the kernel offsets k with (c + p - k) divisible by the stride are k = (c + p) % s, + s, ... - at
+// most ceil(k / s) per axis (8 windows for 3 x 3 x 3 / stride 2)
 __global__ __launch_bounds__(256) void mark_kernel(const int *__restrict__ in_keys, int M_in, Geo g, unsigned char *__restrict__ occ) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int K = g.kD * g.kH * g.kW;
-  if (t >= (long long)M_in * K) return;
-  const int m = (int)(t / K), o = (int)(t - (long long)m * K);
-  const int kd = o / (g.kH * g.kW), kh = (o / g.kW) % g.kH, kw = o % g.kW;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M_in) return;
   int key = in_keys[m];
   const int x = key % g.iW;
   key /= g.iW;
   const int y = key % g.iH;
   key /= g.iH;
   const int z = key % g.iD, b = key / g.iD;
-  const int nz = z + g.pD - kd, ny = y + g.pH - kh, nx = x + g.pW - kw;
-  if (nz < 0 || ny < 0 || nx < 0 || nz % g.sD || ny % g.sH || nx % g.sW) return;
-  const int oz = nz / g.sD, oy = ny / g.sH, ox = nx / g.sW;
-  if (oz >= g.oD || oy >= g.oH || ox >= g.oW) return;
-  occ[((long long)(b * g.oD + oz) * g.oH + oy) * g.oW + ox] = 1;
+  for (int kd = (z + g.pD) % g.sD; kd < g.kD; kd += g.sD) {
+    const int oz = (z + g.pD - kd) / g.sD;
+    if (z + g.pD - kd < 0 || oz >= g.oD) continue;
+    for (int kh = (y + g.pH) % g.sH; kh < g.kH; kh += g.sH) {
+      const int oy = (y + g.pH - kh) / g.sH;
+      if (y + g.pH - kh < 0 || oy >= g.oH) continue;
+      for (int kw = (x + g.pW) % g.sW; kw < g.kW; kw += g.sW) {
+        const int ox = (x + g.pW - kw) / g.sW;
+        if (x + g.pW - kw < 0 || ox >= g.oW) continue;
+        occ[((long long)(b * g.oD + oz) * g.oH + oy) * g.oW + ox] = 1;
+      }
+    }
+  }
 }
 
 // one thread per (kernel row (kd, kh), output voxel): ONE binary search for the row's first in-range x, then the kW neighbours are
@@ -296,8 +303,7 @@ int di_sparse_mark(const int32_t *in_keys, int M_in, const int32_t *geo16, void 
   if (int rc = di::sp::check_geo(g)) return rc;
   DI_REQUIRE(M_in >= 0, "M_in = %d", M_in);
   if (M_in == 0) return DI_OK;
-  const long long n = (long long)M_in * g.kD * g.kH * g.kW;
-  hipLaunchKernelGGL(di::sp::mark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in_keys, M_in, g,
+  hipLaunchKernelGGL(di::sp::mark_kernel, dim3((unsigned)((M_in + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in_keys, M_in, g,
                      (unsigned char *)occ);
   return di::check_launch("sparse_mark");
 }
