@@ -6,11 +6,13 @@ for f in sorted(glob.glob(os.path.join(out, 'p*.csv'))):
     with open(f) as fh:
         for r in csv.DictReader(fh):
             name = r['Kernel_Name'].split('(')[0][-60:]
+            if 'sp::conv_kernel' in r['Kernel_Name']:
+                name = r['Kernel_Name'].split('>')[0][-40:] + '>'
             key = (name, r.get('Grid_Size', ''))
             agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
 res = {}
 for key, cs in sorted(agg.items()):
-    if not any(k in key[0] for k in ('conv3x3', 'local_attn', 'pointwise', 'i2p', 'mha_decode', 'tl_', 'dynconv', 'bevwarp', 'attn_dense')):
+    if not any(k in key[0] for k in ('conv3x3', 'local_attn', 'pointwise', 'i2p', 'mha_decode', 'tl_', 'dynconv', 'bevwarp', 'attn_dense', 'sp::conv', 'sp::nbr')):
         continue
     d = {c: sum(v) / len(v) for c, v in cs.items()}
     res[f'{key[0]} grid={key[1]}'] = d
