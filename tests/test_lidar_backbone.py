@@ -229,3 +229,14 @@ def test_sparse_encoder_device_kernels_against_the_torch_formulation_and_the_ora
     err = (got.float().cpu() - want).abs()
     assert err.max().item() <= 3e-2 * scale and err.mean().item() <= 2e-3 * scale
     assert bool(((got != 0).any(1) == (ref16 != 0).any(1)).all())                    # the same active cells
+
+
+@pytest.mark.gpu
+def test_sparse_encoder_device_kernels_on_an_empty_scan():
+    """No voxel at all: every level is empty, the BEV map is zero (the kernels are launched on empty levels, nothing is read)."""
+    dev = 'cuda'
+    shape = (41, 64, 72)
+    mid = lg.FrozenSparseEncoder(sparse_shape=shape, dtype=torch.float16)
+    mid.load_mmdet_state(mid.synthetic_state(3)).to(dev)
+    out = mid(torch.zeros(0, 5, device=dev), torch.zeros(0, 4, dtype=torch.int32, device=dev), 1)
+    assert out.shape == (1, 256, 8, 9) and not bool(out.any())
