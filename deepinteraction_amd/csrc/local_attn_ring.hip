@@ -1,7 +1,7 @@
 // Fused 9x9 local-window attention on the gfx950 matrix cores, fifth generation (fp16 maps, C = 128):
 // ONE fat workgroup per CU, a 144 KB ring of halo ROWS filled by LDS-DMA, and NO workgroup barrier in the steady state.
 //
-// What the earlier generations measured: a launch takes (rounds of tiles) x (tile latency), and the
+// What the earlier generations measured (docs/DESIGN_history.md section 6): a launch takes (rounds of tiles) x (tile latency), and the
 // tile latency (8.5-9 us) is a chain of dependent phases - stage a unit, barrier, 20 MFMAs per wave, barrier, ... - in which
 // a wave is idle 70 % of the time; no unit of the CU is saturated.  The second generation (local_attn_mfma2.hip) holds two
 // units in registers + two in LDS per workgroup and pays a commit pass and a barrier per unit; the DMA generations
