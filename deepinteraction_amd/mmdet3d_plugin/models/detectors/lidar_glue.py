@@ -18,7 +18,8 @@ reference `models/detectors/deepinteraction.py:120-131`; config `Fusion_0075_ref
 
 State-dict keys mirror mmdet3d's modules (`conv_input.0.weight`, `encoder_layers.encoder_layer1.0.conv1.weight`, `...bn1.*`,
 `conv_out.1.running_var`, `blocks.0.3.weight`, `deblocks.1.0.weight` ...), sparse weights in spconv 2.x layout
-(C_out, kD, kH, kW, C_in), so a reference checkpoint's `pts_middle_encoder.* / pts_backbone.* / pts_neck.*` entries load by name.
+(C_out, kD, kH, kW, C_in) or the spconv 1.x layout of mmdet3d 0.17.1's bundled ops (kD, kH, kW, C_in, C_out) - told apart by
+shape -, so a reference checkpoint's `pts_middle_encoder.* / pts_backbone.* / pts_neck.*` entries load by name.
 Parity: against `oracle/sparse_encoder.py` (dense restatement of the published spconv semantics) - UNPINNED: spconv / mmdet3d
 are not in this image.  Shapes depend on the data (the number of active voxels): this part runs eagerly, in front of the
 captured forward."""
@@ -119,9 +120,27 @@ def sparse_conv(feats, nbr, weight, bias, relu, residual=None):
     return torch.relu_(Y) if relu else Y
 
 
-def _fold(conv_w, bn, prefix, sd):
-    """(K * C_in, C_out) weight and (C_out) bias of `conv (bias=False) -> BatchNorm1d (eval)`; spconv 2.x weight layout."""
+def spconv2_layout(w, ksize, cin, cout):
+    """A sparse-convolution weight in either published layout -> spconv 2.x (C_out, kD, kH, kW, C_in).  mmdet3d 0.17.1 (the
+    reference's version) bundles spconv 1.x, whose `SparseConvolution.weight` is (kD, kH, kW, C_in, C_out): a checkpoint trained
+    there - `Fusion_0075_refactor.pth` - carries that form; spconv 2.x (what `sparse_voxelize.py:3` imports) stores (C_out, kD,
+    kH, kW, C_in).  The two are told apart by where the kernel extents sit (ambiguous only for a cubic kernel with C_in = C_out =
+    its extent, which no layer of the encoder has)."""
+    k = tuple(ksize)
+    if tuple(w.shape) == (cout,) + k + (cin,) and not (tuple(w.shape) == k + (cin, cout)):
+        return w
+    if tuple(w.shape) == k + (cin, cout):
+        return w.permute(4, 0, 1, 2, 3).contiguous()
+    raise ValueError(f'sparse convolution weight of shape {tuple(w.shape)}: neither spconv 2.x {(cout,) + k + (cin,)} nor '
+                     f'spconv 1.x {k + (cin, cout)}')
+
+
+def _fold(conv_w, bn, prefix, sd, ksize=None, cin=None, cout=None):
+    """(K * C_in, C_out) weight and (C_out) bias of `conv (bias=False) -> BatchNorm1d (eval)`; the weight in spconv 2.x layout or
+    (when the geometry is given) in either layout."""
     w = sd[conv_w].float()                                   # (C_out, kD, kH, kW, C_in)
+    if ksize is not None:
+        w = spconv2_layout(w, ksize, cin, cout)
     g, b = sd[f'{bn}.weight'].float(), sd[f'{bn}.bias'].float()
     mu, var = sd[f'{bn}.running_mean'].float(), sd[f'{bn}.running_var'].float()
     scale = g / torch.sqrt(var + 1e-3)                       # norm_cfg: BN1d eps = 1e-3 (mmdet3d SparseEncoder default)
@@ -203,11 +222,11 @@ class FrozenSparseEncoder(nn.Module):
         for st in self.plan():
             if st[0] == 'block':
                 for n in (1, 2):
-                    self._p[f'{st[1]}.{n}'] = _fold(f'{st[1]}.conv{n}.weight', f'{st[1]}.bn{n}', st[1], sd)
+                    self._p[f'{st[1]}.{n}'] = _fold(f'{st[1]}.conv{n}.weight', f'{st[1]}.bn{n}', st[1], sd, (3, 3, 3), st[2], st[3])
                     self._geom[f'{st[1]}.{n}'] = (27, st[2])
             else:
-                self._p[st[1]] = _fold(f'{st[1]}.0.weight', f'{st[1]}.1', st[1], sd)
                 ks = (3, 3, 3) if st[0] == 'subm' else st[4]
+                self._p[st[1]] = _fold(f'{st[1]}.0.weight', f'{st[1]}.1', st[1], sd, ks, st[2], st[3])
                 self._geom[st[1]] = (ks[0] * ks[1] * ks[2], st[2])
         self._master = dict(self._p)                          # float32, where load_mmdet_state ran
         return self

@@ -240,3 +240,20 @@ def test_sparse_encoder_device_kernels_on_an_empty_scan():
     mid.load_mmdet_state(mid.synthetic_state(3)).to(dev)
     out = mid(torch.zeros(0, 5, device=dev), torch.zeros(0, 4, dtype=torch.int32, device=dev), 1)
     assert out.shape == (1, 256, 8, 9) and not bool(out.any())
+
+
+def test_sparse_weights_in_the_spconv1_layout_of_mmdet3d_0_17_load_the_same():
+    """mmdet3d 0.17.1 bundles spconv 1.x: `SparseConvolution.weight` is (kD, kH, kW, C_in, C_out); spconv 2.x stores (C_out, kD, kH,
+    kW, C_in).  A state dict in either layout gives the same module."""
+    shape = (41, 32, 40)
+    feats, coors = _voxels(shape, 1, 300, 21)
+    a = lg.FrozenSparseEncoder(sparse_shape=shape, dtype=torch.float32)
+    sd = a.synthetic_state(5)
+    sd1 = {k: (v.permute(1, 2, 3, 4, 0).contiguous() if v.dim() == 5 else v) for k, v in sd.items()}
+    assert sd1['conv_out.0.weight'].shape == (3, 1, 1, 128, 128) and sd1['conv_input.0.weight'].shape == (3, 3, 3, 5, 16)
+    b = lg.FrozenSparseEncoder(sparse_shape=shape, dtype=torch.float32)
+    ya = a.load_mmdet_state(sd).to('cpu')(feats, coors, 1)
+    yb = b.load_mmdet_state(sd1).to('cpu')(feats, coors, 1)
+    assert torch.equal(ya, yb)
+    with pytest.raises(ValueError):
+        lg.spconv2_layout(torch.zeros(3, 3, 16, 16), (3, 3, 3), 16, 16)
