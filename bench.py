@@ -349,6 +349,13 @@ def main():
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(args))
     import torch
+    # Lines with LIBRARY convolutions (the training step's 3x3 convolutions, the frozen backbones of --from-images / --from-lidar):
+    # MIOpen times its solvers per convolution shape during the warm-up, like the reference's tools do under the config flag
+    # `cudnn_benchmark` (tools/test.py:149-151).  DI_MIOPEN_FIND=0 keeps the immediate-mode pick (A/B); the headline has no
+    # library convolution.
+    lib_convs = args.mode == 'train' or args.from_images or args.from_lidar
+    if os.environ.get('DI_MIOPEN_FIND', '1' if lib_convs else '0') == '1':
+        torch.backends.cudnn.benchmark = True
     from deepinteraction_amd import parallel
     rank, local, world = parallel.env_rank()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
@@ -377,6 +384,7 @@ def main():
     if rank == 0:
         out['config']['ranks_seen'] = ranks_seen
         out['config']['cpu_binding'] = binding
+        out['config']['miopen_find'] = bool(torch.backends.cudnn.benchmark)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -1,6 +1,8 @@
 // Host-side plumbing of libdeepinteraction_hip.so: thread-local error string, ABI version.
 #include <stdarg.h>
 
+#include <stdlib.h>
+
 #include "di_common.h"
 
 namespace di {
@@ -114,7 +116,10 @@ int device_cus() {
       set_error("cannot query the CU count of device %d", dev);
       return 0;
     }
-    cus[dev] = n;
+    // DI_CUS (measurement): the CU count the persistent kernels size their grids by - below the device's count it leaves CUs to
+    // the narrow launches of other streams
+    static const int env = getenv("DI_CUS") ? atoi(getenv("DI_CUS")) : 0;
+    cus[dev] = (env > 0 && env < n) ? env : n;
   }
   return cus[dev];
 }
