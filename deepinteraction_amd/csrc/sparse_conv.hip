@@ -181,6 +181,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       }
     }
   };
+  const unsigned char *fbase = reinterpret_cast<const unsigned char *>(feats);
+  const unsigned rowbytes = (unsigned)cin * 2u;
+  unsigned choff[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) choff[kk] = (32 * kk + 8 * g < cin) ? (unsigned)(32 * kk + 8 * g) * 2u : 0u;
   // branch-free: a missing neighbour reads the ZERO ROW the caller keeps behind the last voxel (row M_in), lanes beyond a short
   // row (cin 8 / 16) re-read its first channels - their weights are the zero padding of the fragments
   auto gather = [&](int o, h8 (&xf)[kVT][KK]) __attribute__((always_inline)) -> bool {
@@ -189,12 +194,12 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int vt = 0; vt < kVT; ++vt) {
       const int idx = nb[o][wave * (kVT * 16) + vt * 16 + i];
       any |= idx >= 0;
-      const __half *row = feats + (long long)(idx >= 0 ? idx : M_in) * cin;
+      // 32-bit byte offsets from the uniform base (M_in * cin < 2^31 elements is checked on the host): one v_mad + the
+      // scalar-base form of the load instead of 64-bit address arithmetic per row
+      const unsigned rowb = (unsigned)(idx >= 0 ? idx : M_in) * rowbytes;
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        const int ch = 32 * kk + 8 * g;
-        xf[vt][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(row + (ch < cin ? ch : 0)));
-      }
+      for (int kk = 0; kk < KK; ++kk)
+        xf[vt][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(fbase + (rowb + choff[kk])));
     }
     return __ballot(any) != 0ull;
   };
