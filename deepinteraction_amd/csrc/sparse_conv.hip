@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void nbr_kernel(const int *__restrict__ in_key
 }
 
 template <int KK, int MT, int kVT>
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_kernel(const __half *__restrict__ feats, const int *__restrict__ nbr,
+__global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__ feats, const int *__restrict__ nbr,
                                                       const __half *__restrict__ wfrag, const float *__restrict__ bias,
                                                       const __half *__restrict__ residual, __half *__restrict__ out, int M_in,
                                                       int M_out, int K, int cin, int relu) {

@@ -3,16 +3,20 @@
 reference `models/detectors/deepinteraction.py:120-131`; config `Fusion_0075_refactor.py:146-184`: hard voxelisation at
 0.075 x 0.075 x 0.2 m, `HardSimpleVFE`, mmdet3d `SparseEncoder` (spconv), `SECOND`, `SECONDFPN`) on PyTorch-ROCm WITHOUT spconv:
 
-* `FrozenSparseEncoder` - mmdet3d 0.17.1 `SparseEncoder(block_type='basicblock')` restated on torch ops.  A sparse tensor is
-  (coordinates (M, 4) int [b, z, y, x], features (M, C)); a convolution is ONE gather + ONE GEMM: the RULEBOOK of a layer is a
-  neighbour table `nbr[M_out, k^3]` (row of the input feature that kernel offset o of output voxel m reads, or the zero row),
-  found by sorting the linear voxel keys once per resolution and `torch.searchsorted` for all k^3 offsets at once (no hash table,
-  no atomics); `X = feats[nbr]` is the im2col matrix (M_out, k^3 C_in) and `Y = X W + b` with BatchNorm folded (eval mode:
-  frozen).  Submanifold convolutions (`SubMConv3d`: outputs exactly on the input's voxels) share the rulebook of their
-  resolution (spconv's `indice_key`), strided `SparseConv3d` layers make the next resolution: an output voxel exists where
-  any input voxel lies in its window.
-* `FrozenSECOND`, `FrozenSECONDFPN` - dense 2-D convolutions through torch / MIOpen (frozen backbones on PyTorch-ROCm: BASELINE
-  configs[2]), BatchNorm folded, channels-last fp16.
+* `FrozenSparseEncoder` - mmdet3d 0.17.1 `SparseEncoder(block_type='basicblock')`.  A sparse tensor is (coordinates (M, 4) int
+  [b, z, y, x], features (M, C)); the RULEBOOK of a layer is a neighbour table (row of the input feature that kernel offset o of
+  output voxel m reads, or none); submanifold convolutions (`SubMConv3d`: outputs exactly on the input's voxels) share the table
+  of their resolution (spconv's `indice_key`), strided `SparseConv3d` layers make the next resolution: an output voxel exists
+  where any input voxel lies in its window; BatchNorm folded (eval mode: frozen).  Two forms of the same arithmetic:
+  - on the device in fp16 (the product): `csrc/sparse_conv.hip` through `ops.sparse_output_keys / sparse_neighbours / sparse_conv` -
+    sorted int32 voxel keys per level, tables by a mark kernel + one binary search per kernel row, every convolution ONE launch
+    (gather, MFMA product, bias / residual / ReLU);
+  - torch operators (CPU tensors, float32, `DI_SPARSE_HIP=0`): tables by sorting the keys and `torch.searchsorted` for all k^3
+    offsets at once, `X = feats[nbr]` as the im2col matrix (M_out, k^3 C_in) and `Y = X W + b` - what the CPU tests pin against
+    brute force and the dense oracle, and what the device form is compared with.
+* `FrozenSECOND`, `FrozenSECONDFPN` - dense 2-D convolutions, BatchNorm folded, channels-last fp16: SECOND's stride-1 layers of 128
+  output channels on the hot path's own 3x3 kernel (`ops.conv3x3`), the rest through torch / MIOpen (frozen backbones on
+  PyTorch-ROCm: BASELINE configs[2]).
 * `FrozenLidarBackbone(points) -> [BEV map (B, 512, 180, 180)]` = `pts_feats` of the hot path; any callable of that signature is
   what `DeepInteractionInference(pts_backbone=...)` takes.
 
