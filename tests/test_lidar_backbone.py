@@ -257,3 +257,32 @@ def test_sparse_weights_in_the_spconv1_layout_of_mmdet3d_0_17_load_the_same():
     assert torch.equal(ya, yb)
     with pytest.raises(ValueError):
         lg.spconv2_layout(torch.zeros(3, 3, 16, 16), (3, 3, 3), 16, 16)
+
+
+@pytest.mark.gpu
+def test_lidar_branch_at_the_benched_shape_equals_its_torch_formulation():
+    """Shape R as `bench.py --from-lidar` runs it (262 144 points, 1440 x 1440 x 41 voxels of 0.075 m, 160 000 -> 402 000 -> 337 000
+    -> 109 000 -> 51 000 active voxels): the branch on `csrc/sparse_conv.hip` + the own 3x3 kernel against the torch formulation of
+    the same fp16 weights - same active BEV cells, values within fp16 round-off of 21 chained convolutions."""
+    from deepinteraction_amd import synth
+    dev = 'cuda'
+    rng = list(synth.PC_RANGE)
+    grid = 1440
+    layer = dict(max_num_points=10, max_voxels=(120000, 160000), point_cloud_range=rng,
+                 voxel_size=[(rng[3] - rng[0]) / grid, (rng[4] - rng[1]) / grid, (rng[5] - rng[2]) / 41.0])
+    net = lg.FrozenLidarBackbone.synthetic(layer, (41, grid, grid), dev).eval()
+    pts = [synth.make_inputs(1, synth.SHAPE_R, seed=0)['pts_metas']['pts'][0].to(dev)]
+    v, c, n = net.pts_voxel_layer(pts[0])
+    feats = v[:, :, :5].sum(1) / n.clamp(min=1).to(v.dtype).unsqueeze(-1)
+    coors = torch.nn.functional.pad(c.long(), (1, 0))
+    got = net.middle(feats, coors, 1)
+    net.middle.HIP = False
+    want = net.middle(feats, coors, 1)
+    net.middle.HIP = True
+    assert got.shape == want.shape == (1, 256, 180, 180)
+    assert bool(((got != 0).any(1) == (want != 0).any(1)).all())
+    scale = want.float().abs().max().item()
+    err = (got.float() - want.float()).abs()
+    assert err.max().item() <= 5e-3 * scale and err.mean().item() <= 2e-4 * scale, (err.max().item(), err.mean().item(), scale)
+    out = net(pts)[0]
+    assert out.shape == (1, 512, 180, 180) and bool(torch.isfinite(out).all())
