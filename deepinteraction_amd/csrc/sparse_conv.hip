@@ -22,6 +22,7 @@
 //                     sorted x-fastest, so a tile is a run of one (z, y) line and most of the 27 offsets of a sparse region are
 //                     empty for the whole tile), wavefronts without a neighbour skip their products.
 //                     Epilogue: + bias, + residual (SparseBasicBlock's identity), ReLU, 8-byte stores.
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -40,7 +41,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kMaxK = 27;      // kernel offsets of a layer
 constexpr int kMaxVT = 4;      // voxel tiles of 16 per wavefront: 2 or 4
-constexpr int kStages = 3;     // register stages of gathered rows: loads run kStages - 1 offsets ahead of the products
 
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void nbr_kernel(const int *__restrict__ in_key
   }
 }
 
-template <int KK, int MT, int kVT>
-__global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__ feats, const int *__restrict__ nbr,
+template <int KK, int MT, int kVT, int NWB>
+__global__ __launch_bounds__(256, NWB * KK * MT >= 96 ? 1 : 2) void conv_kernel(const __half *__restrict__ feats, const int *__restrict__ nbr,
                                                       const __half *__restrict__ wfrag, const float *__restrict__ bias,
                                                       const __half *__restrict__ residual, __half *__restrict__ out, int M_in,
                                                       int M_out, int K, int cin, int relu) {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__
   constexpr int kRows = 4 * kVT * 16;                // output voxels of a workgroup
   extern __shared__ __align__(16) unsigned char lds[];
   uint4(*wbuf)[FRAG] = reinterpret_cast<uint4(*)[FRAG]>(lds);
-  int(*nb)[kRows] = reinterpret_cast<int(*)[kRows]>(lds + 2 * FRAG * 16);
+  int(*nb)[kRows] = reinterpret_cast<int(*)[kRows]>(lds + NWB * FRAG * 16);
   __shared__ int anyo[kMaxK];
   __shared__ int act[kMaxK + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,17 +168,17 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__
   // the gathers).  FRAG / 64 wave instructions of 1 KB, dealt to the four wavefronts; a wavefront waits for its own pieces
   // (`wait_vm<gathers behind them>`) before the barrier that publishes the buffer.
   constexpr int NDMA = FRAG / 64;                    // = KK * MT
+  constexpr int DW = (NDMA + 3) / 4;                 // instructions per wavefront (the same for all four: the wait below counts them;
+                                                     //  where 4 does not divide NDMA the spare wavefronts repeat the last piece)
   const unsigned wbuf_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)lds;
   auto stage_dma = [&](int o, int buf) __attribute__((always_inline)) {
     const unsigned char *src = reinterpret_cast<const unsigned char *>(wfrag) + (long long)__builtin_amdgcn_readfirstlane(o) * (FRAG * 16);
 #pragma unroll
-    for (int c = 0; c < (NDMA + 3) / 4; ++c) {
-      const int piece = c * 4 + wave;                // wave-uniform
-      if (NDMA % 4 == 0 || piece < NDMA) {
-        const unsigned voff = (unsigned)(piece * 1024 + lane * 16);
-        const unsigned dst = __builtin_amdgcn_readfirstlane(wbuf_lds + (unsigned)(buf * FRAG * 16 + piece * 1024));
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(dst) : "memory", "m0");
-      }
+    for (int c = 0; c < DW; ++c) {
+      const int piece = min(c * 4 + wave, NDMA - 1);  // wave-uniform
+      const unsigned voff = (unsigned)(piece * 1024 + lane * 16);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(wbuf_lds + (unsigned)(buf * FRAG * 16 + piece * 1024));
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(dst) : "memory", "m0");
     }
   };
   const unsigned char *fbase = reinterpret_cast<const unsigned char *>(feats);
@@ -196,45 +196,57 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__
       any |= idx >= 0;
       // 32-bit byte offsets from the uniform base (M_in * cin < 2^31 elements is checked on the host): one v_mad + the
       // scalar-base form of the load instead of 64-bit address arithmetic per row
-      const unsigned rowb = (unsigned)(idx >= 0 ? idx : M_in) * rowbytes;
+      const unsigned rowb = (unsigned)((idx >= 0 && !(relu & 2)) ? idx : M_in) * rowbytes;     // relu bit 1 (measurement): every gather reads the zero row
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk)
         xf[vt][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(fbase + (rowb + choff[kk])));
     }
-    return __ballot(any) != 0ull;
+    return __ballot(any) != 0ull && !(relu & 4);     // relu bit 2 (measurement): no products
   };
 
-  // offset list position p: weights in LDS buffer p & 1 (staged during p - 1), gathered rows in register stage p % NS (loads
-  // issued during p - (NS - 1): a gather is an L2 / Infinity Cache miss more often than not, one offset of products hides none of it)
-  constexpr int NS = kStages;
-  static_assert(NS == 3, "three named register stages");
-  h8 x0[kVT][KK], x1[kVT][KK], x2[kVT][KK];          // (one 3-D array is demoted to scratch by hipcc)
+  // offset list position p: weights in LDS buffer p % NWB, on their way since position p - (NWB - 1) (the skeleton of this kernel
+  // without gathers and products is one L2 round trip of the weight DMA per offset: with NWB = 2 it is waited for one position
+  // after its issue, 84 of the 165 us of the 64 -> 64 layers); gathered rows in register stage p % NS, loads issued during
+  // p - (NS - 1): a gather is an L2 / Infinity Cache miss more often than not, one offset of products hides none of it.
+  constexpr int NS = NWB + 1;                         // register stages: gathers run NWB offsets ahead of the products
+  static_assert(NS == 3 || NS == 4, "three or four named register stages");
+  h8 x0[kVT][KK], x1[kVT][KK], x2[kVT][KK], x3[kVT][KK];          // x3: NS = 4 only (one 3-D array is demoted to scratch by hipcc)
+  auto stage_of = [&](auto sc) __attribute__((always_inline)) -> h8(&)[kVT][KK] {
+    constexpr int s = decltype(sc)::value;
+    if constexpr (s == 0) return x0;
+    else if constexpr (s == 1) return x1;
+    else if constexpr (s == 2 || NS == 3) return x2;
+    else return x3;
+  };
   unsigned live = 0;                                  // bit s: register stage s holds at least one real neighbour row of this wave
   // No conditional loads (hipcc answers a conditionally loaded register array with scratch and vmcnt(0)): positions behind the
   // end of the list re-load the last offset and are not multiplied, the list is walked in whole rounds of NS.
   const int last = nact - 1;
   if (nact > 0) {
-    stage_dma(act[1], 0);
+#pragma unroll
+    for (int b = 0; b < NWB - 1; ++b) stage_dma(act[1 + min(b, last)], b);
     static_for<0, NS - 1>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
-      const bool l = gather(act[1 + min(s, last)], s == 0 ? x0 : x1);
+      const bool l = gather(act[1 + min(s, last)], stage_of(sc));
       live |= (unsigned)(l && s < nact) << s;
     });
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   const int npos = (nact + NS - 1) / NS * NS;
+  int bcur = 0;                                       // LDS weight buffer of position p
   for (int a = 0; a < npos; a += NS) {
     static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
       constexpr int sn = (s + NS - 1) % NS;
       const int p = a + s;
-      stage_dma(act[1 + min(p + 1, last)], (p + 1) & 1);
-      h8(&xn)[kVT][KK] = sn == 0 ? x0 : (sn == 1 ? x1 : x2);
-      h8(&xc)[kVT][KK] = s == 0 ? x0 : (s == 1 ? x1 : x2);
+      const int bdma = bcur == 0 ? NWB - 1 : bcur - 1;          // = (p + NWB - 1) % NWB: the buffer position p - 1 was read from
+      stage_dma(act[1 + min(p + NWB - 1, last)], bdma);
+      h8(&xn)[kVT][KK] = stage_of(std::integral_constant<int, sn>{});
+      h8(&xc)[kVT][KK] = stage_of(sc);
       const bool l = gather(act[1 + min(p + NS - 1, last)], xn);
       live = (live & ~(1u << sn)) | ((unsigned)(l && p + NS - 1 < nact) << sn);
       if (live & (1u << s)) {
-        const uint4 *wb = wbuf[p & 1];
+        const uint4 *wb = wbuf[bcur];
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -245,8 +257,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__
               acc[mt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xc[vt][kk], acc[mt][vt], 0, 0, 0);
           }
       }
-      // this wavefront's weight pieces have landed (younger: the kVT * KK row loads of the gather above), then publish
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(kVT * KK) : "memory");
+      // the weights of position p + 1 have landed - this wavefront's pieces, issued NWB - 2 positions ago; younger than them:
+      // NWB - 1 gathers of kVT * KK row loads and the DMAs of NWB - 2 positions - then publish
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"((NWB - 1) * kVT * KK + (NWB - 2) * DW) : "memory");
+      bcur = bcur == NWB - 1 ? 0 : bcur + 1;
     });
   }
 
@@ -268,21 +282,21 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__
       }
       h4 ov;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = (_Float16)(relu ? fmaxf(v[e], 0.f) : v[e]);
+      for (int e = 0; e < 4; ++e) ov[e] = (_Float16)((relu & 1) ? fmaxf(v[e], 0.f) : v[e]);
       *reinterpret_cast<uint2 *>(out + (long long)r * cout + c) = __builtin_bit_cast(uint2, ov);
     }
   }
 }
 
-template <int KK, int MT, int kVT>
+template <int KK, int MT, int kVT, int NWB>
 static int launch(const void *feats, const int *nbr, const void *wfrag, const float *bias, const void *residual, void *out,
                   int M_in, int M_out, int K, int cin, int relu, hipStream_t stream) {
   constexpr int kRows = 4 * kVT * 16;
   const unsigned grid = max(8u, (unsigned)((M_out + kRows - 1) / kRows + 7) / 8 * 8);   // a multiple of 8: see the tile mapping
-  constexpr int lds_bytes = 2 * KK * MT * 64 * 16 + kMaxK * kRows * 4;
+  constexpr int lds_bytes = NWB * KK * MT * 64 * 16 + kMaxK * kRows * 4;
   static LdsRaised lds_raised;
-  if (int rc = ensure_lds(lds_raised, (const void *)conv_kernel<KK, MT, kVT>, lds_bytes)) return rc;
-  hipLaunchKernelGGL((conv_kernel<KK, MT, kVT>), dim3(grid), dim3(256), lds_bytes, stream, (const __half *)feats, nbr,
+  if (int rc = ensure_lds(lds_raised, (const void *)conv_kernel<KK, MT, kVT, NWB>, lds_bytes)) return rc;
+  hipLaunchKernelGGL((conv_kernel<KK, MT, kVT, NWB>), dim3(grid), dim3(256), lds_bytes, stream, (const __half *)feats, nbr,
                      (const __half *)wfrag, bias, (const __half *)residual, (__half *)out, M_in, M_out, K, cin, relu);
   return check_launch("sparse_conv_fwd");
 }
@@ -338,14 +352,26 @@ int di_sparse_conv_fwd(const void *feats, const int32_t *nbr, const void *wfrag,
   DI_REQUIRE(cout % 16 == 0, "cout = %d", cout);
   // voxel tiles of 16 per wavefront: 4 for 64 -> 128 (measured 73.7 against 82.5 us), 2 everywhere else - whole wavefronts skip
   // offsets on the sparse fine levels, 64 -> 64 is slower with 4 (190.6 against 164.5 us), 128 -> 128 needs the registers
-#define DI_SP(KKv, MTv, VTv) \
-  if (kk == KKv && mt == MTv) return di::sp::launch<KKv, MTv, VTv>(feats, nbr, wfrag, bias, residual, out, M_in, M_out, K, cin, relu, s)
-  DI_SP(1, 1, 2);
-  DI_SP(1, 2, 2);
-  DI_SP(1, 4, 2);
-  DI_SP(2, 4, 2);
-  DI_SP(2, 8, 4);
-  DI_SP(4, 8, 2);
+  // LDS weight buffers NWB / register stages NWB + 1: 2 / 3.  Measured and not kept (DI_SPARSE_NWB=3, DI_SPARSE_NWB128=3 run
+  // them): weights two offsets ahead + gathers three ahead - 64 -> 64: 175 us against 169, 32 -> 32: 65.5 against 63.4, 128 ->
+  // 128 (one workgroup per CU then): 178 against 137.  The kernel is not waiting for ONE round trip; see DESIGN 14.8.
+  static const int nwb128 = getenv("DI_SPARSE_NWB128") ? atoi(getenv("DI_SPARSE_NWB128")) : 2;
+  static const int nwb = getenv("DI_SPARSE_NWB") ? atoi(getenv("DI_SPARSE_NWB")) : 2;
+#define DI_SP(KKv, MTv, VTv, NWBv) \
+  if (kk == KKv && mt == MTv) return di::sp::launch<KKv, MTv, VTv, NWBv>(feats, nbr, wfrag, bias, residual, out, M_in, M_out, K, cin, relu, s)
+  if (nwb == 3) {
+    DI_SP(1, 1, 2, 3);
+    DI_SP(1, 2, 2, 3);
+    DI_SP(1, 4, 2, 3);
+    DI_SP(2, 4, 2, 3);
+  }
+  if (nwb128 == 3) DI_SP(4, 8, 2, 3);
+  DI_SP(1, 1, 2, 2);
+  DI_SP(1, 2, 2, 2);
+  DI_SP(1, 4, 2, 2);
+  DI_SP(2, 4, 2, 2);
+  DI_SP(2, 8, 4, 2);
+  DI_SP(4, 8, 2, 2);
 #undef DI_SP
   DI_REQUIRE(false, "sparse convolution %d -> %d channels is not one of the SparseEncoder's shapes (16|32 -> 16|32|64, 64 -> 64|128, 128 -> 128)",
              cin_pad, cout);
