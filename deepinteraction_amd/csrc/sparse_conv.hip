@@ -22,7 +22,6 @@
 //                     sorted x-fastest, so a tile is a run of one (z, y) line and most of the 27 offsets of a sparse region are
 //                     empty for the whole tile), wavefronts without a neighbour skip their products.
 //                     Epilogue: + bias, + residual (SparseBasicBlock's identity), ReLU, 8-byte stores.
-#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -118,16 +117,17 @@ __global__ __launch_bounds__(256) void nbr_kernel(const int *__restrict__ in_key
   }
 }
 
-template <int KK, int MT, int kVT, int NWB>
-__global__ __launch_bounds__(256, NWB * KK * MT >= 96 ? 1 : 2) void conv_kernel(const __half *__restrict__ feats, const int *__restrict__ nbr,
+template <int KK, int MT, int kVT, int OG>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__ feats, const int *__restrict__ nbr,
                                                       const __half *__restrict__ wfrag, const float *__restrict__ bias,
                                                       const __half *__restrict__ residual, __half *__restrict__ out, int M_in,
                                                       int M_out, int K, int cin, int relu) {
   constexpr int FRAG = KK * MT * 64;                 // 16-byte pieces of one offset's weight fragments
+  constexpr int BUF = OG * FRAG;                     // ... of one LDS weight buffer: the OG offsets of a step
   constexpr int kRows = 4 * kVT * 16;                // output voxels of a workgroup
   extern __shared__ __align__(16) unsigned char lds[];
-  uint4(*wbuf)[FRAG] = reinterpret_cast<uint4(*)[FRAG]>(lds);
-  int(*nb)[kRows] = reinterpret_cast<int(*)[kRows]>(lds + NWB * FRAG * 16);
+  uint4(*wbuf)[BUF] = reinterpret_cast<uint4(*)[BUF]>(lds);
+  int(*nb)[kRows] = reinterpret_cast<int(*)[kRows]>(lds + 2 * BUF * 16);
   __shared__ int anyo[kMaxK];
   __shared__ int act[kMaxK + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -164,21 +164,29 @@ __global__ __launch_bounds__(256, NWB * KK * MT >= 96 ? 1 : 2) void conv_kernel(
 #pragma unroll
     for (int vt = 0; vt < kVT; ++vt) acc[mt][vt] = f4{0.f, 0.f, 0.f, 0.f};
 
-  // weights of one offset: L2 -> LDS by LDS-DMA (no registers; inline assembly: the compiler's own wait counting then sees only
-  // the gathers).  FRAG / 64 wave instructions of 1 KB, dealt to the four wavefronts; a wavefront waits for its own pieces
-  // (`wait_vm<gathers behind them>`) before the barrier that publishes the buffer.
+  // A STEP = OG offsets of the tile's list: one weight DMA batch, one gather batch, one barrier.  List entries behind the end
+  // re-load the last offset and are not multiplied: no conditional loads (hipcc answers a conditionally loaded register array
+  // with scratch and vmcnt(0)).
+  const int last = nact - 1;
+  auto offset_at = [&](int step, int og) __attribute__((always_inline)) { return act[1 + min(step * OG + og, last)]; };
+  // weights of a step: L2 -> LDS by LDS-DMA (no registers; inline assembly: the compiler's own wait counting then sees only the
+  // gathers).  FRAG / 64 wave instructions of 1 KB per offset, dealt to the four wavefronts - the same number DW for all four
+  // (where 4 does not divide it the spare wavefronts repeat the last piece): the wait before the publishing barrier counts them
   constexpr int NDMA = FRAG / 64;                    // = KK * MT
-  constexpr int DW = (NDMA + 3) / 4;                 // instructions per wavefront (the same for all four: the wait below counts them;
-                                                     //  where 4 does not divide NDMA the spare wavefronts repeat the last piece)
+  constexpr int DW = (NDMA + 3) / 4;
   const unsigned wbuf_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)lds;
-  auto stage_dma = [&](int o, int buf) __attribute__((always_inline)) {
-    const unsigned char *src = reinterpret_cast<const unsigned char *>(wfrag) + (long long)__builtin_amdgcn_readfirstlane(o) * (FRAG * 16);
+  auto stage_dma = [&](int step, int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < DW; ++c) {
-      const int piece = min(c * 4 + wave, NDMA - 1);  // wave-uniform
-      const unsigned voff = (unsigned)(piece * 1024 + lane * 16);
-      const unsigned dst = __builtin_amdgcn_readfirstlane(wbuf_lds + (unsigned)(buf * FRAG * 16 + piece * 1024));
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(dst) : "memory", "m0");
+    for (int og = 0; og < OG; ++og) {
+      const unsigned char *src =
+          reinterpret_cast<const unsigned char *>(wfrag) + (long long)__builtin_amdgcn_readfirstlane(offset_at(step, og)) * (FRAG * 16);
+#pragma unroll
+      for (int c = 0; c < DW; ++c) {
+        const int piece = min(c * 4 + wave, NDMA - 1);  // wave-uniform
+        const unsigned voff = (unsigned)(piece * 1024 + lane * 16);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(wbuf_lds + (unsigned)((buf * BUF + og * FRAG) * 16 + piece * 1024));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(src), "s"(dst) : "memory", "m0");
+      }
     }
   };
   const unsigned char *fbase = reinterpret_cast<const unsigned char *>(feats);
@@ -186,81 +194,75 @@ __global__ __launch_bounds__(256, NWB * KK * MT >= 96 ? 1 : 2) void conv_kernel(
   unsigned choff[KK];
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) choff[kk] = (32 * kk + 8 * g < cin) ? (unsigned)(32 * kk + 8 * g) * 2u : 0u;
-  // branch-free: a missing neighbour reads the ZERO ROW the caller keeps behind the last voxel (row M_in), lanes beyond a short
-  // row (cin 8 / 16) re-read its first channels - their weights are the zero padding of the fragments
-  auto gather = [&](int o, h8 (&xf)[kVT][KK]) __attribute__((always_inline)) -> bool {
-    bool any = false;
+  // branch-free gathers: a missing neighbour reads the ZERO ROW the caller keeps behind the last voxel (row M_in), lanes beyond a
+  // short row (cin 8 / 16) re-read its first channels - their weights are the zero padding of the fragments.  32-bit byte offsets
+  // from the uniform base (M_in * cin < 2^31 elements is checked on the host).  Returns bit og = this wavefront has a real
+  // neighbour row for offset og of the step.
+  auto gather = [&](int step, h8 (&xf)[OG][kVT][KK]) __attribute__((always_inline)) -> unsigned {
+    unsigned bits = 0;
 #pragma unroll
-    for (int vt = 0; vt < kVT; ++vt) {
-      const int idx = nb[o][wave * (kVT * 16) + vt * 16 + i];
-      any |= idx >= 0;
-      // 32-bit byte offsets from the uniform base (M_in * cin < 2^31 elements is checked on the host): one v_mad + the
-      // scalar-base form of the load instead of 64-bit address arithmetic per row
-      const unsigned rowb = (unsigned)((idx >= 0 && !(relu & 2)) ? idx : M_in) * rowbytes;     // relu bit 1 (measurement): every gather reads the zero row
+    for (int og = 0; og < OG; ++og) {
+      const int o = offset_at(step, og);
+      bool any = false;
 #pragma unroll
-      for (int kk = 0; kk < KK; ++kk)
-        xf[vt][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(fbase + (rowb + choff[kk])));
+      for (int vt = 0; vt < kVT; ++vt) {
+        const int idx = nb[o][wave * (kVT * 16) + vt * 16 + i];
+        any |= idx >= 0;
+        const unsigned rowb = (unsigned)((idx >= 0 && !(relu & 2)) ? idx : M_in) * rowbytes;     // relu bit 1 (measurement): every gather reads the zero row
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+          xf[og][vt][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(fbase + (rowb + choff[kk])));
+      }
+      const bool real = __ballot(any) != 0ull && step * OG + og < nact && !(relu & 4);     // relu bit 2 (measurement): no products
+      bits |= (unsigned)real << og;
     }
-    return __ballot(any) != 0ull && !(relu & 4);     // relu bit 2 (measurement): no products
+    return bits;
   };
 
-  // offset list position p: weights in LDS buffer p % NWB, on their way since position p - (NWB - 1) (the skeleton of this kernel
-  // without gathers and products is one L2 round trip of the weight DMA per offset: with NWB = 2 it is waited for one position
-  // after its issue, 84 of the 165 us of the 64 -> 64 layers); gathered rows in register stage p % NS, loads issued during
-  // p - (NS - 1): a gather is an L2 / Infinity Cache miss more often than not, one offset of products hides none of it.
-  constexpr int NS = NWB + 1;                         // register stages: gathers run NWB offsets ahead of the products
-  static_assert(NS == 3 || NS == 4, "three or four named register stages");
-  h8 x0[kVT][KK], x1[kVT][KK], x2[kVT][KK], x3[kVT][KK];          // x3: NS = 4 only (one 3-D array is demoted to scratch by hipcc)
-  auto stage_of = [&](auto sc) __attribute__((always_inline)) -> h8(&)[kVT][KK] {
+  // step p: weights in LDS buffer p & 1 (DMA issued during step p - 1), gathered rows in register stage p % 3 (loads issued
+  // during step p - 2).  Three NAMED stages (one 4-D array is demoted to scratch by hipcc).
+  h8 x0[OG][kVT][KK], x1[OG][kVT][KK], x2[OG][kVT][KK];
+  auto stage_of = [&](auto sc) __attribute__((always_inline)) -> h8(&)[OG][kVT][KK] {
     constexpr int s = decltype(sc)::value;
     if constexpr (s == 0) return x0;
     else if constexpr (s == 1) return x1;
-    else if constexpr (s == 2 || NS == 3) return x2;
-    else return x3;
+    else return x2;
   };
-  unsigned live = 0;                                  // bit s: register stage s holds at least one real neighbour row of this wave
-  // No conditional loads (hipcc answers a conditionally loaded register array with scratch and vmcnt(0)): positions behind the
-  // end of the list re-load the last offset and are not multiplied, the list is walked in whole rounds of NS.
-  const int last = nact - 1;
+  unsigned live = 0;                                  // bits 4 s + og
+  const int nstep = (nact + OG - 1) / OG;
   if (nact > 0) {
-#pragma unroll
-    for (int b = 0; b < NWB - 1; ++b) stage_dma(act[1 + min(b, last)], b);
-    static_for<0, NS - 1>([&](auto sc) __attribute__((always_inline)) {
-      constexpr int s = decltype(sc)::value;
-      const bool l = gather(act[1 + min(s, last)], stage_of(sc));
-      live |= (unsigned)(l && s < nact) << s;
-    });
+    stage_dma(0, 0);
+    live |= gather(0, x0);
+    live |= gather(1, x1) << 4;
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  const int npos = (nact + NS - 1) / NS * NS;
-  int bcur = 0;                                       // LDS weight buffer of position p
-  for (int a = 0; a < npos; a += NS) {
-    static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
+  for (int a = 0; a < nstep; a += 3) {
+    static_for<0, 3>([&](auto sc) __attribute__((always_inline)) {
       constexpr int s = decltype(sc)::value;
-      constexpr int sn = (s + NS - 1) % NS;
+      constexpr int sn = (s + 2) % 3;
       const int p = a + s;
-      const int bdma = bcur == 0 ? NWB - 1 : bcur - 1;          // = (p + NWB - 1) % NWB: the buffer position p - 1 was read from
-      stage_dma(act[1 + min(p + NWB - 1, last)], bdma);
-      h8(&xn)[kVT][KK] = stage_of(std::integral_constant<int, sn>{});
-      h8(&xc)[kVT][KK] = stage_of(sc);
-      const bool l = gather(act[1 + min(p + NS - 1, last)], xn);
-      live = (live & ~(1u << sn)) | ((unsigned)(l && p + NS - 1 < nact) << sn);
-      if (live & (1u << s)) {
-        const uint4 *wb = wbuf[bcur];
+      stage_dma(p + 1, (p + 1) & 1);
+      h8(&xn)[OG][kVT][KK] = stage_of(std::integral_constant<int, sn>{});
+      h8(&xc)[OG][kVT][KK] = stage_of(sc);
+      live = (live & ~(15u << (4 * sn))) | (gather(p + 2, xn) << (4 * sn));
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
+      for (int og = 0; og < OG; ++og) {
+        if (live & (1u << (4 * s + og))) {
+          const uint4 *wb = wbuf[p & 1] + og * FRAG;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const h8 w = __builtin_bit_cast(h8, wb[(kk * MT + mt) * 64 + lane]);
+          for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-            for (int vt = 0; vt < kVT; ++vt)
-              acc[mt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xc[vt][kk], acc[mt][vt], 0, 0, 0);
-          }
+            for (int mt = 0; mt < MT; ++mt) {
+              const h8 w = __builtin_bit_cast(h8, wb[(kk * MT + mt) * 64 + lane]);
+#pragma unroll
+              for (int vt = 0; vt < kVT; ++vt)
+                acc[mt][vt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xc[og][vt][kk], acc[mt][vt], 0, 0, 0);
+            }
+        }
       }
-      // the weights of position p + 1 have landed - this wavefront's pieces, issued NWB - 2 positions ago; younger than them:
-      // NWB - 1 gathers of kVT * KK row loads and the DMAs of NWB - 2 positions - then publish
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"((NWB - 1) * kVT * KK + (NWB - 2) * DW) : "memory");
-      bcur = bcur == NWB - 1 ? 0 : bcur + 1;
+      // this wavefront's weight pieces of step p + 1 have landed (younger: the OG * kVT * KK row loads of the gather above), then
+      // publish
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(OG * kVT * KK) : "memory");
     });
   }
 
@@ -288,15 +290,15 @@ __global__ __launch_bounds__(256, NWB * KK * MT >= 96 ? 1 : 2) void conv_kernel(
   }
 }
 
-template <int KK, int MT, int kVT, int NWB>
+template <int KK, int MT, int kVT, int OG>
 static int launch(const void *feats, const int *nbr, const void *wfrag, const float *bias, const void *residual, void *out,
                   int M_in, int M_out, int K, int cin, int relu, hipStream_t stream) {
   constexpr int kRows = 4 * kVT * 16;
   const unsigned grid = max(8u, (unsigned)((M_out + kRows - 1) / kRows + 7) / 8 * 8);   // a multiple of 8: see the tile mapping
-  constexpr int lds_bytes = NWB * KK * MT * 64 * 16 + kMaxK * kRows * 4;
+  constexpr int lds_bytes = 2 * OG * KK * MT * 64 * 16 + kMaxK * kRows * 4;
   static LdsRaised lds_raised;
-  if (int rc = ensure_lds(lds_raised, (const void *)conv_kernel<KK, MT, kVT, NWB>, lds_bytes)) return rc;
-  hipLaunchKernelGGL((conv_kernel<KK, MT, kVT, NWB>), dim3(grid), dim3(256), lds_bytes, stream, (const __half *)feats, nbr,
+  if (int rc = ensure_lds(lds_raised, (const void *)conv_kernel<KK, MT, kVT, OG>, lds_bytes)) return rc;
+  hipLaunchKernelGGL((conv_kernel<KK, MT, kVT, OG>), dim3(grid), dim3(256), lds_bytes, stream, (const __half *)feats, nbr,
                      (const __half *)wfrag, bias, (const __half *)residual, (__half *)out, M_in, M_out, K, cin, relu);
   return check_launch("sparse_conv_fwd");
 }
@@ -352,26 +354,19 @@ int di_sparse_conv_fwd(const void *feats, const int32_t *nbr, const void *wfrag,
   DI_REQUIRE(cout % 16 == 0, "cout = %d", cout);
   // voxel tiles of 16 per wavefront: 4 for 64 -> 128 (measured 73.7 against 82.5 us), 2 everywhere else - whole wavefronts skip
   // offsets on the sparse fine levels, 64 -> 64 is slower with 4 (190.6 against 164.5 us), 128 -> 128 needs the registers
-  // LDS weight buffers NWB / register stages NWB + 1: 2 / 3.  Measured and not kept (DI_SPARSE_NWB=3, DI_SPARSE_NWB128=3 run
-  // them): weights two offsets ahead + gathers three ahead - 64 -> 64: 175 us against 169, 32 -> 32: 65.5 against 63.4, 128 ->
-  // 128 (one workgroup per CU then): 178 against 137.  The kernel is not waiting for ONE round trip; see DESIGN 14.8.
-  static const int nwb128 = getenv("DI_SPARSE_NWB128") ? atoi(getenv("DI_SPARSE_NWB128")) : 2;
-  static const int nwb = getenv("DI_SPARSE_NWB") ? atoi(getenv("DI_SPARSE_NWB")) : 2;
-#define DI_SP(KKv, MTv, VTv, NWBv) \
-  if (kk == KKv && mt == MTv) return di::sp::launch<KKv, MTv, VTv, NWBv>(feats, nbr, wfrag, bias, residual, out, M_in, M_out, K, cin, relu, s)
-  if (nwb == 3) {
-    DI_SP(1, 1, 2, 3);
-    DI_SP(1, 2, 2, 3);
-    DI_SP(1, 4, 2, 3);
-    DI_SP(2, 4, 2, 3);
-  }
-  if (nwb128 == 3) DI_SP(4, 8, 2, 3);
-  DI_SP(1, 1, 2, 2);
-  DI_SP(1, 2, 2, 2);
-  DI_SP(1, 4, 2, 2);
-  DI_SP(2, 4, 2, 2);
-  DI_SP(2, 8, 4, 2);
-  DI_SP(4, 8, 2, 2);
+  // Tile shape and pipeline depth, all measured at shape R (`tools/lidar_prof.sh`; 64 -> 64 on 337 k voxels / 32 -> 32 on 402 k):
+  //   voxel tiles of 16 per wavefront  1: 179 / 80 us   2: 165 / 62 us   4: 191 us / -      (64 -> 128: 4 is better, 73.7 against 82.5)
+  //   offsets per step (OG)            1: 165 / 62      2: 195 / 74      3: 215 / 80        (fewer barriers, more registers: fewer workgroups per CU)
+  //   weight buffers / register stages 2 / 3: 169       3 / 4: 175                          (128 -> 128 with 3 / 4 at one workgroup per CU: 178 against 137)
+  // - a local optimum in every direction; the instantiations below are the kept ones.
+#define DI_SP(KKv, MTv, VTv, OGv) \
+  if (kk == KKv && mt == MTv) return di::sp::launch<KKv, MTv, VTv, OGv>(feats, nbr, wfrag, bias, residual, out, M_in, M_out, K, cin, relu, s)
+  DI_SP(1, 1, 2, 1);
+  DI_SP(1, 2, 2, 1);
+  DI_SP(1, 4, 2, 1);
+  DI_SP(2, 4, 2, 1);
+  DI_SP(2, 8, 4, 1);
+  DI_SP(4, 8, 2, 1);
 #undef DI_SP
   DI_REQUIRE(false, "sparse convolution %d -> %d channels is not one of the SparseEncoder's shapes (16|32 -> 16|32|64, 64 -> 64|128, 128 -> 128)",
              cin_pad, cout);
