@@ -286,3 +286,23 @@ def test_lidar_branch_at_the_benched_shape_equals_its_torch_formulation():
     assert err.max().item() <= 5e-3 * scale and err.mean().item() <= 2e-4 * scale, (err.max().item(), err.mean().item(), scale)
     out = net(pts)[0]
     assert out.shape == (1, 512, 180, 180) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ks,st,pd', [((1, 1, 1), (1, 1, 1), (0, 0, 0)), ((1, 3, 3), (1, 1, 1), (0, 1, 1)), ((3, 3, 1), (1, 2, 1), (1, 0, 0)),
+                                      ((2, 2, 2), (2, 2, 2), (0, 0, 0)), ((3, 3, 3), (1, 2, 2), (1, 1, 0)), ((3, 2, 3), (2, 1, 2), (0, 1, 1)),
+                                      ((3, 3, 3), (3, 3, 3), (1, 1, 1))])
+def test_device_rulebooks_for_other_geometries(ks, st, pd):
+    """Kernel extents 1 - 3, strides 1 - 3, paddings 0 - 1 per axis (not only the encoder's three layer types): output set and
+    neighbour table of `di_sparse_mark` / `di_sparse_nbr` equal the torch rulebook's, two samples, voxels on every border."""
+    from deepinteraction_amd import ops
+    dev = 'cuda'
+    shape, batch = (7, 23, 18), 2
+    x = _sorted_level(shape, batch, 400, 9, dev)
+    keys = x.keys().to(torch.int32)
+    ocoords, onbr, oshape = lg.strided_rulebook(x, ks, st, pd)
+    okeys, oshape2 = ops.sparse_output_keys(keys, batch, shape, ks, st, pd)
+    assert oshape2 == oshape
+    want_keys = ((ocoords[:, 0] * oshape[0] + ocoords[:, 1]) * oshape[1] + ocoords[:, 2]) * oshape[2] + ocoords[:, 3]
+    assert torch.equal(okeys.long(), want_keys)
+    assert torch.equal(ops.sparse_neighbours(keys, okeys, batch, shape, oshape, ks, st, pd).t().long(), onbr)
