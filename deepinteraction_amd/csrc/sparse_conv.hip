@@ -208,12 +208,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__
       for (int vt = 0; vt < kVT; ++vt) {
         const int idx = nb[o][wave * (kVT * 16) + vt * 16 + i];
         any |= idx >= 0;
-        const unsigned rowb = (unsigned)((idx >= 0 && !(relu & 2)) ? idx : M_in) * rowbytes;     // relu bit 1 (measurement): every gather reads the zero row
+        const unsigned rowb = (unsigned)(idx >= 0 ? idx : M_in) * rowbytes;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
           xf[og][vt][kk] = __builtin_bit_cast(h8, *reinterpret_cast<const uint4 *>(fbase + (rowb + choff[kk])));
       }
-      const bool real = __ballot(any) != 0ull && step * OG + og < nact && !(relu & 4);     // relu bit 2 (measurement): no products
+      const bool real = __ballot(any) != 0ull && step * OG + og < nact;
       bits |= (unsigned)real << og;
     }
     return bits;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const __half *__restrict__
       }
       h4 ov;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = (_Float16)((relu & 1) ? fmaxf(v[e], 0.f) : v[e]);
+      for (int e = 0; e < 4; ++e) ov[e] = (_Float16)(relu ? fmaxf(v[e], 0.f) : v[e]);
       *reinterpret_cast<uint2 *>(out + (long long)r * cout + c) = __builtin_bit_cast(uint2, ov);
     }
   }

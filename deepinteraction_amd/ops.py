@@ -902,9 +902,6 @@ def sparse_weight_fragments(weight, K, cin):
     return w.contiguous().to(torch.float16), cin_pad
 
 
-_SPARSE_DEBUG = int(os.environ.get('DI_SPARSE_DEBUG', '0')) & 6      # measurement: 2 = every gather reads the zero row, 4 = no products
-
-
 def sparse_conv(feats, nbr, wfrag, bias, cin_pad, cout, relu=True, residual=None):
     """out[m] = act(sum_o feats[nbr[o, m]] W[o] + bias (+ residual[m])): gather, product and epilogue in one launch.  feats
     (M_in + 1, cin) with a ZERO LAST ROW (`sparse_rows`), the result has the same form: (M_out + 1, cout), last row zero."""
@@ -920,7 +917,7 @@ def sparse_conv(feats, nbr, wfrag, bias, cin_pad, cout, relu=True, residual=None
     _profiled('sparse_conv_fwd', M_out, lambda: _lib.call(
         'di_sparse_conv_fwd', feats.data_ptr(), nbr.data_ptr(), wfrag.data_ptr(), bias.data_ptr() if bias is not None else None,
         residual.data_ptr() if residual is not None else None, out.data_ptr(), M_in, M_out, K, cin, cin_pad, cout,
-        int(bool(relu)) | _SPARSE_DEBUG, _stream()))
+        int(bool(relu)), _stream()))
     return out
 
 
