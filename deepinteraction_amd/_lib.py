@@ -55,7 +55,8 @@ SIGNATURES = {
     'di_grid_gather_bwd': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p],
     'di_polar_bev_sample_bwd': [_c_p] * 6 + [_c_i] * 8 + [_c_p],
     'di_sparse_mark': [_c_p, _c_i, _c_p, _c_p, _c_p],
-    'di_sparse_nbr': [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p],
+    'di_sparse_rowstart': [_c_p, _c_i, _c_p, _c_p, _c_p],
+    'di_sparse_nbr': [_c_p, _c_p, _c_i, _c_i, _c_p, _c_p, _c_p, _c_p],
     'di_sparse_conv_fwd': [_c_p] * 6 + [_c_i] * 7 + [_c_p],
     'di_voxel_keys': [_c_p, _c_i, _c_i, _c_p, _c_i, _c_i, _c_i, _c_p, _c_p],
     'di_voxel_heads': [_c_p, _c_i, _c_p, _c_p, _c_p],

@@ -259,10 +259,12 @@ class FrozenSparseEncoder(nn.Module):
         c = coors.long()
         keys, order = torch.sort((((c[:, 0] * D + c[:, 1]) * H + c[:, 2]) * W + c[:, 3]).to(torch.int32))
         feats = ops.sparse_rows(voxel_features[order])       # (M + 1, 8): channels padded, the zero row missing neighbours read
-        nbr = None
+        nbr = rows = None                                     # per level: the submanifold table, the row table of the sorted keys
         for st in self.plan():
+            if rows is None:
+                rows = ops.sparse_rowstart(keys, batch_size, shape)
             if st[0] in ('subm', 'block') and nbr is None:
-                nbr = ops.sparse_neighbours(keys, keys, batch_size, shape, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+                nbr = ops.sparse_neighbours(keys, keys, batch_size, shape, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), rows)
             if st[0] == 'subm':
                 feats = ops.sparse_conv(feats, nbr, *self._h[st[1]], relu=True)
             elif st[0] == 'block':
@@ -270,9 +272,9 @@ class FrozenSparseEncoder(nn.Module):
                 feats = ops.sparse_conv(h, nbr, *self._h[f'{st[1]}.2'], relu=True, residual=feats)
             else:
                 okeys, oshape = ops.sparse_output_keys(keys, batch_size, shape, st[4], st[5], st[6])
-                onbr = ops.sparse_neighbours(keys, okeys, batch_size, shape, oshape, st[4], st[5], st[6])
+                onbr = ops.sparse_neighbours(keys, okeys, batch_size, shape, oshape, st[4], st[5], st[6], rows)
                 feats = ops.sparse_conv(feats, onbr, *self._h[st[1]], relu=True)
-                keys, shape, nbr = okeys, oshape, None
+                keys, shape, nbr, rows = okeys, oshape, None, None
         D, H, W = shape
         d = feats.new_zeros((batch_size * D * H * W, feats.shape[1]))
         d[keys.long()] = feats[:-1]

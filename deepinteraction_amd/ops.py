@@ -878,16 +878,33 @@ def sparse_output_keys(in_keys, batch, in_shape, ksize, stride, padding):
     return torch.nonzero(occ).squeeze(1).to(torch.int32), out_shape
 
 
-def sparse_neighbours(in_keys, out_keys, batch, in_shape, out_shape, ksize, stride, padding):
+def sparse_rowstart(in_keys, batch, in_shape):
+    """First position of the sorted key list for every row (b, z, y) of the level's grid (+ a sentinel): the search ranges of
+    `sparse_neighbours` - once per level."""
+    _dev(in_keys)
+    assert in_keys.dtype == torch.int32 and in_keys.is_contiguous()
+    rowstart = torch.empty(int(batch) * int(in_shape[0]) * int(in_shape[1]) + 1, dtype=torch.int32, device=in_keys.device)
+    geo = _geo16(batch, in_shape, in_shape, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    _lib.call('di_sparse_rowstart', in_keys.data_ptr(), in_keys.numel(), ctypes.addressof(geo), rowstart.data_ptr(), _stream())
+    return rowstart
+
+
+def sparse_neighbours(in_keys, out_keys, batch, in_shape, out_shape, ksize, stride, padding, rowstart=None):
     """The rulebook of a sparse convolution as a neighbour table (K, M_out) int32: row of `in_keys` (sorted) that kernel offset o
-    (index order kd, kh, kw) of output voxel m reads, or -1."""
+    (index order kd, kh, kw) of output voxel m reads, or -1.  rowstart: `sparse_rowstart` of the input level (shared by the tables
+    of a level); None = computed here."""
     _dev(in_keys, out_keys)
     assert in_keys.dtype == out_keys.dtype == torch.int32 and in_keys.is_contiguous() and out_keys.is_contiguous()
     K = int(ksize[0]) * int(ksize[1]) * int(ksize[2])
     nbr = torch.empty((K, out_keys.numel()), dtype=torch.int32, device=in_keys.device)
+    if out_keys.numel() == 0:
+        return nbr
+    if rowstart is None:
+        rowstart = sparse_rowstart(in_keys, batch, in_shape)
+    assert rowstart.dtype == torch.int32 and rowstart.numel() == int(batch) * int(in_shape[0]) * int(in_shape[1]) + 1
     geo = _geo16(batch, in_shape, out_shape, ksize, stride, padding)
     _lib.call('di_sparse_nbr', in_keys.data_ptr(), out_keys.data_ptr(), in_keys.numel(), out_keys.numel(), ctypes.addressof(geo),
-              nbr.data_ptr(), _stream())
+              rowstart.data_ptr(), nbr.data_ptr(), _stream())
     return nbr
 
 

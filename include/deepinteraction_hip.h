@@ -621,6 +621,10 @@ int di_wgrad_f32(const float *x, const float *grad_y, long long npix, int Cin, i
  *   di_sparse_nbr       the rulebook as a neighbour table nbr (K = kD*kH*kW, M_out): row of `in_keys` holding the voxel at
  *                       out * stride - pad + offset (kernel index order kd, kh, kw), or -1.  Submanifold layers pass
  *                       out_keys = in_keys, stride 1, pad (k - 1) / 2 and share the table among the layers of a resolution.
+ *                       `rowstart`: the input level's row table from di_sparse_rowstart (the searches then stay inside one row's
+ *                       slice of the list), or NULL (whole-list searches).
+ *   di_sparse_rowstart  rowstart[r] (B * inD * inH + 1 int32) = first position of `in_keys` with key >= r * inW: once per level,
+ *                       shared by the level's submanifold table and the strided table that leaves it.
  *   di_sparse_conv_fwd  out[m, :] = act(sum_o feats[nbr[o, m], :] . W[o] + bias (+ residual[m, :])), fp16 rows, float32
  *                       accumulation on the matrix cores.  feats (M_in + 1, cin), cin a multiple of 8, ROW M_in ALL ZERO (what a
  *                       missing neighbour reads); out (M_out + 1, cout): the kernel writes the zero row M_out, so an output is the
@@ -630,8 +634,9 @@ int di_wgrad_f32(const float *x, const float *grad_y, long long npix, int Cin, i
  *                       (ops.sparse_weight_fragments); bias (cout) float32 or NULL, residual (>= M_out rows of cout) or NULL, relu 0 / 1.
  *                       Shapes: (cin_pad, cout) in {32} x {16, 32, 64}, {64} x {64, 128}, {128} x {128}; K <= 27. */
 int di_sparse_mark(const int32_t *in_keys, int M_in, const int32_t *geo16, void *occ, void *stream);
-int di_sparse_nbr(const int32_t *in_keys, const int32_t *out_keys, int M_in, int M_out, const int32_t *geo16, int32_t *nbr,
-                  void *stream);
+int di_sparse_rowstart(const int32_t *in_keys, int M_in, const int32_t *geo16, int32_t *rowstart, void *stream);
+int di_sparse_nbr(const int32_t *in_keys, const int32_t *out_keys, int M_in, int M_out, const int32_t *geo16,
+                  const int32_t *rowstart, int32_t *nbr, void *stream);
 int di_sparse_conv_fwd(const void *feats, const int32_t *nbr, const void *wfrag, const float *bias, const void *residual,
                        void *out, int M_in, int M_out, int K, int cin, int cin_pad, int cout, int relu, void *stream);
 
