@@ -7,6 +7,8 @@ from deepinteraction_amd import synth
 from deepinteraction_amd.mmdet3d_plugin.models.detectors import lidar_glue as lg
 
 dev = 'cuda'
+if os.environ.get('LIDAR_ONLY') != '1':          # (under rocprofv3 the solver timing's candidate kernels would fill the table)
+    torch.backends.cudnn.benchmark = True        # MIOpen times its solvers per shape, as bench.py's sensor lines do
 rng = list(synth.PC_RANGE)
 grid = 1440
 layer = dict(max_num_points=10, max_voxels=(120000, 160000), point_cloud_range=rng,
