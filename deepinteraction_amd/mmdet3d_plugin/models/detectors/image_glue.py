@@ -20,6 +20,8 @@ Swin-T, reference `models/backbones/swin.py`, in front of the same FPN) - see it
 `load_mmdet_state` takes the two state dicts in mmdet's own key layout (the reference's checkpoints: `img_backbone.*`,
 `img_neck.*` with the prefix stripped), checks every expected key and shape, and fails loudly on a mismatch.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -72,14 +74,30 @@ class _FrozenImageNet(nn.Module):
         self._put_t(key + '_w', w.to(self.dtype).contiguous(memory_format=torch.channels_last) if w.dim() == 4
                     else w.to(self.dtype).contiguous())
         self._put_t(key + '_b', b.to(self.dtype).contiguous())
+        self._put_t(key + '_b32', b.float().contiguous())       # the one-pass epilogue's bias (ops.bias_act_)
 
     def _get(self, name):
         key = name.replace('.', '_')
         return getattr(self, key + '_w'), getattr(self, key + '_b')
 
-    def _conv(self, x, name, stride=1, pad=0, relu=False):
+    # One-pass epilogue (csrc/epilogue.hip) behind the library convolution on the device: torch's conv2d-with-bias is MIOpen's
+    # convolution + a bias kernel, `relu_` and `add_` one more pass each - in the ResNet-50 these passes took as long as the
+    # convolutions.  DI_FUSED_EPILOGUE=0: the torch statements (A/B, and what CPU tensors / float32 run).
+    FUSED = os.environ.get('DI_FUSED_EPILOGUE', '1') != '0'
+
+    def _conv(self, x, name, stride=1, pad=0, relu=False, residual=None):
         w, b = self._get(name)
+        if self.FUSED and x.is_cuda and x.dtype == torch.float16 and w.shape[0] % 8 == 0:
+            from .... import ops
+            y = F.conv2d(x, w, None, stride=stride, padding=pad)
+            if not y.is_contiguous(memory_format=torch.channels_last):
+                y = y.contiguous(memory_format=torch.channels_last)
+            if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+                residual = residual.contiguous(memory_format=torch.channels_last)
+            return ops.bias_act_(y, getattr(self, name.replace('.', '_') + '_b32'), residual, relu)
         y = F.conv2d(x, w, b, stride=stride, padding=pad)
+        if residual is not None:
+            y = y.add_(residual)
         return y.relu_() if relu else y
 
     def _load_neck(self, neck_state):
@@ -182,8 +200,7 @@ class FrozenResNetFPN(_FrozenImageNet):
         identity = self._conv(x, p + '.downsample', stride) if has_down else x
         y = self._conv(x, p + '.conv1', relu=True)
         y = self._conv(y, p + '.conv2', stride, 1, relu=True)
-        y = self._conv(y, p + '.conv3')
-        return y.add_(identity).relu_()
+        return self._conv(y, p + '.conv3', relu=True, residual=identity)         # conv3 + bias, + identity, ReLU
 
     @torch.no_grad()
     def forward(self, img):

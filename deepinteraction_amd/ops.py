@@ -855,6 +855,20 @@ def voxelize(points, voxel_size, pc_range, max_points, max_voxels, n_feat=None):
     return voxels, coords, num, n_vox
 
 
+def bias_act_(y, bias, residual=None, relu=True):
+    """In place: y = act(y + bias[c] (+ residual)) on a channels-last fp16 map (n, C, H, W) - the one-pass epilogue of a library
+    convolution (torch's conv2d-with-bias, add_ and relu_ are one pass EACH).  bias float32 (C)."""
+    _dev(y, bias)
+    n, C, H, W = y.shape
+    assert y.dtype == torch.float16 and y.is_contiguous(memory_format=torch.channels_last), 'channels-last fp16 map'
+    assert bias.dtype == torch.float32 and bias.numel() == C and bias.is_contiguous()
+    if residual is not None:
+        assert residual.shape == y.shape and residual.dtype == y.dtype and residual.is_contiguous(memory_format=torch.channels_last)
+    _lib.call('di_bias_act_inplace', y.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+              n * H * W, C, int(bool(relu)), _stream())
+    return y
+
+
 # ------------------------------------------------------------------ sparse 3-D convolutions of the frozen LiDAR encoder
 def _geo16(batch, in_shape, out_shape, ksize, stride, padding):
     return (ctypes.c_int32 * 16)(int(batch), *map(int, in_shape), *map(int, out_shape), *map(int, ksize), *map(int, stride),

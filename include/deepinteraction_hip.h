@@ -640,6 +640,12 @@ int di_sparse_nbr(const int32_t *in_keys, const int32_t *out_keys, int M_in, int
 int di_sparse_conv_fwd(const void *feats, const int32_t *nbr, const void *wfrag, const float *bias, const void *residual,
                        void *out, int M_in, int M_out, int K, int cin, int cin_pad, int cout, int relu, void *stream);
 
+/* Epilogue of a LIBRARY convolution of the frozen backbones, in place on a channels-last fp16 map (csrc/epilogue.hip):
+ *   y[p][c] = act(y[p][c] + bias[c] (+ residual[p][c])),  y (npix, C), C a multiple of 8, bias float32, residual NULL or (npix, C).
+ * One pass where torch's conv2d-with-bias + add_ + relu_ are three (img_backbone / img_neck of Fusion_0075_refactor.py:120-145,
+ * called by detectors/deepinteraction.py:100-118). */
+int di_bias_act_inplace(void *y, const float *bias, const void *residual, long long npix, int C, int relu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,3 +228,32 @@ def test_swin_fp16_on_the_device():
         assert g.dtype == torch.float16 and g.is_contiguous(memory_format=torch.channels_last)
         assert torch.isfinite(g).all()
         assert float((g.float().cpu() - w).abs().max()) <= 3e-2 * float(w.abs().max())
+
+
+@pytest.mark.gpu
+def test_one_pass_bias_residual_relu_epilogue_equals_the_torch_statements():
+    """`ops.bias_act_` (csrc/epilogue.hip) against y + b (+ z) -> relu in float32 of the same fp16 inputs, and the frozen ResNet-50 +
+    FPN with it against the same network on torch's conv-with-bias / add_ / relu_ passes (fp16 round-off of a 50-layer network)."""
+    from deepinteraction_amd import ops
+    from deepinteraction_amd.mmdet3d_plugin.models.detectors import image_glue as ig
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(0)
+    for (n, C, H, W) in ((2, 64, 13, 9), (1, 256, 28, 50), (6, 8, 5, 7)):
+        y = torch.randn(n, C, H, W, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+        z = torch.randn(n, C, H, W, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(C, generator=g).to(dev)
+        for res, relu in ((None, True), (z, True), (z, False), (None, False)):
+            want = y.float() + b.view(1, -1, 1, 1) + (0 if res is None else res.float())
+            want = want.relu() if relu else want
+            got = ops.bias_act_(y.clone(memory_format=torch.channels_last), b, res, relu)
+            assert got.is_contiguous(memory_format=torch.channels_last)
+            assert (got.float() - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+    net = ig.FrozenResNetFPN(levels=(0,), dtype=torch.float16)
+    net.load_mmdet_state(*net.synthetic_state(1))
+    net = net.to(dev).eval()
+    img = torch.randn(2, 3, 96, 160, generator=g).to(dev)
+    a = net(img)[0].float()
+    net.FUSED = False
+    bref = net(img)[0].float()
+    net.FUSED = True
+    assert (a - bref).abs().max().item() <= 2e-2 * max(1.0, bref.abs().max().item())
