@@ -54,6 +54,7 @@ SIGNATURES = {
     'di_ms_deform_attn_bwd': [_c_p, _c_p, _c_i, _c_p, _c_i, _c_p, _c_i, _c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p, _c_i, _c_p],
     'di_grid_gather_bwd': [_c_p, _c_p, _c_p, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_p],
     'di_polar_bev_sample_bwd': [_c_p] * 6 + [_c_i] * 8 + [_c_p],
+    'di_upsample_add_inplace': [_c_p, _c_p] + [_c_i] * 6 + [_c_p],
     'di_bias_act_inplace': [_c_p, _c_p, _c_p, ctypes.c_longlong, _c_i, _c_i, _c_p],
     'di_sparse_mark': [_c_p, _c_i, _c_p, _c_p, _c_p],
     'di_sparse_rowstart': [_c_p, _c_i, _c_p, _c_p, _c_p],

@@ -124,7 +124,13 @@ class _FrozenImageNet(nn.Module):
         low, out_convs = self._needed()
         lat = {i: self._conv(feats[i], f'lateral_convs.{i}') for i in range(low, 4)}
         for i in range(3, low, -1):
-            lat[i - 1].add_(F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode='nearest'))
+            lo, hi = lat[i - 1], lat[i]
+            if (self.FUSED and lo.is_cuda and lo.dtype == torch.float16 and lo.shape[1] % 8 == 0
+                    and lo.is_contiguous(memory_format=torch.channels_last) and hi.is_contiguous(memory_format=torch.channels_last)):
+                from .... import ops
+                ops.upsample_add_(lo, hi)
+            else:
+                lo.add_(F.interpolate(hi, size=lo.shape[2:], mode='nearest'))
         outs = {i: self._conv(lat[i], f'fpn_convs.{i}', 1, 1) for i in out_convs}
         for l in range(4, self.levels[-1] + 1):
             outs[l] = F.max_pool2d(outs[l - 1], 1, stride=2)

@@ -376,6 +376,7 @@ class FrozenSECOND(_FrozenConvStack):
             # stride-1 layers of 128 output channels (the whole first stage of the reference configuration) run on the hot
             # path's own 3x3 kernel (csrc/conv3x3.hip, BatchNorm folded, ReLU in the epilogue); the rest through MIOpen
             from .... import ops
+            self._b32 = {key: v[1].float().to(dev) for key, v in self._master.items()}
             for key, (w, b, s, ci, co) in self._master.items():
                 if s == 1 and co == 128 and ci % 32 == 0:
                     wp, ws, bias = ops.pack_conv3x3(w, b)
@@ -394,7 +395,14 @@ class FrozenSECOND(_FrozenConvStack):
                     x = ops.conv3x3(x, h[0], h[1], h[2], relu=True)
                 else:
                     w, b, s = self._p[(i, k)]
-                    x = torch.relu_(F.conv2d(x, w, b, stride=s, padding=1))
+                    b32 = getattr(self, '_b32', {}).get((i, k)) if (x.is_cuda and self.HIP and x.dtype == torch.float16) else None
+                    if b32 is not None and w.shape[0] % 8 == 0:        # library convolution + the one-pass bias / ReLU epilogue
+                        from .... import ops
+                        y = F.conv2d(x, w, None, stride=s, padding=1)
+                        x = ops.bias_act_(y if y.is_contiguous(memory_format=torch.channels_last)
+                                          else y.contiguous(memory_format=torch.channels_last), b32, None, True)
+                    else:
+                        x = torch.relu_(F.conv2d(x, w, b, stride=s, padding=1))
             outs.append(x)
         return tuple(outs)
 
@@ -408,6 +416,7 @@ class FrozenSECONDFPN(_FrozenConvStack):
         super().__init__(dtype)
         self.in_channels, self.out_channels, self.upsample_strides = tuple(in_channels), tuple(out_channels), tuple(upsample_strides)
         self.use_conv_for_no_stride, self.eps = use_conv_for_no_stride, eps
+        self._b32 = {}
 
     def _transposed(self, s):
         return s > 1 or (s == 1 and not self.use_conv_for_no_stride)
@@ -436,8 +445,17 @@ class FrozenSECONDFPN(_FrozenConvStack):
         ups = []
         for i, x in enumerate(xs):
             w, b, s, t = self._p[i]
-            y = F.conv_transpose2d(x, w, b, stride=s) if t else F.conv2d(x, w, b, stride=s)
-            ups.append(torch.relu_(y))
+            if x.is_cuda and x.dtype == torch.float16 and b.numel() % 8 == 0 and FrozenSECOND.HIP:
+                from .... import ops                         # library (de)convolution + the one-pass bias / ReLU epilogue
+                y = F.conv_transpose2d(x, w, None, stride=s) if t else F.conv2d(x, w, None, stride=s)
+                if not y.is_contiguous(memory_format=torch.channels_last):
+                    y = y.contiguous(memory_format=torch.channels_last)
+                if i not in self._b32:
+                    self._b32[i] = b.float().contiguous()
+                ups.append(ops.bias_act_(y, self._b32[i], None, True))
+            else:
+                y = F.conv_transpose2d(x, w, b, stride=s) if t else F.conv2d(x, w, b, stride=s)
+                ups.append(torch.relu_(y))
         out = torch.cat(ups, 1) if len(ups) > 1 else ups[0]
         return [out.contiguous(memory_format=torch.channels_last)]
 

@@ -869,6 +869,17 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
+def upsample_add_(lo, hi):
+    """In place: lo += F.interpolate(hi, size=lo.shape[2:], mode='nearest') on channels-last fp16 maps - the FPN top-down step
+    as one pass."""
+    _dev(lo, hi)
+    n, C, Hl, Wl = lo.shape
+    assert hi.shape[:2] == (n, C) and lo.dtype == hi.dtype == torch.float16
+    assert lo.is_contiguous(memory_format=torch.channels_last) and hi.is_contiguous(memory_format=torch.channels_last)
+    _lib.call('di_upsample_add_inplace', lo.data_ptr(), hi.data_ptr(), n, Hl, Wl, hi.shape[2], hi.shape[3], C, _stream())
+    return lo
+
+
 # ------------------------------------------------------------------ sparse 3-D convolutions of the frozen LiDAR encoder
 def _geo16(batch, in_shape, out_shape, ksize, stride, padding):
     return (ctypes.c_int32 * 16)(int(batch), *map(int, in_shape), *map(int, out_shape), *map(int, ksize), *map(int, stride),

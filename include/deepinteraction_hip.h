@@ -645,6 +645,9 @@ int di_sparse_conv_fwd(const void *feats, const int32_t *nbr, const void *wfrag,
  * One pass where torch's conv2d-with-bias + add_ + relu_ are three (img_backbone / img_neck of Fusion_0075_refactor.py:120-145,
  * called by detectors/deepinteraction.py:100-118). */
 int di_bias_act_inplace(void *y, const float *bias, const void *residual, long long npix, int C, int relu, void *stream);
+/* FPN top-down step in place (mmdet FPN.forward: `laterals[i - 1] += F.interpolate(laterals[i], size=..., mode='nearest')`, the
+ * img_neck of Fusion_0075_refactor.py:137-145): lo (n, Hl, Wl, C) += nearest(hi (n, Hh, Wh, C)), channels-last fp16, C % 8 == 0. */
+int di_upsample_add_inplace(void *lo, const void *hi, int n, int Hl, int Wl, int Hh, int Wh, int C, void *stream);
 
 #ifdef __cplusplus
 }

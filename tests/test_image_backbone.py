@@ -248,6 +248,11 @@ def test_one_pass_bias_residual_relu_epilogue_equals_the_torch_statements():
             got = ops.bias_act_(y.clone(memory_format=torch.channels_last), b, res, relu)
             assert got.is_contiguous(memory_format=torch.channels_last)
             assert (got.float() - want).abs().max().item() <= 2e-3 * max(1.0, want.abs().max().item())
+    for (Hl, Wl, Hh, Wh) in ((56, 100, 28, 50), (7, 9, 4, 5), (5, 5, 5, 5), (9, 4, 3, 1)):
+        lo = torch.randn(2, 16, Hl, Wl, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+        hi = torch.randn(2, 16, Hh, Wh, generator=g).half().to(dev).contiguous(memory_format=torch.channels_last)
+        want = lo + torch.nn.functional.interpolate(hi, size=(Hl, Wl), mode='nearest')
+        assert torch.equal(ops.upsample_add_(lo.clone(memory_format=torch.channels_last), hi), want)        # one fp16 addition: exact
     net = ig.FrozenResNetFPN(levels=(0,), dtype=torch.float16)
     net.load_mmdet_state(*net.synthetic_state(1))
     net = net.to(dev).eval()
