@@ -215,8 +215,17 @@ class FrozenResNetFPN(_FrozenImageNet):
         if not self._loaded:
             raise RuntimeError('FrozenResNetFPN: no weights loaded (load_mmdet_state)')
         x = img.to(dtype=self.dtype, memory_format=torch.channels_last)
-        x = self._conv(x, 'conv1', 2, 3, relu=True)
-        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        if self.FUSED and x.is_cuda and x.dtype == torch.float16:
+            # max-pool(relu(y + b)) == relu(max-pool(y) + b) exactly (per-channel constant, monotonic, rounding is monotonic too):
+            # the epilogue pass runs on the pooled map, a quarter of the stem's output
+            from .... import ops
+            w, _ = self._get('conv1')
+            x = F.max_pool2d(F.conv2d(x, w, None, stride=2, padding=3), kernel_size=3, stride=2, padding=1)
+            x = ops.bias_act_(x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last),
+                              self.conv1_b32, None, True)
+        else:
+            x = self._conv(x, 'conv1', 2, 3, relu=True)
+            x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
         feats = []
         for s, blocks in enumerate(_STAGE_BLOCKS[self.depth]):
             for j in range(blocks):

@@ -262,3 +262,9 @@ def test_one_pass_bias_residual_relu_epilogue_equals_the_torch_statements():
     bref = net(img)[0].float()
     net.FUSED = True
     assert (a - bref).abs().max().item() <= 2e-2 * max(1.0, bref.abs().max().item())
+    # the stem: bias + ReLU behind the max-pool instead of in front of it - exact
+    w, bias = net._get('conv1')
+    y = torch.nn.functional.conv2d(img.half().contiguous(memory_format=torch.channels_last), w, None, stride=2, padding=3)
+    front = torch.nn.functional.max_pool2d(torch.relu(y + bias.view(1, -1, 1, 1)), 3, 2, 1)
+    behind = torch.relu(torch.nn.functional.max_pool2d(y, 3, 2, 1) + bias.view(1, -1, 1, 1))
+    assert torch.equal(front, behind)
