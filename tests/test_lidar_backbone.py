@@ -306,3 +306,23 @@ def test_device_rulebooks_for_other_geometries(ks, st, pd):
     want_keys = ((ocoords[:, 0] * oshape[0] + ocoords[:, 1]) * oshape[1] + ocoords[:, 2]) * oshape[2] + ocoords[:, 3]
     assert torch.equal(okeys.long(), want_keys)
     assert torch.equal(ops.sparse_neighbours(keys, okeys, batch, shape, oshape, ks, st, pd).t().long(), onbr)
+
+
+def test_operand_fragment_order_and_row_form_of_the_device_kernels():
+    """Host-side constants of `csrc/sparse_conv.hip` (no GPU): weight fragments [K][cin_pad / 32][cout / 16][lane = 16 g + i][8] with
+    element e = W[o][32 kk + 8 g + e][16 mt + i] (zero beyond cin), feature rows padded to a multiple of 8 channels + the zero row."""
+    from deepinteraction_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for K, cin, cout in ((27, 5, 16), (27, 16, 32), (3, 128, 128), (27, 64, 128)):
+        w = torch.randn(K * cin, cout, generator=g)
+        frag, cin_pad = ops.sparse_weight_fragments(w, K, cin)
+        assert cin_pad == (cin + 31) // 32 * 32 and frag.shape == (K, cin_pad // 32, cout // 16, 4, 16, 8) and frag.dtype == torch.float16
+        w3 = w.view(K, cin, cout).half()
+        for (o, kk, mt, gq, i, e) in ((0, 0, 0, 0, 0, 0), (K - 1, cin_pad // 32 - 1, cout // 16 - 1, 3, 15, 7), (K // 2, 0, 0, 1, 7, 3)):
+            c = 32 * kk + 8 * gq + e
+            want = w3[o, c, 16 * mt + i] if c < cin else torch.tensor(0.0).half()
+            assert frag[o, kk, mt, gq, i, e] == want
+    f = torch.randn(7, 5, generator=g)
+    rows = ops.sparse_rows(f)
+    assert rows.shape == (8, 8) and rows.dtype == torch.float16 and not bool(rows[-1].any()) and not bool(rows[:, 5:].any())
+    assert torch.equal(rows[:7, :5], f.half())
